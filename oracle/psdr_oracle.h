@@ -1,0 +1,119 @@
+/*
+ * psdr_oracle.h — CPU ORACLE for the PhantomSDR hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a plain-C restatement of the reference's algorithm (file:line cited at
+ * every function in psdr_oracle.c).  It is the *checker* for the HIP path and the
+ * "port" CPU baseline of bench.py.  Nothing in phantomsdr_amd/ may include, link,
+ * dlopen or call it; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg do.
+ *
+ * PINNING STATUS (see DESIGN.md "Oracle"):
+ *   - pinned against the reference's own compiled code (oracle/_ref, built from
+ *     /root/reference/src/utils/{dsp,audioprocessing}.cpp): Hann window, AM
+ *     envelope, FM polar discriminator, negate/add helpers, float->int16, AGC.
+ *   - pinned against an independent float64 numpy DFT: forward C2C/R2C FFT and the
+ *     per-client inverse DFTs (the butterflies live in FFTW 3.3.10, a dependency
+ *     that is not under /root/reference and not installed in this image).
+ *   - PARITY UNPINNED (the reference has no tests / golden vectors, and
+ *     fft_impl.cpp / signal.cpp / samplereader.cpp / utils.h do not compile here
+ *     without fftw3.h / boost / websocketpp): vec_log2 + int8 quantiser + pyramid,
+ *     index maps, AudioClient::send_audio control flow, sample conversion and the
+ *     DC blocker are restated line by line from the cited source only.
+ */
+#ifndef PSDR_ORACLE_H
+#define PSDR_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* sample formats accepted by the reference (src/spectrumserver.cpp:349-364) */
+enum {
+    ORC_FMT_U8 = 0,
+    ORC_FMT_S8 = 1,
+    ORC_FMT_U16 = 2,
+    ORC_FMT_S16 = 3,
+    ORC_FMT_F32 = 4,
+    ORC_FMT_F64 = 5
+};
+
+/* demodulation_mode, src/client.h:43 */
+enum { ORC_USB = 0, ORC_LSB = 1, ORC_AM = 2, ORC_FM = 3 };
+
+void orc_set_threads(int nthreads);
+int orc_get_threads(void);
+
+/* src/samplereader.cpp:29-70 */
+void orc_convert(const void *raw, int fmt, size_t num, float *out);
+/* src/utils/dsp.cpp:6-11 */
+void orc_build_hann_window(float *arr, int num);
+/* src/fft_impl.cpp:14-23 and the quantiser expression at :40-42 */
+float orc_vec_log2(float val, int power_offset);
+int8_t orc_quantize(float power, int power_offset);
+
+/* plain DFTs (stand-in for FFTW 3.3.10's fftwf_plan_dft_1d / _r2c_1d / _c2r_1d) */
+void orc_dft_c2c(const float *in, float *out, size_t n, int sign); /* any n, sign -1 fwd / +1 bwd, unnormalised */
+void orc_dft_r2c(const float *in, float *out, size_t n);           /* n even power of two; out n/2+1 complex */
+void orc_dft_c2r(const float *in, float *out, size_t n);           /* reads in[0..n/2], ignores Im in[0], Im in[n/2] */
+
+/* class FFTW, src/fft_impl.cpp:63-174 (+ the IQ wrap copy of src/fft.cpp:91-98) */
+typedef struct orc_fft orc_fft;
+orc_fft *orc_fft_create(size_t size, int is_real, int downsample_levels,
+                        int brightness_offset, int additional_size);
+void orc_fft_destroy(orc_fft *f);
+void orc_fft_load_real_input(orc_fft *f, const float *a1, const float *a2);
+void orc_fft_load_complex_input(orc_fft *f, const float *a1, const float *a2);
+void orc_fft_execute(orc_fft *f);
+float *orc_fft_output(orc_fft *f);       /* complex interleaved, N+A or N/2+1 bins */
+int8_t *orc_fft_quantized(orc_fft *f);   /* pyramid, levels back to back */
+float *orc_fft_power(orc_fft *f);
+size_t orc_fft_outbuf_len(orc_fft *f);
+size_t orc_fft_quantized_len(orc_fft *f);
+
+/* class AudioClient, src/signal.cpp:8-298 */
+typedef struct orc_client orc_client;
+orc_client *orc_client_create(int is_real, int audio_fft_size, int audio_rate,
+                              int fft_result_size);
+void orc_client_destroy(orc_client *c);
+void orc_client_set_audio_range(orc_client *c, int l, double m, int r);
+void orc_client_set_audio_demodulation(orc_client *c, int mode);
+/* on_window_message validation, src/signal.cpp:300-314; returns 1 if accepted */
+int orc_client_on_window_message(orc_client *c, int l, double m, int r);
+/* send_audio, src/signal.cpp:102-298.  buf = &X[(l+base)%R] (complex interleaved).
+ * audio_pre: n/2 floats before DC/AGC (demodulated, overlap-added);  pcm: n/2 int32
+ * after DC blocker + AGC + float->int16 (may be NULL to skip the post chain).
+ * returns 0 ok, 1 = NaN frame dropped (src/signal.cpp:267-271). */
+int orc_client_send_audio(orc_client *c, const float *buf, size_t frame_num,
+                          float *audio_pre, float *pwr, int32_t *pcm);
+/* state access for parity tests */
+const float *orc_client_real_prev(orc_client *c);
+const float *orc_client_baseband(orc_client *c);
+
+/* post chain pieces, individually (src/utils.h:139-169, src/utils/audioprocessing.cpp,
+ * src/utils/dsp.cpp:152-165) */
+typedef struct orc_dcblocker orc_dcblocker;
+orc_dcblocker *orc_dc_create(int delay);
+void orc_dc_destroy(orc_dcblocker *d);
+void orc_dc_remove(orc_dcblocker *d, float *arr, int length);
+typedef struct orc_agc orc_agc;
+orc_agc *orc_agc_create(float desired, float attack_ms, float release_ms,
+                        float lookahead_ms, float sr);
+void orc_agc_destroy(orc_agc *a);
+void orc_agc_process(orc_agc *a, float *arr, size_t len);
+void orc_agc_reset(orc_agc *a);
+void orc_float_to_int16(const float *arr, int32_t *out, float mult, size_t len);
+void orc_am_demod(const float *cplx, float *out, size_t len);
+void orc_polar_discriminator_fm(const float *cplx, float prev_re, float prev_im,
+                                float *out, size_t len);
+
+/* WaterfallClient level choice, src/waterfall.cpp:53-94.  returns level, updates l,r */
+int orc_waterfall_pick_level(int downsample_levels, int min_waterfall_fft,
+                             int *l, int *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
