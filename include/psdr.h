@@ -1,0 +1,182 @@
+/*
+ * psdr.h — C-ABI of the MI355X-native spectrum-distributor DSP core (libpsdr_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of PhantomSDR (citations are
+ * file:line under the reference tree):
+ *
+ *   Level 1  replaces the `class FFT` plug-in (src/fft.h:33-63; siblings FFTW
+ *            src/fft_impl.cpp:80-183, cuFFT src/fft_cuda.cu).  A ~60-line
+ *            `class hipFFT : public FFT` (phantomsdr_amd/host/hip_fft.h) forwards to it.
+ *   Level 2  replaces the per-frame fan-out + per-client DSP:
+ *            broadcast_server::signal_loop / waterfall_loop (src/websocket.cpp:156-185,
+ *            207-236), AudioClient::send_audio up to the NaN guard
+ *            (src/signal.cpp:102-275) and WaterfallClient::send_waterfall
+ *            (src/waterfall.cpp:44-51), batched over frames and clients on the GPU.
+ *
+ * Conventions: plain pointers and sizes only; every function returns PSDR_OK (0) or a
+ * negative psdr_status and never throws; psdr_last_error() gives the text for the
+ * calling thread.  A context is single-producer (load/execute/process/demod from one
+ * thread, like the reference's fft_thread, src/fft.cpp:14); client add/set/remove may
+ * come from any thread (internal mutex = the reference's signal_slice_mtx,
+ * src/signal.cpp:88).  The HIP library is the only implementation: there is no CPU
+ * fallback behind this ABI.
+ */
+#ifndef PSDR_H
+#define PSDR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct psdr_ctx psdr_ctx;
+
+typedef enum psdr_status {
+    PSDR_OK = 0,
+    PSDR_ERR_INVALID = -1,     /* bad argument / rejected range */
+    PSDR_ERR_NO_DEVICE = -2,   /* no HIP device (cuFFT ctor throws, src/fft_cuda.cu:8-13) */
+    PSDR_ERR_HIP = -3,         /* a HIP runtime call failed */
+    PSDR_ERR_STATE = -4,       /* call order violated (e.g. execute before load) */
+    PSDR_ERR_NOMEM = -5,
+    PSDR_ERR_UNSUPPORTED = -6  /* size outside what the kernels are built for */
+} psdr_status;
+
+/* input.driver.format, src/spectrumserver.cpp:349-364 / src/samplereader.cpp:72-81 */
+typedef enum psdr_format {
+    PSDR_FMT_U8 = 0,
+    PSDR_FMT_S8 = 1,
+    PSDR_FMT_U16 = 2,
+    PSDR_FMT_S16 = 3,
+    PSDR_FMT_F32 = 4,
+    PSDR_FMT_F64 = 5
+} psdr_format;
+
+/* demodulation_mode, src/client.h:43 */
+typedef enum psdr_mode { PSDR_USB = 0, PSDR_LSB = 1, PSDR_AM = 2, PSDR_FM = 3 } psdr_mode;
+
+typedef struct psdr_config {
+    uint32_t struct_size;        /* = sizeof(psdr_config) */
+    uint32_t fft_size;           /* N, power of two (FFT::FFT size, src/fft_impl.cpp:63) */
+    int32_t is_real;             /* plan_r2c vs plan_c2c (src/fft.cpp:25-29) */
+    int32_t downsample_levels;   /* src/spectrumserver.cpp:186-190 */
+    int32_t brightness_offset;   /* src/fft_impl.cpp:69 */
+    int32_t additional_size;     /* set_output_additional_size(), src/spectrumserver.cpp:214 */
+    int32_t audio_fft_size;      /* n = ceil(audio_sps*N/sps/4)*4, src/websocket.cpp:133 */
+    int32_t audio_rate;          /* audio_max_sps (AM carrier cutoff, AGC/DC) */
+    int32_t input_format;        /* psdr_format of the raw ring used by psdr_process_batch */
+    int32_t device;              /* HIP device ordinal */
+    int32_t max_batch;           /* frames per psdr_process_batch call (>=1) */
+    int32_t max_clients;         /* audio client slots */
+    int32_t max_waterfall_clients;
+    int32_t skip_num;            /* waterfall sent when frame_num % skip_num == 0 (src/fft.cpp:33,102) */
+} psdr_config;
+
+const char *psdr_last_error(void);
+const char *psdr_version(void);
+
+/* ---- lifetime -------------------------------------------------------------------- */
+int psdr_create(const psdr_config *cfg, psdr_ctx **out);
+void psdr_destroy(psdr_ctx *ctx);
+
+/* ---- Level 1: the FFT plug-in (src/fft.h:33-63) ----------------------------------- */
+/* FFT::malloc / FFT::free (src/fft.h:36-37; cuFFT twin src/fft_cuda.cu:22-28): pinned,
+ * host-writable buffer of nfloats floats. */
+int psdr_host_alloc(psdr_ctx *ctx, size_t nfloats, float **out);
+int psdr_host_free(psdr_ctx *ctx, float *buf);
+/* FFT::load_real_input / load_complex_input (src/fft.h:45-46, src/fft_impl.cpp:131-143):
+ * a1 = older half-frame, a2 = newer, each N/2 samples (IQ: N floats each). */
+int psdr_load_real_input(psdr_ctx *ctx, const float *a1, const float *a2);
+int psdr_load_complex_input(psdr_ctx *ctx, const float *a1, const float *a2);
+/* FFT::execute (src/fft.h:47, src/fft_impl.cpp:144-174): window, FFT, /N, power, int8
+ * pyramid for the loaded frame.  Synchronous like the reference (src/fft_cuda.cu:175). */
+int psdr_execute(psdr_ctx *ctx);
+/* FFT::get_output_buffer (src/fft.h:43): host pointer, natural k order, N + additional
+ * complex bins (IQ, the wrap copy of src/fft.cpp:91-98 already applied) or N/2+1 (real);
+ * valid until the next execute/process call. */
+int psdr_get_output_buffer(psdr_ctx *ctx, float **out);
+/* FFT::get_quantized_buffer (src/fft.h:44): host pointer to the int8 pyramid, levels
+ * back to back (level i at offset sum_{t<i} R>>t, src/websocket.cpp:233). */
+int psdr_get_quantized_buffer(psdr_ctx *ctx, int8_t **out);
+
+/* ---- device memory helpers (raw sample ring lives in HBM) ------------------------- */
+int psdr_dev_alloc(psdr_ctx *ctx, size_t bytes, void **out);
+int psdr_dev_free(psdr_ctx *ctx, void *p);
+int psdr_memcpy_h2d(psdr_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int psdr_memcpy_d2h(psdr_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int psdr_synchronize(psdr_ctx *ctx);
+/* bytes of one raw half-frame in cfg.input_format (N/2 samples, x2 components for IQ) */
+size_t psdr_half_frame_bytes(const psdr_ctx *ctx);
+
+/* ---- Level 2: batched frames ------------------------------------------------------ */
+/* Frame loop body, src/fft.cpp:47-105, for nframes consecutive frames at once.
+ * d_halves: device pointer to nframes+1 consecutive raw half-frames (cfg.input_format);
+ * frame f = [half f ; half f+1] (50 % overlap, src/fft.cpp:49-53).  Device-side sample
+ * conversion = src/samplereader.cpp:29-40.  Asynchronous on the context's stream. */
+int psdr_process_batch(psdr_ctx *ctx, const void *d_halves, int nframes);
+
+/* audio clients: AudioClient (src/signal.h:53-123) */
+int psdr_client_add(psdr_ctx *ctx, int *id_out);
+int psdr_client_remove(psdr_ctx *ctx, int id);
+/* AudioClient::set_audio_range (src/signal.cpp:81-94): unchecked, like the reference */
+int psdr_client_set_audio_range(psdr_ctx *ctx, int id, int l, double audio_mid, int r);
+/* AudioClient::on_window_message (src/signal.cpp:300-314): validated; PSDR_ERR_INVALID
+ * (and no change) when the reference would silently return */
+int psdr_client_on_window_message(psdr_ctx *ctx, int id, int l, double audio_mid, int r);
+/* AudioClient::set_audio_demodulation / on_demodulation_message (src/signal.cpp:95-97,316-328) */
+int psdr_client_set_audio_demodulation(psdr_ctx *ctx, int id, int mode);
+/* signal_loop + send_audio (src/websocket.cpp:156-185, src/signal.cpp:102-275) for every
+ * active client over the frames of the last psdr_process_batch.  first_frame_num is the
+ * server's frame counter of the first frame (flip parity, src/signal.cpp:160-168,223). */
+int psdr_demod_batch(psdr_ctx *ctx, uint64_t first_frame_num);
+/* results of the last demod batch for one client: audio [nframes][n/2] floats (the
+ * demodulated, overlap-added samples handed to the DC blocker at src/signal.cpp:278),
+ * pwr [nframes] (average_power, src/signal.cpp:117-119), nan_flags [nframes] (1 = the
+ * reference would have dropped the frame, src/signal.cpp:266-271).  Any may be NULL. */
+int psdr_read_audio(psdr_ctx *ctx, int id, float *audio, float *pwr, int32_t *nan_flags);
+/* device-resident results (no copy): audio of client slot `id` */
+int psdr_audio_device_ptr(psdr_ctx *ctx, int id, const float **d_audio, const float **d_pwr);
+
+/* waterfall clients: WaterfallClient (src/waterfall.h) */
+int psdr_waterfall_add(psdr_ctx *ctx, int *id_out);
+int psdr_waterfall_remove(psdr_ctx *ctx, int id);
+/* WaterfallClient::set_waterfall_range (src/waterfall.cpp:25-42); r is clamped to
+ * R>>level (the reference forgets the upper bound, src/waterfall.cpp:55-58) */
+int psdr_waterfall_set_range(psdr_ctx *ctx, int id, int level, int l, int r);
+/* WaterfallClient::on_window_message (src/waterfall.cpp:53-94): picks the level */
+int psdr_waterfall_on_window_message(psdr_ctx *ctx, int id, int l, int r, int *level_out,
+                                     int *l_out, int *r_out);
+/* waterfall_loop + send_waterfall (src/websocket.cpp:207-236, src/waterfall.cpp:44-51):
+ * gathers q_level[l..r) of every waterfall client for every frame f of the last batch
+ * with (first_frame_num+f) % skip_num == 0. */
+int psdr_waterfall_batch(psdr_ctx *ctx, uint64_t first_frame_num);
+/* bytes [nsent][r-l] for one client; *nsent_out = number of sent frames in the batch */
+int psdr_read_waterfall(psdr_ctx *ctx, int id, int8_t *out, size_t out_cap, int *nsent_out);
+
+/* last batch, raw device-side results (for consumers that stay on the GPU, and tests) */
+/* spectrum of frame f: IQ: N complex bins in CLIENT order c (bin k = (c+N/2+1) mod N);
+ * real: N/2+1 bins in k order.  Normalised by 1/N exactly like src/fft_impl.cpp:34-35. */
+int psdr_spectrum_device_ptr(psdr_ctx *ctx, int frame, const float **d_spec, size_t *nbins);
+int psdr_quantized_device_ptr(psdr_ctx *ctx, int frame, const int8_t **d_q, size_t *nbytes);
+/* copies of the same to host; spectrum is delivered in the reference's k order */
+int psdr_read_spectrum(psdr_ctx *ctx, int frame, float *out_k_order);
+int psdr_read_quantized(psdr_ctx *ctx, int frame, int8_t *out);
+
+/* ---- instrumentation --------------------------------------------------------------- */
+/* when enabled, every kernel launch is bracketed by hipEvents on the context's stream */
+int psdr_set_profiling(psdr_ctx *ctx, int enable);
+/* accumulated since the last reset: name[i] (static strings), total ms, launch count */
+int psdr_get_kernel_stats(psdr_ctx *ctx, int max_entries, const char **names, double *total_ms,
+                          int64_t *launches, int *n_out);
+int psdr_reset_kernel_stats(psdr_ctx *ctx);
+/* hipEvent-timed wall time of a region on the context's stream */
+int psdr_timer_start(psdr_ctx *ctx);
+int psdr_timer_stop_ms(psdr_ctx *ctx, double *ms_out);
+/* the HIP stream (hipStream_t) the context launches on, for interop */
+void *psdr_stream(psdr_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSDR_H */

@@ -64,6 +64,7 @@ def lib():
         L.orc_fft_outbuf_len.restype = sz
         L.orc_fft_quantized_len.argtypes = [vp]
         L.orc_fft_quantized_len.restype = sz
+        L.orc_pyramid_from_spectrum.argtypes = [vp, sz, i32, i32, i32, vp, vp]
         L.orc_client_create.argtypes = [i32, i32, i32, i32]
         L.orc_client_create.restype = vp
         L.orc_client_destroy.argtypes = [vp]
@@ -179,6 +180,17 @@ def dft_c2r(a, n):
     out = np.empty(n, np.float32)
     lib().orc_dft_c2r(_p(a), _p(out), n)
     return out
+
+
+def pyramid_from_spectrum(spec_k_order, size, is_real, levels, brightness_offset=0):
+    """int8 pyramid the reference computes from a given (normalised, k-order) spectrum."""
+    import math
+    spec = np.ascontiguousarray(spec_k_order, np.complex64)
+    R = size // 2 if is_real else size
+    q = np.zeros(sum(R >> i for i in range(levels)) + R, np.int8)
+    size_log2 = int(round(math.log2(size))) + brightness_offset
+    lib().orc_pyramid_from_spectrum(_p(spec), size, int(is_real), levels, size_log2, _p(q), None)
+    return q[: sum(R >> i for i in range(levels))]
 
 
 class FFT:

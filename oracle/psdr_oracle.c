@@ -559,6 +559,38 @@ void orc_fft_execute(orc_fft *f) {
         memcpy(&f->outbuf[2 * N], &f->outbuf[0], sizeof(float) * 2 * (size_t)f->additional_size);
 }
 
+/* The quantiser + pyramid of FFTW::execute (src/fft_impl.cpp:149-172) applied to an
+ * ALREADY NORMALISED spectrum in the reference's k order (what get_output_buffer()
+ * holds after execute()).  Lets a test check another implementation's int8 pyramid
+ * bit-exactly against its own spectrum.  power (may be NULL) receives the f32 pyramid. */
+void orc_pyramid_from_spectrum(const float *spec, size_t size, int is_real, int downsample_levels,
+                               int size_log2, int8_t *q, float *power) {
+    size_t L = is_real ? size / 2 : size;
+    size_t base_idx = is_real ? 0 : size / 2 + 1;
+    size_t total = 0;
+    for (int i = 0; i < downsample_levels; i++) total += L >> i;
+    float *pw = power ? power : (float *)xaligned(sizeof(float) * (total + L));
+    long long i;
+#pragma omp parallel for schedule(static) if (L >= 16384)
+    for (i = 0; i < (long long)L; i++) {
+        size_t k = is_real ? (size_t)i : ((size_t)i + base_idx) % size;
+        float re = spec[2 * k], im = spec[2 * k + 1];
+        float p = fmaf(re, re, im * im);
+        pw[i] = p;
+        q[i] = orc_quantize(p, size_log2);
+    }
+    size_t out_len = L;
+    float *pp = pw;
+    int8_t *qq = q;
+    for (int lv = 0; lv < downsample_levels - 1; lv++) {
+        half_and_quantize(pp, pp + out_len, qq + out_len, out_len / 2, size_log2 - lv - 1);
+        pp += out_len;
+        qq += out_len;
+        out_len /= 2;
+    }
+    if (!power) free(pw);
+}
+
 /* ------------------------------------------------------------------------------------
  * Post-demodulation chain pieces.
  * ---------------------------------------------------------------------------------- */

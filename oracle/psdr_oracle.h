@@ -73,6 +73,10 @@ float *orc_fft_power(orc_fft *f);
 size_t orc_fft_outbuf_len(orc_fft *f);
 size_t orc_fft_quantized_len(orc_fft *f);
 
+/* quantiser + pyramid (src/fft_impl.cpp:149-172) on an already normalised k-order spectrum */
+void orc_pyramid_from_spectrum(const float *spec, size_t size, int is_real, int downsample_levels,
+                               int size_log2, int8_t *q, float *power);
+
 /* class AudioClient, src/signal.cpp:8-298 */
 typedef struct orc_client orc_client;
 orc_client *orc_client_create(int is_real, int audio_fft_size, int audio_rate,

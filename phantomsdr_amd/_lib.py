@@ -1,0 +1,102 @@
+"""ctypes binding of the C-ABI in include/psdr.h (libpsdr_hip.so, hand-written HIP for
+gfx950).  There is no CPU fallback: if the library is missing the import fails loudly."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libpsdr_hip.so")
+
+
+class PsdrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"psdr error {code}: {msg}")
+        self.code = code
+
+
+class psdr_config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("fft_size", C.c_uint32), ("is_real", C.c_int32),
+        ("downsample_levels", C.c_int32), ("brightness_offset", C.c_int32),
+        ("additional_size", C.c_int32), ("audio_fft_size", C.c_int32),
+        ("audio_rate", C.c_int32), ("input_format", C.c_int32), ("device", C.c_int32),
+        ("max_batch", C.c_int32), ("max_clients", C.c_int32),
+        ("max_waterfall_clients", C.c_int32), ("skip_num", C.c_int32),
+    ]
+
+
+# every symbol include/psdr.h declares: (name, restype, argtypes)
+_vp, _i, _sz, _u64 = C.c_void_p, C.c_int, C.c_size_t, C.c_uint64
+_pp = C.POINTER(C.c_void_p)
+SYMBOLS = [
+    ("psdr_last_error", C.c_char_p, []),
+    ("psdr_version", C.c_char_p, []),
+    ("psdr_create", _i, [C.POINTER(psdr_config), _pp]),
+    ("psdr_destroy", None, [_vp]),
+    ("psdr_host_alloc", _i, [_vp, _sz, _pp]),
+    ("psdr_host_free", _i, [_vp, _vp]),
+    ("psdr_load_real_input", _i, [_vp, _vp, _vp]),
+    ("psdr_load_complex_input", _i, [_vp, _vp, _vp]),
+    ("psdr_execute", _i, [_vp]),
+    ("psdr_get_output_buffer", _i, [_vp, _pp]),
+    ("psdr_get_quantized_buffer", _i, [_vp, _pp]),
+    ("psdr_dev_alloc", _i, [_vp, _sz, _pp]),
+    ("psdr_dev_free", _i, [_vp, _vp]),
+    ("psdr_memcpy_h2d", _i, [_vp, _vp, _vp, _sz]),
+    ("psdr_memcpy_d2h", _i, [_vp, _vp, _vp, _sz]),
+    ("psdr_synchronize", _i, [_vp]),
+    ("psdr_half_frame_bytes", _sz, [_vp]),
+    ("psdr_process_batch", _i, [_vp, _vp, _i]),
+    ("psdr_client_add", _i, [_vp, C.POINTER(_i)]),
+    ("psdr_client_remove", _i, [_vp, _i]),
+    ("psdr_client_set_audio_range", _i, [_vp, _i, _i, C.c_double, _i]),
+    ("psdr_client_on_window_message", _i, [_vp, _i, _i, C.c_double, _i]),
+    ("psdr_client_set_audio_demodulation", _i, [_vp, _i, _i]),
+    ("psdr_demod_batch", _i, [_vp, _u64]),
+    ("psdr_read_audio", _i, [_vp, _i, _vp, _vp, _vp]),
+    ("psdr_audio_device_ptr", _i, [_vp, _i, _pp, _pp]),
+    ("psdr_waterfall_add", _i, [_vp, C.POINTER(_i)]),
+    ("psdr_waterfall_remove", _i, [_vp, _i]),
+    ("psdr_waterfall_set_range", _i, [_vp, _i, _i, _i, _i]),
+    ("psdr_waterfall_on_window_message", _i,
+     [_vp, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    ("psdr_waterfall_batch", _i, [_vp, _u64]),
+    ("psdr_read_waterfall", _i, [_vp, _i, _vp, _sz, C.POINTER(_i)]),
+    ("psdr_spectrum_device_ptr", _i, [_vp, _i, _pp, C.POINTER(_sz)]),
+    ("psdr_quantized_device_ptr", _i, [_vp, _i, _pp, C.POINTER(_sz)]),
+    ("psdr_read_spectrum", _i, [_vp, _i, _vp]),
+    ("psdr_read_quantized", _i, [_vp, _i, _vp]),
+    ("psdr_set_profiling", _i, [_vp, _i]),
+    ("psdr_get_kernel_stats", _i,
+     [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(_i)]),
+    ("psdr_reset_kernel_stats", _i, [_vp]),
+    ("psdr_timer_start", _i, [_vp]),
+    ("psdr_timer_stop_ms", _i, [_vp, C.POINTER(C.c_double)]),
+    ("psdr_stream", _vp, [_vp]),
+]
+
+_lib = None
+
+
+def load():
+    """dlopen libpsdr_hip.so and bind every declared symbol (no GPU needed for this)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise ImportError(
+            f"{_SO} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "phantomsdr_amd has no CPU fallback.")
+    L = C.CDLL(_SO)
+    for name, res, args in SYMBOLS:
+        fn = getattr(L, name)  # AttributeError if the ABI and the header drift apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise PsdrError(rc, load().psdr_last_error().decode())
+    return rc

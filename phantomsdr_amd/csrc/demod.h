@@ -1,0 +1,255 @@
+// demod.h — batched per-client downconversion: frequency-domain slice -> small inverse
+// DFT -> USB/LSB/AM/FM, with the 50 % overlap-add carried across frames.
+//
+// Replaces AudioClient::send_audio (src/signal.cpp:102-275) for all clients and all
+// frames of a batch at once:
+//   k_demod_idft  one work-group per (client, frame): average_power (:117-119), the
+//                 mode-specific bin copy (:125-153, :175-198), the n-point backward
+//                 transform (fftwf c2r / c2c, :138,154,214), LSB reversal (:155) and the
+//                 odd-frame sign flip (:160-168, :223-234).
+//   k_demod_ola   overlap-add with the previous frame's second half (:171-172,
+//                 :235-237), AM envelope (dsp_am_demod, src/utils/dsp.cpp:116-126),
+//                 FM polar discriminator (src/utils/dsp.cpp:27-35), NaN guard (:266-271)
+//                 and the state carried to the next batch (:200-203, :273-275).
+// The AM "carrier" transform (:205-222,230-241) feeds only the liquid-dsp PLL branch
+// (:242-252), which is not part of the parity target; without liquid it has no
+// observable effect and is not computed.
+//
+// n = audio_fft_size is any multiple of 4 (248, 360, 720, 10068 ...): the transform is
+// a generic-radix Stockham, each radix-R butterfly a direct R-point DFT whose
+// inter-stage twiddle is folded into a single table lookup:
+//   y[j + s*p] = sum_q x[i + q*n/R] * W_n^{ q*(k + s*p)*n/(p*R) },  k = i mod p,
+//   j = (i-k)*R + k,  W_n = exp(+2*pi*i/n)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "butterfly.h"
+
+namespace psdr {
+
+#define PSDR_MAX_STAGES 12
+
+struct ClientParams {
+    int l, r;       // [l, r) in client bin coordinates
+    int m_floor;    // floor(audio_mid)
+    int mode;       // psdr_mode
+    int slot;       // persistent slot (state + output rows)
+    int state_cur;  // which half of the double-buffered state is current
+};
+
+struct DemodArgs {
+    const cf *spec;  // [nframes][spec_stride]; IQ: client order, real: k order
+    size_t spec_stride;
+    int is_real;
+    int n;  // audio_fft_size
+    int nframes;
+    int max_batch;
+    unsigned long long first_frame_num;
+    const ClientParams *clients;  // compact list of active clients
+    const cf *Wn;                 // exp(+2 pi i j / n), j < n
+    int nstages;
+    int radix[PSDR_MAX_STAGES];
+    cf *ypost;  // [slots][max_batch][n]: transform output after reversal/flip
+    float *pwr;  // [slots][max_batch]
+    // workspace for transforms too large for LDS: [gridDim.x*gridDim.y][2][n]
+    cf *gscratch;
+    int lds_mode;  // 0: bufA, bufB, Wn in LDS; 1: bufA, bufB in LDS; 2: all global
+    // ola
+    float *audio;  // [slots][max_batch][n/2]
+    int *nan_flags;  // [slots][max_batch]
+    float *real_prev;  // [2][slots][n/2]
+    cf *bb_tail;       // [2][slots][n/2]
+    cf *bb_last;       // [2][slots]
+    int slots;
+};
+
+__device__ __forceinline__ bool flip_frame(unsigned long long frame_num, int m_idx, int is_real) {
+    // src/signal.cpp:160-162 with C++ remainder semantics for negative m_idx
+    return (frame_num % 2 == 1) && ((m_idx % 2 == 0 && !is_real) || (m_idx % 2 == 1 && is_real));
+}
+
+__global__ __launch_bounds__(256) void k_demod_idft(DemodArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = a.n, tid = threadIdx.x, NT = blockDim.x;
+    const ClientParams cp = a.clients[blockIdx.x];
+    const int f = blockIdx.y;
+    const unsigned long long frame_num = a.first_frame_num + (unsigned long long)f;
+
+    cf *bufA, *bufB;
+    const cf *Wn;
+    if (a.lds_mode == 0) {
+        bufA = reinterpret_cast<cf *>(smem);
+        bufB = bufA + n;
+        cf *w = bufB + n;
+        for (int i = tid; i < n; i += NT) w[i] = a.Wn[i];
+        Wn = w;
+    } else if (a.lds_mode == 1) {
+        bufA = reinterpret_cast<cf *>(smem);
+        bufB = bufA + n;
+        Wn = a.Wn;
+    } else {
+        bufA = a.gscratch + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2) * n;
+        bufB = bufA + n;
+        Wn = a.Wn;
+    }
+    __shared__ float red[256];
+
+    const int len = cp.r - cp.l;
+    const int m = cp.m_floor - cp.l;  // audio_m
+    const cf *S = a.spec + (size_t)f * a.spec_stride + cp.l;
+
+    for (int i = tid; i < n; i += NT) bufA[i] = make_float2(0.f, 0.f);
+    __syncthreads();
+
+    float pw = 0.f;
+    for (int t = tid; t < len; t += NT) {
+        const cf v = S[t];
+        pw += fmaf(v.x, v.x, v.y * v.y);
+        if (cp.mode == 0) {  // USB :125-137
+            if (t >= m && t < m + n) bufA[t - m] = v;
+        } else if (cp.mode == 1) {  // LSB :139-153
+            if (t >= m - n + 1 && t < m + 1) bufA[m - t] = v;
+        } else {  // AM/FM :175-198
+            if (t >= m && t < m + n / 2) bufA[t - m] = v;
+            if (t >= m - n / 2 + 1 && t < m) bufA[n - m + t] = v;
+        }
+    }
+    red[tid] = pw;
+    __syncthreads();
+    for (int s = NT / 2; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) a.pwr[(size_t)cp.slot * a.max_batch + f] = red[0];
+
+    if (cp.mode < 2) {
+        // c2r semantics: bins 0..n/2 only, Im of bin 0 and bin n/2 ignored; extend to the
+        // Hermitian-symmetric full spectrum so the complex transform returns the real signal
+        for (int k = tid + 1; k < n / 2; k += NT) {
+            const cf v = bufA[k];
+            bufA[n - k] = make_float2(v.x, -v.y);
+        }
+        if (tid == 0) {
+            bufA[0].y = 0.f;
+            bufA[n / 2].y = 0.f;
+        }
+        __syncthreads();
+    }
+
+    // generic-radix Stockham, backward
+    cf *src = bufA, *dst = bufB;
+    int p = 1;
+    for (int st = 0; st < a.nstages; st++) {
+        const int R = a.radix[st];
+        const int tlen = n / R;
+        const int step = n / (p * R);
+        for (int o = tid; o < n; o += NT) {
+            const int s = o / tlen, i = o - s * tlen;
+            const int k = i % p;
+            const int j = (i - k) * R + k;
+            const int e1 = (int)(((long long)(k + s * p) * step) % n);
+            float ar = 0.f, ai = 0.f;
+            int e = 0;
+            for (int q = 0; q < R; q++) {
+                const cf x = src[i + q * tlen];
+                const cf w = Wn[e];
+                ar = fmaf(x.x, w.x, fmaf(-x.y, w.y, ar));
+                ai = fmaf(x.x, w.y, fmaf(x.y, w.x, ai));
+                e += e1;
+                if (e >= n) e -= n;
+            }
+            dst[j + s * p] = make_float2(ar, ai);
+        }
+        p *= R;
+        cf *tmp = src;
+        src = dst;
+        dst = tmp;
+        __syncthreads();
+    }
+
+    const bool flip = flip_frame(frame_num, cp.m_floor, a.is_real);
+    const float sg = flip ? -1.f : 1.f;
+    cf *yp = a.ypost + ((size_t)cp.slot * a.max_batch + f) * n;
+    for (int jx = tid; jx < n; jx += NT) {
+        cf v;
+        if (cp.mode == 0)
+            v = make_float2(src[jx].x * sg, 0.f);
+        else if (cp.mode == 1)
+            v = make_float2(src[n - 1 - jx].x * sg, 0.f);  // std::reverse :155
+        else
+            v = make_float2(src[jx].x * sg, src[jx].y * sg);
+        yp[jx] = v;
+    }
+}
+
+__global__ __launch_bounds__(128) void k_demod_ola(DemodArgs a) {
+    const int n = a.n, h = n / 2, tid = threadIdx.x, NT = blockDim.x;
+    const ClientParams cp = a.clients[blockIdx.x];
+    const int f = blockIdx.y;
+    const int F = a.nframes;
+    const size_t srow = (size_t)cp.slot;
+    const cf *yp = a.ypost + (srow * a.max_batch) * n;  // this client's frames
+    const cf *y = yp + (size_t)f * n;
+    const int cur = cp.state_cur, nxt = cur ^ 1;
+    const float *rp_old = a.real_prev + ((size_t)cur * a.slots + srow) * h;
+    float *rp_new = a.real_prev + ((size_t)nxt * a.slots + srow) * h;
+    const cf *bt_old = a.bb_tail + ((size_t)cur * a.slots + srow) * h;
+    cf *bt_new = a.bb_tail + ((size_t)nxt * a.slots + srow) * h;
+    float *out = a.audio + (srow * a.max_batch + f) * h;
+    __shared__ int s_nan;
+    if (tid == 0) s_nan = 0;
+    __syncthreads();
+    const bool last = (f == F - 1);
+
+    if (cp.mode < 2) {
+        for (int j = tid; j < h; j += NT) {
+            const float prev = (f == 0) ? rp_old[j] : yp[(size_t)(f - 1) * n + h + j].x;
+            const float v = y[j].x + prev;  // dsp_add_float :171
+            out[j] = v;
+            if (isnan(v)) s_nan = 1;
+            if (last) {
+                rp_new[j] = y[h + j].x;  // :273-275
+                bt_new[j] = bt_old[j];
+            }
+        }
+        if (last && tid == 0) a.bb_last[(size_t)nxt * a.slots + srow] = a.bb_last[(size_t)cur * a.slots + srow];
+    } else {
+        for (int j = tid; j < h; j += NT) {
+            const cf pv = (f == 0) ? bt_old[j] : yp[(size_t)(f - 1) * n + h + j];
+            const cf b = make_float2(y[j].x + pv.x, y[j].y + pv.y);  // dsp_add_complex :235
+            float v;
+            if (cp.mode == 2) {
+                v = sqrtf(fmaf(b.x, b.x, b.y * b.y));  // dsp_am_demod
+            } else {
+                cf pr;
+                if (j > 0) {
+                    const cf pv1 = (f == 0) ? bt_old[j - 1] : yp[(size_t)(f - 1) * n + h + j - 1];
+                    pr = make_float2(y[j - 1].x + pv1.x, y[j - 1].y + pv1.y);
+                } else if (f == 0) {
+                    pr = a.bb_last[(size_t)cur * a.slots + srow];
+                } else {
+                    // B'_{f-1}[h-1] = y_{f-1}[h-1] + (tail of frame f-2, or the carried tail)
+                    const cf y1 = yp[(size_t)(f - 1) * n + h - 1];
+                    const cf t1 = (f == 1) ? bt_old[h - 1] : yp[(size_t)(f - 2) * n + n - 1];
+                    pr = make_float2(y1.x + t1.x, y1.y + t1.y);
+                }
+                // arg(b * conj(pr)), src/utils/dsp.cpp:32
+                const float re = fmaf(b.x, pr.x, b.y * pr.y);
+                const float im = fmaf(b.x, -pr.y, b.y * pr.x);
+                v = atan2f(im, re);
+            }
+            out[j] = v;
+            if (isnan(v)) s_nan = 1;
+            if (last) {
+                bt_new[j] = y[h + j];  // :200-203 (second half kept for the next frame)
+                rp_new[j] = rp_old[j];
+                if (j == h - 1) a.bb_last[(size_t)nxt * a.slots + srow] = b;  // `prev` of :200
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) a.nan_flags[srow * a.max_batch + f] = s_nan;
+}
+
+}  // namespace psdr

@@ -1,0 +1,170 @@
+// epilogue.h — kernels after the FFT passes: real-input untangle + power/quantise,
+// upper levels of the waterfall pyramid, waterfall slice gather.
+//
+//   k_untangle_real  : R2C as an N/2-point C2C + Hermitian untangle, fused with the
+//                      reference's power_and_quantize (src/fft_impl.cpp:24-44, called
+//                      with base_idx = 0 for real input, :149-160) and pyramid levels 1..7
+//   k_pyramid_tail   : half_and_quantize (src/fft_impl.cpp:45-61,162-172) from the
+//                      partial level left in scratch by the fused pass-2 / untangle kernel
+//   k_waterfall_gather: waterfall_loop + send_waterfall byte ranges
+//                      (src/websocket.cpp:207-236, src/waterfall.cpp:44-51)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "butterfly.h"
+#include "quantize.h"
+
+namespace psdr {
+
+// Wave-level continuation of the pyramid: lane holds `s` = P_lvl[idx]; adjacent lanes
+// hold adjacent indices.  Emits levels lvl+1 .. lvl+6 (pairs across lanes via xor
+// shuffles: the tree (a+b)+(c+d) is exactly the reference's repeated pair sum).
+// Returns the level lvl+6 sum (valid in every lane; lane 0 of the wave owns it).
+__device__ __forceinline__ float wave_pyramid(float s, size_t idx, int lvl, int nlevels,
+                                              int size_log2, int8_t *Qf, size_t R, bool valid) {
+    const int lane = threadIdx.x & 63;
+    size_t qoff = 0;
+    for (int i = 0; i <= lvl; i++) qoff += R >> i;  // byte offset of level lvl+1
+#pragma unroll
+    for (int d = 0; d < 6; d++) {
+        const float o = __shfl_xor(s, 1 << d, 64);
+        s = __fadd_rn(s, o);
+        const int lv = lvl + 1 + d;
+        idx >>= 1;
+        if (valid && lv < nlevels && (lane & ((2 << d) - 1)) == 0 && idx < (R >> lv))
+            Qf[qoff + idx] = (int8_t)quantize_u8(s, size_log2 - lv);
+        qoff += R >> lv;
+    }
+    return s;
+}
+
+struct TailArgs {
+    const float *Pin;  // [nframes][in_stride] level lvl_in powers, len_in valid
+    size_t in_stride;
+    size_t len_in;
+    int lvl_in;
+    int nlevels;
+    int size_log2;
+    int8_t *Q;
+    size_t q_stride;
+    size_t R;
+    float *Pout;  // [nframes][out_stride] level lvl_in+7
+    size_t out_stride;
+};
+
+// each thread sums one pair (level lvl_in+1), then the wave continues 6 more levels
+__global__ __launch_bounds__(256) void k_pyramid_tail(TailArgs a) {
+    const unsigned f = blockIdx.y;
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t npairs = a.len_in >> 1;
+    const bool valid = j < npairs;
+    const float *Pf = a.Pin + (size_t)f * a.in_stride;
+    int8_t *Qf = a.Q + (size_t)f * a.q_stride;
+    float s = 0.f;
+    if (valid) {
+        const float2 p = reinterpret_cast<const float2 *>(Pf)[j];
+        s = __fadd_rn(p.x, p.y);
+        const int lv = a.lvl_in + 1;
+        if (lv < a.nlevels) {
+            size_t qoff = 0;
+            for (int i = 0; i < lv; i++) qoff += a.R >> i;
+            Qf[qoff + j] = (int8_t)quantize_u8(s, a.size_log2 - lv);
+        }
+    }
+    const float top = wave_pyramid(s, j, a.lvl_in + 1, a.nlevels, a.size_log2, Qf, a.R, valid);
+    if (valid && (threadIdx.x & 63) == 0 && a.Pout) a.Pout[(size_t)f * a.out_stride + (j >> 6)] = top;
+}
+
+struct UntangleArgs {
+    const cf *Z;  // [nframes][M] unnormalised N/2-point transform of the packed input
+    cf *X;        // [nframes][spec_stride] (spec_stride >= M+1): k order
+    size_t spec_stride;
+    size_t M;      // N/2
+    const cf *TA;  // W_N^{h*B}
+    const cf *TB;  // W_N^{l}
+    int log2B;
+    float inv_n;
+    int size_log2;
+    int nlevels;
+    int8_t *Q;
+    size_t q_stride;
+    float *Pscr;  // level 7 sums
+    size_t p_stride;
+};
+
+// X[k] = E + W_N^k O, E = (Z[k]+conj Z[M-k])/2, O = -i (Z[k]-conj Z[M-k])/2
+__device__ __forceinline__ cf untangle_one(cf a, cf b, cf w) {
+    const cf E = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+    const cf D = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));
+    const cf O = make_float2(D.y, -D.x);
+    const cf wo = cmul(w, O);
+    return make_float2(E.x + wo.x, E.y + wo.y);
+}
+
+// thread j handles bins k = 2j, 2j+1 (one level-1 pair)
+__global__ __launch_bounds__(256) void k_untangle_real(UntangleArgs a) {
+    const unsigned f = blockIdx.y;
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t M = a.M;
+    const bool valid = j < M / 2;
+    const cf *Zf = a.Z + (size_t)f * M;
+    cf *Xf = a.X + (size_t)f * a.spec_stride;
+    int8_t *Qf = a.Q + (size_t)f * a.q_stride;
+    float s = 0.f;
+    if (valid) {
+        const size_t k0 = 2 * j;
+        const float4 zz = reinterpret_cast<const float4 *>(Zf)[j];  // Z[k0], Z[k0+1]
+        const cf z0 = make_float2(zz.x, zz.y), z1 = make_float2(zz.z, zz.w);
+        const cf m0 = Zf[(M - k0) & (M - 1)];  // Z[(M-k0) mod M]
+        const cf m1 = Zf[M - k0 - 1];
+        const unsigned Bm = (1u << a.log2B) - 1u;
+        const cf w0 = cmul(a.TA[k0 >> a.log2B], a.TB[k0 & Bm]);
+        const cf w1 = cmul(a.TA[(k0 + 1) >> a.log2B], a.TB[(k0 + 1) & Bm]);
+        cf x0 = untangle_one(z0, m0, w0);
+        cf x1 = untangle_one(z1, m1, w1);
+        if (j == 0) {
+            // bin N/2 is never normalised by the reference (src/fft_impl.cpp:156-160
+            // visits k < N/2 only); X[N/2] = Re Z[0] - Im Z[0]
+            Xf[M] = make_float2(z0.x - z0.y, 0.f);
+        }
+        x0.x *= a.inv_n;
+        x0.y *= a.inv_n;
+        x1.x *= a.inv_n;
+        x1.y *= a.inv_n;
+        reinterpret_cast<float4 *>(Xf)[j] = make_float4(x0.x, x0.y, x1.x, x1.y);
+        const float p0 = fmaf(x0.x, x0.x, x0.y * x0.y);
+        const float p1 = fmaf(x1.x, x1.x, x1.y * x1.y);
+        if (0 < a.nlevels)
+            reinterpret_cast<unsigned short *>(Qf)[j] =
+                (unsigned short)(quantize_u8(p0, a.size_log2) | (quantize_u8(p1, a.size_log2) << 8));
+        s = __fadd_rn(p0, p1);
+        if (1 < a.nlevels) Qf[M + j] = (int8_t)quantize_u8(s, a.size_log2 - 1);
+    }
+    const float top = wave_pyramid(s, j, 1, a.nlevels, a.size_log2, Qf, M, valid);
+    if (valid && (threadIdx.x & 63) == 0) a.Pscr[(size_t)f * a.p_stride + (j >> 6)] = top;
+}
+
+struct WfClient {
+    int level, l, r;
+    int active;
+    size_t qoff;     // byte offset of `level` inside a frame's int8 buffer
+    size_t out_off;  // byte offset of this client's output block
+};
+
+// one work-group row per (client, sent frame): copies q_level[l..r)
+__global__ __launch_bounds__(256) void k_waterfall_gather(const int8_t *Q, size_t q_stride,
+                                                          const WfClient *cl, const int *sent_frames,
+                                                          int nsent, int8_t *out) {
+    const WfClient c = cl[blockIdx.x];
+    if (!c.active) return;
+    const int si = blockIdx.y;
+    if (si >= nsent) return;
+    const int f = sent_frames[si];
+    const int len = c.r - c.l;
+    const int8_t *src = Q + (size_t)f * q_stride + c.qoff + c.l;
+    int8_t *dst = out + c.out_off + (size_t)si * len;
+    for (int i = threadIdx.x; i < len; i += blockDim.x) dst[i] = src[i];
+}
+
+}  // namespace psdr

@@ -1,0 +1,1183 @@
+// psdr_api.hip — host side of libpsdr_hip.so: context, tables, launch logic and the
+// C-ABI declared in include/psdr.h.  gfx950 only; no CPU fallback lives here.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/psdr.h"
+#include "demod.h"
+#include "epilogue.h"
+#include "fft_pass.h"
+
+using namespace psdr;
+
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(PSDR_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                \
+    } while (0)
+
+extern "C" const char *psdr_last_error(void) { return g_err.c_str(); }
+extern "C" const char *psdr_version(void) { return "phantomsdr_amd 0.1 (gfx950)"; }
+
+namespace {
+
+enum KernelId { K_PASS1, K_PASS2, K_UNTANGLE, K_TAIL, K_IDFT, K_OLA, K_WFALL, K_COUNT };
+const char *kKernelNames[K_COUNT] = {"fft_pass1",  "fft_pass2", "untangle_real", "pyramid_tail",
+                                     "demod_idft", "demod_ola", "waterfall_gather"};
+
+struct PendingEvent {
+    hipEvent_t a, b;
+    int kid;
+};
+
+struct AudioSlot {
+    bool active = false;
+    int l = 0, r = 0;
+    double mid = 0;
+    int mode = PSDR_USB;
+    int state_cur = 0;
+};
+struct WfSlot {
+    bool active = false;
+    int level = 0, l = 0, r = 0;
+    size_t out_off = 0;
+    int nsent = 0;
+};
+
+// Small host->device parameter blocks (client lists) are double-buffered K deep so a new
+// batch can be enqueued without waiting for the previous one to drain.
+struct ParamRing {
+    static constexpr int K = 8;
+    unsigned char *h = nullptr, *d = nullptr;
+    size_t slot_bytes = 0;
+    hipEvent_t ev[K] = {};
+    bool used[K] = {};
+    int idx = 0;
+    int init(size_t bytes) {
+        slot_bytes = (bytes + 255) & ~(size_t)255;
+        if (hipHostMalloc((void **)&h, slot_bytes * K, hipHostMallocDefault) != hipSuccess) return -1;
+        if (hipMalloc((void **)&d, slot_bytes * K) != hipSuccess) return -1;
+        for (int i = 0; i < K; i++)
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return -1;
+        return 0;
+    }
+    void destroy() {
+        if (h) hipHostFree(h);
+        if (d) hipFree(d);
+        for (int i = 0; i < K; i++)
+            if (ev[i]) hipEventDestroy(ev[i]);
+        h = d = nullptr;
+    }
+    // returns the slot to fill (waits only if the ring wrapped onto a still-busy slot)
+    int acquire() {
+        idx = (idx + 1) % K;
+        if (used[idx]) hipEventSynchronize(ev[idx]);
+        return idx;
+    }
+    void *host(int i) { return h + slot_bytes * i; }
+    void *dev(int i) { return d + slot_bytes * i; }
+    void release(int i, hipStream_t s) {
+        hipEventRecord(ev[i], s);
+        used[i] = true;
+    }
+};
+
+int ilog2(size_t v) {
+    int l = 0;
+    while (((size_t)1 << l) < v) l++;
+    return l;
+}
+
+}  // namespace
+
+struct psdr_ctx {
+    psdr_config cfg;
+    int device = 0;
+    size_t N = 0, M = 0, R = 0;
+    int M1 = 0, M2 = 0, log2M1 = 0, log2M2 = 0;
+    int T1 = 0, T2 = 0;
+    bool is_real = false;
+    int size_log2 = 0;
+    int levels = 0;
+    size_t spec_stride = 0;  // complex elements per frame
+    size_t q_len = 0, q_stride = 0;
+    int LT = 0;  // pyramid levels finished inside the fused kernel
+    size_t p_stride = 0;
+    int max_batch = 1;
+    hipStream_t stream = nullptr;
+
+    float *d_window = nullptr;
+    cf *d_Wl1 = nullptr, *d_Wl2 = nullptr, *d_TA = nullptr, *d_TB = nullptr;
+    cf *d_UA = nullptr, *d_UB = nullptr;
+    int log2B = 0, log2UB = 0;
+    cf *d_Y = nullptr, *d_Z = nullptr, *d_spec = nullptr;
+    int8_t *d_q = nullptr;
+    float *d_pscr[2] = {nullptr, nullptr};
+
+    // level 1
+    float *d_stage = nullptr;
+    float *h_out = nullptr;
+    int8_t *h_q = nullptr;
+    bool loaded = false, executed = false, out_valid = false, q_valid = false;
+    int last_nframes = 0;
+
+    // audio clients
+    std::mutex mtx;
+    std::vector<AudioSlot> aslots;
+    int n = 0;  // audio_fft_size
+    int nstages = 0;
+    int radix[PSDR_MAX_STAGES];
+    int lds_mode = 0;
+    size_t idft_lds = 0;
+    cf *d_Wn = nullptr, *d_ypost = nullptr, *d_gscratch = nullptr, *d_bb_tail = nullptr,
+       *d_bb_last = nullptr;
+    float *d_pwr = nullptr, *d_audio = nullptr, *d_real_prev = nullptr;
+    int *d_nan = nullptr;
+    ParamRing client_ring;
+    int last_demod_frames = 0;
+
+    // waterfall clients
+    std::vector<WfSlot> wslots;
+    ParamRing wf_ring;  // [WfClient x W][int x F]
+    size_t wf_sent_off = 0;
+    int8_t *d_wfout = nullptr;
+    size_t wfout_cap = 0;
+
+    // instrumentation
+    bool profiling = false;
+    std::vector<PendingEvent> pending;
+    std::vector<hipEvent_t> pool;
+    double k_ms[K_COUNT] = {0};
+    int64_t k_n[K_COUNT] = {0};
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+};
+
+namespace {
+
+struct ProfScope {
+    psdr_ctx *c;
+    int kid;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(psdr_ctx *c_, int kid_) : c(c_), kid(kid_) {
+        if (!c->profiling) return;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!c->pool.empty()) {
+                e = c->pool.back();
+                c->pool.pop_back();
+            } else {
+                hipEventCreate(&e);
+            }
+            return e;
+        };
+        a = get();
+        b = get();
+        hipEventRecord(a, c->stream);
+    }
+    ~ProfScope() {
+        if (!c->profiling) return;
+        hipEventRecord(b, c->stream);
+        c->pending.push_back({a, b, kid});
+    }
+};
+
+void resolve_pending(psdr_ctx *c) {
+    if (c->pending.empty()) return;
+    hipStreamSynchronize(c->stream);
+    for (auto &p : c->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            c->k_ms[p.kid] += ms;
+            c->k_n[p.kid] += 1;
+        }
+        c->pool.push_back(p.a);
+        c->pool.push_back(p.b);
+    }
+    c->pending.clear();
+}
+
+std::vector<cf> make_twiddles(size_t count, size_t mult, size_t period, int sign) {
+    // exp(sign * 2 pi i * (j*mult) / period), j < count, generated in double
+    std::vector<cf> w(count);
+    for (size_t j = 0; j < count; j++) {
+        const double a = (double)sign * 2.0 * M_PI * (double)((j * mult) % period) / (double)period;
+        w[j] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    return w;
+}
+
+template <typename T>
+int upload(T **dst, const std::vector<T> &v) {
+    HIPCHK(hipMalloc((void **)dst, v.size() * sizeof(T)));
+    HIPCHK(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return PSDR_OK;
+}
+
+// tile widths: T = min(16384/L, other dimension)
+int pick_T(int L, int other) { return std::min(16384 / L, other); }
+
+template <int L, int T>
+int launch_pass1_t(psdr_ctx *c, const Pass1Args &a, unsigned blocks) {
+    constexpr size_t lds = (size_t)L * T * sizeof(cf) + (size_t)L * sizeof(cf);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass1<L, T>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    ProfScope ps(c, K_PASS1);
+    hipLaunchKernelGGL((k_fft_pass1<L, T>), dim3(blocks), dim3((L / 16) * T), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return PSDR_OK;
+}
+template <int L, int T, bool FUSED>
+int launch_pass2_t(psdr_ctx *c, const Pass2Args &a, unsigned blocks) {
+    constexpr size_t lds = (size_t)L * T * sizeof(cf) + (size_t)L * sizeof(cf);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass2<L, T, FUSED>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    ProfScope ps(c, K_PASS2);
+    hipLaunchKernelGGL((k_fft_pass2<L, T, FUSED>), dim3(blocks), dim3((L / 16) * T), lds, c->stream,
+                       a);
+    HIPCHK(hipGetLastError());
+    return PSDR_OK;
+}
+
+#define P1CASE(L_, T_) \
+    if (L == L_ && T == T_) return launch_pass1_t<L_, T_>(c, a, blocks);
+int launch_pass1(psdr_ctx *c, int L, int T, const Pass1Args &a, unsigned blocks) {
+    P1CASE(64, 64)
+    P1CASE(128, 64)
+    P1CASE(128, 128)
+    P1CASE(256, 64)
+    P1CASE(512, 32)
+    P1CASE(1024, 16)
+    P1CASE(2048, 8)
+    return fail(PSDR_ERR_UNSUPPORTED, "no pass-1 kernel for L=%d T=%d", L, T);
+}
+#define P2CASE(L_, T_)                                                          \
+    if (L == L_ && T == T_)                                                     \
+        return fused ? launch_pass2_t<L_, T_, true>(c, a, blocks)               \
+                     : launch_pass2_t<L_, T_, false>(c, a, blocks);
+int launch_pass2(psdr_ctx *c, int L, int T, bool fused, const Pass2Args &a, unsigned blocks) {
+    P2CASE(64, 64)
+    P2CASE(64, 128)
+    P2CASE(128, 128)
+    P2CASE(256, 64)
+    P2CASE(512, 32)
+    P2CASE(1024, 16)
+    P2CASE(2048, 8)
+    return fail(PSDR_ERR_UNSUPPORTED, "no pass-2 kernel for L=%d T=%d", L, T);
+}
+
+size_t fmt_bytes(int fmt) {
+    switch (fmt) {
+    case PSDR_FMT_U8:
+    case PSDR_FMT_S8:
+        return 1;
+    case PSDR_FMT_U16:
+    case PSDR_FMT_S16:
+        return 2;
+    case PSDR_FMT_F32:
+        return 4;
+    default:
+        return 8;
+    }
+}
+
+// forward FFT + power + int8 pyramid for nframes frames (src/fft.cpp:61-98 per frame)
+int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
+    const unsigned tiles1 = (unsigned)(c->M2 / c->T1), tiles2 = (unsigned)(c->M1 / c->T2);
+    Pass1Args a1{};
+    a1.raw = d_halves;
+    a1.window = c->d_window;
+    a1.Y = c->d_Y;
+    a1.Wl = c->d_Wl1;
+    a1.TA = c->d_TA;
+    a1.TB = c->d_TB;
+    a1.log2B = c->log2B;
+    a1.M2 = c->M2;
+    a1.log2M2 = c->log2M2;
+    a1.fmt = fmt;
+    a1.is_real = c->is_real ? 1 : 0;
+    a1.rot = c->is_real ? 0 : 1;
+    a1.tiles_per_frame = tiles1;
+    a1.total_slots = tiles1 * (unsigned)nframes;
+    int rc = launch_pass1(c, c->M1, c->T1, a1, a1.total_slots);
+    if (rc) return rc;
+
+    Pass2Args a2{};
+    a2.Y = c->d_Y;
+    a2.Wl = c->d_Wl2;
+    a2.M1 = c->M1;
+    a2.log2M1 = c->log2M1;
+    a2.inv_n = 1.0f / (float)c->N;
+    a2.size_log2 = c->size_log2;
+    a2.nlevels = c->levels;
+    a2.Q = c->d_q;
+    a2.q_stride = c->q_stride;
+    a2.Pscr = c->d_pscr[0];
+    a2.p_stride = c->p_stride;
+    a2.tiles_per_frame = tiles2;
+    a2.total_slots = tiles2 * (unsigned)nframes;
+    if (!c->is_real) {
+        a2.X = c->d_spec;
+        a2.spec_stride = c->spec_stride;
+        rc = launch_pass2(c, c->M2, c->T2, true, a2, a2.total_slots);
+        if (rc) return rc;
+    } else {
+        a2.X = c->d_Z;
+        a2.spec_stride = c->M;
+        rc = launch_pass2(c, c->M2, c->T2, false, a2, a2.total_slots);
+        if (rc) return rc;
+        UntangleArgs u{};
+        u.Z = c->d_Z;
+        u.X = c->d_spec;
+        u.spec_stride = c->spec_stride;
+        u.M = c->M;
+        u.TA = c->d_UA;
+        u.TB = c->d_UB;
+        u.log2B = c->log2UB;
+        u.inv_n = 1.0f / (float)c->N;
+        u.size_log2 = c->size_log2;
+        u.nlevels = c->levels;
+        u.Q = c->d_q;
+        u.q_stride = c->q_stride;
+        u.Pscr = c->d_pscr[0];
+        u.p_stride = c->p_stride;
+        ProfScope ps(c, K_UNTANGLE);
+        const unsigned nb = (unsigned)((c->M / 2 + 255) / 256);
+        hipLaunchKernelGGL(k_untangle_real, dim3(nb, nframes), dim3(256), 0, c->stream, u);
+        HIPCHK(hipGetLastError());
+    }
+    // remaining pyramid levels from the partial level in scratch
+    int lvl = c->LT;
+    size_t len = c->R >> lvl;
+    int cur = 0;
+    while (lvl + 1 < c->levels && len >= 2) {
+        TailArgs t{};
+        t.Pin = c->d_pscr[cur];
+        t.in_stride = c->p_stride;
+        t.len_in = len;
+        t.lvl_in = lvl;
+        t.nlevels = c->levels;
+        t.size_log2 = c->size_log2;
+        t.Q = c->d_q;
+        t.q_stride = c->q_stride;
+        t.R = c->R;
+        t.Pout = c->d_pscr[cur ^ 1];
+        t.out_stride = c->p_stride;
+        ProfScope ps(c, K_TAIL);
+        const unsigned nb = (unsigned)((len / 2 + 255) / 256);
+        hipLaunchKernelGGL(k_pyramid_tail, dim3(nb, nframes), dim3(256), 0, c->stream, t);
+        HIPCHK(hipGetLastError());
+        lvl += 7;
+        len >>= 7;
+        cur ^= 1;
+    }
+    c->last_nframes = nframes;
+    c->out_valid = c->q_valid = false;
+    return PSDR_OK;
+}
+
+void free_all(psdr_ctx *c) {
+    auto F = [](void *p) {
+        if (p) hipFree(p);
+    };
+    F(c->d_window);
+    F(c->d_Wl1);
+    if (c->d_Wl2 != c->d_Wl1) F(c->d_Wl2);
+    F(c->d_TA);
+    F(c->d_TB);
+    F(c->d_UA);
+    F(c->d_UB);
+    F(c->d_Y);
+    F(c->d_Z);
+    F(c->d_spec);
+    F(c->d_q);
+    F(c->d_pscr[0]);
+    F(c->d_pscr[1]);
+    F(c->d_stage);
+    F(c->d_Wn);
+    F(c->d_ypost);
+    F(c->d_gscratch);
+    F(c->d_bb_tail);
+    F(c->d_bb_last);
+    F(c->d_pwr);
+    F(c->d_audio);
+    F(c->d_real_prev);
+    F(c->d_nan);
+    c->client_ring.destroy();
+    c->wf_ring.destroy();
+    F(c->d_wfout);
+    auto H = [](void *p) {
+        if (p) hipHostFree(p);
+    };
+    H(c->h_out);
+    H(c->h_q);
+    for (auto &p : c->pending) {
+        hipEventDestroy(p.a);
+        hipEventDestroy(p.b);
+    }
+    for (auto e : c->pool) hipEventDestroy(e);
+    if (c->t0) hipEventDestroy(c->t0);
+    if (c->t1) hipEventDestroy(c->t1);
+    if (c->stream) hipStreamDestroy(c->stream);
+}
+
+int build(psdr_ctx *c) {
+    const psdr_config &g = c->cfg;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&c->t0));
+    HIPCHK(hipEventCreate(&c->t1));
+
+    // ---- window: build_hann_window, src/utils/dsp.cpp:6-11 (same host libm expression)
+    {
+        std::vector<float> w(c->N);
+        for (size_t i = 0; i < c->N; i++) {
+            const float arg = (float)(2 * M_PI * (double)(int)i / (double)(int)c->N);
+            w[i] = (float)(0.5 * (double)(1 - cosf(arg)));
+        }
+        int rc = upload(&c->d_window, w);
+        if (rc) return rc;
+    }
+    // ---- twiddles
+    {
+        int rc = upload(&c->d_Wl1, make_twiddles((size_t)c->M1, 1, (size_t)c->M1, -1));
+        if (rc) return rc;
+        if (c->M2 == c->M1) {
+            c->d_Wl2 = c->d_Wl1;
+        } else {
+            rc = upload(&c->d_Wl2, make_twiddles((size_t)c->M2, 1, (size_t)c->M2, -1));
+            if (rc) return rc;
+        }
+        c->log2B = std::min(10, ilog2(c->M));
+        const size_t B = (size_t)1 << c->log2B;
+        // rot exponents reach M2*... <= (M2-1)*M1 < M; TA needs M/B entries (+1 guard)
+        rc = upload(&c->d_TA, make_twiddles(c->M / B + 1, B, c->M, -1));
+        if (rc) return rc;
+        rc = upload(&c->d_TB, make_twiddles(B, 1, c->M, -1));
+        if (rc) return rc;
+        if (c->is_real) {
+            c->log2UB = std::min(10, ilog2(c->N));
+            const size_t UB = (size_t)1 << c->log2UB;
+            rc = upload(&c->d_UA, make_twiddles(c->N / UB + 1, UB, c->N, -1));
+            if (rc) return rc;
+            rc = upload(&c->d_UB, make_twiddles(UB, 1, c->N, -1));
+            if (rc) return rc;
+        }
+    }
+    // ---- work buffers
+    const size_t F = (size_t)c->max_batch;
+    HIPCHK(hipMalloc((void **)&c->d_Y, F * c->M * sizeof(cf)));
+    if (c->is_real) HIPCHK(hipMalloc((void **)&c->d_Z, F * c->M * sizeof(cf)));
+    HIPCHK(hipMalloc((void **)&c->d_spec, F * c->spec_stride * sizeof(cf)));
+    HIPCHK(hipMemset(c->d_spec, 0, F * c->spec_stride * sizeof(cf)));
+    HIPCHK(hipMalloc((void **)&c->d_q, F * c->q_stride));
+    HIPCHK(hipMemset(c->d_q, 0, F * c->q_stride));
+    HIPCHK(hipMalloc((void **)&c->d_pscr[0], F * c->p_stride * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&c->d_pscr[1], F * c->p_stride * sizeof(float)));
+    // ---- level-1 staging
+    HIPCHK(hipMalloc((void **)&c->d_stage, (c->is_real ? c->N : 2 * c->N) * sizeof(float)));
+    {
+        const size_t nb = c->is_real ? (c->N / 2 + 1) : (c->N + (size_t)g.additional_size);
+        HIPCHK(hipHostMalloc((void **)&c->h_out, nb * sizeof(cf), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&c->h_q, std::max<size_t>(c->q_len, 16), hipHostMallocDefault));
+    }
+    // ---- audio clients
+    c->n = g.audio_fft_size;
+    if (c->n > 0) {
+        const int n = c->n;
+        // factorise n, grouping prime factors into radices <= 16 (fewer barriers)
+        std::vector<int> primes;
+        int m = n;
+        for (int p = 2; (long long)p * p <= m; p++)
+            while (m % p == 0) {
+                primes.push_back(p);
+                m /= p;
+            }
+        if (m > 1) primes.push_back(m);
+        std::vector<int> rad;
+        int cur = 1;
+        for (int p : primes) {
+            if (cur * p <= 16)
+                cur *= p;
+            else {
+                if (cur > 1) rad.push_back(cur);
+                cur = p;
+            }
+        }
+        if (cur > 1) rad.push_back(cur);
+        if ((int)rad.size() > PSDR_MAX_STAGES)
+            return fail(PSDR_ERR_UNSUPPORTED, "audio_fft_size %d has too many factors", n);
+        c->nstages = (int)rad.size();
+        for (int i = 0; i < c->nstages; i++) c->radix[i] = rad[i];
+        const size_t cap = 144 * 1024;
+        if ((size_t)n * 24 <= cap) {
+            c->lds_mode = 0;
+            c->idft_lds = (size_t)n * 24;
+        } else if ((size_t)n * 16 <= cap) {
+            c->lds_mode = 1;
+            c->idft_lds = (size_t)n * 16;
+        } else {
+            c->lds_mode = 2;
+            c->idft_lds = 0;
+        }
+        if (c->idft_lds > 64 * 1024)
+            HIPCHK(hipFuncSetAttribute((const void *)k_demod_idft,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->idft_lds));
+        int rc = upload(&c->d_Wn, make_twiddles((size_t)n, 1, (size_t)n, +1));
+        if (rc) return rc;
+        const size_t S = (size_t)std::max(1, g.max_clients);
+        c->aslots.resize(S);
+        HIPCHK(hipMalloc((void **)&c->d_ypost, S * F * n * sizeof(cf)));
+        HIPCHK(hipMalloc((void **)&c->d_pwr, S * F * sizeof(float)));
+        HIPCHK(hipMalloc((void **)&c->d_audio, S * F * (n / 2) * sizeof(float)));
+        HIPCHK(hipMalloc((void **)&c->d_nan, S * F * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&c->d_real_prev, 2 * S * (n / 2) * sizeof(float)));
+        HIPCHK(hipMalloc((void **)&c->d_bb_tail, 2 * S * (n / 2) * sizeof(cf)));
+        HIPCHK(hipMalloc((void **)&c->d_bb_last, 2 * S * sizeof(cf)));
+        HIPCHK(hipMemset(c->d_real_prev, 0, 2 * S * (n / 2) * sizeof(float)));
+        HIPCHK(hipMemset(c->d_bb_tail, 0, 2 * S * (n / 2) * sizeof(cf)));
+        HIPCHK(hipMemset(c->d_bb_last, 0, 2 * S * sizeof(cf)));
+        HIPCHK(hipMemset(c->d_audio, 0, S * F * (n / 2) * sizeof(float)));
+        HIPCHK(hipMemset(c->d_pwr, 0, S * F * sizeof(float)));
+        HIPCHK(hipMemset(c->d_nan, 0, S * F * sizeof(int)));
+        if (c->lds_mode == 2) HIPCHK(hipMalloc((void **)&c->d_gscratch, S * F * 2 * n * sizeof(cf)));
+        if (c->client_ring.init(S * sizeof(ClientParams)))
+            return fail(PSDR_ERR_HIP, "client parameter ring allocation failed");
+    }
+    // ---- waterfall clients
+    {
+        const size_t W = (size_t)std::max(1, g.max_waterfall_clients);
+        c->wslots.resize(W);
+        c->wf_sent_off = (W * sizeof(WfClient) + 63) & ~(size_t)63;
+        if (c->wf_ring.init(c->wf_sent_off + F * sizeof(int)))
+            return fail(PSDR_ERR_HIP, "waterfall parameter ring allocation failed");
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipDeviceSynchronize());
+    return PSDR_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+extern "C" int psdr_create(const psdr_config *cfg, psdr_ctx **out) {
+    if (!cfg || !out) return fail(PSDR_ERR_INVALID, "null argument");
+    if (cfg->struct_size != sizeof(psdr_config))
+        return fail(PSDR_ERR_INVALID, "psdr_config.struct_size mismatch (%u vs %zu)",
+                    cfg->struct_size, sizeof(psdr_config));
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        return fail(PSDR_ERR_NO_DEVICE, "No HIP devices found");
+    if (cfg->device < 0 || cfg->device >= count)
+        return fail(PSDR_ERR_INVALID, "device %d out of range (%d devices)", cfg->device, count);
+    const size_t N = cfg->fft_size;
+    if (N == 0 || (N & (N - 1))) return fail(PSDR_ERR_INVALID, "fft_size must be a power of two");
+    const bool is_real = cfg->is_real != 0;
+    const size_t M = is_real ? N / 2 : N;
+    const int m = ilog2(M);
+    if (m < 12 || m > 22)
+        return fail(PSDR_ERR_UNSUPPORTED,
+                    "fft_size %zu unsupported: complex transform length must be 2^12..2^22", N);
+    if (cfg->downsample_levels < 1 || ((M >> (cfg->downsample_levels - 1)) < 1))
+        return fail(PSDR_ERR_INVALID, "downsample_levels %d invalid", cfg->downsample_levels);
+    if (cfg->audio_fft_size < 0 || (cfg->audio_fft_size % 4) != 0)
+        return fail(PSDR_ERR_INVALID, "audio_fft_size must be a non-negative multiple of 4");
+    if (cfg->input_format < PSDR_FMT_U8 || cfg->input_format > PSDR_FMT_F64)
+        return fail(PSDR_ERR_INVALID, "unknown input_format %d", cfg->input_format);
+    if (cfg->max_batch < 1) return fail(PSDR_ERR_INVALID, "max_batch must be >= 1");
+
+    psdr_ctx *c = new (std::nothrow) psdr_ctx();
+    if (!c) return fail(PSDR_ERR_NOMEM, "out of memory");
+    c->cfg = *cfg;
+    c->device = cfg->device;
+    c->N = N;
+    c->M = M;
+    c->is_real = is_real;
+    c->R = M;  // fft_result_size: N (IQ) or N/2 (real), src/spectrumserver.cpp:99-105
+    c->log2M2 = m / 2;
+    c->log2M1 = m - c->log2M2;
+    c->M1 = 1 << c->log2M1;
+    c->M2 = 1 << c->log2M2;
+    c->T1 = pick_T(c->M1, c->M2);
+    c->T2 = pick_T(c->M2, c->M1);
+    c->size_log2 = (int)std::lround(std::log2((double)N)) + cfg->brightness_offset;
+    c->levels = cfg->downsample_levels;
+    c->max_batch = cfg->max_batch;
+    c->spec_stride = is_real ? (M + 2) : N;
+    c->q_len = 0;
+    for (int i = 0; i < c->levels; i++) c->q_len += c->R >> i;
+    c->q_stride = (c->q_len + 127) & ~(size_t)127;
+    if (is_real)
+        c->LT = 7;
+    else
+        c->LT = (c->T2 >= 16) ? 4 : 3;
+    c->p_stride = std::max<size_t>(c->R >> c->LT, 64);
+    if (cfg->skip_num < 1) c->cfg.skip_num = 1;
+
+    int rc = build(c);
+    if (rc) {
+        free_all(c);
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return PSDR_OK;
+}
+
+extern "C" void psdr_destroy(psdr_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    free_all(c);
+    delete c;
+}
+
+// ---- level 1 ---------------------------------------------------------------------------
+extern "C" int psdr_host_alloc(psdr_ctx *c, size_t nfloats, float **out) {
+    if (!c || !out) return fail(PSDR_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipHostMalloc((void **)out, std::max<size_t>(nfloats, 1) * sizeof(float),
+                         hipHostMallocDefault));
+    return PSDR_OK;
+}
+extern "C" int psdr_host_free(psdr_ctx *c, float *buf) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    if (buf) HIPCHK(hipHostFree(buf));
+    return PSDR_OK;
+}
+static int load_input(psdr_ctx *c, const float *a1, const float *a2) {
+    if (!c || !a1 || !a2) return fail(PSDR_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t half_floats = c->is_real ? c->N / 2 : c->N;
+    HIPCHK(hipMemcpyAsync(c->d_stage, a1, half_floats * sizeof(float), hipMemcpyHostToDevice,
+                          c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_stage + half_floats, a2, half_floats * sizeof(float),
+                          hipMemcpyHostToDevice, c->stream));
+    c->loaded = true;
+    return PSDR_OK;
+}
+extern "C" int psdr_load_real_input(psdr_ctx *c, const float *a1, const float *a2) {
+    if (c && !c->is_real) return fail(PSDR_ERR_STATE, "context was planned for complex input");
+    return load_input(c, a1, a2);
+}
+extern "C" int psdr_load_complex_input(psdr_ctx *c, const float *a1, const float *a2) {
+    if (c && c->is_real) return fail(PSDR_ERR_STATE, "context was planned for real input");
+    return load_input(c, a1, a2);
+}
+extern "C" int psdr_execute(psdr_ctx *c) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    if (!c->loaded) return fail(PSDR_ERR_STATE, "execute() before load_*_input()");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = process_frames(c, c->d_stage, 1, PSDR_FMT_F32);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->executed = true;
+    return PSDR_OK;
+}
+
+// spectrum of `frame` to host in the reference's k order
+static int copy_spectrum_k_order(psdr_ctx *c, int frame, cf *dst) {
+    const cf *src = c->d_spec + (size_t)frame * c->spec_stride;
+    if (c->is_real) {
+        HIPCHK(hipMemcpyAsync(dst, src, (c->N / 2 + 1) * sizeof(cf), hipMemcpyDeviceToHost,
+                              c->stream));
+    } else {
+        // client order c -> bin k = (c + N/2 + 1) mod N: two contiguous runs
+        const size_t N = c->N, h = N / 2;
+        HIPCHK(hipMemcpyAsync(dst, src + (h - 1), (h + 1) * sizeof(cf), hipMemcpyDeviceToHost,
+                              c->stream));
+        HIPCHK(hipMemcpyAsync(dst + h + 1, src, (h - 1) * sizeof(cf), hipMemcpyDeviceToHost,
+                              c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PSDR_OK;
+}
+extern "C" int psdr_get_output_buffer(psdr_ctx *c, float **out) {
+    if (!c || !out) return fail(PSDR_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    if (c->last_nframes > 0 && !c->out_valid) {
+        int rc = copy_spectrum_k_order(c, 0, (cf *)c->h_out);
+        if (rc) return rc;
+        if (!c->is_real && c->cfg.additional_size > 0)  // wrap copy, src/fft.cpp:91-98
+            memcpy((cf *)c->h_out + c->N, c->h_out, sizeof(cf) * (size_t)c->cfg.additional_size);
+        c->out_valid = true;
+    }
+    *out = c->h_out;
+    return PSDR_OK;
+}
+extern "C" int psdr_get_quantized_buffer(psdr_ctx *c, int8_t **out) {
+    if (!c || !out) return fail(PSDR_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    if (c->last_nframes > 0 && !c->q_valid) {
+        HIPCHK(hipMemcpyAsync(c->h_q, c->d_q, c->q_len, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->q_valid = true;
+    }
+    *out = c->h_q;
+    return PSDR_OK;
+}
+
+// ---- device helpers ----------------------------------------------------------------------
+extern "C" int psdr_dev_alloc(psdr_ctx *c, size_t bytes, void **out) {
+    if (!c || !out) return fail(PSDR_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMalloc(out, std::max<size_t>(bytes, 16)));
+    return PSDR_OK;
+}
+extern "C" int psdr_dev_free(psdr_ctx *c, void *p) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    if (p) HIPCHK(hipFree(p));
+    return PSDR_OK;
+}
+extern "C" int psdr_memcpy_h2d(psdr_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!c || !dst || !src) return fail(PSDR_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PSDR_OK;
+}
+extern "C" int psdr_memcpy_d2h(psdr_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!c || !dst || !src) return fail(PSDR_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PSDR_OK;
+}
+extern "C" int psdr_synchronize(psdr_ctx *c) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PSDR_OK;
+}
+extern "C" size_t psdr_half_frame_bytes(const psdr_ctx *c) {
+    if (!c) return 0;
+    return (c->N / 2) * (c->is_real ? 1 : 2) * fmt_bytes(c->cfg.input_format);
+}
+
+// ---- level 2 -----------------------------------------------------------------------------
+extern "C" int psdr_process_batch(psdr_ctx *c, const void *d_halves, int nframes) {
+    if (!c || !d_halves) return fail(PSDR_ERR_INVALID, "null argument");
+    if (nframes < 1 || nframes > c->max_batch)
+        return fail(PSDR_ERR_INVALID, "nframes %d outside [1, max_batch=%d]", nframes, c->max_batch);
+    HIPCHK(hipSetDevice(c->device));
+    return process_frames(c, d_halves, nframes, c->cfg.input_format);
+}
+
+static int check_slot(psdr_ctx *c, int id) {
+    if (id < 0 || id >= (int)c->aslots.size() || !c->aslots[id].active)
+        return fail(PSDR_ERR_INVALID, "no audio client with id %d", id);
+    return PSDR_OK;
+}
+extern "C" int psdr_client_add(psdr_ctx *c, int *id_out) {
+    if (!c || !id_out) return fail(PSDR_ERR_INVALID, "null argument");
+    if (c->n <= 0) return fail(PSDR_ERR_STATE, "context created with audio_fft_size 0");
+    std::lock_guard<std::mutex> lk(c->mtx);
+    HIPCHK(hipSetDevice(c->device));
+    for (size_t i = 0; i < c->aslots.size(); i++)
+        if (!c->aslots[i].active) {
+            AudioSlot &s = c->aslots[i];
+            s = AudioSlot();
+            s.active = true;
+            // a fresh AudioClient starts from zeroed buffers (src/signal.h:42-51)
+            const size_t S = c->aslots.size(), h = (size_t)c->n / 2;
+            for (int b = 0; b < 2; b++) {
+                HIPCHK(hipMemsetAsync(c->d_real_prev + ((size_t)b * S + i) * h, 0, h * sizeof(float),
+                                      c->stream));
+                HIPCHK(hipMemsetAsync(c->d_bb_tail + ((size_t)b * S + i) * h, 0, h * sizeof(cf),
+                                      c->stream));
+                HIPCHK(hipMemsetAsync(c->d_bb_last + ((size_t)b * S + i), 0, sizeof(cf), c->stream));
+            }
+            *id_out = (int)i;
+            return PSDR_OK;
+        }
+    return fail(PSDR_ERR_NOMEM, "all %zu audio client slots are in use", c->aslots.size());
+}
+extern "C" int psdr_client_remove(psdr_ctx *c, int id) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mtx);
+    int rc = check_slot(c, id);
+    if (rc) return rc;
+    c->aslots[id].active = false;
+    return PSDR_OK;
+}
+extern "C" int psdr_client_set_audio_range(psdr_ctx *c, int id, int l, double mid, int r) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mtx);
+    int rc = check_slot(c, id);
+    if (rc) return rc;
+    // the reference does not validate here (src/signal.cpp:81-94); a range outside the
+    // spectrum would read out of bounds there, so it is refused here
+    if (l < 0 || r < l || (size_t)r > c->R || r - l > c->n)
+        return fail(PSDR_ERR_INVALID, "range [%d,%d) outside the spectrum or wider than %d", l, r, c->n);
+    AudioSlot &s = c->aslots[id];
+    s.l = l;
+    s.r = r;
+    s.mid = mid;
+    return PSDR_OK;
+}
+extern "C" int psdr_client_on_window_message(psdr_ctx *c, int id, int l, double mid, int r) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    {
+        std::lock_guard<std::mutex> lk(c->mtx);
+        int rc = check_slot(c, id);
+        if (rc) return rc;
+    }
+    const int R = (int)c->R;  // src/signal.cpp:305-311
+    if (l < 0 || l >= R || r < 0 || r >= R || l > r)
+        return fail(PSDR_ERR_INVALID, "window [%d,%d] rejected", l, r);
+    if (r - l > c->n) return fail(PSDR_ERR_INVALID, "window wider than audio_fft_size");
+    return psdr_client_set_audio_range(c, id, l, mid, r);
+}
+extern "C" int psdr_client_set_audio_demodulation(psdr_ctx *c, int id, int mode) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mtx);
+    int rc = check_slot(c, id);
+    if (rc) return rc;
+    if (mode < PSDR_USB || mode > PSDR_FM) return fail(PSDR_ERR_INVALID, "unknown mode %d", mode);
+    c->aslots[id].mode = mode;
+    return PSDR_OK;
+}
+
+extern "C" int psdr_demod_batch(psdr_ctx *c, uint64_t first_frame_num) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    if (c->n <= 0) return fail(PSDR_ERR_STATE, "context created with audio_fft_size 0");
+    if (c->last_nframes < 1) return fail(PSDR_ERR_STATE, "demod_batch before process_batch/execute");
+    HIPCHK(hipSetDevice(c->device));
+    int nact = 0;
+    const int ring = c->client_ring.acquire();
+    ClientParams *h_clients = (ClientParams *)c->client_ring.host(ring);
+    ClientParams *d_clients = (ClientParams *)c->client_ring.dev(ring);
+    {
+        std::lock_guard<std::mutex> lk(c->mtx);
+        for (size_t i = 0; i < c->aslots.size(); i++) {
+            AudioSlot &s = c->aslots[i];
+            if (!s.active) continue;
+            ClientParams &p = h_clients[nact++];
+            p.l = s.l;
+            p.r = s.r;
+            p.m_floor = (int)std::floor(s.mid);
+            p.mode = s.mode;
+            p.slot = (int)i;
+            p.state_cur = s.state_cur;
+            s.state_cur ^= 1;
+        }
+    }
+    c->last_demod_frames = c->last_nframes;
+    if (nact == 0) return PSDR_OK;
+    HIPCHK(hipMemcpyAsync(d_clients, h_clients, (size_t)nact * sizeof(ClientParams),
+                          hipMemcpyHostToDevice, c->stream));
+    DemodArgs a{};
+    a.spec = c->d_spec;
+    a.spec_stride = c->spec_stride;
+    a.is_real = c->is_real ? 1 : 0;
+    a.n = c->n;
+    a.nframes = c->last_nframes;
+    a.max_batch = c->max_batch;
+    a.first_frame_num = first_frame_num;
+    a.clients = d_clients;
+    a.Wn = c->d_Wn;
+    a.nstages = c->nstages;
+    for (int i = 0; i < c->nstages; i++) a.radix[i] = c->radix[i];
+    a.ypost = c->d_ypost;
+    a.pwr = c->d_pwr;
+    a.gscratch = c->d_gscratch;
+    a.lds_mode = c->lds_mode;
+    a.audio = c->d_audio;
+    a.nan_flags = c->d_nan;
+    a.real_prev = c->d_real_prev;
+    a.bb_tail = c->d_bb_tail;
+    a.bb_last = c->d_bb_last;
+    a.slots = (int)c->aslots.size();
+    {
+        ProfScope ps(c, K_IDFT);
+        hipLaunchKernelGGL(k_demod_idft, dim3(nact, c->last_nframes), dim3(256), c->idft_lds, c->stream,
+                           a);
+        HIPCHK(hipGetLastError());
+    }
+    {
+        ProfScope ps(c, K_OLA);
+        hipLaunchKernelGGL(k_demod_ola, dim3(nact, c->last_nframes), dim3(128), 0, c->stream, a);
+        HIPCHK(hipGetLastError());
+    }
+    c->client_ring.release(ring, c->stream);
+    return PSDR_OK;
+}
+
+extern "C" int psdr_read_audio(psdr_ctx *c, int id, float *audio, float *pwr, int32_t *nan_flags) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    {
+        std::lock_guard<std::mutex> lk(c->mtx);
+        int rc = check_slot(c, id);
+        if (rc) return rc;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    const size_t F = (size_t)c->last_demod_frames, h = (size_t)c->n / 2, mb = (size_t)c->max_batch;
+    if (F == 0) return fail(PSDR_ERR_STATE, "no demodulated batch to read");
+    if (audio)
+        HIPCHK(hipMemcpyAsync(audio, c->d_audio + (size_t)id * mb * h, F * h * sizeof(float),
+                              hipMemcpyDeviceToHost, c->stream));
+    if (pwr)
+        HIPCHK(hipMemcpyAsync(pwr, c->d_pwr + (size_t)id * mb, F * sizeof(float), hipMemcpyDeviceToHost,
+                              c->stream));
+    if (nan_flags)
+        HIPCHK(hipMemcpyAsync(nan_flags, c->d_nan + (size_t)id * mb, F * sizeof(int),
+                              hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PSDR_OK;
+}
+extern "C" int psdr_audio_device_ptr(psdr_ctx *c, int id, const float **d_audio, const float **d_pwr) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    if (id < 0 || id >= (int)c->aslots.size()) return fail(PSDR_ERR_INVALID, "bad id %d", id);
+    const size_t h = (size_t)c->n / 2, mb = (size_t)c->max_batch;
+    if (d_audio) *d_audio = c->d_audio + (size_t)id * mb * h;
+    if (d_pwr) *d_pwr = c->d_pwr + (size_t)id * mb;
+    return PSDR_OK;
+}
+
+// ---- waterfall ---------------------------------------------------------------------------
+static int check_wslot(psdr_ctx *c, int id) {
+    if (id < 0 || id >= (int)c->wslots.size() || !c->wslots[id].active)
+        return fail(PSDR_ERR_INVALID, "no waterfall client with id %d", id);
+    return PSDR_OK;
+}
+extern "C" int psdr_waterfall_add(psdr_ctx *c, int *id_out) {
+    if (!c || !id_out) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mtx);
+    for (size_t i = 0; i < c->wslots.size(); i++)
+        if (!c->wslots[i].active) {
+            WfSlot &s = c->wslots[i];
+            s = WfSlot();
+            s.active = true;
+            // default = whole spectrum at the coarsest level (src/websocket.cpp:198)
+            s.level = c->levels - 1;
+            s.l = 0;
+            s.r = (int)(c->R >> s.level);
+            *id_out = (int)i;
+            return PSDR_OK;
+        }
+    return fail(PSDR_ERR_NOMEM, "all %zu waterfall client slots are in use", c->wslots.size());
+}
+extern "C" int psdr_waterfall_remove(psdr_ctx *c, int id) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mtx);
+    int rc = check_wslot(c, id);
+    if (rc) return rc;
+    c->wslots[id].active = false;
+    return PSDR_OK;
+}
+extern "C" int psdr_waterfall_set_range(psdr_ctx *c, int id, int level, int l, int r) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mtx);
+    int rc = check_wslot(c, id);
+    if (rc) return rc;
+    if (level < 0 || level >= c->levels) return fail(PSDR_ERR_INVALID, "level %d out of range", level);
+    const int len = (int)(c->R >> level);
+    if (l < 0) l = 0;
+    if (r > len) r = len;  // the reference forgets this bound (src/waterfall.cpp:55-58)
+    if (l > r) return fail(PSDR_ERR_INVALID, "empty waterfall range");
+    WfSlot &s = c->wslots[id];
+    s.level = level;
+    s.l = l;
+    s.r = r;
+    return PSDR_OK;
+}
+extern "C" int psdr_waterfall_on_window_message(psdr_ctx *c, int id, int new_l, int new_r,
+                                                int *level_out, int *l_out, int *r_out) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    // src/waterfall.cpp:53-79
+    if (new_l < 0 || new_r < 0 || new_l >= new_r) return fail(PSDR_ERR_INVALID, "window rejected");
+    const int mwf = (int)(c->R >> (c->levels - 1));  // min_waterfall_fft
+    float new_l_f = (float)new_l, new_r_f = (float)new_r;
+    int new_level = c->levels - 1;
+    float best = (float)(mwf * 2);
+    for (int i = 0; i < c->levels; i++) {
+        const float send_size = std::fabs((new_r_f - new_l_f) - (float)mwf);
+        if (send_size < best) {
+            best = send_size;
+            new_level = i;
+            new_l = (int)std::round(new_l_f);
+            new_r = (int)std::round(new_r_f);
+        }
+        new_l_f /= 2;
+        new_r_f /= 2;
+    }
+    int rc = psdr_waterfall_set_range(c, id, new_level, new_l, new_r);
+    if (rc) return rc;
+    if (level_out) *level_out = new_level;
+    if (l_out) *l_out = c->wslots[id].l;
+    if (r_out) *r_out = c->wslots[id].r;
+    return PSDR_OK;
+}
+
+extern "C" int psdr_waterfall_batch(psdr_ctx *c, uint64_t first_frame_num) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    if (c->last_nframes < 1) return fail(PSDR_ERR_STATE, "waterfall_batch before process_batch/execute");
+    HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->mtx);
+    const int ring = c->wf_ring.acquire();
+    WfClient *h_wf = (WfClient *)c->wf_ring.host(ring);
+    WfClient *d_wf = (WfClient *)c->wf_ring.dev(ring);
+    int *h_sent = (int *)((unsigned char *)c->wf_ring.host(ring) + c->wf_sent_off);
+    int *d_sent = (int *)((unsigned char *)c->wf_ring.dev(ring) + c->wf_sent_off);
+    int nsent = 0;
+    for (int f = 0; f < c->last_nframes; f++)
+        if ((first_frame_num + (uint64_t)f) % (uint64_t)c->cfg.skip_num == 0) h_sent[nsent++] = f;
+    size_t total = 0;
+    int maxid = -1;
+    for (size_t i = 0; i < c->wslots.size(); i++) {
+        WfSlot &s = c->wslots[i];
+        WfClient &w = h_wf[i];
+        w.active = s.active ? 1 : 0;
+        w.level = s.level;
+        w.l = s.l;
+        w.r = s.r;
+        w.qoff = 0;
+        for (int t = 0; t < s.level; t++) w.qoff += c->R >> t;
+        w.out_off = total;
+        s.out_off = total;
+        s.nsent = s.active ? nsent : 0;
+        if (s.active) {
+            total += (size_t)nsent * (size_t)(s.r - s.l);
+            total = (total + 15) & ~(size_t)15;
+            maxid = (int)i;
+        }
+    }
+    if (maxid < 0 || nsent == 0 || total == 0) return PSDR_OK;
+    if (total > c->wfout_cap) {
+        if (c->d_wfout) HIPCHK(hipFree(c->d_wfout));
+        c->d_wfout = nullptr;
+        HIPCHK(hipMalloc((void **)&c->d_wfout, total));
+        c->wfout_cap = total;
+    }
+    HIPCHK(hipMemcpyAsync(d_wf, h_wf, (size_t)(maxid + 1) * sizeof(WfClient), hipMemcpyHostToDevice,
+                          c->stream));
+    HIPCHK(hipMemcpyAsync(d_sent, h_sent, (size_t)nsent * sizeof(int), hipMemcpyHostToDevice,
+                          c->stream));
+    {
+        ProfScope ps(c, K_WFALL);
+        hipLaunchKernelGGL(k_waterfall_gather, dim3(maxid + 1, nsent), dim3(256), 0, c->stream, c->d_q,
+                           c->q_stride, d_wf, d_sent, nsent, c->d_wfout);
+        HIPCHK(hipGetLastError());
+    }
+    c->wf_ring.release(ring, c->stream);
+    return PSDR_OK;
+}
+extern "C" int psdr_read_waterfall(psdr_ctx *c, int id, int8_t *out, size_t out_cap, int *nsent_out) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mtx);
+    int rc = check_wslot(c, id);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    const WfSlot &s = c->wslots[id];
+    const size_t bytes = (size_t)s.nsent * (size_t)(s.r - s.l);
+    if (nsent_out) *nsent_out = s.nsent;
+    if (bytes == 0 || !out) return PSDR_OK;
+    if (bytes > out_cap) return fail(PSDR_ERR_INVALID, "output buffer too small (%zu > %zu)", bytes, out_cap);
+    HIPCHK(hipMemcpyAsync(out, c->d_wfout + s.out_off, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PSDR_OK;
+}
+
+// ---- raw results ---------------------------------------------------------------------------
+extern "C" int psdr_spectrum_device_ptr(psdr_ctx *c, int frame, const float **d_spec, size_t *nbins) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    if (frame < 0 || frame >= c->max_batch) return fail(PSDR_ERR_INVALID, "frame %d out of range", frame);
+    if (d_spec) *d_spec = (const float *)(c->d_spec + (size_t)frame * c->spec_stride);
+    if (nbins) *nbins = c->is_real ? c->N / 2 + 1 : c->N;
+    return PSDR_OK;
+}
+extern "C" int psdr_quantized_device_ptr(psdr_ctx *c, int frame, const int8_t **d_q, size_t *nbytes) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    if (frame < 0 || frame >= c->max_batch) return fail(PSDR_ERR_INVALID, "frame %d out of range", frame);
+    if (d_q) *d_q = c->d_q + (size_t)frame * c->q_stride;
+    if (nbytes) *nbytes = c->q_len;
+    return PSDR_OK;
+}
+extern "C" int psdr_read_spectrum(psdr_ctx *c, int frame, float *out) {
+    if (!c || !out) return fail(PSDR_ERR_INVALID, "null argument");
+    if (frame < 0 || frame >= c->last_nframes) return fail(PSDR_ERR_INVALID, "frame %d not in the last batch", frame);
+    HIPCHK(hipSetDevice(c->device));
+    return copy_spectrum_k_order(c, frame, (cf *)out);
+}
+extern "C" int psdr_read_quantized(psdr_ctx *c, int frame, int8_t *out) {
+    if (!c || !out) return fail(PSDR_ERR_INVALID, "null argument");
+    if (frame < 0 || frame >= c->last_nframes) return fail(PSDR_ERR_INVALID, "frame %d not in the last batch", frame);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(out, c->d_q + (size_t)frame * c->q_stride, c->q_len, hipMemcpyDeviceToHost,
+                          c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PSDR_OK;
+}
+
+// ---- instrumentation -------------------------------------------------------------------------
+extern "C" int psdr_set_profiling(psdr_ctx *c, int enable) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    resolve_pending(c);
+    c->profiling = enable != 0;
+    return PSDR_OK;
+}
+extern "C" int psdr_get_kernel_stats(psdr_ctx *c, int max_entries, const char **names, double *total_ms,
+                                     int64_t *launches, int *n_out) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    resolve_pending(c);
+    int n = 0;
+    for (int k = 0; k < K_COUNT && n < max_entries; k++) {
+        if (c->k_n[k] == 0) continue;
+        if (names) names[n] = kKernelNames[k];
+        if (total_ms) total_ms[n] = c->k_ms[k];
+        if (launches) launches[n] = c->k_n[k];
+        n++;
+    }
+    if (n_out) *n_out = n;
+    return PSDR_OK;
+}
+extern "C" int psdr_reset_kernel_stats(psdr_ctx *c) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    resolve_pending(c);
+    for (int k = 0; k < K_COUNT; k++) {
+        c->k_ms[k] = 0;
+        c->k_n[k] = 0;
+    }
+    return PSDR_OK;
+}
+extern "C" int psdr_timer_start(psdr_ctx *c) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    HIPCHK(hipEventRecord(c->t0, c->stream));
+    return PSDR_OK;
+}
+extern "C" int psdr_timer_stop_ms(psdr_ctx *c, double *ms_out) {
+    if (!c || !ms_out) return fail(PSDR_ERR_INVALID, "null argument");
+    HIPCHK(hipEventRecord(c->t1, c->stream));
+    HIPCHK(hipEventSynchronize(c->t1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->t0, c->t1));
+    *ms_out = ms;
+    return PSDR_OK;
+}
+extern "C" void *psdr_stream(psdr_ctx *c) { return c ? (void *)c->stream : nullptr; }

@@ -1,0 +1,310 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on the
+same seeded inputs.  Tolerances (north_star): float spectra 1e-4 relative (observed
+~1e-6); audio 1e-4 relative L2; int8 pyramid bit-exact against the quantiser applied to
+the GPU's own spectrum, and >= 99.9 % identical (rest +-1) against the oracle's."""
+import numpy as np
+import pytest
+
+from helpers import quantize_raw, rel_err, rel_l2, synth_stream
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SPEC_TOL = 1e-4
+AUDIO_TOL = 1e-4
+
+
+def levels_for(R, waterfall_size=1024):
+    lv, cur = 0, R
+    while cur >= waterfall_size:
+        lv += 1
+        cur //= 2
+    return max(lv, 1)
+
+
+def halves_f32(N, is_real, nhalves, seed):
+    x = synth_stream(nhalves * (N // 2), is_real, seed, fft_size=N)
+    x = x.astype(np.float32) if is_real else x.astype(np.complex64)
+    return x.reshape(nhalves, N // 2)
+
+
+def check_pyramid(q_gpu, spec_gpu_k, q_orc, N, is_real, levels):
+    q_self = O.pyramid_from_spectrum(spec_gpu_k, N, is_real, levels)
+    assert np.array_equal(q_gpu, q_self), (
+        f"int8 pyramid differs from the reference quantiser applied to the GPU's own spectrum: "
+        f"{(q_gpu != q_self).sum()} of {q_gpu.size}")
+    d = np.abs(q_gpu.astype(np.int16) - q_orc.astype(np.int16))
+    assert d.max() <= 1, f"pyramid differs from oracle by {d.max()} LSB"
+    assert (d != 0).mean() <= 1e-3, f"pyramid mismatch rate {(d != 0).mean():.2e}"
+
+
+@pytest.mark.parametrize("N,is_real", [
+    (1 << 12, 0), (1 << 13, 0), (1 << 14, 0), (1 << 15, 0), (1 << 16, 0), (1 << 17, 0),
+    (1 << 18, 0), (1 << 19, 0), (1 << 20, 0), (1 << 21, 0),
+    (1 << 13, 1), (1 << 14, 1), (1 << 15, 1), (1 << 16, 1), (1 << 17, 1), (1 << 19, 1),
+    (1 << 21, 1), (1 << 22, 1),
+])
+def test_fft_plugin_level1(N, is_real):
+    """HipFFT driven exactly like the reference drives class FFT (src/fft.cpp:17-30,61-98)."""
+    from phantomsdr_amd import HipFFT
+    R = N // 2 if is_real else N
+    levels = levels_for(R)
+    A = 360
+    fo = O.FFT(N, is_real, levels, 0, A)
+    fg = HipFFT(N, 1, levels, 0)
+    fg.set_output_additional_size(A)
+    if is_real:
+        fg.plan_r2c(0)
+    else:
+        fg.plan_c2c(HipFFT.FORWARD, 0)
+    nfl = N // 2 * (1 if is_real else 2)
+    bufs = [fg.malloc(nfl) for _ in range(3)]
+    h = halves_f32(N, is_real, 3, seed=100 + int(np.log2(N)) + 50 * is_real)
+    for b, hh in zip(bufs, h):
+        b[:] = hh.view(np.float32)
+    try:
+        for f in range(2):
+            a1, a2 = bufs[f], bufs[f + 1]
+            if is_real:
+                fg.load_real_input(a1, a2)
+            else:
+                fg.load_complex_input(a1, a2)
+            fg.execute()
+            fo.load(h[f], h[f + 1])
+            fo.execute()
+            Xg = fg.get_output_buffer().copy()
+            Xo = fo.output().copy()
+            nb = N // 2 if is_real else N + A   # real: bin N/2 is compared separately
+            assert rel_err(Xg[:nb], Xo[:nb]) < SPEC_TOL
+            assert rel_l2(Xg[:nb], Xo[:nb]) < 1e-5
+            if is_real:   # unnormalised Nyquist bin (src/fft_impl.cpp:156-160 never visits it)
+                assert abs(Xg[N // 2] - Xo[N // 2]) <= 1e-4 * np.abs(Xo[: N // 2]).max() * N
+            check_pyramid(fg.get_quantized_buffer().copy(), Xg, fo.quantized().copy(), N, is_real, levels)
+    finally:
+        for b in bufs:
+            fg.free(b)
+        fg.close()
+
+
+@pytest.mark.parametrize("is_real", [0, 1])
+@pytest.mark.parametrize("fmt", ["u8", "s8", "u16", "s16", "f32", "f64"])
+def test_process_batch_formats(fmt, is_real):
+    """raw ring in HBM -> device-side convert (src/samplereader.cpp:29-40) -> F frames."""
+    from phantomsdr_amd import Context
+    N, F = 1 << 14, 5
+    R = N // 2 if is_real else N
+    levels = levels_for(R)
+    sigma = 2.0 ** -5 if fmt in ("u8", "s8") else 2.0 ** -9
+    x = synth_stream((F + 1) * (N // 2), is_real, seed=7 + is_real, sigma=sigma, fft_size=N)
+    raw = quantize_raw(x, fmt, is_real)
+    conv = O.convert(raw, fmt)
+    halves = (conv if is_real else conv.view(np.complex64)).reshape(F + 1, N // 2)
+    ctx = Context(N, is_real, levels, input_format=fmt, max_batch=F)
+    try:
+        assert ctx.half_frame_bytes() * (F + 1) == raw.nbytes
+        d = ctx.dev_alloc(raw.nbytes)
+        ctx.h2d(d, raw)
+        ctx.process_batch(d, F)
+        fo = O.FFT(N, is_real, levels)
+        for f in range(F):
+            fo.load(halves[f], halves[f + 1])
+            fo.execute()
+            Xg = ctx.read_spectrum(f)
+            nb = N // 2 if is_real else N
+            assert rel_err(Xg[:nb], fo.output()[:nb]) < SPEC_TOL, f"frame {f}"
+            check_pyramid(ctx.read_quantized(f), Xg, fo.quantized().copy(), N, is_real, levels)
+        ctx.dev_free(d)
+    finally:
+        ctx.close()
+
+
+def run_demod_case(N, is_real, n, clients, nbatches, F, seed, fmt="s16", mode_changes=None):
+    """clients: list of (mode, l, mid, r).  Returns nothing; asserts parity frame by frame."""
+    from phantomsdr_amd import AudioClient, Context
+    R = N // 2 if is_real else N
+    levels = levels_for(R)
+    nframes = nbatches * F
+    x = synth_stream((nframes + 1) * (N // 2), is_real, seed=seed, fft_size=N)
+    raw = quantize_raw(x, fmt, is_real)
+    conv = O.convert(raw, fmt)
+    halves = (conv if is_real else conv.view(np.complex64)).reshape(nframes + 1, N // 2)
+    ctx = Context(N, is_real, levels, additional_size=n, audio_fft_size=n, audio_rate=12000,
+                  input_format=fmt, max_batch=F, max_clients=len(clients))
+    try:
+        d = ctx.dev_alloc(raw.nbytes)
+        ctx.h2d(d, raw)
+        gcl, ocl = [], []
+        for mode, l, mid, r in clients:
+            g = AudioClient(ctx)
+            g.set_audio_demodulation(mode)
+            g.set_audio_range(l, mid, r)
+            gcl.append(g)
+            o = O.AudioClient(is_real, n, 12000, R)
+            o.set_audio_demodulation(mode)
+            o.set_audio_range(l, mid, r)
+            ocl.append(o)
+        fo = O.FFT(N, is_real, levels, 0, n)
+        hb = ctx.half_frame_bytes()
+        frame = 0
+        for b in range(nbatches):
+            if mode_changes and b in mode_changes:
+                for ci, mode in mode_changes[b]:
+                    gcl[ci].set_audio_demodulation(mode)
+                    ocl[ci].set_audio_demodulation(mode)
+            ctx.process_batch(d, F, offset_bytes=b * F * hb)
+            ctx.demod_batch(frame)
+            got = [g.read_audio(F) for g in gcl]
+            for f in range(F):
+                fo.load(halves[frame], halves[frame + 1])
+                fo.execute()
+                spec = fo.output().copy()
+                for ci, o in enumerate(ocl):
+                    a_o, p_o, _, dropped = o.send_audio(spec, frame, fft=fo)
+                    a_g, p_g, nan_g = got[ci][0][f], got[ci][1][f], got[ci][2][f]
+                    assert not dropped and nan_g == 0
+                    tag = f"client {ci} {clients[ci]} frame {frame}"
+                    assert abs(p_g - p_o) <= 1e-4 * max(abs(p_o), 1e-30), tag
+                    scale = max(np.abs(a_o).max(), 1e-30)
+                    if o.mode == O.FM:
+                        # phase of a noisy vector: compare where the discriminator input is
+                        # well conditioned (|angle| away from the +-pi cut)
+                        dd = np.abs(np.angle(np.exp(1j * (a_g.astype(np.float64) - a_o))))
+                        assert dd.max() < 2e-3, f"{tag}: FM max abs err {dd.max():.2e}"
+                    else:
+                        assert rel_l2(a_g, a_o) < AUDIO_TOL, f"{tag}: rel L2 {rel_l2(a_g, a_o):.2e}"
+                        assert np.abs(a_g - a_o).max() <= 2e-4 * scale, tag
+                frame += 1
+        ctx.dev_free(d)
+    finally:
+        ctx.close()
+
+
+def tone_bin(N, is_real, fnorm):
+    """client-coordinate bin of a tone at normalised frequency fnorm (cycles/sample)."""
+    if is_real:
+        return fnorm * N
+    return (fnorm * N - (N // 2 + 1)) % N
+
+
+@pytest.mark.parametrize("N,is_real,n", [(1 << 14, 0, 248), (1 << 15, 1, 360), (1 << 16, 0, 248)])
+def test_demod_all_modes(N, is_real, n):
+    R = N // 2 if is_real else N
+    am = int(tone_bin(N, is_real, 0.11))
+    fm = int(tone_bin(N, is_real, 0.31 if is_real else -0.21))
+    w3, w5 = n // 4, n // 2 - 2
+    clients = [
+        ("USB", am, am + 0.0, am + w3),
+        ("USB", am + 1, am + 1.5, am + 1 + w3),            # odd mid, fractional
+        ("LSB", am - w3, float(am), am),
+        ("LSB", am - w3 + 1, am + 1.25, am + 1),
+        ("AM", am - w5, float(am), am + w5),
+        ("AM", am - w5 + 1, am + 1.0, am + 1 + w5),
+        ("FM", fm - w5, float(fm), fm + w5),
+        ("FM", fm - w5 + 1, fm + 1.75, fm + w5),
+        ("USB", 0, 0.0, w3),                                 # lower edge of the spectrum
+        ("LSB", R - 1 - w3, float(R - 1), R - 1),            # upper edge
+        ("USB", 10, 5.0, 10 + w3),                           # mid left of the slice
+        ("AM", 40, 300.0, 60),                               # mid far outside: empty copy
+        ("USB", 100, 100.0, 100),                            # empty slice
+        ("USB", 200, 200.0, 200 + n),                        # widest slice allowed
+    ]
+    if not is_real:
+        dc = N // 2 - 1                                      # k = 0 sits at c = N/2 - 1
+        clients += [("USB", dc - 10, dc - 10.0, dc + 50),    # slice crossing the k-space wrap
+                    ("AM", dc - w5, float(dc), dc + w5)]
+    run_demod_case(N, is_real, n, clients, nbatches=3, F=4, seed=11 + is_real)
+
+
+def test_demod_mode_switch_keeps_state():
+    """buffers are not reset on a mode change (src/signal.cpp:316-328 only resets the AGC):
+    the SSB tail survives AM frames and vice versa."""
+    N, n = 1 << 14, 248
+    am = int(tone_bin(N, 0, 0.11))
+    clients = [("USB", am, float(am), am + 60), ("AM", am - 100, float(am), am + 100)]
+    changes = {1: [(0, "AM"), (1, "USB")], 2: [(0, "USB"), (1, "FM")], 3: [(0, "LSB"), (1, "AM")]}
+    run_demod_case(N, 0, n, clients, nbatches=4, F=3, seed=21, mode_changes=changes)
+
+
+def test_demod_single_frame_batches():
+    """F = 1: the real-time shape (one frame per call), state carried every call."""
+    N, n = 1 << 14, 248
+    am = int(tone_bin(N, 0, 0.11))
+    fm = int(tone_bin(N, 0, -0.21))
+    clients = [("USB", am, float(am), am + 60), ("AM", am - 100, float(am), am + 100),
+               ("FM", fm - 100, float(fm), fm + 100), ("LSB", am - 60, float(am), am)]
+    run_demod_case(N, 0, n, clients, nbatches=6, F=1, seed=31)
+
+
+@pytest.mark.parametrize("n", [8, 60, 124, 256, 720, 1000, 2048, 2 * 839 * 2, 10068])
+def test_demod_audio_fft_sizes(n):
+    """any multiple of 4, including large prime factors (31, 839) and power-of-two sizes."""
+    N = 1 << 16
+    am = int(tone_bin(N, 0, 0.11))
+    w = min(n // 2 - 1, 400)
+    clients = [("USB", am, float(am), am + min(n // 2, 200)), ("AM", am - w, float(am), am + w),
+               ("LSB", am - min(n // 2, 200), float(am), am)]
+    run_demod_case(N, 0, n, clients, nbatches=2, F=2, seed=41)
+
+
+def test_waterfall_batch():
+    from phantomsdr_amd import Context, WaterfallClient
+    N, is_real, F = 1 << 16, 0, 6
+    R = N
+    levels = levels_for(R)
+    x = synth_stream((F + 1) * (N // 2), is_real, seed=5, fft_size=N)
+    raw = quantize_raw(x, "s16", is_real)
+    ctx = Context(N, is_real, levels, input_format="s16", max_batch=F, max_waterfall_clients=6,
+                  skip_num=2)
+    try:
+        d = ctx.dev_alloc(raw.nbytes)
+        ctx.h2d(d, raw)
+        w_full = WaterfallClient(ctx)                       # default: whole span, coarsest level
+        w_zoom = WaterfallClient(ctx)
+        assert w_zoom.on_window_message(1000, 1000 + 2048)  # picks the level by itself
+        lv, l, r = O.waterfall_pick_level(levels, R >> (levels - 1), 1000, 1000 + 2048)
+        assert (w_zoom.level, w_zoom.l, w_zoom.r) == (lv, l, r)
+        w_l0 = WaterfallClient(ctx)
+        w_l0.set_waterfall_range(0, 12345, 12345 + 1024)
+        w_clamp = WaterfallClient(ctx)
+        w_clamp.set_waterfall_range(levels - 1, 10, 10 ** 6)   # r is clamped to R >> level
+        assert w_clamp.r == R >> (levels - 1)
+        assert not w_full.on_window_message(5, 5)            # rejected (src/waterfall.cpp:56-58)
+        first = 3                                            # frames 3..8: sent = 4, 6, 8
+        ctx.process_batch(d, F)
+        ctx.waterfall_batch(first)
+        sent = [f for f in range(F) if (first + f) % 2 == 0]
+        qs = [ctx.read_quantized(f) for f in range(F)]
+        for w in (w_full, w_zoom, w_l0, w_clamp):
+            got, label = w.read_waterfall()
+            assert got.shape == (len(sent), w.r - w.l)
+            assert label == (w.l << w.level, w.r << w.level)
+            for si, f in enumerate(sent):
+                assert np.array_equal(got[si], ctx.quantized_level(qs[f], w.level)[w.l:w.r])
+        ctx.dev_free(d)
+    finally:
+        ctx.close()
+
+
+def test_error_paths():
+    from phantomsdr_amd import AudioClient, Context, PsdrError
+    with pytest.raises(PsdrError):
+        Context(1000, 0, 1)                                  # not a power of two
+    with pytest.raises(PsdrError):
+        Context(1 << 10, 0, 1)                               # below the supported range
+    ctx = Context(1 << 14, 0, 3, audio_fft_size=248, max_clients=2)
+    try:
+        a, b = AudioClient(ctx), AudioClient(ctx)
+        with pytest.raises(PsdrError):
+            AudioClient(ctx)                                 # slots exhausted
+        assert not a.on_window_message(-1, 5.0, 10)          # src/signal.cpp:305-308
+        assert not a.on_window_message(0, 5.0, 1 << 14)      # r >= fft_result_size
+        assert not a.on_window_message(0, 5.0, 249)          # wider than audio_fft_size
+        assert not a.on_window_message(20, 5.0, 10)
+        assert not a.on_window_message(0, None, 10)          # no `m` in the message
+        assert a.on_window_message(0, 5.0, 248)
+        with pytest.raises(PsdrError):
+            ctx.demod_batch(0)                               # nothing processed yet
+        b.on_close()
+        AudioClient(ctx)                                     # slot is reusable
+    finally:
+        ctx.close()
