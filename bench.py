@@ -1,0 +1,392 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the hot path (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of F consecutive frames of a
+device-resident raw sample ring: windowed 50 %-overlap forward FFT + int8 waterfall
+pyramid, then the per-client slice -> inverse DFT -> demodulation for every audio client
+and the byte gather for every waterfall client.  N=1 workload = BASELINE.json configs[1]:
+35 MSPS-shape IQ cs16, 2^20-point FFT, 16 SSB audio clients + 4 waterfall clients.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `value` is whole-job ingest in MSamples/s (new complex
+samples per second = frames/s * N/2) with the ring already resident in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    "cfg2": dict(sps=35_000_000, fft_size=1 << 20, is_real=False, fmt="s16", audio=16, waterfall=4,
+                 modes=("USB", "LSB"), desc="35 MSPS IQ cs16, 2^20-pt C2C, 16 SSB audio + 4 waterfall clients"),
+    # BASELINE.json configs[2]
+    "cfg3": dict(sps=70_000_000, fft_size=1 << 21, is_real=True, fmt="s16", audio=64, waterfall=0,
+                 modes=("USB", "LSB", "AM", "FM"), desc="70 MSPS real s16, 2^21-pt R2C, 64 mixed AM/FM/SSB clients"),
+    # per-GPU share of BASELINE.json configs[3] (256 audio clients over 8 GPUs)
+    "cfg4": dict(sps=35_000_000, fft_size=1 << 20, is_real=False, fmt="s16", audio=32, waterfall=0,
+                 modes=("USB", "LSB", "AM", "FM"), desc="35 MSPS IQ cs16, 2^20-pt C2C, 32 audio clients per GPU"),
+}
+SAMPLE_BYTES = {"u8": 1, "s8": 1, "u16": 2, "s16": 2, "f32": 4, "f64": 8}
+
+
+def make_clients(wl, params, seed, count=None, first=0):
+    """tuned ranges as in SURVEY 8d: centre uniform over the middle 90 % of [0,R); USB
+    [m, m+3 kHz), LSB (m-3 kHz, m], AM/FM m +- 5 kHz; widths BW*N/sps bins."""
+    rng = np.random.default_rng(seed)
+    R = params["fft_result_size"]
+    N, sps = wl["fft_size"], wl["sps"]
+    b3 = int(3000 * N / sps)
+    b5 = int(5000 * N / sps)
+    out = []
+    total = wl["audio"] if count is None else count
+    for i in range(first + total):
+        mode = wl["modes"][i % len(wl["modes"])]
+        m = int(rng.uniform(0.05 * R, 0.95 * R))
+        if mode == "USB":
+            c = (mode, m, float(m), m + b3)
+        elif mode == "LSB":
+            c = (mode, m - b3, float(m), m)
+        else:
+            c = (mode, m - b5, float(m), m + b5)
+        if i >= first:
+            out.append(c)
+    return out
+
+
+def make_waterfalls(wl, params, seed):
+    rng = np.random.default_rng(seed + 1000)
+    R, levels = params["fft_result_size"], params["downsample_levels"]
+    out = [(levels - 1, 0, R >> (levels - 1))]  # full span at the coarsest level
+    for i in range(1, wl["waterfall"]):
+        lv = int(rng.integers(0, levels - 1))
+        width = 1024
+        l = int(rng.integers(0, (R >> lv) - width))
+        out.append((lv, l, l + width))
+    return out[: wl["waterfall"]]
+
+
+def algorithmic_bytes_per_frame(wl, params, clients, waterfalls):
+    """B_frame = N*S_in + 8*R_spec + Q + C*(8*w + 4*n/2 + 4) + W*2*v"""
+    N, is_real = wl["fft_size"], wl["is_real"]
+    R = params["fft_result_size"]
+    n = params["audio_fft_size"]
+    s_in = SAMPLE_BYTES[wl["fmt"]] * (1 if is_real else 2)
+    r_spec = N // 2 + 1 if is_real else N
+    q = sum(R >> i for i in range(params["downsample_levels"]))
+    b_in, b_spec, b_q = N * s_in, 8 * r_spec, q
+    b_cl = sum(8 * (r - l) + 4 * (n // 2) + 4 for _, l, _, r in clients)
+    b_wf = sum(2 * (r - l) for _, l, r in waterfalls) / params["skip_num"]
+    return dict(input=b_in, spectrum=b_spec, pyramid=b_q, clients=b_cl, waterfall=b_wf,
+                total=b_in + b_spec + b_q + b_cl + b_wf)
+
+
+def gen_ring_torch(torch, device, nhalves, N, is_real, seed):
+    """synthetic raw ring on the GPU: white Gaussian noise at sigma = 2^-9 FS plus 8 CW
+    tones, quantised to s16 (interleaved I/Q for IQ)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    comps = 1 if is_real else 2
+    half = (N // 2) * comps
+    ring = torch.empty((nhalves, half), dtype=torch.int16, device=device)
+    rng = np.random.default_rng(seed)
+    tones = [(rng.uniform(-0.45, 0.45), rng.uniform(0.3, 1.0), rng.uniform(0, 6.28)) for _ in range(8)]
+    amp = (2.0 if is_real else 1.0) / np.sqrt(N)
+    for h in range(nhalves):
+        t = torch.arange(h * (N // 2), (h + 1) * (N // 2), device=device, dtype=torch.float64)
+        x = torch.randn((N // 2, comps), generator=g, device=device, dtype=torch.float32) * (2.0 ** -9)
+        for f, a, ph in tones:
+            arg = (2 * np.pi * f) * t + ph
+            x[:, 0] += (amp * a * torch.cos(arg)).float()
+            if not is_real:
+                x[:, 1] += (amp * a * torch.sin(arg)).float()
+        ring[h] = torch.clamp(torch.round(x * 32768.0), -32768, 32767).to(torch.int16).reshape(-1)
+    return ring
+
+
+def cpu_baseline(wl, params, clients, waterfalls, budget_s=15.0):
+    """The oracle ("port") timed on this host's cores over a bounded sample of the same
+    workload: forward FFT + pyramid (all OpenMP threads) + every client's send_audio."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    O.set_threads(cores)
+    N, is_real = wl["fft_size"], wl["is_real"]
+    n, levels = params["audio_fft_size"], params["downsample_levels"]
+    rng = np.random.default_rng(1)
+    nh = 4
+    if is_real:
+        halves = (rng.standard_normal((nh, N // 2)) * 2.0 ** -9).astype(np.float32)
+    else:
+        halves = ((rng.standard_normal((nh, N // 2)) + 1j * rng.standard_normal((nh, N // 2))) * 2.0 ** -9).astype(np.complex64)
+    fo = O.FFT(N, is_real, levels, 0, n)
+    ocl = []
+    for mode, l, m, r in clients:
+        c = O.AudioClient(is_real, n, 12000, params["fft_result_size"])
+        c.set_audio_demodulation(mode)
+        c.set_audio_range(l, m, r)
+        ocl.append(c)
+    frames = 0
+    fo.load(halves[0], halves[1])
+    fo.execute()  # warm-up
+    t0 = time.perf_counter()
+    while True:
+        fo.load(halves[frames % (nh - 1)], halves[frames % (nh - 1) + 1])
+        fo.execute()
+        spec = fo.output()
+        for c in ocl:
+            c.send_audio(spec, frames, fft=fo)
+        if frames % params["skip_num"] == 0:
+            q = fo.quantized()
+            for lv, l, r in waterfalls:
+                off = sum(params["fft_result_size"] >> t for t in range(lv))
+                _ = q[off + l: off + r].tobytes()
+        frames += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or frames >= 2000:
+            break
+    msps = frames * (N // 2) / dt / 1e6
+    return {"value": round(msps, 3), "unit": "MSamples/s", "cores": cores, "kind": "port",
+            "sample": f"{frames} frames of the same workload in {dt:.1f} s (oracle/psdr_oracle.c, "
+                      f"OpenMP {cores} threads for the FFT/pyramid, clients serial)"}
+
+
+def run_sharded_bench(args, torch, rank, world, local_rank):
+    """N > 1 (BASELINE.json configs[3] shape): audio clients sharded over the ranks
+    (32 per GPU, 256 at 8 GPUs); rank 0 ingests + FFTs and broadcasts each spectrum batch
+    over RCCL/xGMI; every rank demodulates its own clients.  scaling = weak in clients."""
+    import torch.distributed as dist
+    from phantomsdr_amd import SpectrumEngine
+    from phantomsdr_amd.distributed import HipBackend, ShardedRunner, assign_clients
+
+    device = torch.device("cuda", local_rank)
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    wl = WORKLOADS[args.workload or "cfg4"]
+    F, N = args.batch, wl["fft_size"]
+    per_gpu = wl["audio"]
+    eng = SpectrumEngine(wl["sps"], N, wl["is_real"], input_format=wl["fmt"], max_batch=F,
+                         max_clients=per_gpu, max_waterfall_clients=1, device=local_rank)
+    params = eng.params
+    hb = eng.ctx.half_frame_bytes()
+    nbatches = max(1, (args.ring_mib * (1 << 20)) // (hb * F))
+    ring = None
+    ring_ptr = 0
+    if rank == 0:
+        ring = gen_ring_torch(torch, device, nbatches * F + 1, N, wl["is_real"], seed=0x5D5D0004)
+        ring_ptr = ring.data_ptr()
+    all_clients = make_clients(wl, params, seed=0x5D5D0004, count=per_gpu * world)
+    mine = assign_clients(len(all_clients), world)[rank]
+    for cid in mine:
+        mode, l, m, r = all_clients[cid]
+        eng.add_audio_client(l, m, r, mode)
+    torch.cuda.synchronize()
+    backend = HipBackend(torch, eng.ctx, device, ring_ptr, nbatches, F)
+    runner = ShardedRunner(backend, dist, rank, world, F)
+
+    for i in range(args.warmup):
+        runner.step(i)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    runner.bytes_broadcast = 0
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        runner.step(args.warmup + i)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    frames = args.steps * F
+    msps = frames * (N // 2) / dt / 1e6
+    if rank == 0:
+        mine_cl = [all_clients[c] for c in mine]
+        ab = algorithmic_bytes_per_frame(wl, params, mine_cl, [])
+        out = {
+            "metric": "ingest MSamples/s + concurrent audio clients at 2^20-pt FFT",
+            "value": round(msps, 2), "unit": "MSamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "cfg4: " + wl["desc"] + f" ({per_gpu * world} clients total)",
+                       "frames_per_step": F, "fft_size": N, "audio_clients": per_gpu * world,
+                       "parallelism": f"clients sharded over {world} GPUs (client i -> rank i mod G); "
+                                      "rank 0 FFT + RCCL broadcast of the spectrum batch",
+                       "realtime_factor": round(msps * 1e6 / wl["sps"], 1)},
+            "roofline": None,
+            "path": {"algorithmic_bytes_per_frame_root": int(ab["total"]),
+                     "frames_per_s": round(frames / dt, 1),
+                     "frac_of_hbm_peak_root": round(ab["total"] * frames / dt / HBM_PEAK, 4)},
+            "xgmi": {"broadcast_bytes_per_frame": 8 * N,
+                     "GB_per_s_per_link": round(runner.bytes_broadcast / dt / 1e9, 2) if world > 1 else None,
+                     "link_peak_GB_per_s": 153.0},
+            "cpu_baseline": None,
+        }
+        print(json.dumps(out))
+    eng.close()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=16, help="frames per step (F)")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ring-mib", type=int, default=512)
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the multi-GPU code path even with one rank (testing)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    if world > 1 or args.force_sharded:
+        return run_sharded_bench(args, torch, rank, world, local_rank)
+
+    from phantomsdr_amd import SpectrumEngine
+    wl_name = args.workload or "cfg2"
+    wl = WORKLOADS[wl_name]
+    F = args.batch
+    eng = SpectrumEngine(wl["sps"], wl["fft_size"], wl["is_real"], input_format=wl["fmt"],
+                         max_batch=F, max_clients=max(wl["audio"], 1),
+                         max_waterfall_clients=max(wl["waterfall"], 1), device=local_rank)
+    params = eng.params
+    N = wl["fft_size"]
+    hb = eng.ctx.half_frame_bytes()
+    # ring > 256 MiB Infinity Cache; a whole number of batches (+1 trailing half)
+    nbatches = max(1, (args.ring_mib * (1 << 20)) // (hb * F))
+    nhalves = nbatches * F + 1
+    ring = gen_ring_torch(torch, device, nhalves, N, wl["is_real"], seed=0x5D5D0002)
+    torch.cuda.synchronize()
+    eng.ring = None
+    ring_ptr = ring.data_ptr()
+
+    clients = make_clients(wl, params, seed=0x5D5D0002)
+    waterfalls = make_waterfalls(wl, params, seed=0x5D5D0002)
+    for mode, l, m, r in clients:
+        eng.add_audio_client(l, m, r, mode)
+    for lv, l, r in waterfalls:
+        eng.add_waterfall_client(lv, l, r)
+
+    def step(i):
+        b = i % nbatches
+        eng.ctx.process_batch(ring_ptr, F, offset_bytes=b * F * hb)
+        if clients:
+            eng.ctx.demod_batch(eng.frame_num)
+        if waterfalls:
+            eng.ctx.waterfall_batch(eng.frame_num)
+        eng.frame_num += F
+
+    for i in range(args.warmup):
+        step(i)
+    eng.ctx.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    eng.ctx.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    frames = args.steps * F
+    msps = frames * (N // 2) / dt / 1e6
+    ms_per_step = dt / args.steps * 1e3
+
+    # per-kernel durations with hipEvents on the library's own stream (second, profiled
+    # replay of the same steps so that the events do not perturb `value`)
+    eng.ctx.set_profiling(True)
+    eng.ctx.reset_kernel_stats()
+    prof_steps = min(args.steps, 50)
+    for i in range(prof_steps):
+        step(args.warmup + i)
+    eng.ctx.synchronize()
+    stats = eng.ctx.kernel_stats()
+    eng.ctx.set_profiling(False)
+
+    ab = algorithmic_bytes_per_frame(wl, params, clients, waterfalls)
+    # algorithmic bytes by kernel (DESIGN.md "Roofline accounting"): pass 1 reads the raw
+    # input once; pass 2 (+fused epilogue) writes the spectrum and pyramid levels < 5; the
+    # demod kernels read slices and write audio; intermediates count zero.
+    per_kernel_bytes = {
+        "fft_pass1": ab["input"] * F,
+        "fft_pass2": (ab["spectrum"] + (ab["pyramid"] if not wl["is_real"] else 0)) * F,
+        "untangle_real": (ab["spectrum"] + ab["pyramid"]) * F if wl["is_real"] else 0,
+        "demod_idft": ab["clients"] * F,
+    }
+    kernels = {}
+    for name, (ms, cnt) in stats.items():
+        kernels[name] = {"avg_us": round(ms / cnt * 1e3, 3), "launches": int(cnt)}
+    dom = max(stats, key=lambda k: stats[k][0]) if stats else None
+    roofline = None
+    if dom:
+        avg_s = stats[dom][0] / stats[dom][1] / 1e3
+        achieved = per_kernel_bytes.get(dom, 0) / avg_s
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(wl_name, {}).get(dom)
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": int(per_kernel_bytes.get(dom, 0)),
+                    "avg_launch_us": round(avg_s * 1e6, 2)}
+    path_frac = ab["total"] * (frames / dt) / HBM_PEAK
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(wl, params, clients, waterfalls)
+        except Exception as e:  # the oracle is optional for the measured value
+            cpu = {"error": repr(e)}
+
+    out = {
+        "metric": "ingest MSamples/s + concurrent audio clients at 2^20-pt FFT",
+        "value": round(msps, 2), "unit": "MSamples/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wl_name + ": " + wl["desc"], "frames_per_step": F,
+                   "fft_size": N, "audio_clients": len(clients), "waterfall_clients": len(waterfalls),
+                   "audio_fft_size": params["audio_fft_size"], "ring_MiB": round(nhalves * hb / 2 ** 20, 1),
+                   "realtime_factor": round(msps * 1e6 / wl["sps"], 1)},
+        "roofline": roofline,
+        "path": {"algorithmic_bytes_per_frame": int(ab["total"]), "frames_per_s": round(frames / dt, 1),
+                 "frac_of_hbm_peak": round(path_frac, 4), "kernels": kernels},
+        "cpu_baseline": cpu,
+    }
+    eng.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

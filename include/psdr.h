@@ -130,6 +130,11 @@ int psdr_client_set_audio_demodulation(psdr_ctx *ctx, int id, int mode);
  * active client over the frames of the last psdr_process_batch.  first_frame_num is the
  * server's frame counter of the first frame (flip parity, src/signal.cpp:160-168,223). */
 int psdr_demod_batch(psdr_ctx *ctx, uint64_t first_frame_num);
+/* same, but reading nframes spectra from a caller-supplied device buffer (client order for
+ * IQ, k order for real; frame_stride_bins complex bins between frames): used when the
+ * spectrum was produced on another GPU and received over xGMI. */
+int psdr_demod_batch_from(psdr_ctx *ctx, const float *d_spec, size_t frame_stride_bins,
+                          int nframes, uint64_t first_frame_num);
 /* results of the last demod batch for one client: audio [nframes][n/2] floats (the
  * demodulated, overlap-added samples handed to the DC blocker at src/signal.cpp:278),
  * pwr [nframes] (average_power, src/signal.cpp:117-119), nan_flags [nframes] (1 = the
@@ -175,6 +180,9 @@ int psdr_timer_start(psdr_ctx *ctx);
 int psdr_timer_stop_ms(psdr_ctx *ctx, double *ms_out);
 /* the HIP stream (hipStream_t) the context launches on, for interop */
 void *psdr_stream(psdr_ctx *ctx);
+/* enqueue on the caller's stream instead (e.g. the stream RCCL collectives are ordered
+ * against); NULL restores the context's own stream */
+int psdr_set_stream(psdr_ctx *ctx, void *hip_stream);
 
 #ifdef __cplusplus
 }

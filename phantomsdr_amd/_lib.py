@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libpsdr_hip.so")
+# PSDR_LIB selects another build of the same library (kernel tuning variants)
+_SO = os.environ.get("PSDR_LIB") or os.path.join(_HERE, "libpsdr_hip.so")
 
 
 class PsdrError(RuntimeError):
@@ -52,6 +53,7 @@ SYMBOLS = [
     ("psdr_client_on_window_message", _i, [_vp, _i, _i, C.c_double, _i]),
     ("psdr_client_set_audio_demodulation", _i, [_vp, _i, _i]),
     ("psdr_demod_batch", _i, [_vp, _u64]),
+    ("psdr_demod_batch_from", _i, [_vp, _vp, _sz, _i, _u64]),
     ("psdr_read_audio", _i, [_vp, _i, _vp, _vp, _vp]),
     ("psdr_audio_device_ptr", _i, [_vp, _i, _pp, _pp]),
     ("psdr_waterfall_add", _i, [_vp, C.POINTER(_i)]),
@@ -72,6 +74,7 @@ SYMBOLS = [
     ("psdr_timer_start", _i, [_vp]),
     ("psdr_timer_stop_ms", _i, [_vp, C.POINTER(C.c_double)]),
     ("psdr_stream", _vp, [_vp]),
+    ("psdr_set_stream", _i, [_vp, _vp]),
 ]
 
 _lib = None

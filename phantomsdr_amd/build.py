@@ -23,15 +23,16 @@ def is_stale():
     return any(os.path.getmtime(s) > t for s in sources())
 
 
-def build_extension(force=False, verbose=False):
+def build_extension(force=False, verbose=False, out=None, defines=()):
     """hipcc --offload-arch=gfx950 ... -> phantomsdr_amd/libpsdr_hip.so"""
-    if not force and not is_stale():
+    out = out or OUT
+    if not force and out == OUT and not is_stale():
         return OUT
-    cmd = [HIPCC] + FLAGS + ["-o", OUT, SRC]
+    cmd = [HIPCC] + FLAGS + [f"-D{d}" for d in defines] + ["-o", out, SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -124,7 +124,8 @@ struct psdr_ctx {
     int LT = 0;  // pyramid levels finished inside the fused kernel
     size_t p_stride = 0;
     int max_batch = 1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream work is enqueued on
+    hipStream_t own_stream = nullptr;  // created by the context (default for `stream`)
 
     float *d_window = nullptr;
     cf *d_Wl1 = nullptr, *d_Wl2 = nullptr, *d_TA = nullptr, *d_TB = nullptr;
@@ -445,13 +446,14 @@ void free_all(psdr_ctx *c) {
     for (auto e : c->pool) hipEventDestroy(e);
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
-    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
 }
 
 int build(psdr_ctx *c) {
     const psdr_config &g = c->cfg;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
     HIPCHK(hipEventCreate(&c->t0));
     HIPCHK(hipEventCreate(&c->t1));
 
@@ -864,10 +866,8 @@ extern "C" int psdr_client_set_audio_demodulation(psdr_ctx *c, int id, int mode)
     return PSDR_OK;
 }
 
-extern "C" int psdr_demod_batch(psdr_ctx *c, uint64_t first_frame_num) {
-    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nframes, uint64_t first_frame_num) {
     if (c->n <= 0) return fail(PSDR_ERR_STATE, "context created with audio_fft_size 0");
-    if (c->last_nframes < 1) return fail(PSDR_ERR_STATE, "demod_batch before process_batch/execute");
     HIPCHK(hipSetDevice(c->device));
     int nact = 0;
     const int ring = c->client_ring.acquire();
@@ -888,16 +888,16 @@ extern "C" int psdr_demod_batch(psdr_ctx *c, uint64_t first_frame_num) {
             s.state_cur ^= 1;
         }
     }
-    c->last_demod_frames = c->last_nframes;
+    c->last_demod_frames = nframes;
     if (nact == 0) return PSDR_OK;
     HIPCHK(hipMemcpyAsync(d_clients, h_clients, (size_t)nact * sizeof(ClientParams),
                           hipMemcpyHostToDevice, c->stream));
     DemodArgs a{};
-    a.spec = c->d_spec;
-    a.spec_stride = c->spec_stride;
+    a.spec = spec;
+    a.spec_stride = spec_stride;
     a.is_real = c->is_real ? 1 : 0;
     a.n = c->n;
-    a.nframes = c->last_nframes;
+    a.nframes = nframes;
     a.max_batch = c->max_batch;
     a.first_frame_num = first_frame_num;
     a.clients = d_clients;
@@ -916,17 +916,32 @@ extern "C" int psdr_demod_batch(psdr_ctx *c, uint64_t first_frame_num) {
     a.slots = (int)c->aslots.size();
     {
         ProfScope ps(c, K_IDFT);
-        hipLaunchKernelGGL(k_demod_idft, dim3(nact, c->last_nframes), dim3(256), c->idft_lds, c->stream,
+        hipLaunchKernelGGL(k_demod_idft, dim3(nact, nframes), dim3(256), c->idft_lds, c->stream,
                            a);
         HIPCHK(hipGetLastError());
     }
     {
         ProfScope ps(c, K_OLA);
-        hipLaunchKernelGGL(k_demod_ola, dim3(nact, c->last_nframes), dim3(128), 0, c->stream, a);
+        hipLaunchKernelGGL(k_demod_ola, dim3(nact, nframes), dim3(128), 0, c->stream, a);
         HIPCHK(hipGetLastError());
     }
     c->client_ring.release(ring, c->stream);
     return PSDR_OK;
+}
+
+extern "C" int psdr_demod_batch(psdr_ctx *c, uint64_t first_frame_num) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    if (c->last_nframes < 1) return fail(PSDR_ERR_STATE, "demod_batch before process_batch/execute");
+    return demod_impl(c, c->d_spec, c->spec_stride, c->last_nframes, first_frame_num);
+}
+extern "C" int psdr_demod_batch_from(psdr_ctx *c, const float *d_spec, size_t frame_stride_bins,
+                                     int nframes, uint64_t first_frame_num) {
+    if (!c || !d_spec) return fail(PSDR_ERR_INVALID, "null argument");
+    if (nframes < 1 || nframes > c->max_batch)
+        return fail(PSDR_ERR_INVALID, "nframes %d outside [1, max_batch=%d]", nframes, c->max_batch);
+    if (frame_stride_bins < (c->is_real ? c->N / 2 + 1 : c->N))
+        return fail(PSDR_ERR_INVALID, "frame stride smaller than one spectrum");
+    return demod_impl(c, (const cf *)d_spec, frame_stride_bins, nframes, first_frame_num);
 }
 
 extern "C" int psdr_read_audio(psdr_ctx *c, int id, float *audio, float *pwr, int32_t *nan_flags) {
@@ -1181,3 +1196,10 @@ extern "C" int psdr_timer_stop_ms(psdr_ctx *c, double *ms_out) {
     return PSDR_OK;
 }
 extern "C" void *psdr_stream(psdr_ctx *c) { return c ? (void *)c->stream : nullptr; }
+extern "C" int psdr_set_stream(psdr_ctx *c, void *hip_stream) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    resolve_pending(c);
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return PSDR_OK;
+}

@@ -1,0 +1,114 @@
+"""Multi-GPU operation: one process per GPU, `torch.distributed` (backend
+"nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+The reference has no multi-GPU path; this is new design.  After ONE exchange step the
+audio clients are independent units, so they shard across ranks:
+
+  rank 0 ("ingest")  owns the raw sample ring, runs the forward FFT + waterfall pyramid
+                     and serves the waterfall clients (they only read the int8 pyramid);
+  every rank         receives the normalised spectrum batch (F x N complex64, client
+                     order, 8*N bytes per frame) through ONE broadcast per batch and
+                     demodulates its own clients: client i lives on rank i mod G, its
+                     overlap-add state never leaves that GPU.
+
+xGMI is point to point (7 links x ~153 GB/s per GPU), so a 1 -> G-1 broadcast is bound
+per link: 8.39 MB per 2^20-point frame / 153 GB/s = 55 us/frame; frames are batched F per
+collective to amortise the launch.  With G = 1 there is no collective at all.
+
+The orchestration below is backend-agnostic (the compute back-end is injected), so the
+sharding and the exchange are covered by world_size-2 gloo tests on CPU
+(tests/test_distributed_cpu.py) with the oracle as compute stand-in, and by the HIP
+back-end on the GPUs.
+"""
+import numpy as np
+
+
+def assign_clients(nclients, world):
+    """client i -> rank i mod G (SURVEY 8e "gpu = hash(client_id) mod G")."""
+    return [list(range(r, nclients, world)) for r in range(world)]
+
+
+class ShardedRunner:
+    """Drives one batch per step() on every rank.
+
+    backend must provide:
+      forward(step_index)      rank 0 only: fill spectrum_tensor() with F fresh spectra
+      spectrum_tensor()        torch tensor (same shape/dtype on every rank) to broadcast
+      demod(first_frame_num)   demodulate this rank's clients from spectrum_tensor()
+    """
+
+    def __init__(self, backend, dist, rank, world, frames_per_step, root=0):
+        self.backend, self.dist = backend, dist
+        self.rank, self.world, self.F, self.root = rank, world, frames_per_step, root
+        self.frame_num = 0
+        self.bytes_broadcast = 0
+
+    def step(self, i):
+        if self.rank == self.root:
+            self.backend.forward(i)
+        if self.world > 1:
+            t = self.backend.spectrum_tensor()
+            self.dist.broadcast(t, src=self.root)
+            self.bytes_broadcast += t.numel() * t.element_size()
+        self.backend.demod(self.frame_num)
+        self.frame_num += self.F
+
+
+class _CudaArray:
+    """minimal __cuda_array_interface__ carrier so torch can alias library-owned HBM"""
+
+    def __init__(self, ptr, nelem, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(nelem),), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2}
+
+
+def alias_device_f32(torch, ptr, nfloats, device):
+    """torch float32 tensor aliasing `nfloats` floats of device memory at `ptr`"""
+    return torch.as_tensor(_CudaArray(ptr, nfloats, "<f4"), device=device)
+
+
+class HipBackend:
+    """ShardedRunner back-end on the HIP library: every rank owns a Context; the
+    broadcast lands directly in the context's own spectrum buffer."""
+
+    def __init__(self, torch, ctx, device, ring_ptr, nbatches, frames_per_step):
+        import ctypes as C
+        self.torch, self.ctx, self.F = torch, ctx, frames_per_step
+        self.ring_ptr, self.nbatches = ring_ptr, nbatches
+        self.hb = ctx.half_frame_bytes()
+        p, nb = C.c_void_p(), C.c_size_t()
+        from ._lib import check
+        check(ctx.lib.psdr_spectrum_device_ptr(ctx.h, 0, C.byref(p), C.byref(nb)))
+        self.spec_ptr = p.value
+        self.stride_bins = ctx.N if not ctx.is_real else ctx.N // 2 + 2
+        self.spec = alias_device_f32(torch, self.spec_ptr, self.F * self.stride_bins * 2, device)
+        # one stream for the kernels and the collective's ordering
+        check(ctx.lib.psdr_set_stream(ctx.h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def forward(self, i):
+        b = i % self.nbatches
+        self.ctx.process_batch(self.ring_ptr, self.F, offset_bytes=b * self.F * self.hb)
+
+    def spectrum_tensor(self):
+        return self.spec
+
+    def demod(self, first_frame_num):
+        import ctypes as C
+        from ._lib import check
+        check(self.ctx.lib.psdr_demod_batch_from(self.ctx.h, C.c_void_p(self.spec_ptr),
+                                                 self.stride_bins, self.F, first_frame_num))
+        self.ctx.last_nframes = self.F
+
+
+def gather_audio_to_root(dist, rank, world, local_ids, local_audio, nclients, root=0):
+    """collects per-client audio blocks [F][n/2] on the root in global client order
+    (results normally go to the host directly from each GPU; this is for tests/tools)."""
+    payload = {cid: np.asarray(a) for cid, a in zip(local_ids, local_audio)}
+    out = [None] * world
+    dist.all_gather_object(out, payload)
+    if rank != root:
+        return None
+    merged = {}
+    for d in out:
+        merged.update(d)
+    return [merged[i] for i in range(nclients)]

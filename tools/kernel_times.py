@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Per-kernel hipEvent timings of the cfg2-shaped hot path (used for ablations/tuning).
+  PSDR_LIB=<variant .so> python tools/kernel_times.py [--fft 20] [--real] [--batch 16]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--fft", type=int, default=20)
+ap.add_argument("--real", action="store_true")
+ap.add_argument("--batch", type=int, default=16)
+ap.add_argument("--steps", type=int, default=40)
+ap.add_argument("--clients", type=int, default=16)
+ap.add_argument("--ring-mib", type=int, default=512)
+ap.add_argument("--tag", default="")
+args = ap.parse_args()
+
+from phantomsdr_amd import SpectrumEngine  # noqa: E402
+
+N, F = 1 << args.fft, args.batch
+sps = 70_000_000 if args.real else 35_000_000
+eng = SpectrumEngine(sps, N, args.real, input_format="s16", max_batch=F, max_clients=max(args.clients, 1),
+                     max_waterfall_clients=4)
+hb = eng.ctx.half_frame_bytes()
+nb = max(1, (args.ring_mib << 20) // (hb * F))
+rng = np.random.default_rng(0)
+raw = rng.integers(-64, 64, size=(nb * F + 1) * hb // 2, dtype=np.int16)
+eng.upload_ring(raw)
+R = eng.params["fft_result_size"]
+for i in range(args.clients):
+    m = int(rng.uniform(0.05 * R, 0.95 * R))
+    eng.add_audio_client(m, float(m), m + 89, "USB" if i % 2 == 0 else "LSB")
+eng.add_waterfall_client()
+for i in range(5):
+    eng.step((i % nb) * F, F)
+eng.ctx.synchronize()
+eng.ctx.set_profiling(True)
+eng.ctx.reset_kernel_stats()
+eng.ctx.timer_start()
+for i in range(args.steps):
+    eng.step((i % nb) * F, F)
+total_ms = eng.ctx.timer_stop_ms()
+st = eng.ctx.kernel_stats()
+out = {"tag": args.tag or os.environ.get("PSDR_LIB", "default"), "N": N, "F": F,
+       "us_per_frame_total": round(total_ms * 1e3 / (args.steps * F), 3)}
+for k, (ms, cnt) in st.items():
+    out[k] = round(ms / cnt * 1e3, 2)
+print(json.dumps(out))
+eng.close()
