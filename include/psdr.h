@@ -163,6 +163,8 @@ int psdr_read_waterfall(psdr_ctx *ctx, int id, int8_t *out, size_t out_cap, int 
 /* spectrum of frame f: IQ: N complex bins in CLIENT order c (bin k = (c+N/2+1) mod N);
  * real: N/2+1 bins in k order.  Normalised by 1/N exactly like src/fft_impl.cpp:34-35. */
 int psdr_spectrum_device_ptr(psdr_ctx *ctx, int frame, const float **d_spec, size_t *nbins);
+/* (level-major layout as in the reference; materialised on demand from the device's tiled
+ * records, so this call synchronises) */
 int psdr_quantized_device_ptr(psdr_ctx *ctx, int frame, const int8_t **d_q, size_t *nbytes);
 /* copies of the same to host; spectrum is delivered in the reference's k order */
 int psdr_read_spectrum(psdr_ctx *ctx, int frame, float *out_k_order);

@@ -148,13 +148,15 @@ __global__ __launch_bounds__(256) void k_untangle_real(UntangleArgs a) {
 struct WfClient {
     int level, l, r;
     int active;
-    size_t qoff;     // byte offset of `level` inside a frame's int8 buffer
+    size_t qoff;     // byte offset of `level` inside a frame's level-major int8 buffer
     size_t out_off;  // byte offset of this client's output block
 };
 
-// one work-group row per (client, sent frame): copies q_level[l..r)
+// one work-group row per (client, sent frame): copies q_level[l..r).  Levels <= tiled_lt live
+// in the tiled records (quantize.h), the upper levels in the level-major buffer.
 __global__ __launch_bounds__(256) void k_waterfall_gather(const int8_t *Q, size_t q_stride,
-                                                          const WfClient *cl, const int *sent_frames,
+                                                          const int8_t *Qt, size_t qt_stride, int tiled_lt,
+                                                          int ch, const WfClient *cl, const int *sent_frames,
                                                           int nsent, int8_t *out) {
     const WfClient c = cl[blockIdx.x];
     if (!c.active) return;
@@ -162,9 +164,34 @@ __global__ __launch_bounds__(256) void k_waterfall_gather(const int8_t *Q, size_
     if (si >= nsent) return;
     const int f = sent_frames[si];
     const int len = c.r - c.l;
-    const int8_t *src = Q + (size_t)f * q_stride + c.qoff + c.l;
     int8_t *dst = out + c.out_off + (size_t)si * len;
-    for (int i = threadIdx.x; i < len; i += blockDim.x) dst[i] = src[i];
+    if (c.level <= tiled_lt) {
+        const int8_t *src = Qt + (size_t)f * qt_stride;
+        const int per = ch >> c.level;  // values of this level per record
+        const int loff = tiled_level_offset(ch, c.level);
+        for (int i = threadIdx.x; i < len; i += blockDim.x) {
+            const size_t j = (size_t)c.l + i;
+            dst[i] = src[(j / per) * (2 * ch) + loff + (j % per)];
+        }
+    } else {
+        const int8_t *src = Q + (size_t)f * q_stride + c.qoff + c.l;
+        for (int i = threadIdx.x; i < len; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+// tiled records -> the reference's level-major layout (levels 0..tiled_lt of one frame)
+__global__ __launch_bounds__(256) void k_untile_q(const int8_t *Qt, int8_t *Q, size_t R, int ch, int tiled_lt,
+                                                  int nlevels) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // record
+    if (g >= R / ch) return;
+    const int8_t *rec = Qt + g * (2 * ch);
+    size_t qoff = 0;
+    for (int lv = 0; lv <= tiled_lt && lv < nlevels; lv++) {
+        const int per = ch >> lv;
+        const int loff = tiled_level_offset(ch, lv);
+        for (int i = 0; i < per; i++) Q[qoff + g * per + i] = rec[loff + i];
+        qoff += R >> lv;
+    }
 }
 
 }  // namespace psdr

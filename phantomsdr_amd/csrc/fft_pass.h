@@ -15,11 +15,24 @@
 // c1 = (k1-1) mod M1 with twiddle (-1)^{n2} W_M^{n2*(c1+1)}; no input modulation, so
 // the arithmetic is that of an ordinary FFT.
 //
-// Work-group = one tile of T sequences x L points (L*T = 16K complex, 128 KiB LDS),
-// (L/16)*T threads; every thread owns the 16 points {i0 + e*L/16} of one sequence at
-// every stage and performs 16/R radix-R butterflies per stage (R in {16,8,4,2}); lanes
-// run along the T (contiguous-in-HBM) dimension, so stage traffic in LDS is
-// conflict-free and HBM segments are T*8 bytes.
+// Execution shape (what the MI355X wants, from measurement — profiles/r01_*):
+//  * a tile of T sequences x L points (L*T = 16K complex = 128 KiB) lives in LDS, so one
+//    work-group owns a CU; a CU can only pull ~10 B/clk from HBM, so memory time and
+//    butterfly time must OVERLAP inside that one work-group: kernels are persistent (one
+//    work-group per CU walks the tile slots) and the global loads of the NEXT tile are
+//    issued into registers before the current tile's butterflies start.
+//  * that needs > 128 VGPRs, so a work-group is 512 threads (2 waves/SIMD, 256 VGPRs)
+//    and each thread plays V = 2 "virtual threads" of the 1024-point-wide schedule.
+//  * every virtual thread owns the 16 points {i0 + e*L/16} of one sequence at every
+//    stage and performs 16/R radix-R butterflies per stage (R in {16,8,4,2}); lanes run
+//    along the T (contiguous-in-HBM) dimension: stage traffic in LDS is conflict-free.
+//  * HBM segments shorter than 128 B run at a fraction of the bandwidth (64-B raw
+//    segments measured 1.4 TB/s), so for <= 16-bit sample formats pass 1 loads TWO
+//    adjacent columns per virtual thread (8-byte loads, 128-B segments for cs16) and
+//    runs the two column sets through the LDS tile one after the other.
+//  * the Hann window is evaluated on the fly from the twiddle tables
+//    (w = 0.5 - 0.5*Re(W_M1^{n1} * W_M^{n2})), the inter-pass twiddles by short power
+//    recurrences from three table look-ups per column: no per-point table traffic.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,6 +42,20 @@
 
 #ifndef PSDR_ABL
 #define PSDR_ABL 0  // ablation bitmask, tuning builds only (tools/ablate.sh)
+#endif
+
+#define PSDR_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// phase timestamps of work-group 0 (debug builds of the tuning tools only)
+#ifdef PSDR_TRACE_ON
+#define PSDR_TRACE(buf, it, k)                                                      \
+    do {                                                                            \
+        if ((buf) && threadIdx.x == 0 && blockIdx.x == 0 && (it) < 8)               \
+            (buf)[(it) * 16 + (k)] = __builtin_readcyclecounter();                  \
+    } while (0)
+#else
+#define PSDR_TRACE(buf, it, k) \
+    do {                       \
+    } while (0)
 #endif
 
 namespace psdr {
@@ -59,6 +86,12 @@ template <>
 struct Plan<2048> {
     static constexpr int NS = 3, R0 = 16, R1 = 16, R2 = 8;
 };
+template <int L>
+struct LastStage {
+    using P = Plan<L>;
+    static constexpr int R = P::NS == 2 ? P::R1 : P::R2;
+    static constexpr int Pp = L / R;  // product of the earlier radices
+};
 
 template <int R>
 __device__ __forceinline__ void dftR(cf (&x)[R]);
@@ -79,9 +112,10 @@ __device__ __forceinline__ void dftR<16>(cf (&x)[16]) {
     dft16(x);
 }
 
-// One Stockham stage on the 16 points a thread owns.  P = product of earlier radices.
-//   butterfly i = i0 + b*L/16, k = i mod P, j = (i-k)*R + k
+// One Stockham stage on the 16 points a virtual thread owns.  P = product of earlier
+// radices.  butterfly i = i0 + b*L/16, k = i mod P, j = (i-k)*R + k
 //   x_q = u[b + q*16/R] * W_L^{q*k*L/(P*R)};  out[j + s*P] = DFT_R(x)[s]
+// emit(b, s, pos, value)
 template <int L, int R, int P, typename Emit>
 __device__ __forceinline__ void stage_compute(cf (&u)[16], int i0, const cf *Wl, Emit emit) {
     constexpr int NB = 16 / R;
@@ -101,7 +135,8 @@ __device__ __forceinline__ void stage_compute(cf (&u)[16], int i0, const cf *Wl,
         }
         dftR<R>(x);
 #pragma unroll
-        for (int s = 0; s < R; s++) emit(j + s * P, x[s]);
+        for (int s = 0; s < R; s++) emit(b, s, j + s * P, x[s]);
+        if (R >= 8) PSDR_SCHED_FENCE();
     }
 }
 
@@ -118,41 +153,109 @@ __device__ __forceinline__ void tile_read(cf (&u)[16], const cf *tile, int i0, i
     for (int e = 0; e < 16; e++) u[e] = tile[lds_idx<T, SWZ>(i0 + e * (L / 16), t)];
 }
 
-// Runs stages 0..NS-1 on data already in `u` (stage 0 input), exchanging through the
-// LDS tile between stages; the last stage's outputs go to emit_last(pos, value).
-template <int L, int T, bool SWZ, typename EmitLast>
-__device__ __forceinline__ void run_stages(cf (&u)[16], cf *tile, const cf *Wl, int i0, int t,
-                                           EmitLast emit_last) {
+// All stages for the V virtual threads of one real thread.
+//   load0(v, u)   produces the stage-0 input of virtual thread v (called right before its
+//                 first butterfly so the V inputs never coexist in registers)
+//   pre_last(v)   runs right before v's last-stage butterflies (twiddle set-up)
+//   emit_last(v, b, s, pos, value)  receives the last stage's outputs
+// When the last stage starts, every thread has passed the barrier that follows the last
+// LDS read (the tile is dead and may be reused by emit_last).
+//   tick(k)       k = stage*V + v, called after each virtual thread's butterflies: the
+//                 caller issues a slice of the next tile's global loads there, so they
+//                 trickle through the compute phases instead of blocking in one burst
+template <int L, int T, int V, bool SWZ, typename Load0, typename PreLast, typename EmitLast, typename Tick,
+          typename Mark>
+__device__ __forceinline__ void run_stages(cf *tile, const cf *Wl, const int (&i0)[V], const int (&t)[V],
+                                           Load0 load0, PreLast pre_last, EmitLast emit_last, Tick tick,
+                                           Mark mark) {
     using P = Plan<L>;
-    auto to_lds = [&](int pos, cf v) { tile[lds_idx<T, SWZ>(pos, t)] = v; };
-    // stage 0
-    stage_compute<L, P::R0, 1>(u, i0, Wl, to_lds);
-    __syncthreads();
-    tile_read<L, T, SWZ>(u, tile, i0, t);
-    if constexpr (P::NS == 2) {
-        __syncthreads();  // everyone has read before the tile is reused by the caller
-        stage_compute<L, P::R1, P::R0>(u, i0, Wl, emit_last);
-    } else {
-        __syncthreads();
-        stage_compute<L, P::R1, P::R0>(u, i0, Wl, to_lds);
-        __syncthreads();
-        tile_read<L, T, SWZ>(u, tile, i0, t);
-        __syncthreads();
-        stage_compute<L, P::R2, P::R0 * P::R1>(u, i0, Wl, emit_last);
+    cf u[V][16];
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+        load0(v, u[v]);
+        stage_compute<L, P::R0, 1>(u[v], i0[v], Wl,
+                                   [&](int, int, int pos, cf x) { tile[lds_idx<T, SWZ>(pos, t[v])] = x; });
+        PSDR_SCHED_FENCE();  // keep the virtual threads' butterflies apart (register pressure)
+        tick(v);
+        PSDR_SCHED_FENCE();
     }
+    mark(4);
+    __syncthreads();
+    mark(5);
+#pragma unroll
+    for (int v = 0; v < V; v++) tile_read<L, T, SWZ>(u[v], tile, i0[v], t[v]);
+    __syncthreads();
+    mark(6);
+    if constexpr (P::NS == 3) {
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            stage_compute<L, P::R1, P::R0>(u[v], i0[v], Wl, [&](int, int, int pos, cf x) {
+                tile[lds_idx<T, SWZ>(pos, t[v])] = x;
+            });
+            PSDR_SCHED_FENCE();
+            tick(V + v);
+            PSDR_SCHED_FENCE();
+        }
+        mark(7);
+        __syncthreads();
+        mark(8);
+#pragma unroll
+        for (int v = 0; v < V; v++) tile_read<L, T, SWZ>(u[v], tile, i0[v], t[v]);
+        __syncthreads();
+        mark(9);
+    }
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+        pre_last(v);
+        stage_compute<L, LastStage<L>::R, LastStage<L>::Pp>(
+            u[v], i0[v], Wl, [&](int b, int s, int pos, cf x) { emit_last(v, b, s, pos, x); });
+        PSDR_SCHED_FENCE();
+        tick((P::NS - 1) * V + v);
+        PSDR_SCHED_FENCE();
+    }
+}
+
+// Global stores are ISSUE-bound on this chip (a VMEM store costs ~100+ cycles of a CU's
+// memory pipe whatever its width), so every store carries 16 bytes per lane: lanes t (even)
+// and t+1 hold adjacent columns of the same rows; they swap one value through DPP and the
+// even lane stores row A (both columns), the odd lane row B.  rowA/rowB point at the even
+// column of the respective row (16-byte aligned).
+__device__ __forceinline__ float dpp_swap1(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ void pair_store(bool odd, cf xa, cf xb, cf *rowA, cf *rowB) {
+    const cf send = odd ? xa : xb;
+    const cf recv = make_float2(dpp_swap1(send.x), dpp_swap1(send.y));
+    const float4 o = odd ? make_float4(recv.x, recv.y, xb.x, xb.y) : make_float4(xa.x, xa.y, recv.x, recv.y);
+    *reinterpret_cast<float4 *>(odd ? rowB : rowA) = o;
 }
 
 // XCD-aware slot mapping: work-group b runs on XCD b%8 (observed; used for speed only).
 // Groups of 8 adjacent tiles (one 128-byte line of int8 output, 1 KiB of spectrum) are
-// given to one XCD back to back so their partial lines merge in that XCD's L2.
+// given to one XCD in the same persistent iteration so their partial lines merge in that
+// XCD's L2.
 __device__ __forceinline__ unsigned xcd_slot(unsigned bid, unsigned total) {
     if (total & 63u) return bid;
     const unsigned x = bid & 7u, y = bid >> 3;
     return ((x + 8u * (y >> 3)) << 3) + (y & 7u);
 }
 
-// raw sample pair -> float2 (src/samplereader.cpp:29-40): unsigned formats flip the MSB,
-// integers are divided by 2^(bits-1) (exact, so multiply by the reciprocal).
+// two-level twiddle: W_M^e = TA[e >> log2B] * TB[e & (B-1)]
+struct Tw2 {
+    const cf *TA, *TB;
+    int log2B;
+    __device__ __forceinline__ cf operator()(unsigned e) const {
+        return cmul(TA[e >> log2B], TB[e & ((1u << log2B) - 1u)]);
+    }
+    // the two factors, not yet multiplied (lets the loads stay in flight)
+    __device__ __forceinline__ void raw(unsigned e, cf &fa, cf &fb) const {
+        fa = TA[e >> log2B];
+        fb = TB[e & ((1u << log2B) - 1u)];
+    }
+};
+
+// ---- raw sample access (src/samplereader.cpp:29-40): unsigned formats flip the MSB,
+// integers are divided by 2^(bits-1) (exact, so multiply by the reciprocal) ----
 __device__ __forceinline__ cf load_raw_pair(const void *raw, size_t idx, int fmt) {
     switch (fmt) {
     case 0: {  // u8
@@ -182,171 +285,508 @@ __device__ __forceinline__ cf load_raw_pair(const void *raw, size_t idx, int fmt
     }
     }
 }
+// two adjacent complex samples of a <=16-bit format, kept packed (1 or 2 VGPRs)
+__device__ __forceinline__ uint2 load_raw_packed2(const void *raw, size_t pair_idx, int fmt) {
+    if (fmt <= 1) return make_uint2(reinterpret_cast<const unsigned *>(raw)[pair_idx], 0u);
+    return reinterpret_cast<const uint2 *>(raw)[pair_idx];
+}
+__device__ __forceinline__ cf unpack_raw(uint2 p, int col, int fmt) {
+    if (fmt <= 1) {
+        unsigned h = col ? (p.x >> 16) : (p.x & 0xFFFFu);
+        if (fmt == 0) h ^= 0x8080u;
+        return make_float2((float)(int8_t)(h & 0xFFu) * (1.0f / 128.0f),
+                           (float)(int8_t)(h >> 8) * (1.0f / 128.0f));
+    }
+    unsigned w = col ? p.y : p.x;
+    if (fmt == 2) w ^= 0x80008000u;
+    return make_float2((float)(int16_t)(w & 0xFFFFu) * (1.0f / 32768.0f),
+                       (float)(int16_t)(w >> 16) * (1.0f / 32768.0f));
+}
 
 struct Pass1Args {
-    const void *raw;      // nframes+1 raw half-frames, contiguous
-    const float *window;  // N floats (Hann, src/utils/dsp.cpp:6-11)
-    cf *Y;                // [nframes][M1][M2]
-    const cf *Wl;         // W_L^j, j < L (L = M1)
-    const cf *TA;         // W_M^{h*B}
-    const cf *TB;         // W_M^{l}, l < B
-    int log2B;
+    const void *raw;  // nframes+1 raw half-frames, contiguous
+    cf *Y;            // blocked: [nframes][tile][M1][T]
+    const cf *Wl;     // W_L^j, j < L (L = M1)
+    const cf *TB;     // W_M^l, l < M2
+    cf wdelta;        // W_N^1 (real input: window angle of the odd sample)
     int M2;
     int log2M2;
     int fmt;
     int is_real;  // window pairs (w[2n], w[2n+1]) instead of (w[n], w[n])
     int rot;      // IQ: produce client order
+    size_t yblk;  // elements between consecutive blocks of Y (>= L*T)
+    size_t yframe;  // elements between frames of Y
     unsigned tiles_per_frame;
     unsigned total_slots;
+    unsigned long long *trace;
 };
 
-// pass 1: convert + window + column FFT (length L = M1) + inter-pass twiddle
-template <int L, int T>
-__global__ __launch_bounds__((L / 16) * T) void k_fft_pass1(Pass1Args a) {
+// one complex sample of the LDS raw image -> float2 (src/samplereader.cpp:29-40): unsigned
+// formats flip the MSB, integers are divided by 2^(bits-1) (exact: multiply by the reciprocal)
+template <int SB>
+__device__ __forceinline__ cf image_to_cf(const unsigned char *img, int elem, int fmt) {
+    if constexpr (SB == 2) {
+        unsigned h = reinterpret_cast<const unsigned short *>(img)[elem];
+        if (fmt == 0) h ^= 0x8080u;
+        return make_float2((float)(int8_t)(h & 0xFFu) * (1.0f / 128.0f),
+                           (float)(int8_t)(h >> 8) * (1.0f / 128.0f));
+    } else if constexpr (SB == 4) {
+        unsigned w = reinterpret_cast<const unsigned *>(img)[elem];
+        if (fmt == 2) w ^= 0x80008000u;
+        return make_float2((float)(int16_t)(w & 0xFFFFu) * (1.0f / 32768.0f),
+                           (float)(int16_t)(w >> 16) * (1.0f / 32768.0f));
+    } else {
+        return reinterpret_cast<const cf *>(img)[elem];
+    }
+}
+
+// pass 1: convert + window + column FFT (length L = M1) + inter-pass twiddle.
+//   T columns per tile, V virtual threads per thread, SB bytes per complex sample of the
+//   raw image (u8/s8: 2, u16/s16: 4, f32 and f64-narrowed-to-f32: 8).
+// HBM throughput on this chip is proportional to the bytes a load instruction carries
+// (measured: dword 1.9 TB/s, dwordx2 3.4, dwordx4 5.6 for the same 128-byte segments), so the
+// raw tile is fetched with 16-byte loads in row order, parked in LDS as an image, and the
+// virtual threads pick their strided points out of LDS.
+template <int L, int T, int V, int SB>
+__global__ __launch_bounds__((L / 16) * T / V) void k_fft_pass1(Pass1Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf *tile = reinterpret_cast<cf *>(smem);
     cf *Wl = tile + L * T;
-    constexpr int NT = (L / 16) * T;
+    constexpr int NTV = (L / 16) * T;  // virtual threads
+    constexpr int NT = NTV / V;
+    constexpr int L16 = L / 16;
+    constexpr int RL = LastStage<L>::R, PL = LastStage<L>::Pp, NBL = 16 / RL;
+    constexpr int ROWB = T * SB;                            // bytes of one image row
+    constexpr int LPR = ROWB / 16 > 0 ? ROWB / 16 : 1;      // 16-byte chunks (lanes) per row
+    constexpr int NCHK = (L * T * SB) / (16 * NT);          // chunks per thread
+    static_assert(ROWB >= 16 && (L * T * SB) % (16 * NT) == 0 && NT % LPR == 0, "tile shape");
+    constexpr int NTICK = (Plan<L>::NS - 1) * V;            // ticks that carry loads
+    constexpr int EARLY = NCHK < 4 ? NCHK : NCHK / 4;       // loads issued right after the image write
+    constexpr int LPT = (NCHK - EARLY + NTICK - 1) / NTICK;
     const int tid = threadIdx.x;
-    const unsigned slot = xcd_slot(blockIdx.x, a.total_slots);
-    const unsigned f = slot / a.tiles_per_frame;
-    const unsigned tl = slot - f * a.tiles_per_frame;
-    const int t = tid % T, i0 = tid / T;
+    int t_[V], i0_[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+        t_[v] = (tid + v * NT) % T;
+        i0_[v] = (tid + v * NT) / T;
+    }
     const int M2 = a.M2;
     const size_t M = (size_t)L << a.log2M2;
-    const int n2 = tl * T + t;
+    const unsigned total = a.total_slots;
+    const int fmt = a.fmt;
 
     for (int i = tid; i < L; i += NT) Wl[i] = a.Wl[i];
+    // two-level W_M table with B = M2: W_M^e = W_M1^{e >> log2M2} * W_M^{e & (M2-1)}.  The
+    // first factor IS the stage table Wl (already in LDS); the second (M2 entries) is staged
+    // next to it, so a per-tile twiddle look-up costs two LDS reads, no L2 round trip.
+    cf *ldsTB = Wl + L;
+    for (int i = tid; i < M2; i += NT) ldsTB[i] = a.TB[i];
+    auto tw = [&](unsigned e) -> cf { return cmul(Wl[e >> a.log2M2], ldsTB[e & (unsigned)(M2 - 1)]); };
 
-    // frame f = M complex samples starting at complex index f*M/2 of the raw stream
-    const size_t base = (size_t)f * (M / 2);
-    cf u[16];
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-        const size_t n = (size_t)(i0 + e * (L / 16)) * M2 + n2;
-        cf v = (PSDR_ABL & 8) ? make_float2(1.f + n, 2.f) : load_raw_pair(a.raw, base + n, a.fmt);
-        if (PSDR_ABL & 2) {
-        } else if (a.is_real) {
-            const cf w = reinterpret_cast<const cf *>(a.window)[n];
-            v.x *= w.x;
-            v.y *= w.y;
+    // chunk i*NT + tid of the image = row (i*NT + tid)/LPR, byte (tid % LPR)*16 of that row.
+    // global: frame f starts at complex sample f*M/2; row r is M2 samples further.
+    const unsigned gsb = fmt == 5 ? 16u : (unsigned)SB;  // bytes per complex sample in HBM
+    const size_t g_row = (size_t)M2 * gsb;
+    const size_t g_step = (size_t)(NT / LPR) * g_row;  // between a thread's consecutive chunks
+    const size_t g_lane = (size_t)(tid / LPR) * g_row + (size_t)(tid % LPR) * (16 / SB) * gsb;
+    uint4 rq[NCHK];
+    const unsigned char *nxt = nullptr;
+    auto point_at = [&](unsigned sidx) {
+        const unsigned slot = xcd_slot(sidx, total);
+        const unsigned f = slot / a.tiles_per_frame;
+        const unsigned tl = slot - f * a.tiles_per_frame;
+        nxt = reinterpret_cast<const unsigned char *>(a.raw) + ((size_t)f * (M / 2) + (size_t)tl * T) * gsb + g_lane;
+    };
+    auto issue = [&](int i) {
+        const unsigned char *p = nxt + (size_t)i * g_step;
+        if (PSDR_ABL & 8) {
+            rq[i] = make_uint4(i, 1u, 2u, 3u);
+        } else if (SB == 8 && fmt == 5) {  // f64: two samples = 32 bytes, narrowed to f32 here
+            const double2 s0 = reinterpret_cast<const double2 *>(p)[0];
+            const double2 s1 = reinterpret_cast<const double2 *>(p)[1];
+            rq[i] = make_uint4(__float_as_uint((float)s0.x), __float_as_uint((float)s0.y),
+                               __float_as_uint((float)s1.x), __float_as_uint((float)s1.y));
         } else {
-            const float w = a.window[n];
-            v.x *= w;
-            v.y *= w;
+            rq[i] = *reinterpret_cast<const uint4 *>(p);
         }
-        u[e] = v;
-    }
-    cf *Yf = a.Y + (size_t)f * M;
-    const unsigned Bm = (1u << a.log2B) - 1u;
-    if (PSDR_ABL & 4) {
+    };
+    unsigned s = blockIdx.x;
+    if (s < total) {
+        point_at(s);
 #pragma unroll
-        for (int e = 0; e < 16; e++) Yf[(size_t)(i0 + e * (L / 16)) * M2 + n2] = u[e];
-        return;
+        for (int i = 0; i < NCHK; i++) issue(i);
     }
-    run_stages<L, T, false>(u, tile, Wl, i0, t, [&](int k1, cf v) {
-        const int c1 = a.rot ? ((k1 - 1) & (L - 1)) : k1;
-        const unsigned ex = (unsigned)n2 * (unsigned)(a.rot ? c1 + 1 : k1);
-        const cf w = (PSDR_ABL & 1) ? make_float2(1.f, 0.f) : cmul(a.TA[ex >> a.log2B], a.TB[ex & Bm]);
-        if (a.rot && (n2 & 1)) {
-            v.x = -v.x;
-            v.y = -v.y;
+    __syncthreads();  // Wl and the twiddle table are visible
+
+    int it = 0;
+    for (; s < total; s += gridDim.x) {
+        PSDR_TRACE(a.trace, it, 0);
+        const unsigned slot = xcd_slot(s, total);
+        const unsigned f = slot / a.tiles_per_frame;
+        const unsigned tl = slot - f * a.tiles_per_frame;
+        cf *Yb = a.Y + (size_t)f * a.yframe + (size_t)tl * a.yblk;  // this tile's block
+        const bool more = s + gridDim.x < total;
+        if (more) point_at(s + gridDim.x);
+        // opaque per-iteration copies: stop LICM from hoisting the ~100 loop-invariant LDS
+        // addresses of all stages out of the persistent loop (that costs >100 VGPRs)
+        int i0[V], t[V], tidx = tid;
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            i0[v] = i0_[v];
+            t[v] = t_[v];
+            asm volatile("" : "+v"(i0[v]), "+v"(t[v]));
         }
-        Yf[(size_t)c1 * M2 + n2] = cmul(v, w);
-    });
+        asm volatile("" : "+v"(tidx));
+
+        // ---- raw image into LDS (linear, 16 bytes per lane)
+#pragma unroll
+        for (int i = 0; i < NCHK; i++) reinterpret_cast<uint4 *>(smem)[i * NT + tidx] = rq[i];
+        PSDR_SCHED_FENCE();
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < EARLY; i++) issue(i);
+        }
+        PSDR_SCHED_FENCE();
+        PSDR_TRACE(a.trace, it, 1);
+        __syncthreads();
+        PSDR_TRACE(a.trace, it, 2);
+
+        // ---- stage-0 input: convert (src/samplereader.cpp:29-40) + Hann window; the image
+        // shares the tile's LDS, so every virtual thread reads before anyone writes
+        int n2[V];
+        cf pre[V][16];
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            n2[v] = (int)tl * T + t[v];
+            const cf wb = tw((unsigned)n2[v]);  // W_M^{n2}: window angle of the column
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                pre[v][e] = image_to_cf<SB>(smem, (i0[v] + e * L16) * T + t[v], fmt);
+            if (!(PSDR_ABL & 2)) {
+                // periodic Hann (src/utils/dsp.cpp:6-11) from the twiddle tables:
+                // exp(-i*2*pi*n/M) = W_M1^{n1} * W_M^{n2}
+                if (a.is_real) {
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const cf z = cmul(Wl[i0[v] + e * L16], wb);
+                        pre[v][e].x *= fmaf(-0.5f, z.x, 0.5f);
+                        pre[v][e].y *= fmaf(-0.5f, cmul(z, a.wdelta).x, 0.5f);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const cf wl = Wl[i0[v] + e * L16];
+                        const float w = fmaf(-0.5f, fmaf(wl.x, wb.x, -wl.y * wb.y), 0.5f);
+                        pre[v][e].x *= w;
+                        pre[v][e].y *= w;
+                    }
+                }
+            }
+            PSDR_SCHED_FENCE();
+        }
+        __syncthreads();
+        PSDR_TRACE(a.trace, it, 3);
+
+        if (PSDR_ABL & 4) {
+#pragma unroll
+            for (int v = 0; v < V; v++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) Yb[(size_t)(i0[v] + e * L16) * T + t[v]] = pre[v][e];
+            if (more) {
+#pragma unroll
+                for (int i = EARLY; i < NCHK; i++) issue(i);
+            }
+            it++;
+            continue;
+        }
+        cf tb[NBL], ts[RL], w00;  // inter-pass twiddles of the virtual thread in flight
+        cf held = make_float2(0.f, 0.f);
+        cf *held_row = nullptr;
+        run_stages<L, T, V, false>(
+            tile, Wl, i0, t,
+            [&](int v, cf(&u)[16]) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) u[e] = pre[v][e];
+            },
+            // ---- inter-pass twiddle W_M^{n2*kappa}, kappa = i0 + b*L/16 + s*P, as
+            // base * stepB^b * stepS^s (three table look-ups per column)
+            [&](int v) {
+                const unsigned n2u = (unsigned)n2[v];
+                cf base = tw(n2u * (unsigned)i0[v]);
+                if (PSDR_ABL & 1) base = make_float2(1.f, 0.f);
+                if (a.rot && (n2u & 1u)) {
+                    base.x = -base.x;
+                    base.y = -base.y;
+                }
+                cf sb = tw(n2u * (unsigned)L16);
+                cf ss = tw(n2u * (unsigned)PL);
+                if (PSDR_ABL & 1) sb = ss = make_float2(1.f, 0.f);
+                tb[0] = base;
+#pragma unroll
+                for (int b = 1; b < NBL; b++) tb[b] = cmul(tb[b - 1], sb);
+                ts[0] = make_float2(1.f, 0.f);
+#pragma unroll
+                for (int q = 1; q < RL; q++) ts[q] = q == 1 ? ss : cmul(ts[q - 1], ss);
+                // output (b=0,s=0) of the virtual thread with i0 = 0 is bin k1 = 0: in
+                // client order it goes to row M1-1 with W_M^{n2*M1}
+                w00 = base;
+                if (a.rot && i0[v] == 0 && !(PSDR_ABL & 1)) {
+                    w00 = tw(n2u * (unsigned)L);
+                    if (n2u & 1u) {
+                        w00.x = -w00.x;
+                        w00.y = -w00.y;
+                    }
+                }
+            },
+            [&](int v, int b, int sidx, int k1, cf x) {
+                const cf w = (sidx == 0) ? (b == 0 ? w00 : tb[b]) : cmul(tb[b], ts[sidx]);
+                const int c1 = a.rot ? ((k1 - 1) & (L - 1)) : k1;
+                const cf y = cmul(x, w);
+                // outputs arrive as (s even, s odd) pairs: one 16-byte store per pair
+                cf *row = Yb + (size_t)c1 * T + (t[v] & ~1);
+                if ((sidx & 1) == 0) {
+                    held = y;
+                    held_row = row;
+                } else {
+                    pair_store(t[v] & 1, held, y, held_row, row);
+                }
+            },
+            // ---- trickle the rest of the next tile's loads through the stages
+            [&](int k) {
+                if (more && k < NTICK) {
+#pragma unroll
+                    for (int j = 0; j < LPT; j++)
+                        if (EARLY + k * LPT + j < NCHK) issue(EARLY + k * LPT + j);
+                }
+            },
+            [&](int k) { PSDR_TRACE(a.trace, it, k); });
+        PSDR_TRACE(a.trace, it, 10);
+        it++;
+    }
 }
 
 struct Pass2Args {
-    const cf *Y;   // [nframes][M1][M2]
+    const cf *Y;   // blocked: [nframes][tiles1][M1][TW]
     cf *X;         // [nframes][spec_stride]: bin c1 + M1*c2
     size_t spec_stride;
     const cf *Wl;  // W_L^j, L = M2
     int M1;
     int log2M1;
+    int TW;       // pass-1 tile width (columns per block of Y)
+    int log2TW;
+    size_t yblk, yframe;  // block / frame strides of Y in elements
     // fused IQ epilogue
     float inv_n;
     int size_log2;
     int nlevels;
-    int8_t *Q;  // [nframes][q_stride]
-    size_t q_stride;
+    int8_t *Qt;  // tiled pyramid records, [nframes][qt_stride] (quantize.h)
+    size_t qt_stride;
     float *Pscr;  // [nframes][R >> LT]
     size_t p_stride;
     unsigned tiles_per_frame;
     unsigned total_slots;
+    unsigned long long *trace;
 };
 
-// pass 2: row FFT (length L = M2); FUSED adds /N, |X|^2, int8 level 0..LT of the pyramid
-template <int L, int T, bool FUSED>
-__global__ __launch_bounds__((L / 16) * T) void k_fft_pass2(Pass2Args a) {
+// pass 2: row FFT (length L = M2); FUSED adds /N, |X|^2, int8 level 0..LT of the pyramid.
+template <int L, int T, bool FUSED, int V>
+__global__ __launch_bounds__((L / 16) * T / V) void k_fft_pass2(Pass2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf *tile = reinterpret_cast<cf *>(smem);
     cf *Wl = tile + L * T;
-    constexpr int NT = (L / 16) * T;
+    constexpr int NTV = (L / 16) * T;
+    constexpr int NT = NTV / V;
+    constexpr int NLD = 8 * V;                       // 16-byte loads per thread and tile
+    constexpr int NTICK = (Plan<L>::NS - 1) * V;     // ticks that carry loads (not the last stage)
+    constexpr int EARLY = 4 < NLD ? 4 : NLD;         // loads issued right after the registers die
+    constexpr int LPT = (NLD - EARLY + NTICK - 1) / NTICK;
     const int tid = threadIdx.x;
-    const unsigned slot = xcd_slot(blockIdx.x, a.total_slots);
-    const unsigned f = slot / a.tiles_per_frame;
-    const unsigned tl = slot - f * a.tiles_per_frame;
-    const int t = tid % T, i0 = tid / T;
+    int t_[V], i0_[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+        t_[v] = (tid + v * NT) % T;
+        i0_[v] = (tid + v * NT) / T;
+    }
     const int M1 = a.M1;
     const size_t M = (size_t)L << a.log2M1;
-    const int c1base = tl * T;
+    const unsigned total = a.total_slots;
+    const int TW = a.TW;
+    const int chunk = T * TW;  // contiguous elements of one pass-1 block that belong to this tile
+    const size_t blk = a.yblk;
 
     for (int i = tid; i < L; i += NT) Wl[i] = a.Wl[i];
 
-    // transposing load: rows c1base..+T of Y (each L contiguous points) -> tile[n2][c1]
-    const cf *Yf = a.Y + (size_t)f * M + (size_t)c1base * L;
+    // Element idx of the tile is (block j, row rr, column cc) with idx = j*chunk + rr*TW + cc:
+    // Y block j, row c1base + rr, column cc, and n2 = j*TW + cc.  A thread loads 16 bytes =
+    // elements idx, idx+1 with idx = 2*(i*NTV + vt), i < 8 (vt = virtual thread id): the
+    // address is a uniform per-i part plus ONE per-lane offset per virtual thread.
+    const int lc = a.log2TW + (31 - __clz(T));  // log2(chunk)
+    float4 r[V][8];
+    const cf *nxt = nullptr;
+    unsigned lane_off[V];  // j0*blk + w  (elements)
+    auto point_at = [&](unsigned sidx) {
+        const unsigned slot = xcd_slot(sidx, total);
+        const unsigned f = slot / a.tiles_per_frame;
+        const unsigned tl = slot - f * a.tiles_per_frame;
+        nxt = a.Y + (size_t)f * a.yframe + (size_t)(tl * T) * TW;
+    };
+    auto issue = [&](int q) {
+        const int v = q / 8, i = q % 8;
+        // uniform part of idx = 2*i*NTV: block (2*i*NTV)>>lc, offset (2*i*NTV)&(chunk-1)
+        const cf *p = nxt + (size_t)((2 * i * NTV) >> lc) * blk + ((2 * i * NTV) & (chunk - 1)) + lane_off[v];
+        r[v][i] = *reinterpret_cast<const float4 *>(p);
+    };
 #pragma unroll
-    for (int e = 0; e < 16; e++) {
-        const int idx = e * NT + tid;
-        const int r = idx / L, n2 = idx % L;
-        tile[lds_idx<T, true>(n2, r)] = Yf[idx];
+    for (int v = 0; v < V; v++) {
+        const int vt2 = 2 * (v * NT + tid);
+        lane_off[v] = (unsigned)((size_t)(vt2 >> lc) * blk + (vt2 & (chunk - 1)));
     }
-    __syncthreads();
-    cf u[16];
-    tile_read<L, T, true>(u, tile, i0, t);
-    __syncthreads();
+    unsigned s = blockIdx.x;
+    if (s < total) {
+        point_at(s);
+#pragma unroll
+        for (int q = 0; q < NLD; q++) issue(q);
+    }
 
-    cf *Xf = a.X + (size_t)f * a.spec_stride;
-    if (PSDR_ABL & 32) {
+    int it = 0;
+    for (; s < total; s += gridDim.x, it++) {
+        PSDR_TRACE(a.trace, it, 0);
+        const unsigned slot = xcd_slot(s, total);
+        const unsigned f = slot / a.tiles_per_frame;
+        const unsigned tl = slot - f * a.tiles_per_frame;
+        const int c1base = tl * T;
+        const bool more = s + gridDim.x < total;
+        if (more) point_at(s + gridDim.x);
+        int i0[V], t[V], tidx = tid;  // opaque copies (see pass 1)
 #pragma unroll
-        for (int e = 0; e < 16; e++) Xf[(size_t)(i0 + e * (L / 16)) * M1 + c1base + t] = u[e];
-        return;
-    }
-    float *Pst = reinterpret_cast<float *>(smem);  // reuses the (dead) tile after the last read
-    run_stages<L, T, true>(u, tile, Wl, i0, t, [&](int c2, cf v) {
-        if (FUSED) {
-            v.x *= a.inv_n;
-            v.y *= a.inv_n;
-            Pst[c2 * T + t] = fmaf(v.x, v.x, v.y * v.y);  // src/fft_impl.cpp:36-38
+        for (int v = 0; v < V; v++) {
+            i0[v] = i0_[v];
+            t[v] = t_[v];
+            asm volatile("" : "+v"(i0[v]), "+v"(t[v]));
         }
-        if (!(PSDR_ABL & 64) || v.x == 1.2345e30f) Xf[(size_t)c2 * M1 + c1base + t] = v;
-    });
-
-    if (FUSED && !(PSDR_ABL & 16)) {
-        __syncthreads();
-        constexpr int CH = T < 16 ? T : 16;  // values per chunk (one aligned group)
-        constexpr int NCH = 16 / CH;
-        constexpr int LT = CH == 16 ? 4 : (CH == 8 ? 3 : 2);
-        const size_t R = M;
-        int8_t *Qf = a.Q + (size_t)f * a.q_stride;
-        float *Pf = a.Pscr + (size_t)f * a.p_stride;
+        asm volatile("" : "+v"(tidx));
+        // transposing store: tile[n2][c1]
 #pragma unroll
-        for (int cc = 0; cc < NCH; cc++) {
-            const int g = tid * NCH + cc;  // chunk id; chunks tile Pst linearly
-            const int row = (g * CH) / T, sub = (g * CH) % T;
-            const size_t c = (size_t)row * M1 + c1base + sub;  // client-order bin of value 0
-            float p[CH];
+        for (int v = 0; v < V; v++)
 #pragma unroll
-            for (int v4 = 0; v4 < CH / 4; v4++) {
-                const float4 q4 = reinterpret_cast<const float4 *>(Pst)[(g * CH) / 4 + v4];
-                p[4 * v4] = q4.x;
-                p[4 * v4 + 1] = q4.y;
-                p[4 * v4 + 2] = q4.z;
-                p[4 * v4 + 3] = q4.w;
+            for (int i = 0; i < 8; i++) {
+                const int vt2 = 2 * (v * NT + tidx);
+                const int w = ((2 * i * NTV) & (chunk - 1)) + (vt2 & (chunk - 1));
+                const int rr = w >> a.log2TW, cc = w & (TW - 1);
+                const int n2 = (((2 * i * NTV) >> lc) + (vt2 >> lc)) * TW + cc;
+                tile[lds_idx<T, true>(n2, rr)] = make_float2(r[v][i].x, r[v][i].y);
+                tile[lds_idx<T, true>(n2 + 1, rr)] = make_float2(r[v][i].z, r[v][i].w);
             }
-            pyr_levels<CH, 0>(p, Qf, 0, R, c, a.nlevels, a.size_log2);
-            Pf[c >> LT] = p[0];
+        PSDR_SCHED_FENCE();
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < EARLY; q++) issue(q);
         }
+        PSDR_SCHED_FENCE();
+        PSDR_TRACE(a.trace, it, 1);
+        __syncthreads();
+        PSDR_TRACE(a.trace, it, 2);
+        // stage-0 input comes from the tile itself: all V reads, then a barrier, before
+        // any in-place write
+        cf pre[V][16];
+#pragma unroll
+        for (int v = 0; v < V; v++) tile_read<L, T, true>(pre[v], tile, i0[v], t[v]);
+        __syncthreads();
+        PSDR_TRACE(a.trace, it, 3);
+
+        cf *Xf = a.X + (size_t)f * a.spec_stride;
+        if (PSDR_ABL & 32) {
+#pragma unroll
+            for (int v = 0; v < V; v++)
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    Xf[(size_t)(i0[v] + e * (L / 16)) * M1 + c1base + t[v]] = pre[v][e];
+            if (more) {
+#pragma unroll
+                for (int q = EARLY; q < NLD; q++) issue(q);
+            }
+            continue;
+        }
+        float *Pst = reinterpret_cast<float *>(smem);  // reuses the (dead) tile after the last read
+        cf held = make_float2(0.f, 0.f);
+        cf *held_row = nullptr;
+        run_stages<L, T, V, true>(
+            tile, Wl, i0, t,
+            [&](int v, cf(&u)[16]) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) u[e] = pre[v][e];
+            },
+            [&](int) {},
+            [&](int v, int, int sidx, int c2, cf x) {
+                if (FUSED) {
+                    x.x *= a.inv_n;
+                    x.y *= a.inv_n;
+                    Pst[c2 * T + t[v]] = fmaf(x.x, x.x, x.y * x.y);  // src/fft_impl.cpp:36-38
+                }
+                if (PSDR_ABL & 64) return;
+                cf *row = Xf + (size_t)c2 * M1 + c1base + (t[v] & ~1);
+                if ((sidx & 1) == 0) {
+                    held = x;
+                    held_row = row;
+                } else {
+                    pair_store(t[v] & 1, held, x, held_row, row);
+                }
+            },
+            [&](int k) {  // trickle the rest of the next tile's loads through the stages
+                if (more && k < NTICK) {
+#pragma unroll
+                    for (int j = 0; j < LPT; j++)
+                        if (EARLY + k * LPT + j < NLD) issue(EARLY + k * LPT + j);
+                }
+            },
+            [&](int k) { PSDR_TRACE(a.trace, it, k); });
+        PSDR_TRACE(a.trace, it, 10);
+
+        if (FUSED && !(PSDR_ABL & 16)) {
+            __syncthreads();
+            PSDR_TRACE(a.trace, it, 11);
+            constexpr int CH = T < 16 ? T : 16;  // values per chunk (one aligned group)
+            constexpr int NCH = 16 / CH;
+            constexpr int LT = CH == 16 ? 4 : 3;
+            static_assert(CH == 16 || CH == 8, "tile width");
+            int8_t *Qf = a.Qt + (size_t)f * a.qt_stride;
+            float *Pf = a.Pscr + (size_t)f * a.p_stride;
+#pragma unroll
+            for (int v = 0; v < V; v++) {
+#pragma unroll
+                for (int cc = 0; cc < NCH; cc++) {
+                    const int g = (tidx + v * NT) * NCH + cc;  // chunk id; chunks tile Pst linearly
+                    const int row = (g * CH) / T, sub = (g * CH) % T;
+                    const size_t c = (size_t)row * M1 + c1base + sub;  // client-order bin of value 0
+                    float p[CH];
+#pragma unroll
+                    for (int v4 = 0; v4 < CH / 4; v4++) {
+                        const float4 q4 = reinterpret_cast<const float4 *>(Pst)[(g * CH) / 4 + v4];
+                        p[4 * v4] = q4.x;
+                        p[4 * v4 + 1] = q4.y;
+                        p[4 * v4 + 2] = q4.z;
+                        p[4 * v4 + 3] = q4.w;
+                    }
+                    // levels 0..LT of this aligned group -> one contiguous record
+                    uint4 *rec = reinterpret_cast<uint4 *>(Qf + (c / CH) * (2 * CH));
+                    if constexpr (CH == 16) {
+                        uint4 lo, hi;
+                        pyr_record16(p, a.size_log2, lo, hi);
+                        rec[0] = lo;
+                        rec[1] = hi;
+                    } else {
+                        uint4 r8;
+                        pyr_record8(p, a.size_log2, r8);
+                        rec[0] = r8;
+                    }
+                    Pf[c >> LT] = p[0];
+                    PSDR_SCHED_FENCE();
+                }
+            }
+        }
+        PSDR_TRACE(a.trace, it, 12);
+        __syncthreads();  // the tile is free again
+        PSDR_TRACE(a.trace, it, 13);
     }
 }
 

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -36,6 +37,7 @@ static int fail(int code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                \
     } while (0)
 
+static int drain(psdr_ctx *c);
 extern "C" const char *psdr_last_error(void) { return g_err.c_str(); }
 extern "C" const char *psdr_version(void) { return "phantomsdr_amd 0.1 (gfx950)"; }
 
@@ -113,6 +115,8 @@ int ilog2(size_t v) {
 struct psdr_ctx {
     psdr_config cfg;
     int device = 0;
+    int num_cus = 256;
+    size_t ypad = 0;  // elements of padding between blocks of Y
     size_t N = 0, M = 0, R = 0;
     int M1 = 0, M2 = 0, log2M1 = 0, log2M2 = 0;
     int T1 = 0, T2 = 0;
@@ -124,15 +128,25 @@ struct psdr_ctx {
     int LT = 0;  // pyramid levels finished inside the fused kernel
     size_t p_stride = 0;
     int max_batch = 1;
-    hipStream_t stream = nullptr;      // the stream work is enqueued on
-    hipStream_t own_stream = nullptr;  // created by the context (default for `stream`)
+    // Two streams: the FFT passes run on `stream`; everything that only consumes a finished
+    // batch (pyramid tail, demodulation, waterfall gather) runs on `side`, so it overlaps
+    // the next batch's pass 1 (its work-groups fit next to the persistent FFT work-groups).
+    hipStream_t stream = nullptr, side = nullptr;
+    hipStream_t own_stream = nullptr, own_side = nullptr;
+    hipEvent_t ev_fft_done = nullptr, ev_side_done = nullptr;
+    bool side_pending = false;
 
-    float *d_window = nullptr;
     cf *d_Wl1 = nullptr, *d_Wl2 = nullptr, *d_TA = nullptr, *d_TB = nullptr;
     cf *d_UA = nullptr, *d_UB = nullptr;
+    cf wdelta = {1.f, 0.f};  // W_N^1
+    unsigned long long *d_trace = nullptr;  // PSDR_TRACE tuning builds: [2][8][16] timestamps
     int log2B = 0, log2UB = 0;
     cf *d_Y = nullptr, *d_Z = nullptr, *d_spec = nullptr;
-    int8_t *d_q = nullptr;
+    int8_t *d_q = nullptr;   // level-major pyramid (the reference's layout)
+    int8_t *d_qt = nullptr;  // tiled records of levels 0..LT (IQ fused epilogue), quantize.h
+    size_t qt_stride = 0;
+    int tiled_lt = -1, tile_ch = 16;
+    std::vector<char> q_untiled;  // per frame: level-major copy of the tiled levels is current
     float *d_pscr[2] = {nullptr, nullptr};
 
     // level 1
@@ -179,7 +193,8 @@ struct ProfScope {
     psdr_ctx *c;
     int kid;
     hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(psdr_ctx *c_, int kid_) : c(c_), kid(kid_) {
+    hipStream_t st;
+    ProfScope(psdr_ctx *c_, int kid_, hipStream_t st_ = nullptr) : c(c_), kid(kid_), st(st_ ? st_ : c_->stream) {
         if (!c->profiling) return;
         auto get = [&]() {
             hipEvent_t e;
@@ -193,11 +208,11 @@ struct ProfScope {
         };
         a = get();
         b = get();
-        hipEventRecord(a, c->stream);
+        hipEventRecord(a, st);
     }
     ~ProfScope() {
         if (!c->profiling) return;
-        hipEventRecord(b, c->stream);
+        hipEventRecord(b, st);
         c->pending.push_back({a, b, kid});
     }
 };
@@ -205,6 +220,7 @@ struct ProfScope {
 void resolve_pending(psdr_ctx *c) {
     if (c->pending.empty()) return;
     hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->side);
     for (auto &p : c->pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -237,60 +253,68 @@ int upload(T **dst, const std::vector<T> &v) {
 // tile widths: T = min(16384/L, other dimension)
 int pick_T(int L, int other) { return std::min(16384 / L, other); }
 
-template <int L, int T>
+template <int L, int T, int V, int SB>
 int launch_pass1_t(psdr_ctx *c, const Pass1Args &a, unsigned blocks) {
-    constexpr size_t lds = (size_t)L * T * sizeof(cf) + (size_t)L * sizeof(cf);
+    // tile + W_L (= first twiddle factor) + second twiddle factor (M2 entries)
+    const size_t lds = (size_t)L * T * sizeof(cf) + (size_t)L * sizeof(cf) + (size_t)a.M2 * sizeof(cf);
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass1<L, T>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass1<L, T, V, SB>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     ProfScope ps(c, K_PASS1);
-    hipLaunchKernelGGL((k_fft_pass1<L, T>), dim3(blocks), dim3((L / 16) * T), lds, c->stream, a);
+    // persistent: one work-group per CU (the 128 KiB tile admits exactly one)
+    const unsigned grid = std::min<unsigned>(blocks, (unsigned)c->num_cus);
+    hipLaunchKernelGGL((k_fft_pass1<L, T, V, SB>), dim3(grid), dim3((L / 16) * T / V), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return PSDR_OK;
 }
-template <int L, int T, bool FUSED>
+template <int L, int T, bool FUSED, int V>
 int launch_pass2_t(psdr_ctx *c, const Pass2Args &a, unsigned blocks) {
     constexpr size_t lds = (size_t)L * T * sizeof(cf) + (size_t)L * sizeof(cf);
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass2<L, T, FUSED>,
+        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass2<L, T, FUSED, V>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     ProfScope ps(c, K_PASS2);
-    hipLaunchKernelGGL((k_fft_pass2<L, T, FUSED>), dim3(blocks), dim3((L / 16) * T), lds, c->stream,
+    const unsigned grid = std::min<unsigned>(blocks, (unsigned)c->num_cus);
+    hipLaunchKernelGGL((k_fft_pass2<L, T, FUSED, V>), dim3(grid), dim3((L / 16) * T / V), lds, c->stream,
                        a);
     HIPCHK(hipGetLastError());
     return PSDR_OK;
 }
 
-#define P1CASE(L_, T_) \
-    if (L == L_ && T == T_) return launch_pass1_t<L_, T_>(c, a, blocks);
-int launch_pass1(psdr_ctx *c, int L, int T, const Pass1Args &a, unsigned blocks) {
-    P1CASE(64, 64)
-    P1CASE(128, 64)
-    P1CASE(128, 128)
-    P1CASE(256, 64)
-    P1CASE(512, 32)
-    P1CASE(1024, 16)
-    P1CASE(2048, 8)
+#define P1CASE(L_, T_, V_)                                                   \
+    if (L == L_ && T == T_) {                                                \
+        if (sb == 2) return launch_pass1_t<L_, T_, V_, 2>(c, a, blocks);     \
+        if (sb == 4) return launch_pass1_t<L_, T_, V_, 4>(c, a, blocks);     \
+        return launch_pass1_t<L_, T_, V_, 8>(c, a, blocks);                  \
+    }
+int launch_pass1(psdr_ctx *c, int L, int T, int sb, const Pass1Args &a, unsigned blocks) {
+    P1CASE(64, 64, 1)
+    P1CASE(128, 64, 1)
+    P1CASE(128, 128, 2)
+    P1CASE(256, 64, 2)
+    P1CASE(512, 32, 2)
+    P1CASE(1024, 16, 2)
+    P1CASE(2048, 8, 2)
     return fail(PSDR_ERR_UNSUPPORTED, "no pass-1 kernel for L=%d T=%d", L, T);
 }
-#define P2CASE(L_, T_)                                                          \
+#define P2CASE(L_, T_, V_)                                                      \
     if (L == L_ && T == T_)                                                     \
-        return fused ? launch_pass2_t<L_, T_, true>(c, a, blocks)               \
-                     : launch_pass2_t<L_, T_, false>(c, a, blocks);
+        return fused ? launch_pass2_t<L_, T_, true, V_>(c, a, blocks)           \
+                     : launch_pass2_t<L_, T_, false, V_>(c, a, blocks);
 int launch_pass2(psdr_ctx *c, int L, int T, bool fused, const Pass2Args &a, unsigned blocks) {
-    P2CASE(64, 64)
-    P2CASE(64, 128)
-    P2CASE(128, 128)
-    P2CASE(256, 64)
-    P2CASE(512, 32)
-    P2CASE(1024, 16)
-    P2CASE(2048, 8)
+    P2CASE(64, 64, 1)
+    P2CASE(64, 128, 1)
+    P2CASE(128, 128, 2)
+    P2CASE(256, 64, 2)
+    P2CASE(512, 32, 2)
+    P2CASE(1024, 16, 2)
+    P2CASE(2048, 8, 2)
     return fail(PSDR_ERR_UNSUPPORTED, "no pass-2 kernel for L=%d T=%d", L, T);
 }
 
@@ -311,23 +335,26 @@ size_t fmt_bytes(int fmt) {
 
 // forward FFT + power + int8 pyramid for nframes frames (src/fft.cpp:61-98 per frame)
 int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
-    const unsigned tiles1 = (unsigned)(c->M2 / c->T1), tiles2 = (unsigned)(c->M1 / c->T2);
+    const int cols = 1;
+    const int sb = fmt <= PSDR_FMT_S8 ? 2 : (fmt <= PSDR_FMT_S16 ? 4 : 8);  // image bytes per sample
+    const unsigned tiles1 = (unsigned)(c->M2 / (c->T1 * cols)), tiles2 = (unsigned)(c->M1 / c->T2);
     Pass1Args a1{};
     a1.raw = d_halves;
-    a1.window = c->d_window;
     a1.Y = c->d_Y;
     a1.Wl = c->d_Wl1;
-    a1.TA = c->d_TA;
     a1.TB = c->d_TB;
-    a1.log2B = c->log2B;
+    a1.yblk = (size_t)c->M1 * (c->T1 * cols) + c->ypad;
+    a1.yframe = a1.yblk * tiles1;
+    a1.wdelta = c->wdelta;
     a1.M2 = c->M2;
     a1.log2M2 = c->log2M2;
     a1.fmt = fmt;
     a1.is_real = c->is_real ? 1 : 0;
     a1.rot = c->is_real ? 0 : 1;
+    a1.trace = c->d_trace;
     a1.tiles_per_frame = tiles1;
     a1.total_slots = tiles1 * (unsigned)nframes;
-    int rc = launch_pass1(c, c->M1, c->T1, a1, a1.total_slots);
+    int rc = launch_pass1(c, c->M1, c->T1, sb, a1, a1.total_slots);
     if (rc) return rc;
 
     Pass2Args a2{};
@@ -335,15 +362,22 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
     a2.Wl = c->d_Wl2;
     a2.M1 = c->M1;
     a2.log2M1 = c->log2M1;
+    a2.TW = c->T1 * cols;
+    a2.yblk = a1.yblk;
+    a2.yframe = a1.yframe;
+    a2.log2TW = ilog2((size_t)(c->T1 * cols));
     a2.inv_n = 1.0f / (float)c->N;
     a2.size_log2 = c->size_log2;
     a2.nlevels = c->levels;
-    a2.Q = c->d_q;
-    a2.q_stride = c->q_stride;
+    a2.Qt = c->d_qt;
+    a2.qt_stride = c->qt_stride;
     a2.Pscr = c->d_pscr[0];
     a2.p_stride = c->p_stride;
+    a2.trace = c->d_trace ? c->d_trace + 128 : nullptr;
     a2.tiles_per_frame = tiles2;
     a2.total_slots = tiles2 * (unsigned)nframes;
+    // pass 2 overwrites the buffers the side stream may still be reading (previous batch)
+    if (c->side_pending && c->side != c->stream) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_side_done, 0));
     if (!c->is_real) {
         a2.X = c->d_spec;
         a2.spec_stride = c->spec_stride;
@@ -374,6 +408,11 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
         hipLaunchKernelGGL(k_untangle_real, dim3(nb, nframes), dim3(256), 0, c->stream, u);
         HIPCHK(hipGetLastError());
     }
+    // consumers of the finished batch go to the side stream
+    if (c->side != c->stream) {
+        HIPCHK(hipEventRecord(c->ev_fft_done, c->stream));
+        HIPCHK(hipStreamWaitEvent(c->side, c->ev_fft_done, 0));
+    }
     // remaining pyramid levels from the partial level in scratch
     int lvl = c->LT;
     size_t len = c->R >> lvl;
@@ -391,16 +430,21 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
         t.R = c->R;
         t.Pout = c->d_pscr[cur ^ 1];
         t.out_stride = c->p_stride;
-        ProfScope ps(c, K_TAIL);
+        ProfScope ps(c, K_TAIL, c->side);
         const unsigned nb = (unsigned)((len / 2 + 255) / 256);
-        hipLaunchKernelGGL(k_pyramid_tail, dim3(nb, nframes), dim3(256), 0, c->stream, t);
+        hipLaunchKernelGGL(k_pyramid_tail, dim3(nb, nframes), dim3(256), 0, c->side, t);
         HIPCHK(hipGetLastError());
         lvl += 7;
         len >>= 7;
         cur ^= 1;
     }
+    if (c->side != c->stream) {
+        HIPCHK(hipEventRecord(c->ev_side_done, c->side));
+        c->side_pending = true;
+    }
     c->last_nframes = nframes;
     c->out_valid = c->q_valid = false;
+    std::fill(c->q_untiled.begin(), c->q_untiled.end(), 0);
     return PSDR_OK;
 }
 
@@ -408,10 +452,10 @@ void free_all(psdr_ctx *c) {
     auto F = [](void *p) {
         if (p) hipFree(p);
     };
-    F(c->d_window);
     F(c->d_Wl1);
     if (c->d_Wl2 != c->d_Wl1) F(c->d_Wl2);
     F(c->d_TA);
+    F(c->d_trace);
     F(c->d_TB);
     F(c->d_UA);
     F(c->d_UB);
@@ -419,6 +463,7 @@ void free_all(psdr_ctx *c) {
     F(c->d_Z);
     F(c->d_spec);
     F(c->d_q);
+    F(c->d_qt);
     F(c->d_pscr[0]);
     F(c->d_pscr[1]);
     F(c->d_stage);
@@ -446,26 +491,34 @@ void free_all(psdr_ctx *c) {
     for (auto e : c->pool) hipEventDestroy(e);
     if (c->t0) hipEventDestroy(c->t0);
     if (c->t1) hipEventDestroy(c->t1);
+    if (c->ev_fft_done) hipEventDestroy(c->ev_fft_done);
+    if (c->ev_side_done) hipEventDestroy(c->ev_side_done);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
+    if (c->own_side) hipStreamDestroy(c->own_side);
 }
 
 int build(psdr_ctx *c) {
     const psdr_config &g = c->cfg;
     HIPCHK(hipSetDevice(c->device));
+    {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, c->device));
+        c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->own_side, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    c->side = c->own_side;
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fft_done, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&c->t0));
     HIPCHK(hipEventCreate(&c->t1));
 
-    // ---- window: build_hann_window, src/utils/dsp.cpp:6-11 (same host libm expression)
+    // The Hann window (build_hann_window, src/utils/dsp.cpp:6-11) is evaluated inside pass 1
+    // from the twiddle tables; only W_N^1 (odd real samples) is needed on top of them.
     {
-        std::vector<float> w(c->N);
-        for (size_t i = 0; i < c->N; i++) {
-            const float arg = (float)(2 * M_PI * (double)(int)i / (double)(int)c->N);
-            w[i] = (float)(0.5 * (double)(1 - cosf(arg)));
-        }
-        int rc = upload(&c->d_window, w);
-        if (rc) return rc;
+        const double ang = -2.0 * M_PI / (double)c->N;
+        c->wdelta = make_float2((float)std::cos(ang), (float)std::sin(ang));
     }
     // ---- twiddles
     {
@@ -477,12 +530,9 @@ int build(psdr_ctx *c) {
             rc = upload(&c->d_Wl2, make_twiddles((size_t)c->M2, 1, (size_t)c->M2, -1));
             if (rc) return rc;
         }
-        c->log2B = std::min(10, ilog2(c->M));
-        const size_t B = (size_t)1 << c->log2B;
-        // rot exponents reach M2*... <= (M2-1)*M1 < M; TA needs M/B entries (+1 guard)
-        rc = upload(&c->d_TA, make_twiddles(c->M / B + 1, B, c->M, -1));
-        if (rc) return rc;
-        rc = upload(&c->d_TB, make_twiddles(B, 1, c->M, -1));
+        // inter-pass twiddle W_M^e = W_M1^{e >> log2M2} * W_M^{e & (M2-1)}: the first factor
+        // is the pass-1 stage table, the second has M2 entries
+        rc = upload(&c->d_TB, make_twiddles((size_t)c->M2, 1, c->M, -1));
         if (rc) return rc;
         if (c->is_real) {
             c->log2UB = std::min(10, ilog2(c->N));
@@ -493,14 +543,24 @@ int build(psdr_ctx *c) {
             if (rc) return rc;
         }
     }
+#ifdef PSDR_TRACE_ON
+    HIPCHK(hipMalloc((void **)&c->d_trace, 256 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(c->d_trace, 0, 256 * sizeof(unsigned long long)));
+#endif
     // ---- work buffers
     const size_t F = (size_t)c->max_batch;
-    HIPCHK(hipMalloc((void **)&c->d_Y, F * c->M * sizeof(cf)));
+    if (const char *e = getenv("PSDR_YPAD")) c->ypad = (size_t)atoi(e);
+    HIPCHK(hipMalloc((void **)&c->d_Y, F * (c->M + c->ypad * (size_t)(c->M2 / c->T1)) * sizeof(cf)));
     if (c->is_real) HIPCHK(hipMalloc((void **)&c->d_Z, F * c->M * sizeof(cf)));
     HIPCHK(hipMalloc((void **)&c->d_spec, F * c->spec_stride * sizeof(cf)));
     HIPCHK(hipMemset(c->d_spec, 0, F * c->spec_stride * sizeof(cf)));
     HIPCHK(hipMalloc((void **)&c->d_q, F * c->q_stride));
     HIPCHK(hipMemset(c->d_q, 0, F * c->q_stride));
+    if (c->tiled_lt >= 0) {
+        HIPCHK(hipMalloc((void **)&c->d_qt, F * c->qt_stride));
+        HIPCHK(hipMemset(c->d_qt, 0, F * c->qt_stride));
+    }
+    c->q_untiled.assign(F, 0);
     HIPCHK(hipMalloc((void **)&c->d_pscr[0], F * c->p_stride * sizeof(float)));
     HIPCHK(hipMalloc((void **)&c->d_pscr[1], F * c->p_stride * sizeof(float)));
     // ---- level-1 staging
@@ -636,10 +696,15 @@ extern "C" int psdr_create(const psdr_config *cfg, psdr_ctx **out) {
     c->q_len = 0;
     for (int i = 0; i < c->levels; i++) c->q_len += c->R >> i;
     c->q_stride = (c->q_len + 127) & ~(size_t)127;
-    if (is_real)
+    if (is_real) {
         c->LT = 7;
-    else
+        c->tiled_lt = -1;
+    } else {
+        c->tile_ch = (c->T2 >= 16) ? 16 : 8;
         c->LT = (c->T2 >= 16) ? 4 : 3;
+        c->tiled_lt = c->LT;
+        c->qt_stride = 2 * c->R;  // R/CH records of 2*CH bytes
+    }
     c->p_stride = std::max<size_t>(c->R >> c->LT, 64);
     if (cfg->skip_num < 1) c->cfg.skip_num = 1;
 
@@ -657,6 +722,7 @@ extern "C" void psdr_destroy(psdr_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->side) hipStreamSynchronize(c->side);
     free_all(c);
     delete c;
 }
@@ -699,14 +765,32 @@ extern "C" int psdr_execute(psdr_ctx *c) {
     HIPCHK(hipSetDevice(c->device));
     int rc = process_frames(c, c->d_stage, 1, PSDR_FMT_F32);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    rc = drain(c);
+    if (rc) return rc;
     c->executed = true;
+    return PSDR_OK;
+}
+
+// make the level-major copy of frame `frame`'s pyramid current (levels 0..LT live in tiled
+// records on the device; the reference's layout is produced on demand)
+static int ensure_level_major(psdr_ctx *c, int frame) {
+    if (c->tiled_lt < 0 || c->q_untiled[frame]) return PSDR_OK;
+    const size_t nrec = c->R / (size_t)c->tile_ch;
+    hipLaunchKernelGGL(k_untile_q, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, c->side,
+                       c->d_qt + (size_t)frame * c->qt_stride, c->d_q + (size_t)frame * c->q_stride, c->R,
+                       c->tile_ch, c->tiled_lt, c->levels);
+    HIPCHK(hipGetLastError());
+    c->q_untiled[frame] = 1;
     return PSDR_OK;
 }
 
 // spectrum of `frame` to host in the reference's k order
 static int copy_spectrum_k_order(psdr_ctx *c, int frame, cf *dst) {
     const cf *src = c->d_spec + (size_t)frame * c->spec_stride;
+    {
+        int rc = drain(c);
+        if (rc) return rc;
+    }
     if (c->is_real) {
         HIPCHK(hipMemcpyAsync(dst, src, (c->N / 2 + 1) * sizeof(cf), hipMemcpyDeviceToHost,
                               c->stream));
@@ -738,6 +822,14 @@ extern "C" int psdr_get_quantized_buffer(psdr_ctx *c, int8_t **out) {
     if (!c || !out) return fail(PSDR_ERR_INVALID, "null argument");
     HIPCHK(hipSetDevice(c->device));
     if (c->last_nframes > 0 && !c->q_valid) {
+        {
+            int rc = drain(c);
+            if (rc) return rc;
+            rc = ensure_level_major(c, 0);
+            if (rc) return rc;
+            rc = drain(c);
+            if (rc) return rc;
+        }
         HIPCHK(hipMemcpyAsync(c->h_q, c->d_q, c->q_len, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         c->q_valid = true;
@@ -768,14 +860,17 @@ extern "C" int psdr_memcpy_h2d(psdr_ctx *c, void *dst, const void *src, size_t b
 extern "C" int psdr_memcpy_d2h(psdr_ctx *c, void *dst, const void *src, size_t bytes) {
     if (!c || !dst || !src) return fail(PSDR_ERR_INVALID, "null argument");
     HIPCHK(hipSetDevice(c->device));
+    {
+        int rc = drain(c);
+        if (rc) return rc;
+    }
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return PSDR_OK;
 }
 extern "C" int psdr_synchronize(psdr_ctx *c) {
     if (!c) return fail(PSDR_ERR_INVALID, "null argument");
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return PSDR_OK;
+    return drain(c);
 }
 extern "C" size_t psdr_half_frame_bytes(const psdr_ctx *c) {
     if (!c) return 0;
@@ -791,6 +886,11 @@ extern "C" int psdr_process_batch(psdr_ctx *c, const void *d_halves, int nframes
     return process_frames(c, d_halves, nframes, c->cfg.input_format);
 }
 
+static int drain(psdr_ctx *c) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->side != c->stream) HIPCHK(hipStreamSynchronize(c->side));
+    return PSDR_OK;
+}
 static int check_slot(psdr_ctx *c, int id) {
     if (id < 0 || id >= (int)c->aslots.size() || !c->aslots[id].active)
         return fail(PSDR_ERR_INVALID, "no audio client with id %d", id);
@@ -810,10 +910,10 @@ extern "C" int psdr_client_add(psdr_ctx *c, int *id_out) {
             const size_t S = c->aslots.size(), h = (size_t)c->n / 2;
             for (int b = 0; b < 2; b++) {
                 HIPCHK(hipMemsetAsync(c->d_real_prev + ((size_t)b * S + i) * h, 0, h * sizeof(float),
-                                      c->stream));
+                                      c->side));
                 HIPCHK(hipMemsetAsync(c->d_bb_tail + ((size_t)b * S + i) * h, 0, h * sizeof(cf),
-                                      c->stream));
-                HIPCHK(hipMemsetAsync(c->d_bb_last + ((size_t)b * S + i), 0, sizeof(cf), c->stream));
+                                      c->side));
+                HIPCHK(hipMemsetAsync(c->d_bb_last + ((size_t)b * S + i), 0, sizeof(cf), c->side));
             }
             *id_out = (int)i;
             return PSDR_OK;
@@ -891,7 +991,7 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     c->last_demod_frames = nframes;
     if (nact == 0) return PSDR_OK;
     HIPCHK(hipMemcpyAsync(d_clients, h_clients, (size_t)nact * sizeof(ClientParams),
-                          hipMemcpyHostToDevice, c->stream));
+                          hipMemcpyHostToDevice, c->side));
     DemodArgs a{};
     a.spec = spec;
     a.spec_stride = spec_stride;
@@ -915,17 +1015,21 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     a.bb_last = c->d_bb_last;
     a.slots = (int)c->aslots.size();
     {
-        ProfScope ps(c, K_IDFT);
-        hipLaunchKernelGGL(k_demod_idft, dim3(nact, nframes), dim3(256), c->idft_lds, c->stream,
+        ProfScope ps(c, K_IDFT, c->side);
+        hipLaunchKernelGGL(k_demod_idft, dim3(nact, nframes), dim3(256), c->idft_lds, c->side,
                            a);
         HIPCHK(hipGetLastError());
     }
     {
-        ProfScope ps(c, K_OLA);
-        hipLaunchKernelGGL(k_demod_ola, dim3(nact, nframes), dim3(128), 0, c->stream, a);
+        ProfScope ps(c, K_OLA, c->side);
+        hipLaunchKernelGGL(k_demod_ola, dim3(nact, nframes), dim3(128), 0, c->side, a);
         HIPCHK(hipGetLastError());
     }
-    c->client_ring.release(ring, c->stream);
+    c->client_ring.release(ring, c->side);
+    if (c->side != c->stream) {
+        HIPCHK(hipEventRecord(c->ev_side_done, c->side));
+        c->side_pending = true;
+    }
     return PSDR_OK;
 }
 
@@ -954,6 +1058,10 @@ extern "C" int psdr_read_audio(psdr_ctx *c, int id, float *audio, float *pwr, in
     HIPCHK(hipSetDevice(c->device));
     const size_t F = (size_t)c->last_demod_frames, h = (size_t)c->n / 2, mb = (size_t)c->max_batch;
     if (F == 0) return fail(PSDR_ERR_STATE, "no demodulated batch to read");
+    {
+        int rc = drain(c);
+        if (rc) return rc;
+    }
     if (audio)
         HIPCHK(hipMemcpyAsync(audio, c->d_audio + (size_t)id * mb * h, F * h * sizeof(float),
                               hipMemcpyDeviceToHost, c->stream));
@@ -1091,16 +1199,21 @@ extern "C" int psdr_waterfall_batch(psdr_ctx *c, uint64_t first_frame_num) {
         c->wfout_cap = total;
     }
     HIPCHK(hipMemcpyAsync(d_wf, h_wf, (size_t)(maxid + 1) * sizeof(WfClient), hipMemcpyHostToDevice,
-                          c->stream));
+                          c->side));
     HIPCHK(hipMemcpyAsync(d_sent, h_sent, (size_t)nsent * sizeof(int), hipMemcpyHostToDevice,
-                          c->stream));
+                          c->side));
     {
-        ProfScope ps(c, K_WFALL);
-        hipLaunchKernelGGL(k_waterfall_gather, dim3(maxid + 1, nsent), dim3(256), 0, c->stream, c->d_q,
-                           c->q_stride, d_wf, d_sent, nsent, c->d_wfout);
+        ProfScope ps(c, K_WFALL, c->side);
+        hipLaunchKernelGGL(k_waterfall_gather, dim3(maxid + 1, nsent), dim3(256), 0, c->side, c->d_q,
+                           c->q_stride, c->d_qt, c->qt_stride, c->tiled_lt, c->tile_ch, d_wf, d_sent, nsent,
+                           c->d_wfout);
         HIPCHK(hipGetLastError());
     }
-    c->wf_ring.release(ring, c->stream);
+    c->wf_ring.release(ring, c->side);
+    if (c->side != c->stream) {
+        HIPCHK(hipEventRecord(c->ev_side_done, c->side));
+        c->side_pending = true;
+    }
     return PSDR_OK;
 }
 extern "C" int psdr_read_waterfall(psdr_ctx *c, int id, int8_t *out, size_t out_cap, int *nsent_out) {
@@ -1114,6 +1227,10 @@ extern "C" int psdr_read_waterfall(psdr_ctx *c, int id, int8_t *out, size_t out_
     if (nsent_out) *nsent_out = s.nsent;
     if (bytes == 0 || !out) return PSDR_OK;
     if (bytes > out_cap) return fail(PSDR_ERR_INVALID, "output buffer too small (%zu > %zu)", bytes, out_cap);
+    {
+        int rc2 = drain(c);
+        if (rc2) return rc2;
+    }
     HIPCHK(hipMemcpyAsync(out, c->d_wfout + s.out_off, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return PSDR_OK;
@@ -1130,6 +1247,14 @@ extern "C" int psdr_spectrum_device_ptr(psdr_ctx *c, int frame, const float **d_
 extern "C" int psdr_quantized_device_ptr(psdr_ctx *c, int frame, const int8_t **d_q, size_t *nbytes) {
     if (!c) return fail(PSDR_ERR_INVALID, "null argument");
     if (frame < 0 || frame >= c->max_batch) return fail(PSDR_ERR_INVALID, "frame %d out of range", frame);
+    {
+        int rc = drain(c);
+        if (rc) return rc;
+        rc = ensure_level_major(c, frame);
+        if (rc) return rc;
+        rc = drain(c);
+        if (rc) return rc;
+    }
     if (d_q) *d_q = c->d_q + (size_t)frame * c->q_stride;
     if (nbytes) *nbytes = c->q_len;
     return PSDR_OK;
@@ -1144,6 +1269,14 @@ extern "C" int psdr_read_quantized(psdr_ctx *c, int frame, int8_t *out) {
     if (!c || !out) return fail(PSDR_ERR_INVALID, "null argument");
     if (frame < 0 || frame >= c->last_nframes) return fail(PSDR_ERR_INVALID, "frame %d not in the last batch", frame);
     HIPCHK(hipSetDevice(c->device));
+    {
+        int rc = drain(c);
+        if (rc) return rc;
+        rc = ensure_level_major(c, frame);
+        if (rc) return rc;
+        rc = drain(c);
+        if (rc) return rc;
+    }
     HIPCHK(hipMemcpyAsync(out, c->d_q + (size_t)frame * c->q_stride, c->q_len, hipMemcpyDeviceToHost,
                           c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1188,6 +1321,7 @@ extern "C" int psdr_timer_start(psdr_ctx *c) {
 }
 extern "C" int psdr_timer_stop_ms(psdr_ctx *c, double *ms_out) {
     if (!c || !ms_out) return fail(PSDR_ERR_INVALID, "null argument");
+    if (c->side_pending && c->side != c->stream) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_side_done, 0));
     HIPCHK(hipEventRecord(c->t1, c->stream));
     HIPCHK(hipEventSynchronize(c->t1));
     float ms = 0;
@@ -1196,10 +1330,28 @@ extern "C" int psdr_timer_stop_ms(psdr_ctx *c, double *ms_out) {
     return PSDR_OK;
 }
 extern "C" void *psdr_stream(psdr_ctx *c) { return c ? (void *)c->stream : nullptr; }
+// tuning builds (-DPSDR_TRACE_ON): phase timestamps of work-group 0, [pass][iteration 0..7][16]
+extern "C" int psdr_debug_trace(psdr_ctx *c, unsigned long long *out256) {
+    if (!c || !out256) return fail(PSDR_ERR_INVALID, "null argument");
+    if (!c->d_trace) return fail(PSDR_ERR_UNSUPPORTED, "library built without PSDR_TRACE_ON");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out256, c->d_trace, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return PSDR_OK;
+}
 extern "C" int psdr_set_stream(psdr_ctx *c, void *hip_stream) {
     if (!c) return fail(PSDR_ERR_INVALID, "null argument");
-    HIPCHK(hipStreamSynchronize(c->stream));
+    {
+        int rc = drain(c);
+        if (rc) return rc;
+    }
     resolve_pending(c);
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->side_pending = false;
+    if (hip_stream) {  // everything in order on the caller's stream
+        c->stream = (hipStream_t)hip_stream;
+        c->side = c->stream;
+    } else {
+        c->stream = c->own_stream;
+        c->side = c->own_side;
+    }
     return PSDR_OK;
 }

@@ -79,4 +79,48 @@ __device__ __forceinline__ void pyr_levels(float (&p)[CH], int8_t *Qf, size_t qo
         pyr_levels<CH, LV + 1>(p, Qf, qoff + len, len >> 1, cidx >> 1, nlevels, size_log2);
 }
 
+// ---- tiled pyramid records (levels 0..LT of one aligned group of CH bins, contiguous) ----
+// The fused pass-2 epilogue owns CH = 16 (or 8) consecutive client-order bins per LDS row;
+// writing every level to its own array costs LT+1 scattered partial-line stores per row.
+// Instead the device keeps levels 0..LT of group g = c / CH in ONE record of 2*CH bytes:
+//   CH = 16: [q0 x16 | q1 x8 | q2 x4 | q3 x2 | q4 | pad]     (offsets 0,16,24,28,30)
+//   CH =  8: [q0 x8 | q1 x4 | q2 x2 | q3 | pad]              (offsets 0, 8,12,14)
+// Consumers on the GPU (waterfall gather) index the records directly; the reference's
+// level-major layout (src/fft_impl.cpp:162-172) is produced on demand by k_untile_q.
+__host__ __device__ __forceinline__ int tiled_level_offset(int ch, int lv) {
+    // ch * (2 - 2^(1-lv)) for lv >= 1, 0 for lv = 0
+    return lv == 0 ? 0 : 2 * ch - (2 * ch >> lv);
+}
+
+__device__ __forceinline__ void pyr_record16(float (&p)[16], int size_log2, uint4 &lo, uint4 &hi) {
+    lo.x = pack4(p[0], p[1], p[2], p[3], size_log2);
+    lo.y = pack4(p[4], p[5], p[6], p[7], size_log2);
+    lo.z = pack4(p[8], p[9], p[10], p[11], size_log2);
+    lo.w = pack4(p[12], p[13], p[14], p[15], size_log2);
+#pragma unroll
+    for (int i = 0; i < 8; i++) p[i] = __fadd_rn(p[2 * i], p[2 * i + 1]);
+    hi.x = pack4(p[0], p[1], p[2], p[3], size_log2 - 1);
+    hi.y = pack4(p[4], p[5], p[6], p[7], size_log2 - 1);
+#pragma unroll
+    for (int i = 0; i < 4; i++) p[i] = __fadd_rn(p[2 * i], p[2 * i + 1]);
+    hi.z = pack4(p[0], p[1], p[2], p[3], size_log2 - 2);
+    p[0] = __fadd_rn(p[0], p[1]);
+    p[1] = __fadd_rn(p[2], p[3]);
+    hi.w = quantize_u8(p[0], size_log2 - 3) | (quantize_u8(p[1], size_log2 - 3) << 8);
+    p[0] = __fadd_rn(p[0], p[1]);
+    hi.w |= quantize_u8(p[0], size_log2 - 4) << 16;
+}
+__device__ __forceinline__ void pyr_record8(float (&p)[8], int size_log2, uint4 &rec) {
+    rec.x = pack4(p[0], p[1], p[2], p[3], size_log2);
+    rec.y = pack4(p[4], p[5], p[6], p[7], size_log2);
+#pragma unroll
+    for (int i = 0; i < 4; i++) p[i] = __fadd_rn(p[2 * i], p[2 * i + 1]);
+    rec.z = pack4(p[0], p[1], p[2], p[3], size_log2 - 1);
+    p[0] = __fadd_rn(p[0], p[1]);
+    p[1] = __fadd_rn(p[2], p[3]);
+    rec.w = quantize_u8(p[0], size_log2 - 2) | (quantize_u8(p[1], size_log2 - 2) << 8);
+    p[0] = __fadd_rn(p[0], p[1]);
+    rec.w |= quantize_u8(p[0], size_log2 - 3) << 16;
+}
+
 }  // namespace psdr

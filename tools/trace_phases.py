@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""Phase timeline (shader clock cycles) of work-group 0 in the two FFT passes.
+Needs a -DPSDR_TRACE_ON build: PSDR_LIB=build/variants/libpsdr_trace.so python tools/trace_phases.py"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from phantomsdr_amd import SpectrumEngine  # noqa: E402
+
+N, F = 1 << 20, 16
+eng = SpectrumEngine(35_000_000, N, False, input_format="s16", max_batch=F, max_clients=1, max_waterfall_clients=1)
+hb = eng.ctx.half_frame_bytes()
+raw = np.random.default_rng(0).integers(-64, 64, size=(F * 4 + 1) * hb // 2, dtype=np.int16)
+eng.upload_ring(raw)
+for i in range(4):
+    eng.step((i % 4) * F, F, demod=False, waterfall=False)
+eng.ctx.synchronize()
+buf = (C.c_ulonglong * 256)()
+fn = eng.ctx.lib._handle and C.CDLL(os.environ.get("PSDR_LIB")).psdr_debug_trace
+fn.argtypes = [C.c_void_p, C.c_void_p]
+rc = fn(eng.ctx.h, buf)
+assert rc == 0, rc
+t = np.array(buf, dtype=np.int64).reshape(2, 8, 16)
+names = {0: "top", 1: "xpose-wr(+ld wait)", 2: "bar", 3: "rd+bar+prefetch", 4: "stage0", 5: "bar", 6: "rd+bar",
+         7: "stage1", 8: "bar", 9: "rd+bar", 10: "last stage+stores", 11: "bar", 12: "epilogue", 13: "bar(end)"}
+for p in range(2):
+    print(f"== pass {p + 1} (cycles, iteration: deltas between marks)")
+    for it in range(4):
+        row = t[p, it]
+        marks = [(k, row[k]) for k in range(16) if row[k] != 0]
+        marks.sort(key=lambda x: x[1])
+        out = []
+        for (k0, c0), (k1, c1) in zip(marks[:-1], marks[1:]):
+            out.append(f"{names.get(k1, k1)}={c1 - c0}")
+        tot = marks[-1][1] - marks[0][1] if marks else 0
+        print(f" it{it}: total={tot}  " + "  ".join(out))
+eng.close()
