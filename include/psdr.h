@@ -82,7 +82,8 @@ void psdr_destroy(psdr_ctx *ctx);
 
 /* ---- Level 1: the FFT plug-in (src/fft.h:33-63) ----------------------------------- */
 /* FFT::malloc / FFT::free (src/fft.h:36-37; cuFFT twin src/fft_cuda.cu:22-28): pinned,
- * host-writable buffer of nfloats floats. */
+ * host-writable buffer of nfloats floats.  ctx may be NULL (the reference allocates its
+ * half-frame buffers before planning, src/fft.cpp:17-29). */
 int psdr_host_alloc(psdr_ctx *ctx, size_t nfloats, float **out);
 int psdr_host_free(psdr_ctx *ctx, float *buf);
 /* FFT::load_real_input / load_complex_input (src/fft.h:45-46, src/fft_impl.cpp:131-143):

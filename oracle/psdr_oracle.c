@@ -250,36 +250,58 @@ static cf32 *make_twiddles_f32(size_t n) {
  * a direct R-point DFT with the inter-stage twiddle folded into one table lookup):
  *   y[j + s*p] = sum_q x[i + q*n/R] * W_n^{ q*(k + s*p)*(n/(p*R)) },  k = i mod p,
  *   j = (i-k)*R + k. */
+/* plan cache (per thread): radices + twiddle table of the last few (n, sign) */
+typedef struct {
+    size_t n;
+    int sign, ns;
+    size_t radices[64];
+    cf64 *W;
+} gen_plan;
+static _Thread_local gen_plan g_plans[8];
+static _Thread_local int g_plan_next = 0;
+static const gen_plan *get_plan(size_t n, int sign) {
+    for (int i = 0; i < 8; i++)
+        if (g_plans[i].n == n && g_plans[i].sign == sign) return &g_plans[i];
+    gen_plan *p = &g_plans[g_plan_next];
+    g_plan_next = (g_plan_next + 1) % 8;
+    free(p->W);
+    p->n = n;
+    p->sign = sign;
+    p->ns = 0;
+    size_t m = n;
+    while (m % 4 == 0) {
+        p->radices[p->ns++] = 4;
+        m /= 4;
+    }
+    while (m % 2 == 0) {
+        p->radices[p->ns++] = 2;
+        m /= 2;
+    }
+    for (size_t f = 3; f * f <= m; f += 2)
+        while (m % f == 0) {
+            p->radices[p->ns++] = f;
+            m /= f;
+        }
+    if (m > 1) p->radices[p->ns++] = m;
+    p->W = (cf64 *)malloc(sizeof(cf64) * n);
+    for (size_t k = 0; k < n; k++) {
+        double a = (double)sign * 2.0 * M_PI * (double)k / (double)n;
+        p->W[k].re = cos(a);
+        p->W[k].im = sin(a);
+    }
+    return p;
+}
+
 static void dft_generic_f64(const cf64 *in, cf64 *out, size_t n, int sign) {
     if (n == 0) return;
     if (n == 1) {
         out[0] = in[0];
         return;
     }
-    size_t radices[64];
-    int ns = 0;
-    size_t m = n;
-    while (m % 4 == 0) {
-        radices[ns++] = 4;
-        m /= 4;
-    }
-    while (m % 2 == 0) {
-        radices[ns++] = 2;
-        m /= 2;
-    }
-    for (size_t f = 3; f * f <= m; f += 2)
-        while (m % f == 0) {
-            radices[ns++] = f;
-            m /= f;
-        }
-    if (m > 1) radices[ns++] = m;
-
-    cf64 *W = (cf64 *)malloc(sizeof(cf64) * n);
-    for (size_t k = 0; k < n; k++) {
-        double a = (double)sign * 2.0 * M_PI * (double)k / (double)n;
-        W[k].re = cos(a);
-        W[k].im = sin(a);
-    }
+    const gen_plan *pl = get_plan(n, sign);
+    const size_t *radices = pl->radices;
+    const int ns = pl->ns;
+    const cf64 *W = pl->W;
     cf64 *bufA = (cf64 *)malloc(sizeof(cf64) * n);
     cf64 *bufB = (cf64 *)malloc(sizeof(cf64) * n);
     memcpy(bufA, in, sizeof(cf64) * n);
@@ -312,7 +334,6 @@ static void dft_generic_f64(const cf64 *in, cf64 *out, size_t n, int sign) {
         dst = tmp;
     }
     memcpy(out, src, sizeof(cf64) * n);
-    free(W);
     free(bufA);
     free(bufB);
 }

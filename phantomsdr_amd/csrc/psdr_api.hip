@@ -729,14 +729,15 @@ extern "C" void psdr_destroy(psdr_ctx *c) {
 
 // ---- level 1 ---------------------------------------------------------------------------
 extern "C" int psdr_host_alloc(psdr_ctx *c, size_t nfloats, float **out) {
-    if (!c || !out) return fail(PSDR_ERR_INVALID, "null argument");
-    HIPCHK(hipSetDevice(c->device));
+    if (!out) return fail(PSDR_ERR_INVALID, "null argument");
+    // ctx may be NULL: the reference allocates its half-frame buffers before planning
+    // (src/fft.cpp:17-29), i.e. before the back-end knows whether the input is real
+    if (c) HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipHostMalloc((void **)out, std::max<size_t>(nfloats, 1) * sizeof(float),
                          hipHostMallocDefault));
     return PSDR_OK;
 }
-extern "C" int psdr_host_free(psdr_ctx *c, float *buf) {
-    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+extern "C" int psdr_host_free(psdr_ctx *, float *buf) {
     if (buf) HIPCHK(hipHostFree(buf));
     return PSDR_OK;
 }

@@ -1,0 +1,126 @@
+"""Host-side checks that need no GPU: the C-ABI library loads and exports every symbol
+include/psdr.h declares; error behaviour without a device; derived parameters and the
+roofline accounting of bench.py against SURVEY Appendix A / 8d."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import HAVE_GPU, ROOT
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "psdr.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(psdr_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from phantomsdr_amd import _lib
+    names = header_functions()
+    assert len(names) >= 40
+    L = C.CDLL(os.path.join(ROOT, "phantomsdr_amd", "libpsdr_hip.so"))
+    for n in names:
+        assert hasattr(L, n), f"{n} is declared in include/psdr.h but not exported"
+    bound = {s[0] for s in _lib.SYMBOLS}
+    assert set(names) <= bound | {"psdr_debug_trace"}, set(names) - bound
+    assert _lib.load().psdr_version().startswith(b"phantomsdr_amd")
+
+
+@pytest.mark.skipif(HAVE_GPU, reason="checks the no-device error path")
+def test_create_without_device_fails_loudly():
+    import phantomsdr_amd as p
+    with pytest.raises(p.PsdrError) as e:
+        p.Context(1 << 16, False, 7)
+    assert e.value.code == -2 and "No HIP devices" in str(e.value)
+
+
+def test_config_struct_matches_header():
+    from phantomsdr_amd._lib import psdr_config
+    txt = open(os.path.join(ROOT, "include", "psdr.h")).read()
+    body = txt[txt.index("typedef struct psdr_config {"): txt.index("} psdr_config;")]
+    fields = re.findall(r"^\s+(?:u?int32_t)\s+([a-z_]+);", body, flags=re.M)
+    assert fields == [f[0] for f in psdr_config._fields_]
+    assert C.sizeof(psdr_config) == 4 * len(fields)
+
+
+def test_no_oracle_in_product_path():
+    """the product never imports/links the oracle (it is test infrastructure only)"""
+    pkg = os.path.join(ROOT, "phantomsdr_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dp, f), errors="ignore").read()
+                for needle in ("import oracle", "from oracle", "liboracle", "psdr_oracle", "orc_", "_ref/"):
+                    assert needle not in src, (os.path.join(dp, f), needle)
+
+
+@pytest.mark.parametrize("sps,N,is_real,n,levels,skip", [
+    (3_200_000, 1 << 16, False, 248, 7, 8),      # cfg1
+    (35_000_000, 1 << 20, False, 360, 11, 6),    # cfg2/4
+    (70_000_000, 1 << 21, True, 360, 11, 6),     # cfg3
+    (70_000_000, 1 << 22, True, 720, 12, 2),     # cfg5
+    (20_000_000, 1 << 20, False, 10068, 10, 2),  # shipped config.toml (audio_sps 192k, wf 2048)
+])
+def test_derived_params_match_survey_appendix_a(sps, N, is_real, n, levels, skip):
+    from phantomsdr_amd.core import derived_params
+    kw = dict(audio_sps=192000, waterfall_size=2048) if n == 10068 else {}
+    p = derived_params(sps, N, is_real, **kw)
+    assert (p["audio_fft_size"], p["downsample_levels"], p["skip_num"]) == (n, levels, skip)
+    assert p["fft_result_size"] == (N // 2 if is_real else N)
+
+
+def test_bench_roofline_accounting_matches_survey_8d():
+    import bench
+    from phantomsdr_amd.core import derived_params
+    wl = bench.WORKLOADS["cfg2"]
+    p = derived_params(wl["sps"], wl["fft_size"], wl["is_real"])
+    cl = bench.make_clients(wl, p, seed=1)
+    wf = bench.make_waterfalls(wl, p, seed=1)
+    assert len(cl) == 16 and len(wf) == 4
+    ab = bench.algorithmic_bytes_per_frame(wl, p, cl, wf)
+    assert ab["input"] == 4 * (1 << 20) and ab["spectrum"] == 8 * (1 << 20)
+    assert ab["pyramid"] == sum((1 << 20) >> i for i in range(11))
+    assert abs(ab["total"] - 14.73e6) < 0.05e6       # SURVEY 8d table, cfg 2
+    for mode, l, m, r in cl:                          # 3 kHz SSB slices: 89 bins
+        assert r - l == 89 and 0 <= l < r < (1 << 20)
+    wl3 = bench.WORKLOADS["cfg3"]
+    p3 = derived_params(wl3["sps"], wl3["fft_size"], wl3["is_real"])
+    ab3 = bench.algorithmic_bytes_per_frame(wl3, p3, bench.make_clients(wl3, p3, seed=1), [])
+    assert abs(ab3["total"] - 14.82e6) < 0.12e6       # cfg 3
+
+
+def test_client_sharding_plan():
+    from phantomsdr_amd.distributed import assign_clients
+    plan = assign_clients(256, 8)
+    assert all(len(x) == 32 for x in plan)
+    assert sorted(sum(plan, [])) == list(range(256))
+    assert plan[3][:3] == [3, 11, 19]
+    assert assign_clients(5, 2) == [[0, 2, 4], [1, 3]]
+
+
+def test_c_example_compiles_and_links_against_the_header():
+    """examples/level1_demo.c: plain C over include/psdr.h (no GPU needed to build it)."""
+    import subprocess
+    import tempfile
+    out = os.path.join(tempfile.mkdtemp(), "level1_demo")
+    subprocess.check_call(["gcc", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "level1_demo.c"),
+                           "-L" + os.path.join(ROOT, "phantomsdr_amd"), "-lpsdr_hip", "-lm",
+                           "-Wl,-rpath," + os.path.join(ROOT, "phantomsdr_amd"), "-o", out])
+    r = subprocess.run([out], capture_output=True, text=True)
+    if HAVE_GPU:
+        assert r.returncode == 0 and "peak bin 1000" in r.stdout, r.stdout + r.stderr
+    else:
+        assert r.returncode == 2 and "No HIP devices found" in r.stderr
+
+
+def test_cpp_adapter_mirrors_the_reference_interface():
+    """phantomsdr_amd/host/hip_fft.h overrides every pure virtual of class FFT (src/fft.h:33-63)"""
+    txt = open(os.path.join(ROOT, "phantomsdr_amd", "host", "hip_fft.h")).read()
+    for member in ("malloc(size_t", "free(float", "plan_c2c(direction", "plan_r2c(int", "load_real_input(float",
+                   "load_complex_input(float", "execute()", "get_output_buffer()", "get_quantized_buffer()"):
+        assert member in txt, member
+    assert "class hipFFT : public FFT" in txt
