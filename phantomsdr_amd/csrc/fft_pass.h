@@ -37,6 +37,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "butterfly.h"
 #include "quantize.h"
 
@@ -59,6 +61,25 @@
 #endif
 
 namespace psdr {
+
+// compile-time loops/dispatch: register arrays must only ever be indexed by constants
+// (a runtime-looking index puts the whole array in scratch memory)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_switch(int k, F &&f) {
+    if constexpr (I < N) {
+        if (k == I)
+            f(std::integral_constant<int, I>{});
+        else
+            static_switch<I + 1, N>(k, f);
+    }
+}
 
 template <int L>
 struct Plan;
@@ -389,7 +410,8 @@ __global__ __launch_bounds__((L / 16) * T / V) void k_fft_pass1(Pass1Args a) {
     const size_t g_row = (size_t)M2 * gsb;
     const size_t g_step = (size_t)(NT / LPR) * g_row;  // between a thread's consecutive chunks
     const size_t g_lane = (size_t)(tid / LPR) * g_row + (size_t)(tid % LPR) * (16 / SB) * gsb;
-    uint4 rq[NCHK];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // plain vector: SROA keeps it in VGPRs
+    u32x4 rq[NCHK];
     const unsigned char *nxt = nullptr;
     auto point_at = [&](unsigned sidx) {
         const unsigned slot = xcd_slot(sidx, total);
@@ -397,24 +419,24 @@ __global__ __launch_bounds__((L / 16) * T / V) void k_fft_pass1(Pass1Args a) {
         const unsigned tl = slot - f * a.tiles_per_frame;
         nxt = reinterpret_cast<const unsigned char *>(a.raw) + ((size_t)f * (M / 2) + (size_t)tl * T) * gsb + g_lane;
     };
-    auto issue = [&](int i) {
+    auto issue = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
         const unsigned char *p = nxt + (size_t)i * g_step;
         if (PSDR_ABL & 8) {
-            rq[i] = make_uint4(i, 1u, 2u, 3u);
+            rq[i] = u32x4{(unsigned)i, 1u, 2u, 3u};
         } else if (SB == 8 && fmt == 5) {  // f64: two samples = 32 bytes, narrowed to f32 here
             const double2 s0 = reinterpret_cast<const double2 *>(p)[0];
             const double2 s1 = reinterpret_cast<const double2 *>(p)[1];
-            rq[i] = make_uint4(__float_as_uint((float)s0.x), __float_as_uint((float)s0.y),
-                               __float_as_uint((float)s1.x), __float_as_uint((float)s1.y));
+            rq[i] = u32x4{__float_as_uint((float)s0.x), __float_as_uint((float)s0.y),
+                          __float_as_uint((float)s1.x), __float_as_uint((float)s1.y)};
         } else {
-            rq[i] = *reinterpret_cast<const uint4 *>(p);
+            rq[i] = *reinterpret_cast<const u32x4 *>(p);
         }
     };
     unsigned s = blockIdx.x;
     if (s < total) {
         point_at(s);
-#pragma unroll
-        for (int i = 0; i < NCHK; i++) issue(i);
+        static_for<0, NCHK>(issue);
     }
     __syncthreads();  // Wl and the twiddle table are visible
 
@@ -439,13 +461,12 @@ __global__ __launch_bounds__((L / 16) * T / V) void k_fft_pass1(Pass1Args a) {
         asm volatile("" : "+v"(tidx));
 
         // ---- raw image into LDS (linear, 16 bytes per lane)
-#pragma unroll
-        for (int i = 0; i < NCHK; i++) reinterpret_cast<uint4 *>(smem)[i * NT + tidx] = rq[i];
+        static_for<0, NCHK>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            reinterpret_cast<u32x4 *>(smem)[i * NT + tidx] = rq[i];
+        });
         PSDR_SCHED_FENCE();
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < EARLY; i++) issue(i);
-        }
+        if (more) static_for<0, EARLY>(issue);
         PSDR_SCHED_FENCE();
         PSDR_TRACE(a.trace, it, 1);
         __syncthreads();
@@ -492,10 +513,7 @@ __global__ __launch_bounds__((L / 16) * T / V) void k_fft_pass1(Pass1Args a) {
             for (int v = 0; v < V; v++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) Yb[(size_t)(i0[v] + e * L16) * T + t[v]] = pre[v][e];
-            if (more) {
-#pragma unroll
-                for (int i = EARLY; i < NCHK; i++) issue(i);
-            }
+            if (more) static_for<EARLY, NCHK>(issue);
             it++;
             continue;
         }
@@ -544,7 +562,9 @@ __global__ __launch_bounds__((L / 16) * T / V) void k_fft_pass1(Pass1Args a) {
                 const cf y = cmul(x, w);
                 // outputs arrive as (s even, s odd) pairs: one 16-byte store per pair
                 cf *row = Yb + (size_t)c1 * T + (t[v] & ~1);
-                if ((sidx & 1) == 0) {
+                if (PSDR_ABL & 256) {
+                    Yb[(size_t)c1 * T + t[v]] = y;
+                } else if ((sidx & 1) == 0) {
                     held = y;
                     held_row = row;
                 } else {
@@ -553,11 +573,13 @@ __global__ __launch_bounds__((L / 16) * T / V) void k_fft_pass1(Pass1Args a) {
             },
             // ---- trickle the rest of the next tile's loads through the stages
             [&](int k) {
-                if (more && k < NTICK) {
-#pragma unroll
-                    for (int j = 0; j < LPT; j++)
-                        if (EARLY + k * LPT + j < NCHK) issue(EARLY + k * LPT + j);
-                }
+                if (more)
+                    static_switch<0, NTICK>(k, [&](auto kc) {
+                        constexpr int K = decltype(kc)::value;
+                        constexpr int lo = EARLY + K * LPT < NCHK ? EARLY + K * LPT : NCHK;
+                        constexpr int hi = lo + LPT < NCHK ? lo + LPT : NCHK;
+                        static_for<lo, hi>(issue);
+                    });
             },
             [&](int k) { PSDR_TRACE(a.trace, it, k); });
         PSDR_TRACE(a.trace, it, 10);
@@ -630,8 +652,9 @@ __global__ __launch_bounds__((L / 16) * T / V) void k_fft_pass2(Pass2Args a) {
         const unsigned tl = slot - f * a.tiles_per_frame;
         nxt = a.Y + (size_t)f * a.yframe + (size_t)(tl * T) * TW;
     };
-    auto issue = [&](int q) {
-        const int v = q / 8, i = q % 8;
+    auto issue = [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int v = q / 8, i = q % 8;
         // uniform part of idx = 2*i*NTV: block (2*i*NTV)>>lc, offset (2*i*NTV)&(chunk-1)
         const cf *p = nxt + (size_t)((2 * i * NTV) >> lc) * blk + ((2 * i * NTV) & (chunk - 1)) + lane_off[v];
         r[v][i] = *reinterpret_cast<const float4 *>(p);
@@ -644,8 +667,7 @@ __global__ __launch_bounds__((L / 16) * T / V) void k_fft_pass2(Pass2Args a) {
     unsigned s = blockIdx.x;
     if (s < total) {
         point_at(s);
-#pragma unroll
-        for (int q = 0; q < NLD; q++) issue(q);
+        static_for<0, NLD>(issue);
     }
 
     int it = 0;
@@ -678,10 +700,7 @@ __global__ __launch_bounds__((L / 16) * T / V) void k_fft_pass2(Pass2Args a) {
                 tile[lds_idx<T, true>(n2 + 1, rr)] = make_float2(r[v][i].z, r[v][i].w);
             }
         PSDR_SCHED_FENCE();
-        if (more) {
-#pragma unroll
-            for (int q = 0; q < EARLY; q++) issue(q);
-        }
+        if (more) static_for<0, EARLY>(issue);
         PSDR_SCHED_FENCE();
         PSDR_TRACE(a.trace, it, 1);
         __syncthreads();
@@ -701,10 +720,7 @@ __global__ __launch_bounds__((L / 16) * T / V) void k_fft_pass2(Pass2Args a) {
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                     Xf[(size_t)(i0[v] + e * (L / 16)) * M1 + c1base + t[v]] = pre[v][e];
-            if (more) {
-#pragma unroll
-                for (int q = EARLY; q < NLD; q++) issue(q);
-            }
+            if (more) static_for<EARLY, NLD>(issue);
             continue;
         }
         float *Pst = reinterpret_cast<float *>(smem);  // reuses the (dead) tile after the last read
@@ -733,11 +749,13 @@ __global__ __launch_bounds__((L / 16) * T / V) void k_fft_pass2(Pass2Args a) {
                 }
             },
             [&](int k) {  // trickle the rest of the next tile's loads through the stages
-                if (more && k < NTICK) {
-#pragma unroll
-                    for (int j = 0; j < LPT; j++)
-                        if (EARLY + k * LPT + j < NLD) issue(EARLY + k * LPT + j);
-                }
+                if (more)
+                    static_switch<0, NTICK>(k, [&](auto kc) {
+                        constexpr int K = decltype(kc)::value;
+                        constexpr int lo = EARLY + K * LPT < NLD ? EARLY + K * LPT : NLD;
+                        constexpr int hi = lo + LPT < NLD ? lo + LPT : NLD;
+                        static_for<lo, hi>(issue);
+                    });
             },
             [&](int k) { PSDR_TRACE(a.trace, it, k); });
         PSDR_TRACE(a.trace, it, 10);

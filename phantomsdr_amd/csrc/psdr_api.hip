@@ -135,6 +135,16 @@ struct psdr_ctx {
     hipStream_t own_stream = nullptr, own_side = nullptr;
     hipEvent_t ev_fft_done = nullptr, ev_side_done = nullptr;
     bool side_pending = false;
+    // Result buffers (spectrum, pyramid, level powers) exist twice: batch b+1 is produced
+    // into the other set while the side stream still consumes batch b, so the FFT stream only
+    // ever waits for the consumers of batch b-1.  d_spec/d_q/d_qt/d_pscr point at the set of
+    // the LAST processed batch.
+    int cur_set = 0;
+    cf *spec_pool[2] = {nullptr, nullptr};
+    int8_t *q_pool[2] = {nullptr, nullptr}, *qt_pool[2] = {nullptr, nullptr};
+    float *pscr_pool[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    hipEvent_t ev_set_done[2] = {nullptr, nullptr};
+    bool set_pending[2] = {false, false};
 
     cf *d_Wl1 = nullptr, *d_Wl2 = nullptr, *d_TA = nullptr, *d_TB = nullptr;
     cf *d_UA = nullptr, *d_UB = nullptr;
@@ -334,7 +344,18 @@ size_t fmt_bytes(int fmt) {
 }
 
 // forward FFT + power + int8 pyramid for nframes frames (src/fft.cpp:61-98 per frame)
+void select_set(psdr_ctx *c, int set) {
+    c->cur_set = set;
+    c->d_spec = c->spec_pool[set];
+    c->d_q = c->q_pool[set];
+    c->d_qt = c->qt_pool[set];
+    c->d_pscr[0] = c->pscr_pool[set][0];
+    c->d_pscr[1] = c->pscr_pool[set][1];
+}
+
 int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
+    // alternate the result set when the consumers run on their own stream
+    if (c->side != c->stream) select_set(c, c->cur_set ^ 1);
     const int cols = 1;
     const int sb = fmt <= PSDR_FMT_S8 ? 2 : (fmt <= PSDR_FMT_S16 ? 4 : 8);  // image bytes per sample
     const unsigned tiles1 = (unsigned)(c->M2 / (c->T1 * cols)), tiles2 = (unsigned)(c->M1 / c->T2);
@@ -376,8 +397,9 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
     a2.trace = c->d_trace ? c->d_trace + 128 : nullptr;
     a2.tiles_per_frame = tiles2;
     a2.total_slots = tiles2 * (unsigned)nframes;
-    // pass 2 overwrites the buffers the side stream may still be reading (previous batch)
-    if (c->side_pending && c->side != c->stream) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_side_done, 0));
+    // pass 2 overwrites this result set: its previous consumers (two batches ago) must be done
+    if (c->set_pending[c->cur_set] && c->side != c->stream)
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_set_done[c->cur_set], 0));
     if (!c->is_real) {
         a2.X = c->d_spec;
         a2.spec_stride = c->spec_stride;
@@ -441,6 +463,8 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
     if (c->side != c->stream) {
         HIPCHK(hipEventRecord(c->ev_side_done, c->side));
         c->side_pending = true;
+        HIPCHK(hipEventRecord(c->ev_set_done[c->cur_set], c->side));
+        c->set_pending[c->cur_set] = true;
     }
     c->last_nframes = nframes;
     c->out_valid = c->q_valid = false;
@@ -461,11 +485,14 @@ void free_all(psdr_ctx *c) {
     F(c->d_UB);
     F(c->d_Y);
     F(c->d_Z);
-    F(c->d_spec);
-    F(c->d_q);
-    F(c->d_qt);
-    F(c->d_pscr[0]);
-    F(c->d_pscr[1]);
+    for (int s = 0; s < 2; s++) {
+        F(c->spec_pool[s]);
+        F(c->q_pool[s]);
+        F(c->qt_pool[s]);
+        F(c->pscr_pool[s][0]);
+        F(c->pscr_pool[s][1]);
+        if (c->ev_set_done[s]) hipEventDestroy(c->ev_set_done[s]);
+    }
     F(c->d_stage);
     F(c->d_Wn);
     F(c->d_ypost);
@@ -506,7 +533,13 @@ int build(psdr_ctx *c) {
         c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&c->own_side, hipStreamNonBlocking));
+    {
+        // the consumers are short kernels that must squeeze in next to the persistent FFT
+        // work-groups: give their stream the highest priority
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&c->own_side, hipStreamNonBlocking, hi));
+    }
     c->stream = c->own_stream;
     c->side = c->own_side;
     HIPCHK(hipEventCreateWithFlags(&c->ev_fft_done, hipEventDisableTiming));
@@ -552,17 +585,21 @@ int build(psdr_ctx *c) {
     if (const char *e = getenv("PSDR_YPAD")) c->ypad = (size_t)atoi(e);
     HIPCHK(hipMalloc((void **)&c->d_Y, F * (c->M + c->ypad * (size_t)(c->M2 / c->T1)) * sizeof(cf)));
     if (c->is_real) HIPCHK(hipMalloc((void **)&c->d_Z, F * c->M * sizeof(cf)));
-    HIPCHK(hipMalloc((void **)&c->d_spec, F * c->spec_stride * sizeof(cf)));
-    HIPCHK(hipMemset(c->d_spec, 0, F * c->spec_stride * sizeof(cf)));
-    HIPCHK(hipMalloc((void **)&c->d_q, F * c->q_stride));
-    HIPCHK(hipMemset(c->d_q, 0, F * c->q_stride));
-    if (c->tiled_lt >= 0) {
-        HIPCHK(hipMalloc((void **)&c->d_qt, F * c->qt_stride));
-        HIPCHK(hipMemset(c->d_qt, 0, F * c->qt_stride));
+    for (int s = 0; s < 2; s++) {
+        HIPCHK(hipMalloc((void **)&c->spec_pool[s], F * c->spec_stride * sizeof(cf)));
+        HIPCHK(hipMemset(c->spec_pool[s], 0, F * c->spec_stride * sizeof(cf)));
+        HIPCHK(hipMalloc((void **)&c->q_pool[s], F * c->q_stride));
+        HIPCHK(hipMemset(c->q_pool[s], 0, F * c->q_stride));
+        if (c->tiled_lt >= 0) {
+            HIPCHK(hipMalloc((void **)&c->qt_pool[s], F * c->qt_stride));
+            HIPCHK(hipMemset(c->qt_pool[s], 0, F * c->qt_stride));
+        }
+        HIPCHK(hipMalloc((void **)&c->pscr_pool[s][0], F * c->p_stride * sizeof(float)));
+        HIPCHK(hipMalloc((void **)&c->pscr_pool[s][1], F * c->p_stride * sizeof(float)));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_set_done[s], hipEventDisableTiming));
     }
+    select_set(c, 0);
     c->q_untiled.assign(F, 0);
-    HIPCHK(hipMalloc((void **)&c->d_pscr[0], F * c->p_stride * sizeof(float)));
-    HIPCHK(hipMalloc((void **)&c->d_pscr[1], F * c->p_stride * sizeof(float)));
     // ---- level-1 staging
     HIPCHK(hipMalloc((void **)&c->d_stage, (c->is_real ? c->N : 2 * c->N) * sizeof(float)));
     {
@@ -1030,6 +1067,8 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     if (c->side != c->stream) {
         HIPCHK(hipEventRecord(c->ev_side_done, c->side));
         c->side_pending = true;
+        HIPCHK(hipEventRecord(c->ev_set_done[c->cur_set], c->side));
+        c->set_pending[c->cur_set] = true;
     }
     return PSDR_OK;
 }
@@ -1214,6 +1253,8 @@ extern "C" int psdr_waterfall_batch(psdr_ctx *c, uint64_t first_frame_num) {
     if (c->side != c->stream) {
         HIPCHK(hipEventRecord(c->ev_side_done, c->side));
         c->side_pending = true;
+        HIPCHK(hipEventRecord(c->ev_set_done[c->cur_set], c->side));
+        c->set_pending[c->cur_set] = true;
     }
     return PSDR_OK;
 }
@@ -1347,6 +1388,8 @@ extern "C" int psdr_set_stream(psdr_ctx *c, void *hip_stream) {
     }
     resolve_pending(c);
     c->side_pending = false;
+    c->set_pending[0] = c->set_pending[1] = false;
+    select_set(c, 0);
     if (hip_stream) {  // everything in order on the caller's stream
         c->stream = (hipStream_t)hip_stream;
         c->side = c->stream;
