@@ -178,49 +178,83 @@ def cpu_baseline(wl, params, clients, waterfalls, budget_s=15.0):
 
 
 def run_sharded_bench(args, torch, rank, world, local_rank):
-    """N > 1 (BASELINE.json configs[3] shape): audio clients sharded over the ranks
-    (32 per GPU, 256 at 8 GPUs); rank 0 ingests + FFTs and broadcasts each spectrum batch
-    over RCCL/xGMI; every rank demodulates its own clients.  scaling = weak in clients."""
+    """N > 1.  Default (--shard time): the STREAM is sharded - batch g goes to rank g mod G
+    with a two-frame warm-up instead of any exchange (phantomsdr_amd/distributed.py); every
+    rank serves all the clients of its frames; weak scaling (per-GPU work fixed), no data-path
+    collective.  --shard clients: BASELINE.json configs[3] shape - audio clients sharded over
+    the ranks, rank 0 FFTs and broadcasts each spectrum batch over RCCL/xGMI."""
     import torch.distributed as dist
     from phantomsdr_amd import SpectrumEngine
-    from phantomsdr_amd.distributed import HipBackend, ShardedRunner, assign_clients
+    from phantomsdr_amd.distributed import (HipBackend, HipTimeBackend, ShardedRunner, TimeShardedRunner,
+                                            assign_clients)
 
     device = torch.device("cuda", local_rank)
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    wl = WORKLOADS[args.workload or "cfg4"]
+    time_mode = args.shard == "time"
+    wl = WORKLOADS[args.workload or ("cfg2" if time_mode else "cfg4")]
     F, N = args.batch, wl["fft_size"]
+    warm = TimeShardedRunner.WARMUP if time_mode else 0
     per_gpu = wl["audio"]
-    eng = SpectrumEngine(wl["sps"], N, wl["is_real"], input_format=wl["fmt"], max_batch=F,
-                         max_clients=per_gpu, max_waterfall_clients=1, device=local_rank)
+    eng = SpectrumEngine(wl["sps"], N, wl["is_real"], input_format=wl["fmt"], max_batch=F + warm,
+                         max_clients=max(per_gpu, 1), max_waterfall_clients=max(wl["waterfall"], 1),
+                         device=local_rank)
     params = eng.params
     hb = eng.ctx.half_frame_bytes()
-    nbatches = max(1, (args.ring_mib * (1 << 20)) // (hb * F))
+    nbatches = max(2, (args.ring_mib * (1 << 20)) // (hb * F))
     ring = None
     ring_ptr = 0
-    if rank == 0:
+    if time_mode or rank == 0:
         ring = gen_ring_torch(torch, device, nbatches * F + 1, N, wl["is_real"], seed=0x5D5D0004)
         ring_ptr = ring.data_ptr()
-    all_clients = make_clients(wl, params, seed=0x5D5D0004, count=per_gpu * world)
-    mine = assign_clients(len(all_clients), world)[rank]
-    for cid in mine:
-        mode, l, m, r = all_clients[cid]
-        eng.add_audio_client(l, m, r, mode)
     torch.cuda.synchronize()
-    backend = HipBackend(torch, eng.ctx, device, ring_ptr, nbatches, F)
-    runner = ShardedRunner(backend, dist, rank, world, F)
+
+    if time_mode:
+        clients = make_clients(wl, params, seed=0x5D5D0002)
+        waterfalls = make_waterfalls(wl, params, seed=0x5D5D0002)
+        for mode, l, m, r in clients:
+            eng.add_audio_client(l, m, r, mode)
+        for lv, l, r in waterfalls:
+            eng.add_waterfall_client(lv, l, r)
+        backend = HipTimeBackend(eng.ctx, ring_ptr, nbatches * F + 1, F + warm)
+        runner = TimeShardedRunner(backend, rank, world, F)
+
+        def step(i):
+            first, skip = runner.step(i)
+            if waterfalls:
+                eng.ctx.waterfall_batch(first - skip)
+        nclients_total, par = len(clients), (
+            f"stream sharded over {world} GPUs: batch g -> rank g mod G, 2-frame warm-up, no data-path collective")
+        bytes_bcast = None
+    else:
+        all_clients = make_clients(wl, params, seed=0x5D5D0004, count=per_gpu * world)
+        mine = assign_clients(len(all_clients), world)[rank]
+        clients = [all_clients[c] for c in mine]
+        waterfalls = []
+        for mode, l, m, r in clients:
+            eng.add_audio_client(l, m, r, mode)
+        torch.cuda.synchronize()
+        backend = HipBackend(torch, eng.ctx, device, ring_ptr, nbatches, F)
+        runner = ShardedRunner(backend, dist, rank, world, F)
+        step = runner.step
+        nclients_total, par = per_gpu * world, (
+            f"clients sharded over {world} GPUs (client i -> rank i mod G); rank 0 FFT + RCCL broadcast "
+            "of the spectrum batch")
 
     for i in range(args.warmup):
-        runner.step(i)
+        step(i)
+    eng.ctx.synchronize()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
-    runner.bytes_broadcast = 0
+    if not time_mode:
+        runner.bytes_broadcast = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
-        runner.step(args.warmup + i)
+        step(args.warmup + i)
+    eng.ctx.synchronize()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -229,29 +263,29 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    frames = args.steps * F
+    # time mode: every rank ingests its own F new frames per step; client mode: one stream
+    frames = args.steps * F * (world if time_mode else 1)
     msps = frames * (N // 2) / dt / 1e6
     if rank == 0:
-        mine_cl = [all_clients[c] for c in mine]
-        ab = algorithmic_bytes_per_frame(wl, params, mine_cl, [])
+        ab = algorithmic_bytes_per_frame(wl, params, clients, waterfalls)
         out = {
             "metric": "ingest MSamples/s + concurrent audio clients at 2^20-pt FFT",
             "value": round(msps, 2), "unit": "MSamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "cfg4: " + wl["desc"] + f" ({per_gpu * world} clients total)",
-                       "frames_per_step": F, "fft_size": N, "audio_clients": per_gpu * world,
-                       "parallelism": f"clients sharded over {world} GPUs (client i -> rank i mod G); "
-                                      "rank 0 FFT + RCCL broadcast of the spectrum batch",
+            "config": {"workload": (args.workload or ("cfg2" if time_mode else "cfg4")) + ": " + wl["desc"],
+                       "frames_per_step": F, "fft_size": N, "audio_clients": nclients_total,
+                       "waterfall_clients": len(waterfalls), "parallelism": par,
                        "realtime_factor": round(msps * 1e6 / wl["sps"], 1)},
             "roofline": None,
-            "path": {"algorithmic_bytes_per_frame_root": int(ab["total"]),
+            "path": {"algorithmic_bytes_per_frame": int(ab["total"]),
                      "frames_per_s": round(frames / dt, 1),
-                     "frac_of_hbm_peak_root": round(ab["total"] * frames / dt / HBM_PEAK, 4)},
-            "xgmi": {"broadcast_bytes_per_frame": 8 * N,
-                     "GB_per_s_per_link": round(runner.bytes_broadcast / dt / 1e9, 2) if world > 1 else None,
-                     "link_peak_GB_per_s": 153.0},
+                     "frac_of_hbm_peak_per_gpu": round(ab["total"] * frames / dt / HBM_PEAK / (world if time_mode else 1), 4)},
+            "xgmi": None if time_mode else {
+                "broadcast_bytes_per_frame": 8 * N,
+                "GB_per_s_per_link": round(runner.bytes_broadcast / dt / 1e9, 2) if world > 1 else None,
+                "link_peak_GB_per_s": 153.0},
             "cpu_baseline": None,
         }
         print(json.dumps(out))
@@ -265,10 +299,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=16, help="frames per step (F)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="frames per step (F); default 16 on one GPU, 32 per GPU when the stream is sharded "
+                         "(amortises the two warm-up frames)")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ring-mib", type=int, default=512)
+    ap.add_argument("--shard", default="time", choices=["time", "clients"],
+                    help="N > 1: shard the stream (default) or the clients (spectrum broadcast)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path even with one rank (testing)")
     args = ap.parse_args()
@@ -278,6 +316,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    if args.batch <= 0:
+        args.batch = 32 if (world > 1 and args.shard == "time") else 16
 
     import torch
     if not torch.cuda.is_available():

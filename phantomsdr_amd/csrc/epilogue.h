@@ -89,7 +89,7 @@ struct UntangleArgs {
     int nlevels;
     int8_t *Q;
     size_t q_stride;
-    float *Pscr;  // level 7 sums
+    float *Pscr;  // level 8 sums
     size_t p_stride;
 };
 
@@ -102,47 +102,97 @@ __device__ __forceinline__ cf untangle_one(cf a, cf b, cf w) {
     return make_float2(E.x + wo.x, E.y + wo.y);
 }
 
-// thread j handles bins k = 2j, 2j+1 (one level-1 pair)
+// X[M-k] from the same pair of inputs: W_N^{M-k} = -conj(W_N^k)
+__device__ __forceinline__ cf untangle_mirror(cf zk, cf zmk, cf w) {
+    return untangle_one(zmk, zk, make_float2(-w.x, w.y));
+}
+
+// Thread j (< M/8) owns the forward group k0..k0+3 (k0 = 4j) AND the mirrored aligned group
+// M-k0-4..M-k0-1: both come from the same ten inputs Z[k0..k0+4], Z[M-k0-4..M-k0], so Z is
+// read once; every store and all but two loads are 16 bytes per lane.  Lanes ascend through
+// the forward groups and descend through the mirrored ones; the pair-sum tree is the same.
 __global__ __launch_bounds__(256) void k_untangle_real(UntangleArgs a) {
     const unsigned f = blockIdx.y;
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t M = a.M;
-    const bool valid = j < M / 2;
+    const bool valid = j < M / 8;
     const cf *Zf = a.Z + (size_t)f * M;
     cf *Xf = a.X + (size_t)f * a.spec_stride;
     int8_t *Qf = a.Q + (size_t)f * a.q_stride;
-    float s = 0.f;
+    float sF = 0.f, sM = 0.f;
+    const size_t gF = j, gM = M / 4 - 1 - j;  // level-2 indices of the two groups
     if (valid) {
-        const size_t k0 = 2 * j;
-        const float4 zz = reinterpret_cast<const float4 *>(Zf)[j];  // Z[k0], Z[k0+1]
-        const cf z0 = make_float2(zz.x, zz.y), z1 = make_float2(zz.z, zz.w);
-        const cf m0 = Zf[(M - k0) & (M - 1)];  // Z[(M-k0) mod M]
-        const cf m1 = Zf[M - k0 - 1];
+        const size_t k0 = 4 * j;
+        const float4 f0 = reinterpret_cast<const float4 *>(Zf)[2 * j];      // Z[k0], Z[k0+1]
+        const float4 f1 = reinterpret_cast<const float4 *>(Zf)[2 * j + 1];  // Z[k0+2], Z[k0+3]
+        const cf zx = Zf[k0 + 4];                                            // k0+4 <= M/2
+        const size_t mb = (M - k0 - 4) / 2;
+        const float4 g0 = reinterpret_cast<const float4 *>(Zf)[mb];      // Z[M-k0-4], Z[M-k0-3]
+        const float4 g1 = reinterpret_cast<const float4 *>(Zf)[mb + 1];  // Z[M-k0-2], Z[M-k0-1]
+        const cf m0 = Zf[(M - k0) & (M - 1)];
+        // fwd[i] = Z[k0+i], mir[i] = Z[M-k0-i], i = 0..4
+        const cf fwd[5] = {make_float2(f0.x, f0.y), make_float2(f0.z, f0.w), make_float2(f1.x, f1.y),
+                           make_float2(f1.z, f1.w), zx};
+        const cf mir[5] = {m0, make_float2(g1.z, g1.w), make_float2(g1.x, g1.y), make_float2(g0.z, g0.w),
+                           make_float2(g0.x, g0.y)};
         const unsigned Bm = (1u << a.log2B) - 1u;
-        const cf w0 = cmul(a.TA[k0 >> a.log2B], a.TB[k0 & Bm]);
-        const cf w1 = cmul(a.TA[(k0 + 1) >> a.log2B], a.TB[(k0 + 1) & Bm]);
-        cf x0 = untangle_one(z0, m0, w0);
-        cf x1 = untangle_one(z1, m1, w1);
+        cf xf[4], xm[4];  // xm[i] = X[M-k0-4+i]
+        float pf[4], pm[4];
+        // W_N^{k0} from the two-level table, W_N^{k0+i} by four multiplications with W_N^1
+        cf w = cmul(a.TA[k0 >> a.log2B], a.TB[k0 & Bm]);
+        const cf w1 = a.TB[1];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            if (i > 0) w = cmul(w, w1);
+            if (i < 4) {
+                cf x = untangle_one(fwd[i], mir[i], w);
+                x.x *= a.inv_n;
+                x.y *= a.inv_n;
+                xf[i] = x;
+                pf[i] = fmaf(x.x, x.x, x.y * x.y);
+            }
+            if (i > 0) {  // bin M-k0-i lands at slot 4-i of the mirrored group
+                cf x = untangle_mirror(fwd[i], mir[i], w);
+                x.x *= a.inv_n;
+                x.y *= a.inv_n;
+                xm[4 - i] = x;
+                pm[4 - i] = fmaf(x.x, x.x, x.y * x.y);
+            }
+        }
         if (j == 0) {
             // bin N/2 is never normalised by the reference (src/fft_impl.cpp:156-160
             // visits k < N/2 only); X[N/2] = Re Z[0] - Im Z[0]
-            Xf[M] = make_float2(z0.x - z0.y, 0.f);
+            Xf[M] = make_float2(fwd[0].x - fwd[0].y, 0.f);
         }
-        x0.x *= a.inv_n;
-        x0.y *= a.inv_n;
-        x1.x *= a.inv_n;
-        x1.y *= a.inv_n;
-        reinterpret_cast<float4 *>(Xf)[j] = make_float4(x0.x, x0.y, x1.x, x1.y);
-        const float p0 = fmaf(x0.x, x0.x, x0.y * x0.y);
-        const float p1 = fmaf(x1.x, x1.x, x1.y * x1.y);
-        if (0 < a.nlevels)
-            reinterpret_cast<unsigned short *>(Qf)[j] =
-                (unsigned short)(quantize_u8(p0, a.size_log2) | (quantize_u8(p1, a.size_log2) << 8));
-        s = __fadd_rn(p0, p1);
-        if (1 < a.nlevels) Qf[M + j] = (int8_t)quantize_u8(s, a.size_log2 - 1);
+        reinterpret_cast<float4 *>(Xf)[2 * j] = make_float4(xf[0].x, xf[0].y, xf[1].x, xf[1].y);
+        reinterpret_cast<float4 *>(Xf)[2 * j + 1] = make_float4(xf[2].x, xf[2].y, xf[3].x, xf[3].y);
+        reinterpret_cast<float4 *>(Xf)[mb] = make_float4(xm[0].x, xm[0].y, xm[1].x, xm[1].y);
+        reinterpret_cast<float4 *>(Xf)[mb + 1] = make_float4(xm[2].x, xm[2].y, xm[3].x, xm[3].y);
+        if (0 < a.nlevels) {
+            reinterpret_cast<unsigned *>(Qf)[gF] = pack4(pf[0], pf[1], pf[2], pf[3], a.size_log2);
+            reinterpret_cast<unsigned *>(Qf)[gM] = pack4(pm[0], pm[1], pm[2], pm[3], a.size_log2);
+        }
+        const float f01 = __fadd_rn(pf[0], pf[1]), f23 = __fadd_rn(pf[2], pf[3]);
+        const float m01 = __fadd_rn(pm[0], pm[1]), m23 = __fadd_rn(pm[2], pm[3]);
+        if (1 < a.nlevels) {
+            unsigned short *q1 = reinterpret_cast<unsigned short *>(Qf + M);
+            q1[gF] = (unsigned short)(quantize_u8(f01, a.size_log2 - 1) | (quantize_u8(f23, a.size_log2 - 1) << 8));
+            q1[gM] = (unsigned short)(quantize_u8(m01, a.size_log2 - 1) | (quantize_u8(m23, a.size_log2 - 1) << 8));
+        }
+        sF = __fadd_rn(f01, f23);
+        sM = __fadd_rn(m01, m23);
+        if (2 < a.nlevels) {
+            Qf[M + M / 2 + gF] = (int8_t)quantize_u8(sF, a.size_log2 - 2);
+            Qf[M + M / 2 + gM] = (int8_t)quantize_u8(sM, a.size_log2 - 2);
+        }
     }
-    const float top = wave_pyramid(s, j, 1, a.nlevels, a.size_log2, Qf, M, valid);
-    if (valid && (threadIdx.x & 63) == 0) a.Pscr[(size_t)f * a.p_stride + (j >> 6)] = top;
+    // lanes hold level-2 values of adjacent groups: levels 3..8 across the wave
+    const float topF = wave_pyramid(sF, gF, 2, a.nlevels, a.size_log2, Qf, M, valid);
+    const float topM = wave_pyramid(sM, gM, 2, a.nlevels, a.size_log2, Qf, M, valid);
+    if (valid && (threadIdx.x & 63) == 0) {
+        a.Pscr[(size_t)f * a.p_stride + (gF >> 6)] = topF;
+        a.Pscr[(size_t)f * a.p_stride + (gM >> 6)] = topM;
+    }
 }
 
 struct WfClient {

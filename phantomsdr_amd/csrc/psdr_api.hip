@@ -426,7 +426,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
         u.Pscr = c->d_pscr[0];
         u.p_stride = c->p_stride;
         ProfScope ps(c, K_UNTANGLE);
-        const unsigned nb = (unsigned)((c->M / 2 + 255) / 256);
+        const unsigned nb = (unsigned)((c->M / 8 + 255) / 256);
         hipLaunchKernelGGL(k_untangle_real, dim3(nb, nframes), dim3(256), 0, c->stream, u);
         HIPCHK(hipGetLastError());
     }
@@ -734,7 +734,7 @@ extern "C" int psdr_create(const psdr_config *cfg, psdr_ctx **out) {
     for (int i = 0; i < c->levels; i++) c->q_len += c->R >> i;
     c->q_stride = (c->q_len + 127) & ~(size_t)127;
     if (is_real) {
-        c->LT = 7;
+        c->LT = 8;  // the untangle kernel finishes levels 0..8 (4 bins per lane, 64 lanes)
         c->tiled_lt = -1;
     } else {
         c->tile_ch = (c->T2 >= 16) ? 16 : 8;

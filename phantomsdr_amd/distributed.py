@@ -1,8 +1,21 @@
 """Multi-GPU operation: one process per GPU, `torch.distributed` (backend
 "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 
-The reference has no multi-GPU path; this is new design.  After ONE exchange step the
-audio clients are independent units, so they shard across ranks:
+The reference has no multi-GPU path; this is new design.  Two ways to shard the path:
+
+TIME sharding (default, `TimeShardedRunner`): the stream itself is the partitioned object.
+Frames are independent for the forward FFT and for every client's inverse transform; the
+only cross-frame state is the overlap-add tail (second half of the previous frame's
+transform) and FM's last sample, and both are functions of the two preceding frames alone.
+So batch g (frames [g*F, (g+1)*F)) goes to rank g mod G, which additionally re-runs the two
+frames before its batch as warm-up (their outputs are discarded, they only rebuild the
+tails): ingest scales with the number of GPUs, each GPU reads its own slice of the sample
+ring (its own PCIe link in a deployment), and there is NO data-path collective at all.
+Cost: (F+2)/F work per batch.  (The reference's stale cross-mode state - buffers that
+survive a mode switch, src/signal.cpp:316-328 - is carried only within a rank.)
+
+CLIENT sharding (`ShardedRunner`, the shape BASELINE.json's north_star names): after ONE
+exchange step the audio clients are independent units, so they shard across ranks:
 
   rank 0 ("ingest")  owns the raw sample ring, runs the forward FFT + waterfall pyramid
                      and serves the waterfall clients (they only read the int8 pyramid);
@@ -52,6 +65,52 @@ class ShardedRunner:
             self.bytes_broadcast += t.numel() * t.element_size()
         self.backend.demod(self.frame_num)
         self.frame_num += self.F
+
+
+class TimeShardedRunner:
+    """Batch g of the stream -> rank g mod G, with a two-frame warm-up instead of any
+    exchange.  backend must provide
+      run(first_half, nframes, first_frame_num)   forward + demodulate `nframes` frames that
+                                                  start at half-frame `first_half`
+      collect(skip)                               per-client audio of the last run without
+                                                  the first `skip` (warm-up) frames
+    """
+    WARMUP = 2
+
+    def __init__(self, backend, rank, world, frames_per_step):
+        self.backend, self.rank, self.world, self.F = backend, rank, world, frames_per_step
+        self.step_index = 0
+
+    def batch_of(self, step):
+        return step * self.world + self.rank
+
+    def step(self, step=None):
+        """runs this rank's batch of global step `step`; returns (first_frame, skip)"""
+        s = self.step_index if step is None else step
+        g = self.batch_of(s)
+        first = g * self.F
+        skip = min(self.WARMUP, first)  # the very first batch of the stream has no past
+        self.backend.run(first - skip, self.F + skip, first - skip)
+        self.step_index = s + 1
+        return first, skip
+
+
+class HipTimeBackend:
+    """TimeShardedRunner back-end on the HIP library (ring = device pointer to raw halves;
+    the ring is cycled modulo `ring_batches` batches for the benchmark)."""
+
+    def __init__(self, ctx, ring_ptr, ring_halves, max_frames):
+        self.ctx, self.ring_ptr, self.ring_halves = ctx, ring_ptr, ring_halves
+        self.hb = ctx.half_frame_bytes()
+        self.max_frames = max_frames
+        self.last = (0, 0)
+
+    def run(self, first_half, nframes, first_frame_num):
+        span = nframes + 1
+        off = first_half % max(1, self.ring_halves - span)  # stay inside the synthetic ring
+        self.ctx.process_batch(self.ring_ptr, nframes, offset_bytes=off * self.hb)
+        self.ctx.demod_batch(first_frame_num)
+        self.last = (first_frame_num, nframes)
 
 
 class _CudaArray:

@@ -136,3 +136,92 @@ def test_two_rank_sharding_matches_single_process():
     assert len(merged) == len(ref)
     for a, b in zip(merged, ref):
         assert np.array_equal(a, b)                    # bit-identical to the unsharded run
+
+
+# ---------------------------------------------------------------------------------------
+# time sharding: batch g -> rank g mod G with a two-frame warm-up and NO exchange
+# ---------------------------------------------------------------------------------------
+TF, TSTEPS = 4, 3     # frames per batch, steps per rank (world 2 -> 24 frames in total)
+
+
+class OracleTimeBackend:
+    """TimeShardedRunner back-end on the CPU oracle: fresh (zero-state) clients per run, like
+    a GPU that has never seen the frames before its warm-up."""
+
+    def __init__(self, halves, clients):
+        from oracle import oracle as O
+        self.O, self.halves, self.specs = O, halves, clients
+        self.fo = O.FFT(N, False, 3, 0, NAUD)
+        self.out = None
+
+    def run(self, first_half, nframes, first_frame_num):
+        O = self.O
+        cl = []
+        for mode, l, m, r in self.specs:
+            c = O.AudioClient(False, NAUD, 12000, N)
+            c.set_audio_demodulation(mode)
+            c.set_audio_range(l, m, r)
+            cl.append(c)
+        self.out = np.zeros((len(cl), nframes, NAUD // 2), np.float32)
+        for f in range(nframes):
+            self.fo.load(self.halves[first_half + f], self.halves[first_half + f + 1])
+            self.fo.execute()
+            for ci, c in enumerate(cl):
+                self.out[ci, f], _, _, _ = c.send_audio(self.fo.output(), first_frame_num + f, fft=self.fo)
+
+
+def _time_halves():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import synth_stream
+    nfr = 2 * TSTEPS * TF
+    x = synth_stream((nfr + 1) * (N // 2), False, seed=9, fft_size=N).astype(np.complex64)
+    return x.reshape(nfr + 1, N // 2)
+
+
+def _time_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from phantomsdr_amd.distributed import TimeShardedRunner
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        be = OracleTimeBackend(_time_halves(), _clients())
+        runner = TimeShardedRunner(be, rank, world, TF)
+        got = {}
+        for s in range(TSTEPS):
+            first, skip = runner.step(s)
+            got[first] = be.out[:, skip:, :].copy()      # warm-up frames are discarded
+        out = [None] * world
+        dist.all_gather_object(out, got)                  # result collection only (not data path)
+        if rank == 0:
+            merged = {}
+            for d in out:
+                merged.update(d)
+            q.put(merged)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_time_sharding_matches_sequential_run():
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    halves = _time_halves()
+    nfr = 2 * TSTEPS * TF
+    seq = OracleTimeBackend(halves, _clients())
+    seq.run(0, nfr, 0)                                    # one process, all frames in order
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_time_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    merged = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(merged) == [g * TF for g in range(2 * TSTEPS)]
+    for first, block in merged.items():
+        assert block.shape[1] == TF
+        # the two warm-up frames rebuild the overlap-add tails and FM's last sample exactly
+        assert np.array_equal(block, seq.out[:, first:first + TF, :]), first
