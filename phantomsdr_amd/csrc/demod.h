@@ -50,6 +50,7 @@ struct DemodArgs {
     const cf *Wn;                 // exp(+2 pi i j / n), j < n
     int nstages;
     int radix[PSDR_MAX_STAGES];
+    const int4 *stage_tab;  // [nstages][n]: {first input i, output index j+s*p, twiddle step e1, 0}
     cf *ypost;  // [slots][max_batch][n]: transform output after reversal/flip
     float *pwr;  // [slots][max_batch]
     // workspace for transforms too large for LDS: [gridDim.x*gridDim.y][2][n]
@@ -69,6 +70,49 @@ __device__ __forceinline__ bool flip_frame(unsigned long long frame_num, int m_i
     return (frame_num % 2 == 1) && ((m_idx % 2 == 0 && !is_real) || (m_idx % 2 == 1 && is_real));
 }
 
+// one Stockham stage; RC > 0: radix known at compile time (all operand loads of a butterfly
+// are issued before the MAC chain), RC == 0: run-time radix (large prime factors)
+template <int RC>
+__device__ __forceinline__ void idft_stage(const cf *src, cf *dst, const cf *Wn, const int4 *tab, int n,
+                                           int R, int tid, int NT) {
+    const int tlen = n / R;
+    for (int o = tid; o < n; o += NT) {
+        const int4 tb = tab[o];
+        const int e1 = tb.z;
+        const cf *xp = src + tb.x;
+        float ar = 0.f, ai = 0.f;
+        if constexpr (RC > 0) {
+            cf x[RC], w[RC];
+            int e = 0;
+#pragma unroll
+            for (int q = 0; q < RC; q++) {
+                x[q] = xp[q * tlen];
+                w[q] = Wn[e];
+                e += e1;
+                if (e >= n) e -= n;
+            }
+#pragma unroll
+            for (int q = 0; q < RC; q++) {
+                ar = fmaf(x[q].x, w[q].x, fmaf(-x[q].y, w[q].y, ar));
+                ai = fmaf(x[q].x, w[q].y, fmaf(x[q].y, w[q].x, ai));
+            }
+        } else {
+            int e = 0;
+#pragma unroll 4
+            for (int q = 0; q < R; q++) {
+                const cf x = xp[q * tlen];
+                const cf w = Wn[e];
+                ar = fmaf(x.x, w.x, fmaf(-x.y, w.y, ar));
+                ai = fmaf(x.x, w.y, fmaf(x.y, w.x, ai));
+                e += e1;
+                if (e >= n) e -= n;
+            }
+        }
+        dst[tb.y] = make_float2(ar, ai);
+    }
+}
+
+// blockDim.x = 128 (n <= 512) or 256
 __global__ __launch_bounds__(256) void k_demod_idft(DemodArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n = a.n, tid = threadIdx.x, NT = blockDim.x;
@@ -93,7 +137,7 @@ __global__ __launch_bounds__(256) void k_demod_idft(DemodArgs a) {
         bufB = bufA + n;
         Wn = a.Wn;
     }
-    __shared__ float red[256];
+    __shared__ float red[4];
 
     const int len = cp.r - cp.l;
     const int m = cp.m_floor - cp.l;  // audio_m
@@ -115,13 +159,15 @@ __global__ __launch_bounds__(256) void k_demod_idft(DemodArgs a) {
             if (t >= m - n / 2 + 1 && t < m) bufA[n - m + t] = v;
         }
     }
-    red[tid] = pw;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) pw += __shfl_xor(pw, d, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = pw;
     __syncthreads();
-    for (int s = NT / 2; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
-        __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int w = 0; w < NT / 64; w++) tot += red[w];
+        a.pwr[(size_t)cp.slot * a.max_batch + f] = tot;
     }
-    if (tid == 0) a.pwr[(size_t)cp.slot * a.max_batch + f] = red[0];
 
     if (cp.mode < 2) {
         // c2r semantics: bins 0..n/2 only, Im of bin 0 and bin n/2 ignored; extend to the
@@ -137,31 +183,20 @@ __global__ __launch_bounds__(256) void k_demod_idft(DemodArgs a) {
         __syncthreads();
     }
 
-    // generic-radix Stockham, backward
+    // generic-radix Stockham, backward; the index arithmetic of every (stage, output) pair is
+    // precomputed on the host (stage_tab), the butterfly is R complex MACs
     cf *src = bufA, *dst = bufB;
-    int p = 1;
     for (int st = 0; st < a.nstages; st++) {
         const int R = a.radix[st];
-        const int tlen = n / R;
-        const int step = n / (p * R);
-        for (int o = tid; o < n; o += NT) {
-            const int s = o / tlen, i = o - s * tlen;
-            const int k = i % p;
-            const int j = (i - k) * R + k;
-            const int e1 = (int)(((long long)(k + s * p) * step) % n);
-            float ar = 0.f, ai = 0.f;
-            int e = 0;
-            for (int q = 0; q < R; q++) {
-                const cf x = src[i + q * tlen];
-                const cf w = Wn[e];
-                ar = fmaf(x.x, w.x, fmaf(-x.y, w.y, ar));
-                ai = fmaf(x.x, w.y, fmaf(x.y, w.x, ai));
-                e += e1;
-                if (e >= n) e -= n;
-            }
-            dst[j + s * p] = make_float2(ar, ai);
+        const int4 *tab = a.stage_tab + (size_t)st * n;
+        switch (R) {
+#define PSDR_RCASE(r) case r: idft_stage<r>(src, dst, Wn, tab, n, r, tid, NT); break;
+            PSDR_RCASE(2) PSDR_RCASE(3) PSDR_RCASE(4) PSDR_RCASE(5) PSDR_RCASE(6) PSDR_RCASE(7)
+            PSDR_RCASE(8) PSDR_RCASE(9) PSDR_RCASE(10) PSDR_RCASE(12) PSDR_RCASE(14)
+            PSDR_RCASE(15) PSDR_RCASE(16)
+#undef PSDR_RCASE
+            default: idft_stage<0>(src, dst, Wn, tab, n, R, tid, NT); break;
         }
-        p *= R;
         cf *tmp = src;
         src = dst;
         dst = tmp;

@@ -174,6 +174,8 @@ struct psdr_ctx {
     int radix[PSDR_MAX_STAGES];
     int lds_mode = 0;
     size_t idft_lds = 0;
+    int4 *d_stage_tab = nullptr;
+    int idft_threads = 256;
     cf *d_Wn = nullptr, *d_ypost = nullptr, *d_gscratch = nullptr, *d_bb_tail = nullptr,
        *d_bb_last = nullptr;
     float *d_pwr = nullptr, *d_audio = nullptr, *d_real_prev = nullptr;
@@ -495,6 +497,7 @@ void free_all(psdr_ctx *c) {
     }
     F(c->d_stage);
     F(c->d_Wn);
+    F(c->d_stage_tab);
     F(c->d_ypost);
     F(c->d_gscratch);
     F(c->d_bb_tail);
@@ -651,6 +654,25 @@ int build(psdr_ctx *c) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->idft_lds));
         int rc = upload(&c->d_Wn, make_twiddles((size_t)n, 1, (size_t)n, +1));
         if (rc) return rc;
+        {
+            // stage tables of the generic-radix Stockham: output o = s*(n/R) + i of a stage with
+            // radix R and p = product of the earlier radices reads x[i + q*n/R] and writes
+            // y[j + s*p], j = (i - i%p)*R + i%p, with twiddle exponent q*e1, e1 = (i%p + s*p)*n/(p*R)
+            std::vector<int4> tab((size_t)c->nstages * n);
+            int pp = 1;
+            for (int st = 0; st < c->nstages; st++) {
+                const int R = c->radix[st], tlen = n / R, step = n / (pp * R);
+                for (int o = 0; o < n; o++) {
+                    const int s = o / tlen, i = o - s * tlen, k = i % pp, j = (i - k) * R + k;
+                    const long long e1 = ((long long)(k + s * pp) * step) % n;
+                    tab[(size_t)st * n + o] = make_int4(i, j + s * pp, (int)e1, 0);
+                }
+                pp *= R;
+            }
+            rc = upload(&c->d_stage_tab, tab);
+            if (rc) return rc;
+            c->idft_threads = n <= 512 ? 128 : 256;
+        }
         const size_t S = (size_t)std::max(1, g.max_clients);
         c->aslots.resize(S);
         HIPCHK(hipMalloc((void **)&c->d_ypost, S * F * n * sizeof(cf)));
@@ -1042,6 +1064,7 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     a.Wn = c->d_Wn;
     a.nstages = c->nstages;
     for (int i = 0; i < c->nstages; i++) a.radix[i] = c->radix[i];
+    a.stage_tab = c->d_stage_tab;
     a.ypost = c->d_ypost;
     a.pwr = c->d_pwr;
     a.gscratch = c->d_gscratch;
@@ -1054,7 +1077,7 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     a.slots = (int)c->aslots.size();
     {
         ProfScope ps(c, K_IDFT, c->side);
-        hipLaunchKernelGGL(k_demod_idft, dim3(nact, nframes), dim3(256), c->idft_lds, c->side,
+        hipLaunchKernelGGL(k_demod_idft, dim3(nact, nframes), dim3(c->idft_threads), c->idft_lds, c->side,
                            a);
         HIPCHK(hipGetLastError());
     }
