@@ -132,7 +132,21 @@ struct psdr_ctx {
     // batch (pyramid tail, demodulation, waterfall gather) runs on `side`, so it overlaps
     // the next batch's pass 1 (its work-groups fit next to the persistent FFT work-groups).
     hipStream_t stream = nullptr, side = nullptr;
-    hipStream_t own_stream = nullptr, own_side = nullptr;
+    hipStream_t own_stream = nullptr, own_side = nullptr, own_p1 = nullptr;
+    // pass 1 runs on its own stream so that pass 1 of batch i+1 fills the CUs that pass 2 of
+    // batch i leaves one by one (persistent work-groups: launch ramp, prologue and tail of one
+    // kernel overlap with the other kernel's steady state); Y is double-buffered for that
+    hipStream_t p1 = nullptr;
+    cf *y_pool[2] = {nullptr, nullptr};
+    int cur_y = 0;
+    bool y_pending[2] = {false, false};
+    // TileQueue counters: a ring of TICKET_SLOTS launches x 8 counters per pass; half the ring is
+    // re-zeroed (in stream order) whenever the other half starts being used
+    unsigned *d_tickets[2] = {nullptr, nullptr};
+    unsigned ticket_pos[2] = {0, 0};
+    bool static_tiles = false, no_p1_stream = true;  // tuning knobs (PSDR_STATIC_TILES, PSDR_P1_STREAM)
+    bool input_on_main = false;  // level-1 H2D staging was enqueued on the main stream
+    hipEvent_t ev_in = nullptr, ev_p1[2] = {nullptr, nullptr}, ev_p2[2] = {nullptr, nullptr};
     hipEvent_t ev_fft_done = nullptr, ev_side_done = nullptr;
     bool side_pending = false;
     // Result buffers (spectrum, pyramid, level powers) exist twice: batch b+1 is produced
@@ -149,9 +163,9 @@ struct psdr_ctx {
     cf *d_Wl1 = nullptr, *d_Wl2 = nullptr, *d_TA = nullptr, *d_TB = nullptr;
     cf *d_UA = nullptr, *d_UB = nullptr;
     cf wdelta = {1.f, 0.f};  // W_N^1
-    unsigned long long *d_trace = nullptr;  // PSDR_TRACE tuning builds: [2][8][16] timestamps
+    unsigned long long *d_trace = nullptr;  // PSDR_TRACE tuning builds: per pass [8][16] phase stamps + [256][8] work-group timeline
     int log2B = 0, log2UB = 0;
-    cf *d_Y = nullptr, *d_Z = nullptr, *d_spec = nullptr;
+    cf *d_Z = nullptr, *d_spec = nullptr;
     int8_t *d_q = nullptr;   // level-major pyramid (the reference's layout)
     int8_t *d_qt = nullptr;  // tiled records of levels 0..LT (IQ fused epilogue), quantize.h
     size_t qt_stride = 0;
@@ -231,6 +245,7 @@ struct ProfScope {
 
 void resolve_pending(psdr_ctx *c) {
     if (c->pending.empty()) return;
+    hipStreamSynchronize(c->p1);
     hipStreamSynchronize(c->stream);
     hipStreamSynchronize(c->side);
     for (auto &p : c->pending) {
@@ -262,71 +277,99 @@ int upload(T **dst, const std::vector<T> &v) {
     return PSDR_OK;
 }
 
+constexpr unsigned TICKET_SLOTS = 64;
+// counters for the next launch of pass `which` on stream st
+int next_tickets(psdr_ctx *c, int which, hipStream_t st, unsigned **out) {
+    if (c->static_tiles) {
+        *out = nullptr;
+        return PSDR_OK;
+    }
+    unsigned &pos = c->ticket_pos[which];
+    const unsigned slot = pos % TICKET_SLOTS;
+    if (slot % (TICKET_SLOTS / 2) == 0 && pos >= TICKET_SLOTS / 2) {
+        // entering a half of the ring: its counters were last used TICKET_SLOTS/2 launches ago on
+        // this same stream, so clearing them here is ordered after those launches
+        HIPCHK(hipMemsetAsync(c->d_tickets[which] + (size_t)slot * 8, 0, (TICKET_SLOTS / 2) * 8 * sizeof(unsigned), st));
+    }
+    *out = c->d_tickets[which] + (size_t)slot * 8;
+    pos++;
+    return PSDR_OK;
+}
+
 // tile widths: T = min(16384/L, other dimension)
 int pick_T(int L, int other) { return std::min(16384 / L, other); }
 
-template <int L, int T, int V, int SB>
+// persistent launch: as many work-groups as the CUs hold (LDS-limited), a multiple of 8 (XCD
+// round-robin of the TileQueue), or one per tile when there are fewer tiles than that
+unsigned persistent_grid(psdr_ctx *c, unsigned blocks, size_t lds) {
+    const unsigned cap = ((unsigned)c->num_cus * (unsigned)std::max<size_t>(1, 160 * 1024 / lds)) & ~7u;
+    return blocks <= cap ? blocks : std::max(cap, 8u);
+}
+
+template <int L, int T, int SB>
 int launch_pass1_t(psdr_ctx *c, const Pass1Args &a, unsigned blocks) {
     // tile + W_L (= first twiddle factor) + second twiddle factor (M2 entries)
     const size_t lds = (size_t)L * T * sizeof(cf) + (size_t)L * sizeof(cf) + (size_t)a.M2 * sizeof(cf);
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass1<L, T, V, SB>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass1<L, T, SB>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         attr_set = true;
     }
-    ProfScope ps(c, K_PASS1);
-    // persistent: one work-group per CU (the 128 KiB tile admits exactly one)
-    const unsigned grid = std::min<unsigned>(blocks, (unsigned)c->num_cus);
-    hipLaunchKernelGGL((k_fft_pass1<L, T, V, SB>), dim3(grid), dim3((L / 16) * T / V), lds, c->stream, a);
+    ProfScope ps(c, K_PASS1, c->p1);
+    // persistent: as many work-groups per CU as their LDS admits (a 128 KiB tile: one)
+    const unsigned grid = persistent_grid(c, blocks, lds);
+    hipLaunchKernelGGL((k_fft_pass1<L, T, SB>), dim3(grid), dim3(L * T / 32), lds, c->p1, a);
     HIPCHK(hipGetLastError());
     return PSDR_OK;
 }
-template <int L, int T, bool FUSED, int V>
+template <int L, int T, bool FUSED, int TWC>
 int launch_pass2_t(psdr_ctx *c, const Pass2Args &a, unsigned blocks) {
     constexpr size_t lds = (size_t)L * T * sizeof(cf) + (size_t)L * sizeof(cf);
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass2<L, T, FUSED, V>,
+        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass2<L, T, FUSED, TWC>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     ProfScope ps(c, K_PASS2);
-    const unsigned grid = std::min<unsigned>(blocks, (unsigned)c->num_cus);
-    hipLaunchKernelGGL((k_fft_pass2<L, T, FUSED, V>), dim3(grid), dim3((L / 16) * T / V), lds, c->stream,
-                       a);
+    const unsigned grid = persistent_grid(c, blocks, lds);
+    hipLaunchKernelGGL((k_fft_pass2<L, T, FUSED, TWC>), dim3(grid), dim3(L * T / 32), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return PSDR_OK;
 }
 
-#define P1CASE(L_, T_, V_)                                                   \
-    if (L == L_ && T == T_) {                                                \
-        if (sb == 2) return launch_pass1_t<L_, T_, V_, 2>(c, a, blocks);     \
-        if (sb == 4) return launch_pass1_t<L_, T_, V_, 4>(c, a, blocks);     \
-        return launch_pass1_t<L_, T_, V_, 8>(c, a, blocks);                  \
+#define P1CASE(L_, T_)                                                   \
+    if (L == L_ && T == T_) {                                            \
+        if (sb == 2) return launch_pass1_t<L_, T_, 2>(c, a, blocks);     \
+        if (sb == 4) return launch_pass1_t<L_, T_, 4>(c, a, blocks);     \
+        return launch_pass1_t<L_, T_, 8>(c, a, blocks);                  \
     }
 int launch_pass1(psdr_ctx *c, int L, int T, int sb, const Pass1Args &a, unsigned blocks) {
-    P1CASE(64, 64, 1)
-    P1CASE(128, 64, 1)
-    P1CASE(128, 128, 2)
-    P1CASE(256, 64, 2)
-    P1CASE(512, 32, 2)
-    P1CASE(1024, 16, 2)
-    P1CASE(2048, 8, 2)
+    P1CASE(64, 64)
+    P1CASE(128, 64)
+    P1CASE(128, 128)
+    P1CASE(256, 64)
+    P1CASE(512, 32)
+    P1CASE(1024, 16)
+    P1CASE(2048, 8)
     return fail(PSDR_ERR_UNSUPPORTED, "no pass-1 kernel for L=%d T=%d", L, T);
 }
-#define P2CASE(L_, T_, V_)                                                      \
-    if (L == L_ && T == T_)                                                     \
-        return fused ? launch_pass2_t<L_, T_, true, V_>(c, a, blocks)           \
-                     : launch_pass2_t<L_, T_, false, V_>(c, a, blocks);
+#define P2CASE(L_, T_)                                                         \
+    if (L == L_ && T == T_)                                                    \
+        return fused ? launch_pass2_t<L_, T_, true, 0>(c, a, blocks)           \
+                     : launch_pass2_t<L_, T_, false, 0>(c, a, blocks);
 int launch_pass2(psdr_ctx *c, int L, int T, bool fused, const Pass2Args &a, unsigned blocks) {
-    P2CASE(64, 64, 1)
-    P2CASE(64, 128, 1)
-    P2CASE(128, 128, 2)
-    P2CASE(256, 64, 2)
-    P2CASE(512, 32, 2)
-    P2CASE(1024, 16, 2)
-    P2CASE(2048, 8, 2)
+    P2CASE(64, 64)
+    P2CASE(64, 128)
+    P2CASE(128, 128)
+    P2CASE(256, 64)
+    P2CASE(512, 32)
+    if (L == 1024 && T == 16 && a.TW == 16)  // the 2^20-point transform: fill addresses fold
+        return fused ? launch_pass2_t<1024, 16, true, 16>(c, a, blocks)
+                     : launch_pass2_t<1024, 16, false, 16>(c, a, blocks);
+    P2CASE(1024, 16)
+    P2CASE(2048, 8)
     return fail(PSDR_ERR_UNSUPPORTED, "no pass-2 kernel for L=%d T=%d", L, T);
 }
 
@@ -361,9 +404,21 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
     const int cols = 1;
     const int sb = fmt <= PSDR_FMT_S8 ? 2 : (fmt <= PSDR_FMT_S16 ? 4 : 8);  // image bytes per sample
     const unsigned tiles1 = (unsigned)(c->M2 / (c->T1 * cols)), tiles2 = (unsigned)(c->M1 / c->T2);
+    const bool piped = c->p1 != c->stream;
+    if (piped) {
+        c->cur_y ^= 1;
+        if (c->input_on_main) {  // the staged input was copied on the main stream
+            HIPCHK(hipEventRecord(c->ev_in, c->stream));
+            HIPCHK(hipStreamWaitEvent(c->p1, c->ev_in, 0));
+        }
+        // this Y buffer's previous reader (pass 2, two batches ago) must be done
+        if (c->y_pending[c->cur_y]) HIPCHK(hipStreamWaitEvent(c->p1, c->ev_p2[c->cur_y], 0));
+    }
+    c->input_on_main = false;
+    cf *Y = c->y_pool[c->cur_y];
     Pass1Args a1{};
     a1.raw = d_halves;
-    a1.Y = c->d_Y;
+    a1.Y = Y;
     a1.Wl = c->d_Wl1;
     a1.TB = c->d_TB;
     a1.yblk = (size_t)c->M1 * (c->T1 * cols) + c->ypad;
@@ -375,13 +430,21 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
     a1.is_real = c->is_real ? 1 : 0;
     a1.rot = c->is_real ? 0 : 1;
     a1.trace = c->d_trace;
+    {
+        int rc = next_tickets(c, 0, c->p1, &a1.tickets);
+        if (rc) return rc;
+    }
     a1.tiles_per_frame = tiles1;
     a1.total_slots = tiles1 * (unsigned)nframes;
     int rc = launch_pass1(c, c->M1, c->T1, sb, a1, a1.total_slots);
     if (rc) return rc;
+    if (piped) {
+        HIPCHK(hipEventRecord(c->ev_p1[c->cur_y], c->p1));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_p1[c->cur_y], 0));
+    }
 
     Pass2Args a2{};
-    a2.Y = c->d_Y;
+    a2.Y = Y;
     a2.Wl = c->d_Wl2;
     a2.M1 = c->M1;
     a2.log2M1 = c->log2M1;
@@ -396,7 +459,11 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
     a2.qt_stride = c->qt_stride;
     a2.Pscr = c->d_pscr[0];
     a2.p_stride = c->p_stride;
-    a2.trace = c->d_trace ? c->d_trace + 128 : nullptr;
+    a2.trace = c->d_trace ? c->d_trace + 128 + 2304 : nullptr;
+    {
+        int rc2 = next_tickets(c, 1, c->stream, &a2.tickets);
+        if (rc2) return rc2;
+    }
     a2.tiles_per_frame = tiles2;
     a2.total_slots = tiles2 * (unsigned)nframes;
     // pass 2 overwrites this result set: its previous consumers (two batches ago) must be done
@@ -431,6 +498,10 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
         const unsigned nb = (unsigned)((c->M / 8 + 255) / 256);
         hipLaunchKernelGGL(k_untangle_real, dim3(nb, nframes), dim3(256), 0, c->stream, u);
         HIPCHK(hipGetLastError());
+    }
+    if (piped) {
+        HIPCHK(hipEventRecord(c->ev_p2[c->cur_y], c->stream));
+        c->y_pending[c->cur_y] = true;
     }
     // consumers of the finished batch go to the side stream
     if (c->side != c->stream) {
@@ -485,7 +556,10 @@ void free_all(psdr_ctx *c) {
     F(c->d_TB);
     F(c->d_UA);
     F(c->d_UB);
-    F(c->d_Y);
+    F(c->d_tickets[0]);
+    F(c->d_tickets[1]);
+    F(c->y_pool[0]);
+    F(c->y_pool[1]);
     F(c->d_Z);
     for (int s = 0; s < 2; s++) {
         F(c->spec_pool[s]);
@@ -524,6 +598,12 @@ void free_all(psdr_ctx *c) {
     if (c->ev_fft_done) hipEventDestroy(c->ev_fft_done);
     if (c->ev_side_done) hipEventDestroy(c->ev_side_done);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
+    if (c->own_p1) hipStreamDestroy(c->own_p1);
+    if (c->ev_in) hipEventDestroy(c->ev_in);
+    for (int i = 0; i < 2; i++) {
+        if (c->ev_p1[i]) hipEventDestroy(c->ev_p1[i]);
+        if (c->ev_p2[i]) hipEventDestroy(c->ev_p2[i]);
+    }
     if (c->own_side) hipStreamDestroy(c->own_side);
 }
 
@@ -543,8 +623,20 @@ int build(psdr_ctx *c) {
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(hipStreamCreateWithPriority(&c->own_side, hipStreamNonBlocking, hi));
     }
+    HIPCHK(hipStreamCreateWithFlags(&c->own_p1, hipStreamNonBlocking));
     c->stream = c->own_stream;
     c->side = c->own_side;
+    c->static_tiles = getenv("PSDR_STATIC_TILES") != nullptr;
+    // pass 1 on its own stream overlaps the two passes of consecutive batches; it pays only when
+    // both batches' intermediates fit the 256 MiB MALL together (measured: F=16 2^20-point frames
+    // lose 12 %, F>=32 gain nothing), so it is opt-in
+    c->no_p1_stream = getenv("PSDR_P1_STREAM") == nullptr;
+    c->p1 = c->no_p1_stream ? c->own_stream : c->own_p1;
+    HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipEventCreateWithFlags(&c->ev_p1[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_p2[i], hipEventDisableTiming));
+    }
     HIPCHK(hipEventCreateWithFlags(&c->ev_fft_done, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&c->t0));
@@ -580,13 +672,18 @@ int build(psdr_ctx *c) {
         }
     }
 #ifdef PSDR_TRACE_ON
-    HIPCHK(hipMalloc((void **)&c->d_trace, 256 * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(c->d_trace, 0, 256 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&c->d_trace, 4864 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(c->d_trace, 0, 4864 * sizeof(unsigned long long)));
 #endif
     // ---- work buffers
     const size_t F = (size_t)c->max_batch;
     if (const char *e = getenv("PSDR_YPAD")) c->ypad = (size_t)atoi(e);
-    HIPCHK(hipMalloc((void **)&c->d_Y, F * (c->M + c->ypad * (size_t)(c->M2 / c->T1)) * sizeof(cf)));
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipMalloc((void **)&c->d_tickets[i], TICKET_SLOTS * 8 * sizeof(unsigned)));
+        HIPCHK(hipMemset(c->d_tickets[i], 0, TICKET_SLOTS * 8 * sizeof(unsigned)));
+    }
+    for (int i = 0; i < 2; i++)
+        HIPCHK(hipMalloc((void **)&c->y_pool[i], F * (c->M + c->ypad * (size_t)(c->M2 / c->T1)) * sizeof(cf)));
     if (c->is_real) HIPCHK(hipMalloc((void **)&c->d_Z, F * c->M * sizeof(cf)));
     for (int s = 0; s < 2; s++) {
         HIPCHK(hipMalloc((void **)&c->spec_pool[s], F * c->spec_stride * sizeof(cf)));
@@ -809,6 +906,7 @@ static int load_input(psdr_ctx *c, const float *a1, const float *a2) {
     HIPCHK(hipMemcpyAsync(c->d_stage + half_floats, a2, half_floats * sizeof(float),
                           hipMemcpyHostToDevice, c->stream));
     c->loaded = true;
+    c->input_on_main = true;
     return PSDR_OK;
 }
 extern "C" int psdr_load_real_input(psdr_ctx *c, const float *a1, const float *a2) {
@@ -947,6 +1045,7 @@ extern "C" int psdr_process_batch(psdr_ctx *c, const void *d_halves, int nframes
 }
 
 static int drain(psdr_ctx *c) {
+    if (c->p1 != c->stream) HIPCHK(hipStreamSynchronize(c->p1));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->side != c->stream) HIPCHK(hipStreamSynchronize(c->side));
     return PSDR_OK;
@@ -1395,12 +1494,13 @@ extern "C" int psdr_timer_stop_ms(psdr_ctx *c, double *ms_out) {
     return PSDR_OK;
 }
 extern "C" void *psdr_stream(psdr_ctx *c) { return c ? (void *)c->stream : nullptr; }
-// tuning builds (-DPSDR_TRACE_ON): phase timestamps of work-group 0, [pass][iteration 0..7][16]
+// tuning builds (-DPSDR_TRACE_ON): 4864 values; pass 1 at [0], pass 2 at [128 + 2304]: 128 phase
+// stamps of work-group 0 ([iteration 0..7][16]) ... [256..]: wall clock [work-group][8]
 extern "C" int psdr_debug_trace(psdr_ctx *c, unsigned long long *out256) {
     if (!c || !out256) return fail(PSDR_ERR_INVALID, "null argument");
     if (!c->d_trace) return fail(PSDR_ERR_UNSUPPORTED, "library built without PSDR_TRACE_ON");
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(out256, c->d_trace, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out256, c->d_trace, 4864 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PSDR_OK;
 }
 extern "C" int psdr_set_stream(psdr_ctx *c, void *hip_stream) {
@@ -1416,9 +1516,12 @@ extern "C" int psdr_set_stream(psdr_ctx *c, void *hip_stream) {
     if (hip_stream) {  // everything in order on the caller's stream
         c->stream = (hipStream_t)hip_stream;
         c->side = c->stream;
+        c->p1 = c->stream;
     } else {
         c->stream = c->own_stream;
         c->side = c->own_side;
+        c->p1 = c->no_p1_stream ? c->own_stream : c->own_p1;
     }
+    c->y_pending[0] = c->y_pending[1] = false;
     return PSDR_OK;
 }

@@ -32,9 +32,82 @@ __device__ __forceinline__ unsigned quantize_u8(float power, int power_offset) {
     return (unsigned)i & 0xFFu;
 }
 
+// ---- the same quantiser on packed pairs (the fused pass-2 epilogue is VALU-issue bound:
+// ~16 instructions per value as plain C, 8 here).  Same operations in the same order and
+// the same fusions as quantize_u8, two values per v_pk_*_f32; constants ride in three
+// register pairs and are broadcast by op_sel.
+typedef float q_v2f __attribute__((ext_vector_type(2)));
+struct QConst {
+    q_v2f c21, c0k, s20;  // (-0.3448.., 2.0246..), (-0.6748.., 0.30103), (20, 127)
+    unsigned mmask, mone; // 0x807FFFFF (keeps the sign bit like the reference's &= ~(255<<23)), 127<<23
+    float lo, hi;         // -128, 127
+};
+__device__ __forceinline__ QConst qconst() {
+    QConst k;
+    k.c21 = q_v2f{-0.34484843f, 2.02466578f};
+    k.c0k = q_v2f{-0.67487759f, 0.3010299956639812f};
+    k.s20 = q_v2f{20.f, 127.f};
+    k.mmask = 0x807FFFFFu;
+    k.mone = 127u << 23;
+    k.lo = -128.f;
+    k.hi = 127.f;
+    return k;
+}
+// q (still float, clamped to [-128, 127]) of two powers; koff = (float)(power_offset - 128)
+__device__ __forceinline__ q_v2f quantize2(float a, float b, float koff, const QConst &k) {
+    const unsigned ba = __float_as_uint(a), bb = __float_as_uint(b);
+    // exponent: (float)((bits >> 23) & 255) + (power_offset - 128), exact in either order
+    q_v2f lf = {(float)((ba >> 23) & 0xFFu), (float)((bb >> 23) & 0xFFu)};
+    const q_v2f kk = {koff, koff};
+    unsigned ma, mb;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ma) : "v"(ba), "v"(k.mmask), "v"(k.mone));
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(mb) : "v"(bb), "v"(k.mmask), "v"(k.mone));
+    const q_v2f m = {__uint_as_float(ma), __uint_as_float(mb)};
+    q_v2f t, poly, lg, v, q;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lf) : "v"(lf), "v"(kk));
+    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(m), "v"(k.c21));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "=v"(poly) : "v"(t), "v"(m), "v"(k.c0k));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lg) : "v"(lf), "v"(poly));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(v) : "v"(lg), "v"(k.c0k));
+    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(q) : "v"(v), "v"(k.s20));
+    // max(-128, q) and the saturation at +127 in one instruction (NaN -> -128 like std::max)
+    float qa, qb;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(qa) : "v"(q.x), "v"(k.lo), "v"(k.hi));
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(qb) : "v"(q.y), "v"(k.lo), "v"(k.hi));
+    return q_v2f{qa, qb};
+}
+// truncation toward zero + insertion of the low byte into byte B of acc
+template <int B>
+__device__ __forceinline__ void q_insert(unsigned &acc, float c) {
+    if constexpr (B == 0)
+        asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(acc) : "v"(c));
+    else if constexpr (B == 1)
+        asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(acc) : "v"(c));
+    else if constexpr (B == 2)
+        asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(acc) : "v"(c));
+    else
+        asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(acc) : "v"(c));
+}
+
 __device__ __forceinline__ unsigned pack4(float a, float b, float c, float d, int off) {
-    return quantize_u8(a, off) | (quantize_u8(b, off) << 8) | (quantize_u8(c, off) << 16) |
-           (quantize_u8(d, off) << 24);
+    const QConst k = qconst();
+    const float koff = (float)(off - 128);
+    const q_v2f q01 = quantize2(a, b, koff, k), q23 = quantize2(c, d, koff, k);
+    unsigned w = 0;
+    q_insert<0>(w, q01.x);
+    q_insert<1>(w, q01.y);
+    q_insert<2>(w, q23.x);
+    q_insert<3>(w, q23.y);
+    return w;
+}
+// two values -> low 16 bits
+__device__ __forceinline__ unsigned pack2(float a, float b, int off) {
+    const QConst k = qconst();
+    const q_v2f q01 = quantize2(a, b, (float)(off - 128), k);
+    unsigned w = 0;
+    q_insert<0>(w, q01.x);
+    q_insert<1>(w, q01.y);
+    return w;
 }
 
 // stores CNT (16/8/4/2/1) consecutive quantised values with one store
@@ -56,7 +129,7 @@ __device__ __forceinline__ void store_q(int8_t *dst, const float *p, int off) {
         *reinterpret_cast<unsigned *>(dst) = pack4(p[0], p[1], p[2], p[3], off);
     } else if constexpr (CNT == 2) {
         *reinterpret_cast<unsigned short *>(dst) =
-            (unsigned short)(quantize_u8(p[0], off) | (quantize_u8(p[1], off) << 8));
+            (unsigned short)pack2(p[0], p[1], off);
     } else {
         *dst = (int8_t)quantize_u8(p[0], off);
     }
@@ -106,7 +179,7 @@ __device__ __forceinline__ void pyr_record16(float (&p)[16], int size_log2, uint
     hi.z = pack4(p[0], p[1], p[2], p[3], size_log2 - 2);
     p[0] = __fadd_rn(p[0], p[1]);
     p[1] = __fadd_rn(p[2], p[3]);
-    hi.w = quantize_u8(p[0], size_log2 - 3) | (quantize_u8(p[1], size_log2 - 3) << 8);
+    hi.w = pack2(p[0], p[1], size_log2 - 3);
     p[0] = __fadd_rn(p[0], p[1]);
     hi.w |= quantize_u8(p[0], size_log2 - 4) << 16;
 }
@@ -118,7 +191,7 @@ __device__ __forceinline__ void pyr_record8(float (&p)[8], int size_log2, uint4 
     rec.z = pack4(p[0], p[1], p[2], p[3], size_log2 - 1);
     p[0] = __fadd_rn(p[0], p[1]);
     p[1] = __fadd_rn(p[2], p[3]);
-    rec.w = quantize_u8(p[0], size_log2 - 2) | (quantize_u8(p[1], size_log2 - 2) << 8);
+    rec.w = pack2(p[0], p[1], size_log2 - 2);
     p[0] = __fadd_rn(p[0], p[1]);
     rec.w |= quantize_u8(p[0], size_log2 - 3) << 16;
 }

@@ -19,23 +19,42 @@ eng.upload_ring(raw)
 for i in range(4):
     eng.step((i % 4) * F, F, demod=False, waterfall=False)
 eng.ctx.synchronize()
-buf = (C.c_ulonglong * 256)()
+buf = (C.c_ulonglong * 4864)()
 fn = eng.ctx.lib._handle and C.CDLL(os.environ.get("PSDR_LIB")).psdr_debug_trace
 fn.argtypes = [C.c_void_p, C.c_void_p]
 rc = fn(eng.ctx.h, buf)
 assert rc == 0, rc
-t = np.array(buf, dtype=np.int64).reshape(2, 8, 16)
+allv = np.array(buf, dtype=np.int64)
+t = np.stack([allv[0:128].reshape(8, 16), allv[2432:2560].reshape(8, 16)])
+wg = np.stack([allv[256:2304].reshape(256, 8), allv[2688:4736].reshape(256, 8)])
 names = {0: "top", 1: "xpose-wr(+ld wait)", 2: "bar", 3: "rd+bar+prefetch", 4: "stage0", 5: "bar", 6: "rd+bar",
          7: "stage1", 8: "bar", 9: "rd+bar", 10: "last stage+stores", 11: "bar", 12: "epilogue", 13: "bar(end)"}
 for p in range(2):
     print(f"== pass {p + 1} (cycles, iteration: deltas between marks)")
     for it in range(4):
         row = t[p, it]
-        marks = [(k, row[k]) for k in range(16) if row[k] != 0]
+        marks = [(k, row[k]) for k in range(14) if row[k] != 0]
+        if row[14] and row[15] and row[10]:
+            ns = (row[15] - row[14]) * 10.0
+            print(f"   wall {ns:.0f} ns for {row[10] - row[0]} ticks -> {(row[10] - row[0]) / ns:.2f} ticks/ns")
         marks.sort(key=lambda x: x[1])
         out = []
         for (k0, c0), (k1, c1) in zip(marks[:-1], marks[1:]):
             out.append(f"{names.get(k1, k1)}={c1 - c0}")
         tot = marks[-1][1] - marks[0][1] if marks else 0
         print(f" it{it}: total={tot}  " + "  ".join(out))
+for p in range(2):
+    w = wg[p].astype(np.float64)
+    t0 = w[:, 0].min()
+    rel = (w - t0) / 100.0  # us
+    rel[w == 0] = np.nan
+    names2 = ["entry", "prologue", "it0", "it1", "it2", "it3", "it4", "exit"]
+    print(f"== pass {p + 1}: work-group timeline, us after the first entry (min / median / max over 256 WGs)")
+    for k in range(8):
+        col = rel[:, k]
+        if np.all(np.isnan(col)):
+            continue
+        print(f"   {names2[k]:9s} {np.nanmin(col):7.2f} {np.nanmedian(col):7.2f} {np.nanmax(col):7.2f}")
+    # per XCD (wg % 8) exit medians
+    print("   exit by XCD:", " ".join(f"{np.nanmedian(rel[x::8, 7]):.1f}" for x in range(8)))
 eng.close()
