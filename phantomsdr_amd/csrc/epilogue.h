@@ -51,6 +51,7 @@ struct TailArgs {
     size_t R;
     float *Pout;  // [nframes][out_stride] level lvl_in+7
     size_t out_stride;
+    RecMap map;  // order of Pin (the fused pass-2 epilogue leaves it tile-major)
 };
 
 // each thread sums one pair (level lvl_in+1), then the wave continues 6 more levels
@@ -63,8 +64,7 @@ __global__ __launch_bounds__(256) void k_pyramid_tail(TailArgs a) {
     int8_t *Qf = a.Q + (size_t)f * a.q_stride;
     float s = 0.f;
     if (valid) {
-        const float2 p = reinterpret_cast<const float2 *>(Pf)[j];
-        s = __fadd_rn(p.x, p.y);
+        s = __fadd_rn(Pf[a.map.pos(2 * j)], Pf[a.map.pos(2 * j + 1)]);
         const int lv = a.lvl_in + 1;
         if (lv < a.nlevels) {
             size_t qoff = 0;
@@ -206,8 +206,8 @@ struct WfClient {
 // in the tiled records (quantize.h), the upper levels in the level-major buffer.
 __global__ __launch_bounds__(256) void k_waterfall_gather(const int8_t *Q, size_t q_stride,
                                                           const int8_t *Qt, size_t qt_stride, int tiled_lt,
-                                                          int ch, const WfClient *cl, const int *sent_frames,
-                                                          int nsent, int8_t *out) {
+                                                          int ch, RecMap map, const WfClient *cl,
+                                                          const int *sent_frames, int nsent, int8_t *out) {
     const WfClient c = cl[blockIdx.x];
     if (!c.active) return;
     const int si = blockIdx.y;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_waterfall_gather(const int8_t *Q, size_
         const int loff = tiled_level_offset(ch, c.level);
         for (int i = threadIdx.x; i < len; i += blockDim.x) {
             const size_t j = (size_t)c.l + i;
-            dst[i] = src[(j / per) * (2 * ch) + loff + (j % per)];
+            dst[i] = src[map.pos(j / per) * (2 * ch) + loff + (j % per)];
         }
     } else {
         const int8_t *src = Q + (size_t)f * q_stride + c.qoff + c.l;
@@ -231,10 +231,10 @@ __global__ __launch_bounds__(256) void k_waterfall_gather(const int8_t *Q, size_
 
 // tiled records -> the reference's level-major layout (levels 0..tiled_lt of one frame)
 __global__ __launch_bounds__(256) void k_untile_q(const int8_t *Qt, int8_t *Q, size_t R, int ch, int tiled_lt,
-                                                  int nlevels) {
+                                                  int nlevels, RecMap map) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // record
     if (g >= R / ch) return;
-    const int8_t *rec = Qt + g * (2 * ch);
+    const int8_t *rec = Qt + map.pos(g) * (2 * ch);
     size_t qoff = 0;
     for (int lv = 0; lv <= tiled_lt && lv < nlevels; lv++) {
         const int per = ch >> lv;

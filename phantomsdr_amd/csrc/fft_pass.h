@@ -683,7 +683,6 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2(Pass2Args a) {
             __syncthreads();
             PSDR_TRACE(a.trace, it, 11);
             constexpr int CH = T < 16 ? T : 16;  // values per chunk (one aligned group)
-            constexpr int LT = CH == 16 ? 4 : 3;
             constexpr int NG = (L * T / CH) / NT;  // chunks per thread; chunks tile Pst linearly
             static_assert(CH == 16 || CH == 8, "tile width");
             int8_t *Qf = a.Qt + (size_t)f * a.qt_stride;
@@ -691,8 +690,6 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2(Pass2Args a) {
 #pragma unroll
             for (int k = 0; k < NG; k++) {
                 const int g = k * NT + tidx;  // chunk id
-                const int row = (g * CH) / T, sub = (g * CH) % T;
-                const size_t c = ((size_t)row << a.log2M1) + c1base + sub;  // client-order bin of value 0
                 float pw[CH];
 #pragma unroll
                 for (int v4 = 0; v4 < CH / 4; v4++) {
@@ -702,8 +699,10 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2(Pass2Args a) {
                     pw[4 * v4 + 2] = q4.z;
                     pw[4 * v4 + 3] = q4.w;
                 }
-                // levels 0..LT of this aligned group -> one contiguous record
-                uint4 *rec = reinterpret_cast<uint4 *>(Qf + (c / CH) * (2 * CH));
+                // levels 0..LT of this aligned group -> one record; tile-major record order
+                // (RecMap, quantize.h): chunk g of tile tl is record tl*(L*T/CH) + g
+                const size_t rp = (size_t)tl * (L * T / CH) + g;
+                uint4 *rec = reinterpret_cast<uint4 *>(Qf + rp * (2 * CH));
                 if constexpr (CH == 16) {
                     uint4 lo, hi;
                     pyr_record16(pw, a.size_log2, lo, hi);
@@ -714,7 +713,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2(Pass2Args a) {
                     pyr_record8(pw, a.size_log2, r8);
                     rec[0] = r8;
                 }
-                Pf[c >> LT] = pw[0];
+                Pf[rp] = pw[0];
                 PSDR_SCHED_FENCE();
             }
         }

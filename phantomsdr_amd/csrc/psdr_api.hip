@@ -170,6 +170,7 @@ struct psdr_ctx {
     int8_t *d_qt = nullptr;  // tiled records of levels 0..LT (IQ fused epilogue), quantize.h
     size_t qt_stride = 0;
     int tiled_lt = -1, tile_ch = 16;
+    RecMap recmap{};  // order of the tiled records and of the level-LT scratch
     std::vector<char> q_untiled;  // per frame: level-major copy of the tiled levels is current
     float *d_pscr[2] = {nullptr, nullptr};
 
@@ -525,6 +526,8 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
         t.R = c->R;
         t.Pout = c->d_pscr[cur ^ 1];
         t.out_stride = c->p_stride;
+        t.map = c->recmap;
+        if (cur != 0 || lvl != c->LT) t.map.mapped = 0;  // only pass 2's own output is tile-major
         ProfScope ps(c, K_TAIL, c->side);
         const unsigned nb = (unsigned)((len / 2 + 255) / 256);
         hipLaunchKernelGGL(k_pyramid_tail, dim3(nb, nframes), dim3(256), 0, c->side, t);
@@ -859,6 +862,10 @@ extern "C" int psdr_create(const psdr_config *cfg, psdr_ctx **out) {
         c->tile_ch = (c->T2 >= 16) ? 16 : 8;
         c->LT = (c->T2 >= 16) ? 4 : 3;
         c->tiled_lt = c->LT;
+        c->recmap.l2tpr = ilog2((size_t)(c->M1 / c->tile_ch));
+        c->recmap.l2gpt = ilog2((size_t)(c->T2 / c->tile_ch));
+        c->recmap.l2rows = c->log2M2;
+        c->recmap.mapped = 1;
         c->qt_stride = 2 * c->R;  // R/CH records of 2*CH bytes
     }
     c->p_stride = std::max<size_t>(c->R >> c->LT, 64);
@@ -936,7 +943,7 @@ static int ensure_level_major(psdr_ctx *c, int frame) {
     const size_t nrec = c->R / (size_t)c->tile_ch;
     hipLaunchKernelGGL(k_untile_q, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, c->side,
                        c->d_qt + (size_t)frame * c->qt_stride, c->d_q + (size_t)frame * c->q_stride, c->R,
-                       c->tile_ch, c->tiled_lt, c->levels);
+                       c->tile_ch, c->tiled_lt, c->levels, c->recmap);
     HIPCHK(hipGetLastError());
     c->q_untiled[frame] = 1;
     return PSDR_OK;
@@ -1367,7 +1374,7 @@ extern "C" int psdr_waterfall_batch(psdr_ctx *c, uint64_t first_frame_num) {
     {
         ProfScope ps(c, K_WFALL, c->side);
         hipLaunchKernelGGL(k_waterfall_gather, dim3(maxid + 1, nsent), dim3(256), 0, c->side, c->d_q,
-                           c->q_stride, c->d_qt, c->qt_stride, c->tiled_lt, c->tile_ch, d_wf, d_sent, nsent,
+                           c->q_stride, c->d_qt, c->qt_stride, c->tiled_lt, c->tile_ch, c->recmap, d_wf, d_sent, nsent,
                            c->d_wfout);
         HIPCHK(hipGetLastError());
     }

@@ -160,6 +160,23 @@ __device__ __forceinline__ void pyr_levels(float (&p)[CH], int8_t *Qf, size_t qo
 //   CH =  8: [q0 x8 | q1 x4 | q2 x2 | q3 | pad]              (offsets 0, 8,12,14)
 // Consumers on the GPU (waterfall gather) index the records directly; the reference's
 // level-major layout (src/fft_impl.cpp:162-172) is produced on demand by k_untile_q.
+// Record ORDER: tile-major.  The pass-2 work-group that owns rows c1base..c1base+T-1 writes
+// the records of all its L output rows back to back (one contiguous stream of full lines
+// instead of one 32-byte piece per 2 KiB: the piecewise order cost 16 % of pass 2).  Group
+// g = c / CH of client-order bin c sits in record
+//   pos(g) = tl * (rows * gpt) + row * gpt + k,  row = g / tpr, tl = (g % tpr) / gpt, k = g % gpt
+// (tpr = M1/CH groups per output row, gpt = T/CH groups per tile and row, rows = M2).
+struct RecMap {
+    int l2tpr, l2gpt, l2rows;
+    int mapped;  // 0: identity (level-major producers: the real-input untangle kernel)
+    __host__ __device__ __forceinline__ size_t pos(size_t g) const {
+        if (!mapped) return g;
+        const size_t row = g >> l2tpr, gc = g & (((size_t)1 << l2tpr) - 1);
+        const size_t tl = gc >> l2gpt, k = gc & (((size_t)1 << l2gpt) - 1);
+        return (((tl << l2rows) + row) << l2gpt) + k;
+    }
+};
+
 __host__ __device__ __forceinline__ int tiled_level_offset(int ch, int lv) {
     // ch * (2 - 2^(1-lv)) for lv >= 1, 0 for lv = 0
     return lv == 0 ? 0 : 2 * ch - (2 * ch >> lv);
