@@ -177,6 +177,50 @@ def cpu_baseline(wl, params, clients, waterfalls, budget_s=15.0):
                       f"OpenMP {cores} of {ncpu} host threads for the FFT/pyramid (best of a probe), clients serial)"}
 
 
+def kernel_roofline(ctx, step, first_step, nsteps, wl, wl_name, params, clients, waterfalls, frames_per_launch):
+    """per-kernel durations from a profiled replay (hipEvents on the library's own streams) and the
+    roofline block of the dominant kernel (DESIGN.md "Roofline accounting")"""
+    ctx.set_profiling(True)
+    ctx.reset_kernel_stats()
+    for i in range(nsteps):
+        step(first_step + i)
+    ctx.synchronize()
+    stats = ctx.kernel_stats()
+    ctx.set_profiling(False)
+    ab = algorithmic_bytes_per_frame(wl, params, clients, waterfalls)
+    Fl = frames_per_launch
+    # algorithmic bytes by kernel: pass 1 reads the raw input once; pass 2 (+fused epilogue)
+    # writes the spectrum and the pyramid; the demod kernels read slices and write audio;
+    # intermediates count zero.
+    per_kernel_bytes = {
+        "fft_pass1": ab["input"] * Fl,
+        "fft_pass2": (ab["spectrum"] + (ab["pyramid"] if not wl["is_real"] else 0)) * Fl,
+        "untangle_real": (ab["spectrum"] + ab["pyramid"]) * Fl if wl["is_real"] else 0,
+        "demod_idft": ab["clients"] * Fl,
+    }
+    kernels = {name: {"avg_us": round(ms / cnt * 1e3, 3), "launches": int(cnt)} for name, (ms, cnt) in stats.items()}
+    dom = max(stats, key=lambda k: stats[k][0]) if stats else None
+    roofline = None
+    if dom:
+        avg_s = stats[dom][0] / stats[dom][1] / 1e3
+        achieved = per_kernel_bytes.get(dom, 0) / avg_s
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile)).get(wl_name, {})
+                traffic = tj.get(dom)
+                if traffic is not None:  # measured at tj["_frames_per_launch"] frames per launch
+                    traffic = int(traffic * Fl / tj.get("_frames_per_launch", Fl))
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": int(per_kernel_bytes.get(dom, 0)),
+                    "avg_launch_us": round(avg_s * 1e6, 2)}
+    return roofline, kernels, ab
+
+
 def run_sharded_bench(args, torch, rank, world, local_rank):
     """N > 1.  Default (--shard time): the STREAM is sharded - batch g goes to rank g mod G
     with a two-frame warm-up instead of any exchange (phantomsdr_amd/distributed.py); every
@@ -266,6 +310,13 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
     # time mode: every rank ingests its own F new frames per step; client mode: one stream
     frames = args.steps * F * (world if time_mode else 1)
     msps = frames * (N // 2) / dt / 1e6
+    # roofline of the dominant kernel on rank 0's GPU (all ranks replay: client mode broadcasts)
+    wl_name_s = args.workload or ("cfg2" if time_mode else "cfg4")
+    roofline, kernels, _ = kernel_roofline(eng.ctx, step, args.warmup + args.steps, min(args.steps, 20), wl,
+                                           wl_name_s, params, clients, waterfalls, F + warm)
+    eng.ctx.synchronize()
+    torch.cuda.synchronize()
+    dist.barrier()
     if rank == 0:
         ab = algorithmic_bytes_per_frame(wl, params, clients, waterfalls)
         out = {
@@ -278,9 +329,9 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
                        "frames_per_step": F, "fft_size": N, "audio_clients": nclients_total,
                        "waterfall_clients": len(waterfalls), "parallelism": par,
                        "realtime_factor": round(msps * 1e6 / wl["sps"], 1)},
-            "roofline": None,
+            "roofline": roofline,
             "path": {"algorithmic_bytes_per_frame": int(ab["total"]),
-                     "frames_per_s": round(frames / dt, 1),
+                     "frames_per_s": round(frames / dt, 1), "kernels": kernels,
                      "frac_of_hbm_peak_per_gpu": round(ab["total"] * frames / dt / HBM_PEAK / (world if time_mode else 1), 4)},
             "xgmi": None if time_mode else {
                 "broadcast_bytes_per_frame": 8 * N,
@@ -377,46 +428,9 @@ def main():
     msps = frames * (N // 2) / dt / 1e6
     ms_per_step = dt / args.steps * 1e3
 
-    # per-kernel durations with hipEvents on the library's own stream (second, profiled
-    # replay of the same steps so that the events do not perturb `value`)
-    eng.ctx.set_profiling(True)
-    eng.ctx.reset_kernel_stats()
-    prof_steps = min(args.steps, 50)
-    for i in range(prof_steps):
-        step(args.warmup + i)
-    eng.ctx.synchronize()
-    stats = eng.ctx.kernel_stats()
-    eng.ctx.set_profiling(False)
-
-    ab = algorithmic_bytes_per_frame(wl, params, clients, waterfalls)
-    # algorithmic bytes by kernel (DESIGN.md "Roofline accounting"): pass 1 reads the raw
-    # input once; pass 2 (+fused epilogue) writes the spectrum and pyramid levels < 5; the
-    # demod kernels read slices and write audio; intermediates count zero.
-    per_kernel_bytes = {
-        "fft_pass1": ab["input"] * F,
-        "fft_pass2": (ab["spectrum"] + (ab["pyramid"] if not wl["is_real"] else 0)) * F,
-        "untangle_real": (ab["spectrum"] + ab["pyramid"]) * F if wl["is_real"] else 0,
-        "demod_idft": ab["clients"] * F,
-    }
-    kernels = {}
-    for name, (ms, cnt) in stats.items():
-        kernels[name] = {"avg_us": round(ms / cnt * 1e3, 3), "launches": int(cnt)}
-    dom = max(stats, key=lambda k: stats[k][0]) if stats else None
-    roofline = None
-    if dom:
-        avg_s = stats[dom][0] / stats[dom][1] / 1e3
-        achieved = per_kernel_bytes.get(dom, 0) / avg_s
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get(wl_name, {}).get(dom)
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": int(per_kernel_bytes.get(dom, 0)),
-                    "avg_launch_us": round(avg_s * 1e6, 2)}
+    # per-kernel durations: second, profiled replay of the same steps (the events do not perturb `value`)
+    roofline, kernels, ab = kernel_roofline(eng.ctx, step, args.warmup, min(args.steps, 50), wl, wl_name, params,
+                                            clients, waterfalls, F)
     path_frac = ab["total"] * (frames / dt) / HBM_PEAK
 
     cpu = None

@@ -843,6 +843,7 @@ extern "C" int psdr_create(const psdr_config *cfg, psdr_ctx **out) {
     c->is_real = is_real;
     c->R = M;  // fft_result_size: N (IQ) or N/2 (real), src/spectrumserver.cpp:99-105
     c->log2M2 = m / 2;
+    if (const char *e = getenv("PSDR_LOG2M2")) c->log2M2 = atoi(e);  // tuning: split M = M1 * M2
     c->log2M1 = m - c->log2M2;
     c->M1 = 1 << c->log2M1;
     c->M2 = 1 << c->log2M2;

@@ -2,7 +2,7 @@
 """Summarise rocprofv3 PMC passes into per-kernel HBM traffic per launch.
 
 usage: pmc_summary.py <dir with p_counter_collection.csv for FETCH_SIZE> <dir for WRITE_SIZE>
-                      <workload name> <out pmc json> <out traffic json>
+                      <workload name> <out pmc json> <out traffic json> [frames per launch]
 
 FETCH_SIZE / WRITE_SIZE are KiB.  Corrections (MI355X_MICROARCH.md, "HBM"): on gfx950
 FETCH_SIZE tallies the 128-B requests of wide coalesced reads (16 B/lane) at 64 B, so it is
@@ -38,6 +38,7 @@ def read(dirname, counter):
 
 def main():
     fdir, wdir, wl, out_pmc, out_traffic = sys.argv[1:6]
+    frames = int(sys.argv[6]) if len(sys.argv) > 6 else 64
     fetch, write = read(fdir, "FETCH_SIZE"), read(wdir, "WRITE_SIZE")
     kernels, traffic = {}, {}
     for k in sorted(set(fetch) | set(write)):
@@ -52,11 +53,12 @@ def main():
             if s in k:
                 traffic[short] = int(corrected)
     json.dump({"note": __doc__.split("usage")[0].strip() + " Corrections: see tools/pmc_summary.py.",
-               "workload": wl, "kernels": kernels}, open(out_pmc, "w"), indent=1)
+               "workload": wl, "frames_per_launch": frames, "kernels": kernels}, open(out_pmc, "w"), indent=1)
     try:
         allt = json.load(open(out_traffic))
     except Exception:
         allt = {}
+    traffic["_frames_per_launch"] = frames  # bench.py scales to its own batch size
     allt[wl] = traffic
     json.dump(allt, open(out_traffic, "w"), indent=1)
     print(json.dumps(traffic))
