@@ -82,19 +82,27 @@ __device__ __forceinline__ void idft_stage(const cf *src, cf *dst, const cf *Wn,
         const cf *xp = src + tb.x;
         float ar = 0.f, ai = 0.f;
         if constexpr (RC > 0) {
-            cf x[RC], w[RC];
+            // operands in groups of 4: enough loads in flight, few registers (the kernel shares
+            // the SIMDs' register file with the FFT passes: <= 48 VGPRs doubles its occupancy)
             int e = 0;
 #pragma unroll
-            for (int q = 0; q < RC; q++) {
-                x[q] = xp[q * tlen];
-                w[q] = Wn[e];
-                e += e1;
-                if (e >= n) e -= n;
-            }
+            for (int q0 = 0; q0 < RC; q0 += 4) {
+                constexpr int G = 4;
+                cf x[G], w[G];
 #pragma unroll
-            for (int q = 0; q < RC; q++) {
-                ar = fmaf(x[q].x, w[q].x, fmaf(-x[q].y, w[q].y, ar));
-                ai = fmaf(x[q].x, w[q].y, fmaf(x[q].y, w[q].x, ai));
+                for (int g = 0; g < G; g++)
+                    if (q0 + g < RC) {
+                        x[g] = xp[(q0 + g) * tlen];
+                        w[g] = Wn[e];
+                        e += e1;
+                        if (e >= n) e -= n;
+                    }
+#pragma unroll
+                for (int g = 0; g < G; g++)
+                    if (q0 + g < RC) {
+                        ar = fmaf(x[g].x, w[g].x, fmaf(-x[g].y, w[g].y, ar));
+                        ai = fmaf(x[g].x, w[g].y, fmaf(x[g].y, w[g].x, ai));
+                    }
             }
         } else {
             int e = 0;
@@ -218,10 +226,105 @@ __global__ __launch_bounds__(256) void k_demod_idft(DemodArgs a) {
     }
 }
 
-__global__ __launch_bounds__(128) void k_demod_ola(DemodArgs a) {
-    const int n = a.n, h = n / 2, tid = threadIdx.x, NT = blockDim.x;
-    const ClientParams cp = a.clients[blockIdx.x];
-    const int f = blockIdx.y;
+// The same transform with one WAVE per (client, frame) and no work-group barrier: the 64
+// lanes of a wave execute their LDS operations in order, so a stage boundary is just
+// "s_waitcnt lgkmcnt(0)".  With hundreds of clients the one-work-group-per-item kernel above
+// is bound by its ~10 barriers per item while it shares the CUs with the persistent FFT
+// passes; here a 128-thread work-group carries two independent items in < 16 KiB of LDS (the
+// space an FFT pass leaves free on a CU).  n <= 512 (audio_fft_size 248, 360, ...).
+//   grid = ceil(nact * nframes / WAVES); dynamic LDS = (2 * WAVES + 1) * n * 8 bytes
+#define PSDR_IDFT_WAVES 2
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__global__ __launch_bounds__(64 * PSDR_IDFT_WAVES) void k_demod_idft_wave(DemodArgs a, int nact) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = a.n, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    cf *Wn = reinterpret_cast<cf *>(smem);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) Wn[i] = a.Wn[i];
+    __syncthreads();  // the only work-group barrier: the shared twiddle table
+    const int item = blockIdx.x * PSDR_IDFT_WAVES + wv;
+    if (item >= nact * a.nframes) return;
+    // consecutive items = consecutive frames of one client: the slice addresses of a
+    // work-group's waves are F*8N bytes apart, their table look-ups identical
+    const int ci = item / a.nframes, f = item - ci * a.nframes;
+    const ClientParams cp = a.clients[ci];
+    const unsigned long long frame_num = a.first_frame_num + (unsigned long long)f;
+    cf *bufA = Wn + n + (size_t)wv * 2 * n, *bufB = bufA + n;
+
+    const int len = cp.r - cp.l;
+    const int m = cp.m_floor - cp.l;  // audio_m
+    const cf *S = a.spec + (size_t)f * a.spec_stride + cp.l;
+    for (int i = lane; i < n; i += 64) bufA[i] = make_float2(0.f, 0.f);
+    wave_lds_sync();
+    float pw = 0.f;
+    for (int t = lane; t < len; t += 64) {
+        const cf v = S[t];
+        pw += fmaf(v.x, v.x, v.y * v.y);
+        if (cp.mode == 0) {  // USB :125-137
+            if (t >= m && t < m + n) bufA[t - m] = v;
+        } else if (cp.mode == 1) {  // LSB :139-153
+            if (t >= m - n + 1 && t < m + 1) bufA[m - t] = v;
+        } else {  // AM/FM :175-198
+            if (t >= m && t < m + n / 2) bufA[t - m] = v;
+            if (t >= m - n / 2 + 1 && t < m) bufA[n - m + t] = v;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) pw += __shfl_xor(pw, d, 64);
+    if (lane == 0) a.pwr[(size_t)cp.slot * a.max_batch + f] = pw;
+    wave_lds_sync();
+    if (cp.mode < 2) {  // c2r semantics, see k_demod_idft
+        for (int k = lane + 1; k < n / 2; k += 64) {
+            const cf v = bufA[k];
+            bufA[n - k] = make_float2(v.x, -v.y);
+        }
+        if (lane == 0) {
+            bufA[0].y = 0.f;
+            bufA[n / 2].y = 0.f;
+        }
+        wave_lds_sync();
+    }
+    cf *src = bufA, *dst = bufB;
+    for (int st = 0; st < a.nstages; st++) {
+        const int R = a.radix[st];
+        const int4 *tab = a.stage_tab + (size_t)st * n;
+        switch (R) {
+#define PSDR_RCASE(r) case r: idft_stage<r>(src, dst, Wn, tab, n, r, lane, 64); break;
+            PSDR_RCASE(2) PSDR_RCASE(3) PSDR_RCASE(4) PSDR_RCASE(5) PSDR_RCASE(6) PSDR_RCASE(7)
+            PSDR_RCASE(8) PSDR_RCASE(9) PSDR_RCASE(10) PSDR_RCASE(12) PSDR_RCASE(14)
+            PSDR_RCASE(15) PSDR_RCASE(16)
+#undef PSDR_RCASE
+            default: idft_stage<0>(src, dst, Wn, tab, n, R, lane, 64); break;
+        }
+        cf *tmp = src;
+        src = dst;
+        dst = tmp;
+        wave_lds_sync();
+    }
+    const bool flip = flip_frame(frame_num, cp.m_floor, a.is_real);
+    const float sg = flip ? -1.f : 1.f;
+    cf *yp = a.ypost + ((size_t)cp.slot * a.max_batch + f) * n;
+    for (int jx = lane; jx < n; jx += 64) {
+        cf v;
+        if (cp.mode == 0)
+            v = make_float2(src[jx].x * sg, 0.f);
+        else if (cp.mode == 1)
+            v = make_float2(src[n - 1 - jx].x * sg, 0.f);  // std::reverse :155
+        else
+            v = make_float2(src[jx].x * sg, src[jx].y * sg);
+        yp[jx] = v;
+    }
+}
+
+// one WAVE per (client, frame): no shared memory, no barrier (NaN flag by wave vote);
+// grid = ceil(nact * nframes / 4) work-groups of 256 threads
+__global__ __launch_bounds__(256) void k_demod_ola(DemodArgs a, int nact) {
+    const int n = a.n, h = n / 2, tid = threadIdx.x & 63, NT = 64;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= nact * a.nframes) return;
+    const int ci = item / a.nframes;
+    const ClientParams cp = a.clients[ci];
+    const int f = item - ci * a.nframes;
     const int F = a.nframes;
     const size_t srow = (size_t)cp.slot;
     const cf *yp = a.ypost + (srow * a.max_batch) * n;  // this client's frames
@@ -232,9 +335,7 @@ __global__ __launch_bounds__(128) void k_demod_ola(DemodArgs a) {
     const cf *bt_old = a.bb_tail + ((size_t)cur * a.slots + srow) * h;
     cf *bt_new = a.bb_tail + ((size_t)nxt * a.slots + srow) * h;
     float *out = a.audio + (srow * a.max_batch + f) * h;
-    __shared__ int s_nan;
-    if (tid == 0) s_nan = 0;
-    __syncthreads();
+    int s_nan = 0;  // per lane; combined by a wave vote at the end
     const bool last = (f == F - 1);
 
     if (cp.mode < 2) {
@@ -283,8 +384,8 @@ __global__ __launch_bounds__(128) void k_demod_ola(DemodArgs a) {
             }
         }
     }
-    __syncthreads();
-    if (tid == 0) a.nan_flags[srow * a.max_batch + f] = s_nan;
+    const int any_nan = __any(s_nan);
+    if (tid == 0) a.nan_flags[srow * a.max_batch + f] = any_nan ? 1 : 0;
 }
 
 }  // namespace psdr

@@ -191,6 +191,7 @@ struct psdr_ctx {
     size_t idft_lds = 0;
     int4 *d_stage_tab = nullptr;
     int idft_threads = 256;
+    bool idft_block = false;  // tuning (PSDR_IDFT_BLOCK=1): force the one-work-group-per-item kernel
     cf *d_Wn = nullptr, *d_ypost = nullptr, *d_gscratch = nullptr, *d_bb_tail = nullptr,
        *d_bb_last = nullptr;
     float *d_pwr = nullptr, *d_audio = nullptr, *d_real_prev = nullptr;
@@ -772,6 +773,7 @@ int build(psdr_ctx *c) {
             rc = upload(&c->d_stage_tab, tab);
             if (rc) return rc;
             c->idft_threads = n <= 512 ? 128 : 256;
+            c->idft_block = getenv("PSDR_IDFT_BLOCK") != nullptr;
         }
         const size_t S = (size_t)std::max(1, g.max_clients);
         c->aslots.resize(S);
@@ -1184,13 +1186,22 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     a.slots = (int)c->aslots.size();
     {
         ProfScope ps(c, K_IDFT, c->side);
-        hipLaunchKernelGGL(k_demod_idft, dim3(nact, nframes), dim3(c->idft_threads), c->idft_lds, c->side,
-                           a);
+        if (c->n <= 512 && !c->idft_block) {
+            // one wave per (client, frame), no work-group barriers (demod.h)
+            const unsigned items = (unsigned)nact * (unsigned)nframes;
+            const size_t lds = (size_t)(2 * PSDR_IDFT_WAVES + 1) * c->n * sizeof(cf);
+            hipLaunchKernelGGL(k_demod_idft_wave, dim3((items + PSDR_IDFT_WAVES - 1) / PSDR_IDFT_WAVES),
+                               dim3(64 * PSDR_IDFT_WAVES), lds, c->side, a, nact);
+        } else {
+            hipLaunchKernelGGL(k_demod_idft, dim3(nact, nframes), dim3(c->idft_threads), c->idft_lds, c->side,
+                               a);
+        }
         HIPCHK(hipGetLastError());
     }
     {
         ProfScope ps(c, K_OLA, c->side);
-        hipLaunchKernelGGL(k_demod_ola, dim3(nact, nframes), dim3(128), 0, c->side, a);
+        const unsigned items = (unsigned)nact * (unsigned)nframes;
+        hipLaunchKernelGGL(k_demod_ola, dim3((items + 3) / 4), dim3(256), 0, c->side, a, nact);
         HIPCHK(hipGetLastError());
     }
     c->client_ring.release(ring, c->side);
