@@ -144,6 +144,18 @@ int psdr_read_audio(psdr_ctx *ctx, int id, float *audio, float *pwr, int32_t *na
 /* device-resident results (no copy): audio of client slot `id` */
 int psdr_audio_device_ptr(psdr_ctx *ctx, int id, const float **d_audio, const float **d_pwr);
 
+/* Post-demodulation chain of AudioClient::send_audio (src/signal.cpp:277-284), batched for all
+ * clients: DCBlocker (src/utils.h:139-169, delay audio_rate/750*2), AGC(0.2, 50 ms, 300 ms,
+ * 200 ms look-ahead) (src/utils/audioprocessing.cpp:5-68; reset by
+ * psdr_client_set_audio_demodulation like src/signal.cpp:316-328), dsp_float_to_int16 with
+ * mult 65536/4 (src/utils/dsp.cpp:152-165).  Off by default; when on, every demod_batch also
+ * produces the int16 PCM (held in int32, like the reference's int32_t buffer) that the reference
+ * hands to its audio encoder.  Frames whose NaN flag is set are skipped by the chain (the
+ * reference drops them before it, src/signal.cpp:266-271); their PCM rows are zero. */
+int psdr_set_post_chain(psdr_ctx *ctx, int enable);
+/* pcm: [frames of the last demod_batch][audio_fft_size/2] */
+int psdr_read_pcm(psdr_ctx *ctx, int id, int32_t *pcm);
+
 /* waterfall clients: WaterfallClient (src/waterfall.h) */
 int psdr_waterfall_add(psdr_ctx *ctx, int *id_out);
 int psdr_waterfall_remove(psdr_ctx *ctx, int id);

@@ -314,6 +314,35 @@ class AudioClient:
             np.complex64).copy()
 
 
+class PostChain:
+    """DCBlocker + AGC + dsp_float_to_int16 exactly as AudioClient applies them after a frame
+    survived the NaN guard (src/signal.cpp:277-284; state created at src/signal.cpp:54-55)."""
+
+    def __init__(self, audio_rate):
+        L = lib()
+        self._L = L
+        self.dc = L.orc_dc_create(audio_rate // 750 * 2)
+        self.agc = L.orc_agc_create(0.2, 50.0, 300.0, 200.0, float(audio_rate))
+
+    def __del__(self):
+        if getattr(self, "dc", None):
+            self._L.orc_dc_destroy(self.dc)
+            self._L.orc_agc_destroy(self.agc)
+            self.dc = None
+
+    def reset_agc(self):
+        self._L.orc_agc_reset(self.agc)
+
+    def process(self, audio):
+        """audio: float32 [h] of one frame -> int32 [h] (int16 range)"""
+        a = np.ascontiguousarray(audio, np.float32).copy()
+        self._L.orc_dc_remove(self.dc, _p(a), a.size)
+        self._L.orc_agc_process(self.agc, _p(a), a.size)
+        pcm = np.zeros(a.size, np.int32)
+        self._L.orc_float_to_int16(_p(a), _p(pcm), 16384.0, a.size)
+        return pcm
+
+
 def waterfall_pick_level(levels, min_waterfall_fft, l, r):
     cl, cr = C.c_int(l), C.c_int(r)
     lv = lib().orc_waterfall_pick_level(levels, min_waterfall_fft, C.byref(cl), C.byref(cr))

@@ -56,6 +56,8 @@ SYMBOLS = [
     ("psdr_demod_batch_from", _i, [_vp, _vp, _sz, _i, _u64]),
     ("psdr_read_audio", _i, [_vp, _i, _vp, _vp, _vp]),
     ("psdr_audio_device_ptr", _i, [_vp, _i, _pp, _pp]),
+    ("psdr_set_post_chain", _i, [_vp, _i]),
+    ("psdr_read_pcm", _i, [_vp, _i, _vp]),
     ("psdr_waterfall_add", _i, [_vp, C.POINTER(_i)]),
     ("psdr_waterfall_remove", _i, [_vp, _i]),
     ("psdr_waterfall_set_range", _i, [_vp, _i, _i, _i, _i]),

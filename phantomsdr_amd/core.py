@@ -120,6 +120,10 @@ class Context:
         check(self.lib.psdr_process_batch(self.h, C.c_void_p(base + offset_bytes), nframes))
         self.last_nframes = nframes
 
+    def set_post_chain(self, enable=True):
+        """batched DC blocker + AGC + int16 conversion after every demod_batch"""
+        check(self.lib.psdr_set_post_chain(self.h, 1 if enable else 0))
+
     def demod_batch(self, first_frame_num):
         check(self.lib.psdr_demod_batch(self.h, first_frame_num))
 
@@ -298,6 +302,15 @@ class AudioClient:
         nan = np.empty(F, np.int32)
         check(self.ctx.lib.psdr_read_audio(self.ctx.h, self.id, _ptr(audio), _ptr(pwr), _ptr(nan)))
         return audio, pwr, nan
+
+    def read_pcm(self, nframes=None):
+        """int16 PCM (in int32, like the reference's buffer) of the last demod batch after the
+        DC blocker / AGC / int16 conversion (src/signal.cpp:277-284); needs
+        Context.set_post_chain(True)."""
+        F = nframes or self.ctx.last_nframes
+        pcm = np.empty((F, self.ctx.n // 2), np.int32)
+        check(self.ctx.lib.psdr_read_pcm(self.ctx.h, self.id, _ptr(pcm)))
+        return pcm
 
     def on_close(self):
         if self.id >= 0 and self.ctx.h:

@@ -36,6 +36,8 @@ struct ClientParams {
     int mode;       // psdr_mode
     int slot;       // persistent slot (state + output rows)
     int state_cur;  // which half of the double-buffered state is current
+    int agc_reset;  // post chain: 1 = the demodulation changed since the last batch (AGC::reset),
+                    // 2 = a new client took this slot (all chain state starts from zero)
 };
 
 struct DemodArgs {

@@ -16,6 +16,7 @@
 #include "demod.h"
 #include "epilogue.h"
 #include "fft_pass.h"
+#include "postchain.h"
 
 using namespace psdr;
 
@@ -43,9 +44,9 @@ extern "C" const char *psdr_version(void) { return "phantomsdr_amd 0.1 (gfx950)"
 
 namespace {
 
-enum KernelId { K_PASS1, K_PASS2, K_UNTANGLE, K_TAIL, K_IDFT, K_OLA, K_WFALL, K_COUNT };
+enum KernelId { K_PASS1, K_PASS2, K_UNTANGLE, K_TAIL, K_IDFT, K_OLA, K_WFALL, K_POST, K_COUNT };
 const char *kKernelNames[K_COUNT] = {"fft_pass1",  "fft_pass2", "untangle_real", "pyramid_tail",
-                                     "demod_idft", "demod_ola", "waterfall_gather"};
+                                     "demod_idft", "demod_ola", "waterfall_gather", "post_chain"};
 
 struct PendingEvent {
     hipEvent_t a, b;
@@ -58,6 +59,7 @@ struct AudioSlot {
     double mid = 0;
     int mode = PSDR_USB;
     int state_cur = 0;
+    int agc_reset = 2;  // post chain: 1 = AGC::reset pending (set_audio_demodulation), 2 = fresh client
 };
 struct WfSlot {
     bool active = false;
@@ -194,6 +196,10 @@ struct psdr_ctx {
     bool idft_block = false;  // tuning (PSDR_IDFT_BLOCK=1): force the one-work-group-per-item kernel
     cf *d_Wn = nullptr, *d_ypost = nullptr, *d_gscratch = nullptr, *d_bb_tail = nullptr,
        *d_bb_last = nullptr;
+    // post-demodulation chain (postchain.h), allocated by psdr_set_post_chain
+    bool post_on = false;
+    PostArgs post{};
+    std::vector<void *> post_allocs;
     float *d_pwr = nullptr, *d_audio = nullptr, *d_real_prev = nullptr;
     int *d_nan = nullptr;
     ParamRing client_ring;
@@ -580,6 +586,7 @@ void free_all(psdr_ctx *c) {
     F(c->d_gscratch);
     F(c->d_bb_tail);
     F(c->d_bb_last);
+    for (void *q : c->post_allocs) hipFree(q);
     F(c->d_pwr);
     F(c->d_audio);
     F(c->d_real_prev);
@@ -1132,6 +1139,7 @@ extern "C" int psdr_client_set_audio_demodulation(psdr_ctx *c, int id, int mode)
     if (rc) return rc;
     if (mode < PSDR_USB || mode > PSDR_FM) return fail(PSDR_ERR_INVALID, "unknown mode %d", mode);
     c->aslots[id].mode = mode;
+    if (c->aslots[id].agc_reset == 0) c->aslots[id].agc_reset = 1;  // src/signal.cpp:316-328: resets the AGC
     return PSDR_OK;
 }
 
@@ -1155,6 +1163,8 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
             p.slot = (int)i;
             p.state_cur = s.state_cur;
             s.state_cur ^= 1;
+            p.agc_reset = c->post_on ? s.agc_reset : 0;
+            if (c->post_on) s.agc_reset = 0;
         }
     }
     c->last_demod_frames = nframes;
@@ -1204,6 +1214,22 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
         hipLaunchKernelGGL(k_demod_ola, dim3((items + 3) / 4), dim3(256), 0, c->side, a, nact);
         HIPCHK(hipGetLastError());
     }
+    if (c->post_on && nact > 0) {
+        ProfScope ps(c, K_POST, c->side);
+        PostArgs pa = c->post;
+        pa.clients = d_clients;
+        pa.nact = nact;
+        pa.nframes = nframes;
+        const unsigned cb = (unsigned)((nact + 63) / 64), jb = (unsigned)((pa.h + 31) / 32);
+        const unsigned nblk = (unsigned)((pa.L - 1 + (size_t)nframes * pa.h + pa.L - 1) / pa.L);
+        hipLaunchKernelGGL(k_pc_gather, dim3(cb, nframes, jb), dim3(256), 0, c->side, pa);
+        hipLaunchKernelGGL(k_pc_dc, dim3(cb), dim3(64), (size_t)2 * pa.D * 64 * sizeof(float), c->side, pa);
+        hipLaunchKernelGGL(k_pc_scan, dim3(cb, nblk, 2), dim3(64), 0, c->side, pa);
+        hipLaunchKernelGGL(k_pc_gain, dim3(cb), dim3(64), 0, c->side, pa);
+        hipLaunchKernelGGL(k_pc_history, dim3(cb), dim3(64), 0, c->side, pa);
+        hipLaunchKernelGGL(k_pc_scatter, dim3(cb, nframes, jb), dim3(256), 0, c->side, pa);
+        HIPCHK(hipGetLastError());
+    }
     c->client_ring.release(ring, c->side);
     if (c->side != c->stream) {
         HIPCHK(hipEventRecord(c->ev_side_done, c->side));
@@ -1211,6 +1237,86 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
         HIPCHK(hipEventRecord(c->ev_set_done[c->cur_set], c->side));
         c->set_pending[c->cur_set] = true;
     }
+    return PSDR_OK;
+}
+
+// ---- post-demodulation chain ---------------------------------------------------
+extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    if (c->n <= 0) return fail(PSDR_ERR_STATE, "context created with audio_fft_size 0");
+    HIPCHK(hipSetDevice(c->device));
+    {
+        int rc = drain(c);
+        if (rc) return rc;
+    }
+    if (!enable) {
+        c->post_on = false;
+        return PSDR_OK;
+    }
+    if (c->post_allocs.empty()) {
+        const int rate = c->cfg.audio_rate;
+        if (rate < 750) return fail(PSDR_ERR_INVALID, "audio_rate %d too small for the DC blocker", rate);
+        PostArgs &a = c->post;
+        const size_t S = c->aslots.size(), h = (size_t)c->n / 2, Tm = (size_t)c->max_batch * h;
+        a.max_batch = c->max_batch;
+        a.h = (int)h;
+        a.slots = (int)S;
+        a.D = rate / 750 * 2;  // DCBlocker(audio_max_sps / 750 * 2), src/signal.cpp:54
+        // AGC(0.2f, 50.0f, 300.0f, 200.0f, audio_max_sps), src/signal.cpp:55 and
+        // src/utils/audioprocessing.cpp:5-16 (exp() on a float argument is C's double exp)
+        const float sr = (float)rate;
+        a.L = (int)(size_t)(200.0f * sr / 1000.0f);
+        a.desired = 0.2f;
+        a.attack = (float)(1 - std::exp((double)(-1.0f / (50.0f * 0.001f * sr))));
+        a.release = (float)(1 - std::exp((double)(-1.0f / (300.0f * 0.001f * sr))));
+        if ((size_t)2 * a.D * 64 * sizeof(float) > 64 * 1024 || a.L < 2)
+            return fail(PSDR_ERR_UNSUPPORTED, "audio_rate %d: DC delay %d / look-ahead %d unsupported", rate, a.D, a.L);
+        auto alloc = [&](void **ptr, size_t bytes) -> int {
+            HIPCHK(hipMalloc(ptr, std::max<size_t>(bytes, 16)));
+            HIPCHK(hipMemset(*ptr, 0, std::max<size_t>(bytes, 16)));
+            c->post_allocs.push_back(*ptr);
+            return PSDR_OK;
+        };
+        const size_t rows1 = (size_t)a.L - 1 + Tm;
+        int rc = 0;
+        rc |= alloc((void **)&a.fstart, S * c->max_batch * sizeof(int));
+        rc |= alloc((void **)&a.len, S * sizeof(int));
+        rc |= alloc((void **)&a.v0, Tm * S * sizeof(float));
+        rc |= alloc((void **)&a.v1, rows1 * S * sizeof(float));
+        rc |= alloc((void **)&a.P, rows1 * S * sizeof(float));
+        rc |= alloc((void **)&a.S, rows1 * S * sizeof(float));
+        rc |= alloc((void **)&a.pcm_t, Tm * S * sizeof(int));
+        rc |= alloc((void **)&a.pcm, S * Tm * sizeof(int32_t));
+        rc |= alloc((void **)&a.dc_s1, S * sizeof(float));
+        rc |= alloc((void **)&a.dc_s2, S * sizeof(float));
+        rc |= alloc((void **)&a.dc_rx, (size_t)a.D * S * sizeof(float));
+        rc |= alloc((void **)&a.dc_rm, (size_t)a.D * S * sizeof(float));
+        rc |= alloc((void **)&a.dc_head, S * sizeof(int));
+        rc |= alloc((void **)&a.agc_gain, S * sizeof(float));
+        rc |= alloc((void **)&a.agc_n0, S * sizeof(int));
+        if (rc) return PSDR_ERR_NOMEM;
+        a.audio = c->d_audio;
+        a.nan_flags = c->d_nan;
+    }
+    c->post_on = true;
+    return PSDR_OK;
+}
+extern "C" int psdr_read_pcm(psdr_ctx *c, int id, int32_t *pcm) {
+    if (!c || !pcm) return fail(PSDR_ERR_INVALID, "null argument");
+    {
+        std::lock_guard<std::mutex> lk(c->mtx);
+        int rc = check_slot(c, id);
+        if (rc) return rc;
+    }
+    if (!c->post_on) return fail(PSDR_ERR_STATE, "post chain not enabled (psdr_set_post_chain)");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t F = (size_t)c->last_demod_frames, h = (size_t)c->n / 2, mb = (size_t)c->max_batch;
+    if (F == 0) return fail(PSDR_ERR_STATE, "no demodulated batch to read");
+    {
+        int rc = drain(c);
+        if (rc) return rc;
+    }
+    HIPCHK(hipMemcpy(pcm, c->post.pcm + (size_t)id * mb * h, F * h * sizeof(int32_t), hipMemcpyDeviceToHost));
     return PSDR_OK;
 }
 

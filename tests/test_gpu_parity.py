@@ -308,3 +308,59 @@ def test_error_paths():
         AudioClient(ctx)                                     # slot is reusable
     finally:
         ctx.close()
+
+
+def test_post_chain_bit_exact():
+    """DC blocker + AGC + int16 conversion on the GPU (psdr_set_post_chain) against the oracle's
+    chain fed with the SAME float audio (the GPU's own demodulator output): the recurrences are
+    sequential f32, so the PCM must be identical.  Covers the AGC look-ahead start-up (2400
+    samples), several batches, a mode change (AGC reset, src/signal.cpp:316-328) and a client
+    added late."""
+    from phantomsdr_amd import AudioClient, Context
+    N, n, F, nb = 1 << 14, 248, 8, 5
+    R, levels = N, levels_for(N)
+    nframes = nb * F
+    x = synth_stream((nframes + 1) * (N // 2), False, seed=77, fft_size=N)
+    raw = quantize_raw(x, "s16", False)
+    ctx = Context(N, False, levels, additional_size=n, audio_fft_size=n, audio_rate=12000,
+                  input_format="s16", max_batch=F, max_clients=4)
+    try:
+        ctx.set_post_chain(True)
+        d = ctx.dev_alloc(raw.nbytes)
+        ctx.h2d(d, raw)
+        specs = [("USB", 3000, 3010.0, 3200), ("AM", 5000, 5100.5, 5200), ("FM", 9000, 9100.0, 9200)]
+        gcl, chains = [], []
+        for mode, l, mid, r in specs:
+            g = AudioClient(ctx)
+            g.set_audio_demodulation(mode)
+            g.set_audio_range(l, mid, r)
+            gcl.append(g)
+            chains.append(O.PostChain(12000))
+        hb = ctx.half_frame_bytes()
+        total = 0
+        for b in range(nb):
+            if b == 2:  # mode change of client 0: AGC reset
+                gcl[0].set_audio_demodulation("LSB")
+                chains[0].reset_agc()
+            if b == 3:  # a client that joins late starts with fresh state
+                g = AudioClient(ctx)
+                g.set_audio_demodulation("USB")
+                g.set_audio_range(12000, 12010.0, 12200)
+                gcl.append(g)
+                chains.append(O.PostChain(12000))
+            ctx.process_batch(d, F, offset_bytes=b * F * hb)
+            ctx.demod_batch(b * F)
+            for g, ch in zip(gcl, chains):
+                audio, _, nan = g.read_audio(F)
+                pcm = g.read_pcm(F)
+                assert not nan.any()
+                for f in range(F):
+                    want = ch.process(audio[f])
+                    assert np.array_equal(pcm[f], want), (
+                        f"batch {b} frame {f}: {np.count_nonzero(pcm[f] != want)} of {want.size} samples differ, "
+                        f"max |d| {np.abs(pcm[f] - want).max()}")
+                    total += int(np.count_nonzero(want))
+        assert total > 1000, "the AGC never opened: the test did not exercise the chain"
+        ctx.dev_free(d)
+    finally:
+        ctx.close()

@@ -19,6 +19,7 @@ ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--clients", type=int, default=16)
 ap.add_argument("--ring-mib", type=int, default=512)
 ap.add_argument("--tag", default="")
+ap.add_argument("--post", action="store_true", help="enable the post-demodulation chain")
 args = ap.parse_args()
 
 from phantomsdr_amd import SpectrumEngine  # noqa: E402
@@ -27,6 +28,8 @@ N, F = 1 << args.fft, args.batch
 sps = 70_000_000 if args.real else 35_000_000
 eng = SpectrumEngine(sps, N, args.real, input_format="s16", max_batch=F, max_clients=max(args.clients, 1),
                      max_waterfall_clients=4)
+if args.post:
+    eng.ctx.set_post_chain(True)
 hb = eng.ctx.half_frame_bytes()
 nb = max(1, (args.ring_mib << 20) // (hb * F))
 rng = np.random.default_rng(0)
