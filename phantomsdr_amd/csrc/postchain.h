@@ -103,30 +103,78 @@ __global__ __launch_bounds__(64) void k_pc_dc(PostArgs a) {
             rm[i * 64 + lane] = fresh ? 0.f : a.dc_rm[(size_t)i * a.slots + slot];
         }
     }
-    int Tmax = T;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, d, 64));
     const float fD = (float)D;
+    const bool pow2 = (D & (D - 1)) == 0;  // x / 2^k == x * 2^-k exactly
+    const float rD = 1.0f / fD;
     const size_t hist = (size_t)(a.L - 1);
-    for (int t = 0; t < Tmax; t++) {
-        if (t < T) {
-            const float x = a.v0[(size_t)t * a.slots + slot];
-            // MovingAverage::insert (src/utils.h:84-93): sum -= oldest; push_front; sum += val
-            int oldest = head + D - 1;
-            if (oldest >= D) oldest -= D;
-            s1 = __fadd_rn(s1, -rx[oldest * 64 + lane]);
-            s2 = __fadd_rn(s2, -rm[oldest * 64 + lane]);
-            head = oldest;  // (head + D - 1) % D
-            rx[head * 64 + lane] = x;
-            s1 = __fadd_rn(s1, x);
-            const float m1 = __fdiv_rn(s1, fD);
+    // Blocks of KB steps: the inputs and the ring entries the block will evict are fetched up
+    // front (they are all older than the block: KB < D), so the only latency left inside the
+    // block is the f32 recurrence itself.
+    constexpr int KB = 16;
+    const float *__restrict__ v0 = a.v0;
+    float *__restrict__ v1 = a.v1;
+    auto fetch = [&](float (&x)[KB], int t0) {
+#pragma unroll
+        for (int i = 0; i < KB; i++) x[i] = v0[(size_t)(t0 + i) * a.slots + slot];
+    };
+    auto block = [&](const float (&x)[KB], int t0) {
+        float ox[KB + 1], om[KB], out[KB];
+        int idx = head;  // entry evicted by step i: head - 1 - i (mod D)
+#pragma unroll
+        for (int i = 0; i <= KB; i++) {
+            idx = idx == 0 ? D - 1 : idx - 1;
+            ox[i] = rx[idx * 64 + lane];
+            if (i < KB) om[i] = rm[idx * 64 + lane];
+        }
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            s1 = __fadd_rn(s1, -ox[i]);
+            s2 = __fadd_rn(s2, -om[i]);
+            head = head == 0 ? D - 1 : head - 1;
+            rx[head * 64 + lane] = x[i];
+            s1 = __fadd_rn(s1, x[i]);
+            const float m1 = pow2 ? __fmul_rn(s1, rD) : __fdiv_rn(s1, fD);
             rm[head * 64 + lane] = m1;
             s2 = __fadd_rn(s2, m1);
-            const float m2 = __fdiv_rn(s2, fD);
-            int back = head + D - 1;  // getLatest(delay - 1): the oldest after the insert
-            if (back >= D) back -= D;
-            a.v1[(hist + t) * a.slots + slot] = __fsub_rn(rx[back * 64 + lane], m2);
+            const float m2 = pow2 ? __fmul_rn(s2, rD) : __fdiv_rn(s2, fD);
+            out[i] = __fsub_rn(ox[i + 1], m2);  // getLatest(delay-1) = the next step's evictee
         }
+#pragma unroll
+        for (int i = 0; i < KB; i++) v1[(hist + t0 + i) * a.slots + slot] = out[i];
+    };
+    // whole blocks, the loads of block b+1 in flight while block b runs (two register sets)
+    const int nblk = (D > KB) ? T / KB : 0;
+    int t0 = 0;
+    if (nblk > 0) {
+        float xa[KB], xb[KB];
+        fetch(xa, 0);
+        int b = 0;
+        for (; b + 1 < nblk; b += 2) {
+            fetch(xb, (b + 1) * KB);
+            block(xa, b * KB);
+            if (b + 2 < nblk) fetch(xa, (b + 2) * KB);
+            block(xb, (b + 1) * KB);
+        }
+        if (b < nblk) block(xa, b * KB);
+        t0 = nblk * KB;
+    }
+    for (int t = t0; t < T; t++) {  // remainder (and D <= KB): the plain form
+        const float x = v0[(size_t)t * a.slots + slot];
+        // MovingAverage::insert (src/utils.h:84-93): sum -= oldest; push_front; sum += val
+        int oldest = head + D - 1;
+        if (oldest >= D) oldest -= D;
+        s1 = __fadd_rn(s1, -rx[oldest * 64 + lane]);
+        s2 = __fadd_rn(s2, -rm[oldest * 64 + lane]);
+        head = oldest;  // (head + D - 1) % D
+        rx[head * 64 + lane] = x;
+        s1 = __fadd_rn(s1, x);
+        const float m1 = __fdiv_rn(s1, fD);
+        rm[head * 64 + lane] = m1;
+        s2 = __fadd_rn(s2, m1);
+        const float m2 = __fdiv_rn(s2, fD);
+        int back = head + D - 1;  // getLatest(delay - 1): the oldest after the insert
+        if (back >= D) back -= D;
+        v1[(hist + t) * a.slots + slot] = __fsub_rn(rx[back * 64 + lane], m2);
     }
     if (on) {
         a.dc_s1[slot] = s1;
@@ -148,15 +196,41 @@ __global__ __launch_bounds__(64) void k_pc_scan(PostArgs a) {
     const int r0 = blockIdx.y * a.L, r1 = min(r0 + a.L, rows);
     if (r0 >= rows) return;
     float m = 0.f;
+    constexpr int KB = 16;
+    const float *__restrict__ v1 = a.v1;
     if (blockIdx.z == 0) {
-        for (int r = r0; r < r1; r++) {
-            m = fmaxf(m, fabsf(a.v1[(size_t)r * a.slots + slot]));
-            a.P[(size_t)r * a.slots + slot] = m;
+        float *__restrict__ P = a.P;
+        int r = r0;
+        for (; r + KB <= r1; r += KB) {
+            float x[KB];
+#pragma unroll
+            for (int i = 0; i < KB; i++) x[i] = v1[(size_t)(r + i) * a.slots + slot];
+#pragma unroll
+            for (int i = 0; i < KB; i++) {
+                m = fmaxf(m, fabsf(x[i]));
+                P[(size_t)(r + i) * a.slots + slot] = m;
+            }
+        }
+        for (; r < r1; r++) {
+            m = fmaxf(m, fabsf(v1[(size_t)r * a.slots + slot]));
+            P[(size_t)r * a.slots + slot] = m;
         }
     } else {
-        for (int r = r1 - 1; r >= r0; r--) {
-            m = fmaxf(m, fabsf(a.v1[(size_t)r * a.slots + slot]));
-            a.S[(size_t)r * a.slots + slot] = m;
+        float *__restrict__ S = a.S;
+        int r = r1 - 1;
+        for (; r - KB + 1 >= r0; r -= KB) {
+            float x[KB];
+#pragma unroll
+            for (int i = 0; i < KB; i++) x[i] = v1[(size_t)(r - i) * a.slots + slot];
+#pragma unroll
+            for (int i = 0; i < KB; i++) {
+                m = fmaxf(m, fabsf(x[i]));
+                S[(size_t)(r - i) * a.slots + slot] = m;
+            }
+        }
+        for (; r >= r0; r--) {
+            m = fmaxf(m, fabsf(v1[(size_t)r * a.slots + slot]));
+            S[(size_t)r * a.slots + slot] = m;
         }
     }
 }
@@ -173,11 +247,61 @@ __global__ __launch_bounds__(64) void k_pc_gain(PostArgs a) {
         gain = 0.f;
         n0 = 0;
     }
-    for (int t = 0; t < T; t++) {
+    constexpr int KB = 16;
+    const float *__restrict__ v1 = a.v1;
+    const float *__restrict__ Sx = a.S;
+    const float *__restrict__ Px = a.P;
+    int *__restrict__ pcm_t = a.pcm_t;
+    auto to_i16 = [](float y) {  // dsp_float_to_int16, src/utils/dsp.cpp:152-165
+        int v = (int)__fmaf_rn(y, 16384.f, 32768.5f) - 32768;
+        return v > 32767 ? 32767 : (v < -32768 ? -32768 : v);
+    };
+    auto fetch = [&](float (&cur)[KB], float (&s)[KB], float (&p)[KB], int t0) {
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            cur[i] = v1[(size_t)(t0 + i) * a.slots + slot];
+            s[i] = Sx[(size_t)(t0 + i) * a.slots + slot];
+            p[i] = Px[(size_t)(t0 + i + L - 1) * a.slots + slot];
+        }
+    };
+    auto block = [&](const float (&cur)[KB], const float (&s)[KB], const float (&p)[KB], int t0) {
+        float want[KB];
+#pragma unroll
+        for (int i = 0; i < KB; i++)  // everything that does not depend on the gain, up front
+            want[i] = __fdiv_rn(a.desired, __fadd_rn(fmaxf(s[i], p[i]), 1e-10f));
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            float y = 0.f;
+            if (n0 + t0 + i + 1 >= L) {  // the look-ahead buffer is full
+                if (want[i] < gain)
+                    gain = __fmaf_rn(-a.attack, __fsub_rn(gain, want[i]), gain);
+                else
+                    gain = __fmaf_rn(a.release, __fsub_rn(want[i], gain), gain);
+                y = __fmul_rn(cur[i], gain);
+            }
+            pcm_t[(size_t)(t0 + i) * a.slots + slot] = to_i16(y);
+        }
+    };
+    const int nblk = T / KB;
+    int t = 0;
+    if (nblk > 0) {
+        float ca[KB], sa[KB], pa[KB], cb[KB], sb[KB], pb[KB];
+        fetch(ca, sa, pa, 0);
+        int b = 0;
+        for (; b + 1 < nblk; b += 2) {
+            fetch(cb, sb, pb, (b + 1) * KB);
+            block(ca, sa, pa, b * KB);
+            if (b + 2 < nblk) fetch(ca, sa, pa, (b + 2) * KB);
+            block(cb, sb, pb, (b + 1) * KB);
+        }
+        if (b < nblk) block(ca, sa, pa, b * KB);
+        t = nblk * KB;
+    }
+    for (; t < T; t++) {
         float y = 0.f;
-        if (n0 + t + 1 >= L) {  // the look-ahead buffer is full: sample t-L+1.. of the stream
-            const float cur = a.v1[(size_t)t * a.slots + slot];
-            const float peak = fmaxf(a.S[(size_t)t * a.slots + slot], a.P[(size_t)(t + L - 1) * a.slots + slot]);
+        if (n0 + t + 1 >= L) {
+            const float cur = v1[(size_t)t * a.slots + slot];
+            const float peak = fmaxf(Sx[(size_t)t * a.slots + slot], Px[(size_t)(t + L - 1) * a.slots + slot]);
             const float want = __fdiv_rn(a.desired, __fadd_rn(peak, 1e-10f));
             if (want < gain)
                 gain = __fmaf_rn(-a.attack, __fsub_rn(gain, want), gain);
@@ -185,10 +309,7 @@ __global__ __launch_bounds__(64) void k_pc_gain(PostArgs a) {
                 gain = __fmaf_rn(a.release, __fsub_rn(want, gain), gain);
             y = __fmul_rn(cur, gain);
         }
-        // dsp_float_to_int16, src/utils/dsp.cpp:152-165
-        int v = (int)__fmaf_rn(y, 16384.f, 32768.5f) - 32768;
-        v = v > 32767 ? 32767 : (v < -32768 ? -32768 : v);
-        a.pcm_t[(size_t)t * a.slots + slot] = v;
+        pcm_t[(size_t)t * a.slots + slot] = to_i16(y);
     }
     a.agc_gain[slot] = gain;
     a.agc_n0[slot] = min(n0 + T, L);
@@ -202,7 +323,16 @@ __global__ __launch_bounds__(64) void k_pc_history(PostArgs a) {
     const int slot = a.clients[ci].slot;
     const int T = a.len[slot];
     if (T == 0) return;
-    for (int r = 0; r < a.L - 1; r++) a.v1[(size_t)r * a.slots + slot] = a.v1[(size_t)(r + T) * a.slots + slot];
+    constexpr int KB = 16;
+    int r = 0;
+    for (; r + KB <= a.L - 1; r += KB) {  // the KB reads of a block happen before its writes
+        float x[KB];
+#pragma unroll
+        for (int i = 0; i < KB; i++) x[i] = a.v1[(size_t)(r + i + T) * a.slots + slot];
+#pragma unroll
+        for (int i = 0; i < KB; i++) a.v1[(size_t)(r + i) * a.slots + slot] = x[i];
+    }
+    for (; r < a.L - 1; r++) a.v1[(size_t)r * a.slots + slot] = a.v1[(size_t)(r + T) * a.slots + slot];
 }
 
 __global__ __launch_bounds__(256) void k_pc_scatter(PostArgs a) {

@@ -364,3 +364,48 @@ def test_post_chain_bit_exact():
         ctx.dev_free(d)
     finally:
         ctx.close()
+
+
+def test_post_chain_skips_nan_frames():
+    """A frame whose audio contains a NaN is dropped by the reference before the chain
+    (src/signal.cpp:266-271): the chain's state must advance only over the surviving frames."""
+    import ctypes as C
+    from phantomsdr_amd import AudioClient, Context
+    from phantomsdr_amd._lib import check
+    N, n, F, nb = 1 << 14, 248, 8, 4
+    levels = levels_for(N)
+    x = synth_stream((nb * F + 1) * (N // 2), False, seed=78, fft_size=N)
+    raw = quantize_raw(x, "s16", False)
+    ctx = Context(N, False, levels, additional_size=n, audio_fft_size=n, audio_rate=12000,
+                  input_format="s16", max_batch=F, max_clients=2)
+    try:
+        ctx.set_post_chain(True)
+        d = ctx.dev_alloc(raw.nbytes)
+        ctx.h2d(d, raw)
+        g = AudioClient(ctx)
+        g.set_audio_demodulation("USB")
+        g.set_audio_range(3000, 3010.0, 3200)
+        ch = O.PostChain(12000)
+        hb = ctx.half_frame_bytes()
+        poison = np.full(4, np.nan, np.float32)
+        dropped_total = 0
+        for b in range(nb):
+            ctx.process_batch(d, F, offset_bytes=b * F * hb)
+            p, nbytes = C.c_void_p(), C.c_size_t()
+            check(ctx.lib.psdr_spectrum_device_ptr(ctx.h, 0, C.byref(p), C.byref(nbytes)))
+            for f in ((2, 5) if b % 2 == 0 else (0,)):  # NaN into two bins of the client's slice
+                ctx.synchronize()
+                ctx.h2d(p, poison, offset=(f * N + 3050) * 8)
+            ctx.demod_batch(b * F)
+            audio, _, nan = g.read_audio(F)
+            pcm = g.read_pcm(F)
+            for f in range(F):
+                if nan[f]:
+                    dropped_total += 1
+                    continue
+                want = ch.process(audio[f])
+                assert np.array_equal(pcm[f], want), f"batch {b} frame {f}"
+        assert dropped_total >= 5
+        ctx.dev_free(d)
+    finally:
+        ctx.close()
