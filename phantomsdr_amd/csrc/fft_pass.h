@@ -234,7 +234,8 @@ __device__ __forceinline__ unsigned xcd_slot(unsigned bid, unsigned total) {
 
 // Dynamic tile hand-out for the persistent passes.  Work-group b takes sequence indices b
 // and b + gridDim.x first; every further index is drawn from a ticket counter, one counter
-// per XCD (index s belongs to XCD s%8, as in a static round-robin).  Work-groups of one launch do not start together (they share the
+// per XCD (index s belongs to XCD s%8, as in a static round-robin) or, where XCD affinity buys
+// nothing, from one chip-wide counter.  Work-groups of one launch do not start together (they share the
 // CUs with the previous batch's consumer kernels and with the other pass): with tickets a
 // late starter simply takes fewer tiles.  A ticket is drawn a whole tile ahead of its use
 // (the atomic goes to memory through the same queues as the passes' HBM streams).
@@ -244,8 +245,10 @@ struct TileQueue {
     unsigned *tickets;
     unsigned total, base;  // indices below 2*gridDim.x are the static first tiles
     unsigned pending;      // thread 0: ticket drawn from the own counter, not yet examined
-    bool dynamic;
-    __device__ __forceinline__ void init(unsigned *t, unsigned total_) {
+    bool dynamic, global;
+    // global_: ONE counter for the whole chip (perfect balance, no XCD affinity)
+    __device__ __forceinline__ void init(unsigned *t, unsigned total_, bool global_ = false) {
+        global = global_;
         tickets = t;
         total = total_;
         base = gridDim.x >> 2;  // 2*gridDim.x / 8
@@ -254,7 +257,7 @@ struct TileQueue {
     }
     // thread 0: start drawing (no wait)
     __device__ __forceinline__ void draw_begin() {
-        if (threadIdx.x == 0 && dynamic) pending = atomicAdd(tickets + (blockIdx.x & 7u), 1u);
+        if (threadIdx.x == 0 && dynamic) pending = atomicAdd(tickets + (global ? 0u : (blockIdx.x & 7u)), 1u);
     }
     // thread 0: finish the draw begun one tile ago and publish the index (or 0xFFFFFFFF) to
     // *slot; `prev` is the index two positions earlier in this work-group's sequence
@@ -265,7 +268,7 @@ struct TileQueue {
                 if (prev2 < total) s = prev2 + 2u * gridDim.x;
             } else if (dynamic) {
                 const unsigned x = blockIdx.x & 7u;
-                s = (pending + base) * 8u + x;
+                s = global ? pending + 2u * gridDim.x : (pending + base) * 8u + x;
                 if (s >= total) s = 0xFFFFFFFFu;  // no stealing across XCDs: probing seven more
                                                   // counters costs a memory round trip each
             }
@@ -603,7 +606,10 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2(Pass2Args a) {
     };
     __shared__ unsigned s_next[2];
     TileQueue tq;
-    tq.init(a.tickets, total);
+    // pass 2 has no use for XCD affinity (full-line stores, tile-major records) and the XCDs
+    // differ by ~10 % in speed: one chip-wide counter (pass 1 keeps the per-XCD queues: adjacent
+    // tiles share the 128-byte lines of the raw rows)
+    tq.init(a.tickets, total, true);
     unsigned s = blockIdx.x, snext = blockIdx.x + gridDim.x;
     if (s < total) {
         point_at(s);

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from phantomsdr_amd import SpectrumEngine  # noqa: E402
 
-N, F = 1 << 20, 16
+N, F = 1 << 20, int(os.environ.get("TRACE_F", "16"))
 eng = SpectrumEngine(35_000_000, N, False, input_format="s16", max_batch=F, max_clients=1, max_waterfall_clients=1)
 hb = eng.ctx.half_frame_bytes()
 raw = np.random.default_rng(0).integers(-64, 64, size=(F * 4 + 1) * hb // 2, dtype=np.int16)
