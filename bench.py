@@ -37,6 +37,10 @@ WORKLOADS = {
     # per-GPU share of BASELINE.json configs[3] (256 audio clients over 8 GPUs)
     "cfg4": dict(sps=35_000_000, fft_size=1 << 20, is_real=False, fmt="s16", audio=32, waterfall=0,
                  modes=("USB", "LSB", "AM", "FM"), desc="35 MSPS IQ cs16, 2^20-pt C2C, 32 audio clients per GPU"),
+    # per-GPU share of BASELINE.json configs[4] (1024 clients + 64 zoomed waterfalls over 8 GPUs)
+    "cfg5": dict(sps=70_000_000, fft_size=1 << 22, is_real=True, fmt="s16", audio=128, waterfall=8,
+                 modes=("USB", "LSB", "AM", "FM"),
+                 desc="70 MSPS real s16, 2^22-pt R2C, 128 audio clients + 8 zoomed waterfalls per GPU"),
 }
 SAMPLE_BYTES = {"u8": 1, "s8": 1, "u16": 2, "s16": 2, "f32": 4, "f64": 8}
 

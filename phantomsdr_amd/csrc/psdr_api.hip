@@ -376,6 +376,9 @@ int launch_pass2(psdr_ctx *c, int L, int T, bool fused, const Pass2Args &a, unsi
     if (L == 1024 && T == 16 && a.TW == 16)  // the 2^20-point transform: fill addresses fold
         return fused ? launch_pass2_t<1024, 16, true, 16>(c, a, blocks)
                      : launch_pass2_t<1024, 16, false, 16>(c, a, blocks);
+    if (L == 1024 && T == 16 && a.TW == 8)  // 2^21 points (2^22 real): 2048 x 1024
+        return fused ? launch_pass2_t<1024, 16, true, 8>(c, a, blocks)
+                     : launch_pass2_t<1024, 16, false, 8>(c, a, blocks);
     P2CASE(1024, 16)
     P2CASE(2048, 8)
     return fail(PSDR_ERR_UNSUPPORTED, "no pass-2 kernel for L=%d T=%d", L, T);
