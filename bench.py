@@ -437,6 +437,30 @@ def main():
                                             clients, waterfalls, F)
     path_frac = ab["total"] * (frames / dt) / HBM_PEAK
 
+    # SURVEY 8f-2 (widened row): the optional post-demodulation chain (DC blocker + AGC + int16),
+    # measured separately - it is NOT part of `value` (the metric's clients end at float audio)
+    post = None
+    if clients:
+        try:
+            eng.ctx.set_post_chain(True)
+            psteps = 6
+            for i in range(2):
+                step(i)
+            eng.ctx.synchronize()
+            t0 = time.perf_counter()
+            for i in range(psteps):
+                step(2 + i)
+            eng.ctx.synchronize()
+            pdt = (time.perf_counter() - t0) / psteps
+            eng.ctx.set_post_chain(False)
+            h = params["audio_fft_size"] // 2
+            post = {"ms_per_step": round(pdt * 1e3, 3), "MSamples_per_s_ingest": round(F * (N // 2) / pdt / 1e6, 1),
+                    "audio_samples_per_s": round(len(clients) * F * h / pdt, 1),
+                    "realtime_factor": round(F * (N // 2) / pdt / wl["sps"], 1),
+                    "note": "whole step with psdr_set_post_chain(1): f32 recurrences, sequential per client"}
+        except Exception as e:
+            post = {"error": repr(e)}
+
     cpu = None
     if not args.no_cpu_baseline:
         try:
@@ -456,6 +480,7 @@ def main():
         "roofline": roofline,
         "path": {"algorithmic_bytes_per_frame": int(ab["total"]), "frames_per_s": round(frames / dt, 1),
                  "frac_of_hbm_peak": round(path_frac, 4), "kernels": kernels},
+        "post_chain": post,
         "cpu_baseline": cpu,
     }
     eng.close()

@@ -6,16 +6,24 @@
 // Frames dropped by the NaN guard (src/signal.cpp:266-271) never reach the chain: each
 // client's stream is the concatenation of its surviving frames.
 //
-// Every stage is a float recurrence along time (running sums, one-pole gain), sequential per
-// client and bit-exact only in the reference's order.  The parallelism is ACROSS clients:
-// the stream is transposed to time-major [t][slot], a lane owns a client, a wave walks time
-// and every step is one coalesced row access.
-//   k_pc_gather   audio[slot][frame][j] -> v0[t][slot], frames with the NaN flag skipped
-//   k_pc_dc       two cascaded moving averages (f32 running sums, rings in LDS) -> v1
-//   k_pc_scan     AGC look-ahead peak: the sliding maximum of |x| over L samples (the
-//                 reference's monotonic deque) as van Herk prefix / suffix maxima of blocks of L
-//   k_pc_gain     attack / release gain recurrence, delayed sample * gain, int16 conversion
-//   k_pc_history  keeps the last L-1 samples of v1 for the next batch
+// Three f32 recurrences run along time and are bit-exact only in the reference's order:
+//   s1_t = (s1_{t-1} - x_{t-D}) + x_t            first moving average  (m1 = s1 / D)
+//   s2_t = (s2_{t-1} - m1_{t-D}) + m1_t          second moving average (out = x_{t-D+1} - s2 / D)
+//   g_t  = fma(-a, g - w_t, g) or fma(r, w_t - g, g)        AGC attack / release
+// Everything else is a pure function of the streams and runs fully parallel.  The streams are
+// time-major [t][slot] with the history they need kept IN FRONT of the new samples (D rows for
+// the averages, L-1 rows for the AGC look-ahead), so there are no rings: a lane owns a client,
+// a wave walks time, every step is a few coalesced row accesses fetched a block ahead, and the
+// loop bodies are just the recurrences.
+//   k_pc_gather   audio[slot][frame][j] -> X[D + t][slot], frames with the NaN flag skipped
+//   k_pc_ma<0|1>  the two running sums                                     (sequential)
+//   k_pc_scan     AGC look-ahead peak: sliding maximum of |x| over L samples (the reference's
+//                 monotonic deque) as van Herk prefix / suffix maxima of blocks of L (sequential,
+//                 but over (client, block) pairs)
+//   k_pc_want     w_t = desired / (peak_t + 1e-10)                          (parallel)
+//   k_pc_gain     the gain recurrence                                       (sequential)
+//   k_pc_out      delayed sample * gain, int16 conversion                   (parallel)
+//   k_pc_history  the last D / L-1 rows become the next batch's history
 //   k_pc_scatter  pcm[t][slot] -> pcm[slot][frame][j]
 #pragma once
 #include <hip/hip_runtime.h>
@@ -35,17 +43,21 @@ struct PostArgs {
     const int *nan_flags;             // [slots][max_batch]
     int *fstart;                      // [slots][max_batch] stream offset of a frame, -1 = dropped
     int *len;                         // [slots] samples of this batch's stream
-    float *v0;                        // [max_batch*h][slots]
-    float *v1;                        // [L-1 + max_batch*h][slots], rows < L-1: history
-    float *P, *S;                     // prefix / suffix maxima, like v1
+    float *X;                         // [D + max_batch*h][slots]: demodulated audio, rows < D history
+    float *M1;                        // [D + max_batch*h][slots]: first moving average, rows < D history
+    float *V1;                        // [L-1 + max_batch*h][slots]: DC-blocked stream, rows < L-1 history
+    float *P, *S;                     // like V1: prefix / suffix maxima; then S = w_t, P = g_t
     int *pcm_t;                       // [max_batch*h][slots]
     int32_t *pcm;                     // [slots][max_batch][h]
     // carried state
-    float *dc_s1, *dc_s2, *dc_rx, *dc_rm;  // [slots], [slots], [D][slots], [D][slots]
-    int *dc_head;                          // [slots]
+    float *dc_s1, *dc_s2;             // [slots] running sums
     float *agc_gain;
     int *agc_n0;  // samples pushed since the last reset, saturating at L
 };
+
+__device__ __forceinline__ unsigned pc_at(const PostArgs &a, int row, int slot) {
+    return (unsigned)row * (unsigned)a.slots + (unsigned)slot;
+}
 
 // tile of 64 clients x 32 samples of one frame through LDS (both accesses coalesced)
 __global__ __launch_bounds__(256) void k_pc_gather(PostArgs a) {
@@ -63,10 +75,15 @@ __global__ __launch_bounds__(256) void k_pc_gather(PostArgs a) {
         if (blockIdx.z == 0 && ty == 0) {
             a.fstart[(size_t)slot * a.max_batch + f] = pos;
             if (f == a.nframes - 1) a.len[slot] = (cnt + (nf[f] ? 0 : 1)) * a.h;
+            // a new client in this slot starts from zero history (the sums are reset in k_pc_ma)
+            if (f == 0 && a.clients[c0 + tx].agc_reset == 2)
+                for (int r = 0; r < a.D; r++) {
+                    a.X[pc_at(a, r, slot)] = 0.f;
+                    a.M1[pc_at(a, r, slot)] = 0.f;
+                }
         }
     }
-    // load: lanes along j
-    for (int r = ty; r < 64; r += 4) {
+    for (int r = ty; r < 64; r += 4) {  // load: lanes along j
         const int ci = c0 + r;
         const int j = j0 + (tx & 31);
         if ((tx < 32) && ci < a.nact && j < a.h) {
@@ -77,117 +94,78 @@ __global__ __launch_bounds__(256) void k_pc_gather(PostArgs a) {
     __syncthreads();
     if (pos >= 0)
         for (int jj = ty; jj < 32; jj += 4)
-            if (j0 + jj < a.h) a.v0[(size_t)(pos + j0 + jj) * a.slots + slot] = tile[jj][tx];
+            if (j0 + jj < a.h) a.X[pc_at(a, a.D + pos + j0 + jj, slot)] = tile[jj][tx];
 }
 
-// lane = client; rings [D][64] in dynamic LDS (2 * D * 64 floats)
-__global__ __launch_bounds__(64) void k_pc_dc(PostArgs a) {
-    extern __shared__ float rings[];
-    float *rx = rings, *rm = rings + (size_t)a.D * 64;
+// One moving average (MovingAverage::insert, src/utils.h:84-93: sum -= oldest; push; sum += val).
+//   SECOND = false: in = X,  sum = s1, writes M1[D + t] = s1 / D
+//   SECOND = true : in = M1, sum = s2, writes V1[L-1 + t] = X[t + 1] - s2 / D
+//                   (getLatest(delay - 1) = x_{t-D+1}, src/utils.h:160-166)
+// lane = client; the evicted value of step t is row t, the inserted one row D + t.
+// POW2: D is a power of two (x / 2^k == x * 2^-k exactly: no division in the loop)
+template <bool SECOND, bool POW2>
+__global__ __launch_bounds__(64) void k_pc_ma(PostArgs a) {
     const int lane = threadIdx.x, ci = blockIdx.x * 64 + lane;
-    const bool on = ci < a.nact;
-    const int slot = on ? a.clients[ci].slot : 0;
-    const bool fresh = on && a.clients[ci].agc_reset == 2;  // a new client in this slot: zero state
-    const int D = a.D;
-    float s1 = 0.f, s2 = 0.f;
-    int head = 0, T = 0;
-    if (on) {
-        T = a.len[slot];
-        if (!fresh) {
-            s1 = a.dc_s1[slot];
-            s2 = a.dc_s2[slot];
-            head = a.dc_head[slot];
-        }
-        for (int i = 0; i < D; i++) {
-            rx[i * 64 + lane] = fresh ? 0.f : a.dc_rx[(size_t)i * a.slots + slot];
-            rm[i * 64 + lane] = fresh ? 0.f : a.dc_rm[(size_t)i * a.slots + slot];
-        }
-    }
-    const float fD = (float)D;
-    const bool pow2 = (D & (D - 1)) == 0;  // x / 2^k == x * 2^-k exactly
-    const float rD = 1.0f / fD;
-    const size_t hist = (size_t)(a.L - 1);
-    // Blocks of KB steps: the inputs and the ring entries the block will evict are fetched up
-    // front (they are all older than the block: KB < D), so the only latency left inside the
-    // block is the f32 recurrence itself.
+    if (ci >= a.nact) return;
+    const ClientParams cp = a.clients[ci];
+    const int slot = cp.slot, D = a.D;
+    const bool fresh = cp.agc_reset == 2;  // a new client in this slot: zero sums (k_pc_gather zeroed the history)
+    const int T = a.len[slot];
+    const float *__restrict__ in = SECOND ? a.M1 : a.X;
+    const float *__restrict__ X = a.X;
+    float *__restrict__ out = SECOND ? a.V1 : a.M1;
+    const int orow = SECOND ? a.L - 1 : D;
+    float s = fresh ? 0.f : (SECOND ? a.dc_s2 : a.dc_s1)[slot];
+    const float fD = (float)D, rD = 1.0f / fD;
     constexpr int KB = 16;
-    const float *__restrict__ v0 = a.v0;
-    float *__restrict__ v1 = a.v1;
-    auto fetch = [&](float (&x)[KB], int t0) {
-#pragma unroll
-        for (int i = 0; i < KB; i++) x[i] = v0[(size_t)(t0 + i) * a.slots + slot];
-    };
-    auto block = [&](const float (&x)[KB], int t0) {
-        float ox[KB + 1], om[KB], out[KB];
-        int idx = head;  // entry evicted by step i: head - 1 - i (mod D)
-#pragma unroll
-        for (int i = 0; i <= KB; i++) {
-            idx = idx == 0 ? D - 1 : idx - 1;
-            ox[i] = rx[idx * 64 + lane];
-            if (i < KB) om[i] = rm[idx * 64 + lane];
-        }
+    auto fetch = [&](float (&ev)[KB], float (&nw)[KB], float (&xd)[KB], int t0) {
 #pragma unroll
         for (int i = 0; i < KB; i++) {
-            s1 = __fadd_rn(s1, -ox[i]);
-            s2 = __fadd_rn(s2, -om[i]);
-            head = head == 0 ? D - 1 : head - 1;
-            rx[head * 64 + lane] = x[i];
-            s1 = __fadd_rn(s1, x[i]);
-            const float m1 = pow2 ? __fmul_rn(s1, rD) : __fdiv_rn(s1, fD);
-            rm[head * 64 + lane] = m1;
-            s2 = __fadd_rn(s2, m1);
-            const float m2 = pow2 ? __fmul_rn(s2, rD) : __fdiv_rn(s2, fD);
-            out[i] = __fsub_rn(ox[i + 1], m2);  // getLatest(delay-1) = the next step's evictee
+            const int t = t0 + i;
+            ev[i] = in[pc_at(a, t, slot)];
+            nw[i] = in[pc_at(a, D + t, slot)];
+            if (SECOND) xd[i] = X[pc_at(a, t + 1, slot)];
+        }
+    };
+    auto block = [&](const float (&ev)[KB], const float (&nw)[KB], const float (&xd)[KB], int t0) {
+        float o[KB];
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            s = __fadd_rn(s, -ev[i]);
+            s = __fadd_rn(s, nw[i]);
+            const float m = POW2 ? __fmul_rn(s, rD) : __fdiv_rn(s, fD);
+            o[i] = SECOND ? __fsub_rn(xd[i], m) : m;
         }
 #pragma unroll
-        for (int i = 0; i < KB; i++) v1[(hist + t0 + i) * a.slots + slot] = out[i];
+        for (int i = 0; i < KB; i++) out[pc_at(a, orow + t0 + i, slot)] = o[i];
     };
-    // whole blocks, the loads of block b+1 in flight while block b runs (two register sets)
-    const int nblk = (D > KB) ? T / KB : 0;
-    int t0 = 0;
-    if (nblk > 0) {
-        float xa[KB], xb[KB];
-        fetch(xa, 0);
+    const int nblk = T / KB;
+    if (nblk > 0) {  // the loads of block b+1 in flight while block b runs (two register sets)
+        float ea[KB], na[KB], xa[KB], eb[KB], nb[KB], xb[KB];
+        fetch(ea, na, xa, 0);
         int b = 0;
         for (; b + 1 < nblk; b += 2) {
-            fetch(xb, (b + 1) * KB);
-            block(xa, b * KB);
-            if (b + 2 < nblk) fetch(xa, (b + 2) * KB);
-            block(xb, (b + 1) * KB);
+            fetch(eb, nb, xb, (b + 1) * KB);
+            block(ea, na, xa, b * KB);
+            if (b + 2 < nblk) fetch(ea, na, xa, (b + 2) * KB);
+            block(eb, nb, xb, (b + 1) * KB);
         }
-        if (b < nblk) block(xa, b * KB);
-        t0 = nblk * KB;
+        if (b < nblk) block(ea, na, xa, b * KB);
     }
-    for (int t = t0; t < T; t++) {  // remainder (and D <= KB): the plain form
-        const float x = v0[(size_t)t * a.slots + slot];
-        // MovingAverage::insert (src/utils.h:84-93): sum -= oldest; push_front; sum += val
-        int oldest = head + D - 1;
-        if (oldest >= D) oldest -= D;
-        s1 = __fadd_rn(s1, -rx[oldest * 64 + lane]);
-        s2 = __fadd_rn(s2, -rm[oldest * 64 + lane]);
-        head = oldest;  // (head + D - 1) % D
-        rx[head * 64 + lane] = x;
-        s1 = __fadd_rn(s1, x);
-        const float m1 = __fdiv_rn(s1, fD);
-        rm[head * 64 + lane] = m1;
-        s2 = __fadd_rn(s2, m1);
-        const float m2 = __fdiv_rn(s2, fD);
-        int back = head + D - 1;  // getLatest(delay - 1): the oldest after the insert
-        if (back >= D) back -= D;
-        v1[(hist + t) * a.slots + slot] = __fsub_rn(rx[back * 64 + lane], m2);
-    }
-    if (on) {
-        a.dc_s1[slot] = s1;
-        a.dc_s2[slot] = s2;
-        a.dc_head[slot] = head;
-        for (int i = 0; i < D; i++) {
-            a.dc_rx[(size_t)i * a.slots + slot] = rx[i * 64 + lane];
-            a.dc_rm[(size_t)i * a.slots + slot] = rm[i * 64 + lane];
+    for (int t = nblk * KB; t < T; t++) {
+        s = __fadd_rn(s, -in[pc_at(a, t, slot)]);
+        s = __fadd_rn(s, in[pc_at(a, D + t, slot)]);
+        const float m = POW2 ? __fmul_rn(s, rD) : __fdiv_rn(s, fD);
+        if (SECOND) {
+            out[pc_at(a, orow + t, slot)] = __fsub_rn(X[pc_at(a, t + 1, slot)], m);
+        } else {
+            out[pc_at(a, orow + t, slot)] = m;
         }
     }
+    (SECOND ? a.dc_s2 : a.dc_s1)[slot] = s;
 }
 
-// blockIdx.y = block k of L rows, blockIdx.z = 0: prefix maxima, 1: suffix maxima
+// blockIdx.y = block k of L rows of V1, blockIdx.z = 0: prefix maxima, 1: suffix maxima
 __global__ __launch_bounds__(64) void k_pc_scan(PostArgs a) {
     const int lane = threadIdx.x, ci = blockIdx.x * 64 + lane;
     if (ci >= a.nact) return;
@@ -197,23 +175,23 @@ __global__ __launch_bounds__(64) void k_pc_scan(PostArgs a) {
     if (r0 >= rows) return;
     float m = 0.f;
     constexpr int KB = 16;
-    const float *__restrict__ v1 = a.v1;
+    const float *__restrict__ v1 = a.V1;
     if (blockIdx.z == 0) {
         float *__restrict__ P = a.P;
         int r = r0;
         for (; r + KB <= r1; r += KB) {
             float x[KB];
 #pragma unroll
-            for (int i = 0; i < KB; i++) x[i] = v1[(size_t)(r + i) * a.slots + slot];
+            for (int i = 0; i < KB; i++) x[i] = v1[pc_at(a, r + i, slot)];
 #pragma unroll
             for (int i = 0; i < KB; i++) {
                 m = fmaxf(m, fabsf(x[i]));
-                P[(size_t)(r + i) * a.slots + slot] = m;
+                P[pc_at(a, r + i, slot)] = m;
             }
         }
         for (; r < r1; r++) {
-            m = fmaxf(m, fabsf(v1[(size_t)r * a.slots + slot]));
-            P[(size_t)r * a.slots + slot] = m;
+            m = fmaxf(m, fabsf(v1[pc_at(a, r, slot)]));
+            P[pc_at(a, r, slot)] = m;
         }
     } else {
         float *__restrict__ S = a.S;
@@ -221,20 +199,35 @@ __global__ __launch_bounds__(64) void k_pc_scan(PostArgs a) {
         for (; r - KB + 1 >= r0; r -= KB) {
             float x[KB];
 #pragma unroll
-            for (int i = 0; i < KB; i++) x[i] = v1[(size_t)(r - i) * a.slots + slot];
+            for (int i = 0; i < KB; i++) x[i] = v1[pc_at(a, r - i, slot)];
 #pragma unroll
             for (int i = 0; i < KB; i++) {
                 m = fmaxf(m, fabsf(x[i]));
-                S[(size_t)(r - i) * a.slots + slot] = m;
+                S[pc_at(a, r - i, slot)] = m;
             }
         }
         for (; r >= r0; r--) {
-            m = fmaxf(m, fabsf(v1[(size_t)r * a.slots + slot]));
-            S[(size_t)r * a.slots + slot] = m;
+            m = fmaxf(m, fabsf(v1[pc_at(a, r, slot)]));
+            S[pc_at(a, r, slot)] = m;
         }
     }
 }
 
+// w_t = desired / (peak_t + 1e-10), peak_t = max |V1| over rows [t, t+L-1] = max(S[t], P[t+L-1]);
+// in place into S[t] (only this thread reads S[t]).  256 threads = 4 rows x 64 clients.
+__global__ __launch_bounds__(256) void k_pc_want(PostArgs a) {
+    const int ci = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int t = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ci >= a.nact) return;
+    const int slot = a.clients[ci].slot;
+    if (t >= a.len[slot]) return;
+    const float peak = fmaxf(a.S[pc_at(a, t, slot)], a.P[pc_at(a, t + a.L - 1, slot)]);
+    a.S[pc_at(a, t, slot)] = __fdiv_rn(a.desired, __fadd_rn(peak, 1e-10f));
+}
+
+// the gain recurrence (src/utils/audioprocessing.cpp:55-66); g_t -> P[t] (0 while the
+// look-ahead buffer is still filling: the reference outputs 0 there and leaves the gain alone;
+// an active gain is never 0: w_t > 0)
 __global__ __launch_bounds__(64) void k_pc_gain(PostArgs a) {
     const int lane = threadIdx.x, ci = blockIdx.x * 64 + lane;
     if (ci >= a.nact) return;
@@ -248,75 +241,61 @@ __global__ __launch_bounds__(64) void k_pc_gain(PostArgs a) {
         n0 = 0;
     }
     constexpr int KB = 16;
-    const float *__restrict__ v1 = a.v1;
-    const float *__restrict__ Sx = a.S;
-    const float *__restrict__ Px = a.P;
-    int *__restrict__ pcm_t = a.pcm_t;
-    auto to_i16 = [](float y) {  // dsp_float_to_int16, src/utils/dsp.cpp:152-165
-        int v = (int)__fmaf_rn(y, 16384.f, 32768.5f) - 32768;
-        return v > 32767 ? 32767 : (v < -32768 ? -32768 : v);
+    const float *__restrict__ W = a.S;
+    float *__restrict__ G = a.P;
+    const float natt = -a.attack, rel = a.release;
+    auto fetch = [&](float (&w)[KB], int t0) {
+#pragma unroll
+        for (int i = 0; i < KB; i++) w[i] = W[pc_at(a, t0 + i, slot)];
     };
-    auto fetch = [&](float (&cur)[KB], float (&s)[KB], float (&p)[KB], int t0) {
-#pragma unroll
-        for (int i = 0; i < KB; i++) {
-            cur[i] = v1[(size_t)(t0 + i) * a.slots + slot];
-            s[i] = Sx[(size_t)(t0 + i) * a.slots + slot];
-            p[i] = Px[(size_t)(t0 + i + L - 1) * a.slots + slot];
-        }
+    auto step = [&](float w, int t) -> float {
+        if (n0 + t + 1 < L) return 0.f;  // the look-ahead buffer is not full yet
+        const bool att = w < gain;
+        gain = __fmaf_rn(att ? natt : rel, att ? __fsub_rn(gain, w) : __fsub_rn(w, gain), gain);
+        return gain;
     };
-    auto block = [&](const float (&cur)[KB], const float (&s)[KB], const float (&p)[KB], int t0) {
-        float want[KB];
+    auto block = [&](const float (&w)[KB], int t0) {
+        float g[KB];
 #pragma unroll
-        for (int i = 0; i < KB; i++)  // everything that does not depend on the gain, up front
-            want[i] = __fdiv_rn(a.desired, __fadd_rn(fmaxf(s[i], p[i]), 1e-10f));
+        for (int i = 0; i < KB; i++) g[i] = step(w[i], t0 + i);
 #pragma unroll
-        for (int i = 0; i < KB; i++) {
-            float y = 0.f;
-            if (n0 + t0 + i + 1 >= L) {  // the look-ahead buffer is full
-                if (want[i] < gain)
-                    gain = __fmaf_rn(-a.attack, __fsub_rn(gain, want[i]), gain);
-                else
-                    gain = __fmaf_rn(a.release, __fsub_rn(want[i], gain), gain);
-                y = __fmul_rn(cur[i], gain);
-            }
-            pcm_t[(size_t)(t0 + i) * a.slots + slot] = to_i16(y);
-        }
+        for (int i = 0; i < KB; i++) G[pc_at(a, t0 + i, slot)] = g[i];
     };
     const int nblk = T / KB;
-    int t = 0;
     if (nblk > 0) {
-        float ca[KB], sa[KB], pa[KB], cb[KB], sb[KB], pb[KB];
-        fetch(ca, sa, pa, 0);
+        float wa[KB], wb[KB];
+        fetch(wa, 0);
         int b = 0;
         for (; b + 1 < nblk; b += 2) {
-            fetch(cb, sb, pb, (b + 1) * KB);
-            block(ca, sa, pa, b * KB);
-            if (b + 2 < nblk) fetch(ca, sa, pa, (b + 2) * KB);
-            block(cb, sb, pb, (b + 1) * KB);
+            fetch(wb, (b + 1) * KB);
+            block(wa, b * KB);
+            if (b + 2 < nblk) fetch(wa, (b + 2) * KB);
+            block(wb, (b + 1) * KB);
         }
-        if (b < nblk) block(ca, sa, pa, b * KB);
-        t = nblk * KB;
+        if (b < nblk) block(wa, b * KB);
     }
-    for (; t < T; t++) {
-        float y = 0.f;
-        if (n0 + t + 1 >= L) {
-            const float cur = v1[(size_t)t * a.slots + slot];
-            const float peak = fmaxf(Sx[(size_t)t * a.slots + slot], Px[(size_t)(t + L - 1) * a.slots + slot]);
-            const float want = __fdiv_rn(a.desired, __fadd_rn(peak, 1e-10f));
-            if (want < gain)
-                gain = __fmaf_rn(-a.attack, __fsub_rn(gain, want), gain);
-            else
-                gain = __fmaf_rn(a.release, __fsub_rn(want, gain), gain);
-            y = __fmul_rn(cur, gain);
-        }
-        pcm_t[(size_t)t * a.slots + slot] = to_i16(y);
-    }
+    for (int t = nblk * KB; t < T; t++) G[pc_at(a, t, slot)] = step(W[pc_at(a, t, slot)], t);
     a.agc_gain[slot] = gain;
     a.agc_n0[slot] = min(n0 + T, L);
 }
 
-// rows [T, T+L-1) of v1 become the history rows [0, L-1) of the next batch (in place:
-// ascending order reads ahead of the writes)
+// current_sample * gain (row t of V1 is the oldest sample of the look-ahead window; gain 0 =
+// buffer still filling -> 0) and dsp_float_to_int16 (src/utils/dsp.cpp:152-165)
+__global__ __launch_bounds__(256) void k_pc_out(PostArgs a) {
+    const int ci = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int t = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ci >= a.nact) return;
+    const int slot = a.clients[ci].slot;
+    if (t >= a.len[slot]) return;
+    const float g = a.P[pc_at(a, t, slot)];
+    const float y = g == 0.f ? 0.f : __fmul_rn(a.V1[pc_at(a, t, slot)], g);
+    int v = (int)__fmaf_rn(y, 16384.f, 32768.5f) - 32768;
+    v = v > 32767 ? 32767 : (v < -32768 ? -32768 : v);
+    a.pcm_t[pc_at(a, t, slot)] = v;
+}
+
+// the last D rows of X / M1 and the last L-1 rows of V1 become the history rows of the next
+// batch (in place, ascending: the reads stay ahead of the writes); blockIdx.y: 0 = X and M1, 1 = V1
 __global__ __launch_bounds__(64) void k_pc_history(PostArgs a) {
     const int lane = threadIdx.x, ci = blockIdx.x * 64 + lane;
     if (ci >= a.nact) return;
@@ -324,15 +303,22 @@ __global__ __launch_bounds__(64) void k_pc_history(PostArgs a) {
     const int T = a.len[slot];
     if (T == 0) return;
     constexpr int KB = 16;
+    if (blockIdx.y == 0) {
+        for (int r = 0; r < a.D; r++) {  // D is small
+            a.X[pc_at(a, r, slot)] = a.X[pc_at(a, r + T, slot)];
+            a.M1[pc_at(a, r, slot)] = a.M1[pc_at(a, r + T, slot)];
+        }
+        return;
+    }
     int r = 0;
     for (; r + KB <= a.L - 1; r += KB) {  // the KB reads of a block happen before its writes
         float x[KB];
 #pragma unroll
-        for (int i = 0; i < KB; i++) x[i] = a.v1[(size_t)(r + i + T) * a.slots + slot];
+        for (int i = 0; i < KB; i++) x[i] = a.V1[pc_at(a, r + i + T, slot)];
 #pragma unroll
-        for (int i = 0; i < KB; i++) a.v1[(size_t)(r + i) * a.slots + slot] = x[i];
+        for (int i = 0; i < KB; i++) a.V1[pc_at(a, r + i, slot)] = x[i];
     }
-    for (; r < a.L - 1; r++) a.v1[(size_t)r * a.slots + slot] = a.v1[(size_t)(r + T) * a.slots + slot];
+    for (; r < a.L - 1; r++) a.V1[pc_at(a, r, slot)] = a.V1[pc_at(a, r + T, slot)];
 }
 
 __global__ __launch_bounds__(256) void k_pc_scatter(PostArgs a) {
@@ -343,7 +329,7 @@ __global__ __launch_bounds__(256) void k_pc_scatter(PostArgs a) {
         const int slot = a.clients[c0 + tx].slot;
         const int pos = a.fstart[(size_t)slot * a.max_batch + f];
         for (int jj = ty; jj < 32; jj += 4)
-            tile[jj][tx] = (pos >= 0 && j0 + jj < a.h) ? a.pcm_t[(size_t)(pos + j0 + jj) * a.slots + slot] : 0;
+            tile[jj][tx] = (pos >= 0 && j0 + jj < a.h) ? a.pcm_t[pc_at(a, pos + j0 + jj, slot)] : 0;
     }
     __syncthreads();
     for (int r = ty; r < 64; r += 4) {

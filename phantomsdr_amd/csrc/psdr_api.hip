@@ -1225,11 +1225,20 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
         pa.nframes = nframes;
         const unsigned cb = (unsigned)((nact + 63) / 64), jb = (unsigned)((pa.h + 31) / 32);
         const unsigned nblk = (unsigned)((pa.L - 1 + (size_t)nframes * pa.h + pa.L - 1) / pa.L);
+        const unsigned rb = (unsigned)(((size_t)nframes * pa.h + 3) / 4);
         hipLaunchKernelGGL(k_pc_gather, dim3(cb, nframes, jb), dim3(256), 0, c->side, pa);
-        hipLaunchKernelGGL(k_pc_dc, dim3(cb), dim3(64), (size_t)2 * pa.D * 64 * sizeof(float), c->side, pa);
+        if ((pa.D & (pa.D - 1)) == 0) {
+            hipLaunchKernelGGL((k_pc_ma<false, true>), dim3(cb), dim3(64), 0, c->side, pa);
+            hipLaunchKernelGGL((k_pc_ma<true, true>), dim3(cb), dim3(64), 0, c->side, pa);
+        } else {
+            hipLaunchKernelGGL((k_pc_ma<false, false>), dim3(cb), dim3(64), 0, c->side, pa);
+            hipLaunchKernelGGL((k_pc_ma<true, false>), dim3(cb), dim3(64), 0, c->side, pa);
+        }
         hipLaunchKernelGGL(k_pc_scan, dim3(cb, nblk, 2), dim3(64), 0, c->side, pa);
+        hipLaunchKernelGGL(k_pc_want, dim3(cb, rb), dim3(256), 0, c->side, pa);
         hipLaunchKernelGGL(k_pc_gain, dim3(cb), dim3(64), 0, c->side, pa);
-        hipLaunchKernelGGL(k_pc_history, dim3(cb), dim3(64), 0, c->side, pa);
+        hipLaunchKernelGGL(k_pc_out, dim3(cb, rb), dim3(256), 0, c->side, pa);
+        hipLaunchKernelGGL(k_pc_history, dim3(cb, 2), dim3(64), 0, c->side, pa);
         hipLaunchKernelGGL(k_pc_scatter, dim3(cb, nframes, jb), dim3(256), 0, c->side, pa);
         HIPCHK(hipGetLastError());
     }
@@ -1272,7 +1281,7 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
         a.desired = 0.2f;
         a.attack = (float)(1 - std::exp((double)(-1.0f / (50.0f * 0.001f * sr))));
         a.release = (float)(1 - std::exp((double)(-1.0f / (300.0f * 0.001f * sr))));
-        if ((size_t)2 * a.D * 64 * sizeof(float) > 64 * 1024 || a.L < 2)
+        if (a.D < 1 || a.L < 2)
             return fail(PSDR_ERR_UNSUPPORTED, "audio_rate %d: DC delay %d / look-ahead %d unsupported", rate, a.D, a.L);
         auto alloc = [&](void **ptr, size_t bytes) -> int {
             HIPCHK(hipMalloc(ptr, std::max<size_t>(bytes, 16)));
@@ -1284,17 +1293,15 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
         int rc = 0;
         rc |= alloc((void **)&a.fstart, S * c->max_batch * sizeof(int));
         rc |= alloc((void **)&a.len, S * sizeof(int));
-        rc |= alloc((void **)&a.v0, Tm * S * sizeof(float));
-        rc |= alloc((void **)&a.v1, rows1 * S * sizeof(float));
+        rc |= alloc((void **)&a.X, ((size_t)a.D + Tm) * S * sizeof(float));
+        rc |= alloc((void **)&a.M1, ((size_t)a.D + Tm) * S * sizeof(float));
+        rc |= alloc((void **)&a.V1, rows1 * S * sizeof(float));
         rc |= alloc((void **)&a.P, rows1 * S * sizeof(float));
         rc |= alloc((void **)&a.S, rows1 * S * sizeof(float));
         rc |= alloc((void **)&a.pcm_t, Tm * S * sizeof(int));
         rc |= alloc((void **)&a.pcm, S * Tm * sizeof(int32_t));
         rc |= alloc((void **)&a.dc_s1, S * sizeof(float));
         rc |= alloc((void **)&a.dc_s2, S * sizeof(float));
-        rc |= alloc((void **)&a.dc_rx, (size_t)a.D * S * sizeof(float));
-        rc |= alloc((void **)&a.dc_rm, (size_t)a.D * S * sizeof(float));
-        rc |= alloc((void **)&a.dc_head, S * sizeof(int));
         rc |= alloc((void **)&a.agc_gain, S * sizeof(float));
         rc |= alloc((void **)&a.agc_n0, S * sizeof(int));
         if (rc) return PSDR_ERR_NOMEM;
