@@ -246,6 +246,19 @@ def test_demod_audio_fft_sizes(n):
     run_demod_case(N, 0, n, clients, nbatches=2, F=2, seed=41)
 
 
+def test_baseline_cfg1_shape():
+    """BASELINE.json configs[0]: 3.2 MSPS IQ u8 (rtl_sdr), 2^16-point FFT, one audio client
+    (n = ceil(12000 * 2^16 / 3.2e6 / 4) * 4 = 248) - the reference's own CPU-runnable case,
+    frame by frame against the oracle from the raw u8 bytes on."""
+    from phantomsdr_amd import derived_params
+    p = derived_params(3_200_000, 1 << 16, False)
+    assert p["audio_fft_size"] == 248 and p["fft_result_size"] == 1 << 16
+    N = 1 << 16
+    m = int(tone_bin(N, 0, 0.11))
+    run_demod_case(N, 0, p["audio_fft_size"], [("USB", m, float(m), m + 61)], nbatches=3, F=4, seed=21,
+                   fmt="u8")
+
+
 def test_waterfall_batch():
     from phantomsdr_amd import Context, WaterfallClient
     N, is_real, F = 1 << 16, 0, 6
