@@ -53,6 +53,7 @@ struct PostArgs {
     float *dc_s1, *dc_s2;             // [slots] running sums
     float *agc_gain;
     int *agc_n0;  // samples pushed since the last reset, saturating at L
+    int ma_fused;  // k_pc_ma2 keeps M1's history itself (k_pc_history leaves M1 alone)
 };
 
 __device__ __forceinline__ unsigned pc_at(const PostArgs &a, int row, int slot) {
@@ -163,6 +164,94 @@ __global__ __launch_bounds__(64) void k_pc_ma(PostArgs a) {
         }
     }
     (SECOND ? a.dc_s2 : a.dc_s1)[slot] = s;
+}
+
+// Both moving averages in one loop for D = 32: the m1 values the second average evicts are
+// the ones this lane produced two 16-step blocks ago - they stay in registers (two alternating
+// sets), M1 only holds the 32 carried values (time order, oldest first).  Two independent
+// recurrences per step instead of one: the same time as a single average.  A stream that is
+// not a whole number of blocks ends with a partial block whose surplus steps are predicated off.
+__global__ __launch_bounds__(64) void k_pc_ma2(PostArgs a) {
+    const int lane = threadIdx.x, ci = blockIdx.x * 64 + lane;
+    if (ci >= a.nact) return;
+    const ClientParams cp = a.clients[ci];
+    const int slot = cp.slot;
+    constexpr int KB = 16, D = 32;
+    const bool fresh = cp.agc_reset == 2;  // zero sums (k_pc_gather zeroed the history rows)
+    const int T = a.len[slot];
+    if (T == 0) return;
+    const int nfull = T / KB, rem = T - nfull * KB;
+    const float *__restrict__ X = a.X;
+    float *__restrict__ M1 = a.M1;
+    float *__restrict__ V1 = a.V1;
+    float s1 = fresh ? 0.f : a.dc_s1[slot], s2 = fresh ? 0.f : a.dc_s2[slot];
+    const float rD = 1.0f / 32.0f;
+    const int orow = a.L - 1;
+    float ma[KB], mb[KB];  // m1 of the blocks two and one back (alternating roles)
+#pragma unroll
+    for (int i = 0; i < KB; i++) {
+        ma[i] = M1[pc_at(a, i, slot)];
+        mb[i] = M1[pc_at(a, KB + i, slot)];
+    }
+    auto fetch = [&](float (&ev)[KB], float (&nw)[KB], float &xlast, int t0) {
+#pragma unroll
+        for (int i = 0; i < KB; i++) {  // (rows past the stream exist: the arrays are padded)
+            ev[i] = X[pc_at(a, t0 + i, slot)];
+            nw[i] = X[pc_at(a, D + t0 + i, slot)];
+        }
+        xlast = X[pc_at(a, t0 + KB, slot)];  // x_{t-D+1} of the block's last step
+    };
+    // m2old: m1 of block b-2 (evicted, then overwritten with block b's m1); valid < KB: only
+    // the first `valid` steps exist
+    auto block = [&](const float (&ev)[KB], const float (&nw)[KB], float xlast, float (&m2old)[KB], int t0,
+                     int valid) {
+        float o[KB];
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            const bool ok = i < valid;
+            const float s1n = __fadd_rn(__fadd_rn(s1, -ev[i]), nw[i]);
+            const float m1 = __fmul_rn(s1n, rD);
+            const float s2n = __fadd_rn(__fadd_rn(s2, -m2old[i]), m1);
+            s1 = ok ? s1n : s1;
+            s2 = ok ? s2n : s2;
+            m2old[i] = ok ? m1 : m2old[i];
+            // getLatest(delay - 1) = x_{t-D+1} = the next step's evictee
+            o[i] = __fsub_rn(i + 1 < KB ? ev[i + 1] : xlast, __fmul_rn(s2n, rD));
+        }
+#pragma unroll
+        for (int i = 0; i < KB; i++)
+            if (i < valid) V1[pc_at(a, orow + t0 + i, slot)] = o[i];
+    };
+    const int nblk = nfull + (rem ? 1 : 0);
+    float ea[KB], na[KB], eb[KB], nb[KB], xa, xb;
+    fetch(ea, na, xa, 0);
+    int b = 0;
+    for (; b + 1 < nblk; b += 2) {
+        fetch(eb, nb, xb, (b + 1) * KB);
+        block(ea, na, xa, ma, b * KB, KB);
+        if (b + 2 < nblk) fetch(ea, na, xa, (b + 2) * KB);
+        block(eb, nb, xb, mb, (b + 1) * KB, (b + 1 == nblk - 1 && rem) ? rem : KB);
+    }
+    const bool odd = b < nblk;
+    if (odd) block(ea, na, xa, ma, b * KB, rem ? rem : KB);
+    // the last 32 m1 values in time order.  After the loop the set of the LAST block is `ma` if
+    // the block count is odd, else `mb`; with a partial last block (rem steps) that set holds
+    // [new m1 x rem | m1 of three blocks ago x (KB-rem)], the other set the block before.
+    const int r = rem ? rem : KB;  // valid entries of the last block's set
+#pragma unroll
+    for (int i = 0; i < KB; i++) {
+        const float lastv = odd ? ma[i] : mb[i], prevv = odd ? mb[i] : ma[i];
+        // time order of the 32 + (KB - r) candidates: [last set's stale tail (i >= r), prev set, last set's head]
+        // rows: stale tail entry i -> row i - r - (KB - r) ... dropped unless it is among the newest 32
+        const int row_prev = KB - r + i;        // prev set entry i
+        const int row_last = 2 * KB - r + i;    // last set entry i (valid for i < r)
+        const int row_stale = i - r;            // last set entry i >= r: m1 of the block before prev
+        if (i < r) M1[pc_at(a, row_last, slot)] = lastv;
+        M1[pc_at(a, row_prev, slot)] = prevv;
+        if (i >= r) M1[pc_at(a, row_stale, slot)] = lastv;
+    }
+    a.dc_s1[slot] = s1;
+    a.dc_s2[slot] = s2;
 }
 
 // blockIdx.y = block k of L rows of V1, blockIdx.z = 0: prefix maxima, 1: suffix maxima
@@ -306,7 +395,7 @@ __global__ __launch_bounds__(64) void k_pc_history(PostArgs a) {
     if (blockIdx.y == 0) {
         for (int r = 0; r < a.D; r++) {  // D is small
             a.X[pc_at(a, r, slot)] = a.X[pc_at(a, r + T, slot)];
-            a.M1[pc_at(a, r, slot)] = a.M1[pc_at(a, r + T, slot)];
+            if (!a.ma_fused) a.M1[pc_at(a, r, slot)] = a.M1[pc_at(a, r + T, slot)];
         }
         return;
     }

@@ -1227,7 +1227,10 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
         const unsigned nblk = (unsigned)((pa.L - 1 + (size_t)nframes * pa.h + pa.L - 1) / pa.L);
         const unsigned rb = (unsigned)(((size_t)nframes * pa.h + 3) / 4);
         hipLaunchKernelGGL(k_pc_gather, dim3(cb, nframes, jb), dim3(256), 0, c->side, pa);
-        if ((pa.D & (pa.D - 1)) == 0) {
+        pa.ma_fused = pa.D == 32 ? 1 : 0;  // both averages in one loop (postchain.h)
+        if (pa.ma_fused) {
+            hipLaunchKernelGGL(k_pc_ma2, dim3(cb), dim3(64), 0, c->side, pa);
+        } else if ((pa.D & (pa.D - 1)) == 0) {
             hipLaunchKernelGGL((k_pc_ma<false, true>), dim3(cb), dim3(64), 0, c->side, pa);
             hipLaunchKernelGGL((k_pc_ma<true, true>), dim3(cb), dim3(64), 0, c->side, pa);
         } else {
@@ -1293,8 +1296,8 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
         int rc = 0;
         rc |= alloc((void **)&a.fstart, S * c->max_batch * sizeof(int));
         rc |= alloc((void **)&a.len, S * sizeof(int));
-        rc |= alloc((void **)&a.X, ((size_t)a.D + Tm) * S * sizeof(float));
-        rc |= alloc((void **)&a.M1, ((size_t)a.D + Tm) * S * sizeof(float));
+        rc |= alloc((void **)&a.X, ((size_t)a.D + Tm + 32) * S * sizeof(float));  // + one block of padding
+        rc |= alloc((void **)&a.M1, ((size_t)a.D + Tm + 32) * S * sizeof(float));
         rc |= alloc((void **)&a.V1, rows1 * S * sizeof(float));
         rc |= alloc((void **)&a.P, rows1 * S * sizeof(float));
         rc |= alloc((void **)&a.S, rows1 * S * sizeof(float));
