@@ -696,7 +696,8 @@ int build(psdr_ctx *c) {
         HIPCHK(hipMalloc((void **)&c->d_tickets[i], TICKET_SLOTS * 8 * sizeof(unsigned)));
         HIPCHK(hipMemset(c->d_tickets[i], 0, TICKET_SLOTS * 8 * sizeof(unsigned)));
     }
-    for (int i = 0; i < 2; i++)
+    // the second Y buffer only exists when pass 1 runs on its own stream (PSDR_P1_STREAM)
+    for (int i = 0; i < (c->no_p1_stream ? 1 : 2); i++)
         HIPCHK(hipMalloc((void **)&c->y_pool[i], F * (c->M + c->ypad * (size_t)(c->M2 / c->T1)) * sizeof(cf)));
     if (c->is_real) HIPCHK(hipMalloc((void **)&c->d_Z, F * c->M * sizeof(cf)));
     for (int s = 0; s < 2; s++) {
