@@ -181,6 +181,19 @@ def cpu_baseline(wl, params, clients, waterfalls, budget_s=15.0):
                       f"OpenMP {cores} of {ncpu} host threads for the FFT/pyramid (best of a probe), clients serial)"}
 
 
+def emit(out):
+    """the ONE JSON line, as the last thing on stdout: RCCL prints a banner through C stdio whose
+    buffer would otherwise be flushed after Python's at exit"""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
 def kernel_roofline(ctx, step, first_step, nsteps, wl, wl_name, params, clients, waterfalls, frames_per_launch):
     """per-kernel durations from a profiled replay (hipEvents on the library's own streams) and the
     roofline block of the dominant kernel (DESIGN.md "Roofline accounting")"""
@@ -343,10 +356,16 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
                 "link_peak_GB_per_s": 153.0},
             "cpu_baseline": None,
         }
-        print(json.dumps(out))
+    else:
+        out = None
     eng.close()
     if dist.is_initialized():
+        emit(None)  # every rank flushes what RCCL wrote through C stdio ...
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        time.sleep(0.2)  # ... and rank 0's line comes last
+    emit(out)
 
 
 def main():
@@ -484,7 +503,7 @@ def main():
         "cpu_baseline": cpu,
     }
     eng.close()
-    print(json.dumps(out))
+    emit(out)
 
 
 if __name__ == "__main__":
