@@ -245,19 +245,27 @@ struct TileQueue {
     unsigned *tickets;
     unsigned total, base;  // indices below 2*gridDim.x are the static first tiles
     unsigned pending;      // thread 0: ticket drawn from the own counter, not yet examined
-    bool dynamic, global;
+    bool dynamic, global, nostatic;
     // global_: ONE counter for the whole chip (perfect balance, no XCD affinity)
-    __device__ __forceinline__ void init(unsigned *t, unsigned total_, bool global_ = false) {
+    // all_dynamic: no static first tiles (the second phase of a single launch: work-groups
+    // arrive one by one); the first two indices come from draw_now()
+    __device__ __forceinline__ void init(unsigned *t, unsigned total_, bool global_ = false, bool all_dynamic = false) {
         global = global_;
+        nostatic = all_dynamic;
         tickets = t;
         total = total_;
-        base = gridDim.x >> 2;  // 2*gridDim.x / 8
+        base = all_dynamic ? 0u : gridDim.x >> 2;  // 2*gridDim.x / 8
         pending = 0;
-        dynamic = t != nullptr && 2u * gridDim.x < total_;
+        dynamic = t != nullptr && (all_dynamic || 2u * gridDim.x < total_);
     }
     // thread 0: start drawing (no wait)
     __device__ __forceinline__ void draw_begin() {
         if (threadIdx.x == 0 && dynamic) pending = atomicAdd(tickets + (global ? 0u : (blockIdx.x & 7u)), 1u);
+    }
+    // thread 0, synchronous (phase start, all_dynamic + global only): one index
+    __device__ __forceinline__ unsigned draw_now() {
+        const unsigned s = atomicAdd(tickets, 1u);
+        return s < total ? s : 0xFFFFFFFFu;
     }
     // thread 0: finish the draw begun one tile ago and publish the index (or 0xFFFFFFFF) to
     // *slot; `prev` is the index two positions earlier in this work-group's sequence
@@ -268,13 +276,25 @@ struct TileQueue {
                 if (prev2 < total) s = prev2 + 2u * gridDim.x;
             } else if (dynamic) {
                 const unsigned x = blockIdx.x & 7u;
-                s = global ? pending + 2u * gridDim.x : (pending + base) * 8u + x;
+                s = global ? pending + (nostatic ? 0u : 2u * gridDim.x) : (pending + base) * 8u + x;
                 if (s >= total) s = 0xFFFFFFFFu;  // no stealing across XCDs: probing seven more
                                                   // counters costs a memory round trip each
             }
             *slot = s;
         }
     }
+};
+
+// Single-launch operation (k_fft_two_phase): pass 2 starts inside the same launch as soon as a
+// work-group runs out of pass-1 tiles.  Y crosses XCDs (non-coherent L2s) inside one kernel:
+// pass 1 stores it write-through (sc1), every wave drains its stores (counted wait at the next
+// tile's second barrier), one lane bumps the frame's counter with a relaxed agent-scope atomic;
+// pass 2 reads Y with sc1 loads after a relaxed poll of the counter
+// (cdna_hip_programming.md, "in-launch combine", sc1 form).
+struct CoopArgs {
+    unsigned *cnt1;     // [nframes] pass-1 tiles completed per frame, zeroed
+    unsigned need;      // pass-1 tiles per frame
+    unsigned y_bytes;   // size of Y (buffer descriptor range)
 };
 
 struct Pass1Args {
@@ -330,8 +350,9 @@ __device__ __forceinline__ constexpr float image_scale() {
 // pass 1: convert + window + column FFT (length L = M1) + inter-pass twiddle.
 //   T columns per tile (T/2 couples), SB bytes per complex sample of the raw image
 //   (u8/s8: 2, u16/s16: 4, f32 and f64-narrowed-to-f32: 8).  L*T/32 threads.
-template <int L, int T, int SB>
-__global__ __launch_bounds__(L *T / 32) void k_fft_pass1(Pass1Args a) {
+// COOP: part of a single launch with pass 2 (CoopArgs): sc1 stores of Y, completion counters
+template <int L, int T, int SB, bool COOP>
+__device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &co) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *tile = reinterpret_cast<float4 *>(smem);
     cf *Wl = reinterpret_cast<cf *>(smem) + L * T;
@@ -390,6 +411,10 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass1(Pass1Args a) {
     __shared__ unsigned s_next[2];
     TileQueue tq;
     tq.init(a.tickets, total);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, COOP ? (int)co.y_bytes : 0, 0x00020000);
+    (void)yrs;
+    bool have_prev = false;  // COOP: the previous tile's completion is not published yet
+    unsigned prev_f = 0;
     unsigned s = blockIdx.x, snext = blockIdx.x + gridDim.x;
     if (s < total) {
         point_at(s);
@@ -409,6 +434,8 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass1(Pass1Args a) {
         const unsigned f = slot / a.tiles_per_frame;
         const unsigned tl = slot - f * a.tiles_per_frame;
         cf *Yb = a.Y + (size_t)f * a.yframe + (size_t)tl * a.yblk;  // this tile's block
+        const unsigned yb_bytes = (unsigned)(((size_t)f * a.yframe + (size_t)tl * a.yblk) * sizeof(cf));
+        (void)yb_bytes;
         const bool more = snext < total;
         if (more) point_at(snext);
         // the index after `snext`: drawn one tile ago, published now, read after the barrier
@@ -472,9 +499,26 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass1(Pass1Args a) {
                 }
             }
         }
+        if constexpr (COOP) {
+            // drain point for the PREVIOUS tile's Y stores: only the EARLY loads of the next
+            // tile are younger (wave 0 also has the ticket atomic in flight: it waits for all)
+            if (have_prev) {
+                if (!more || tid < 64)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EARLY) : "memory");
+            }
+        }
         __syncthreads();
         PSDR_TRACE(a.trace, it, 3);
         const unsigned s2 = s_next[it & 1];
+        if constexpr (COOP) {
+            if (have_prev && tid == 0) {
+                __hip_atomic_fetch_add(co.cnt1 + prev_f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            have_prev = true;
+            prev_f = f;
+        }
 
         cf tbA[NBL], tbB[NBL], tsA[RL], tsB[RL], w00A, w00B;  // inter-pass twiddles
         run_stages<L, T, false>(
@@ -514,7 +558,19 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass1(Pass1Args a) {
                 const cf wB = (sidx == 0) ? (b == 0 ? w00B : tbB[b]) : cmul(tbB[b], tsB[sidx]);
                 const int c1 = a.rot ? ((k1 - 1) & (L - 1)) : k1;
                 const cf yA = cmul(x.a, wA), yB = cmul(x.b, wB);
-                *reinterpret_cast<float4 *>(Yb + (size_t)c1 * T + 2 * p) = make_float4(yA.x, yA.y, yB.x, yB.y);
+                if constexpr (COOP) {
+                    const u32x4 v = {__float_as_uint(yA.x), __float_as_uint(yA.y), __float_as_uint(yB.x),
+                                     __float_as_uint(yB.y)};
+                    // sc1: write through, the reader is on another XCD.  The whole offset goes in
+                    // the VGPR (soffset = 0): with an SGPR soffset the compiler puts no wait state
+                    // between a 128-bit buffer store and a VALU write of its data registers (its
+                    // hazard recogniser assumes none is needed in that form), and on gfx950 the
+                    // butterflies that follow then corrupt the stored rows (measured: the even
+                    // rows of some tiles, deterministically; gone with soffset = 0).
+                    __builtin_amdgcn_raw_buffer_store_b128(v, yrs, yb_bytes + (unsigned)((c1 * T + 2 * p) * (int)sizeof(cf)), 0, 16);
+                } else {
+                    *reinterpret_cast<float4 *>(Yb + (size_t)c1 * T + 2 * p) = make_float4(yA.x, yA.y, yB.x, yB.y);
+                }
             },
             // ---- trickle the rest of the next tile's loads through the stages
             [&](int k) {
@@ -532,7 +588,21 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass1(Pass1Args a) {
         s = snext;
         snext = s2;
     }
+    if constexpr (COOP) {
+        if (have_prev) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(co.cnt1 + prev_f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();  // the LDS is about to change hands
+    }
     PSDR_WGTRACE(a.trace, 7);
+}
+template <int L, int T, int SB>
+__global__ __launch_bounds__(L *T / 32) void k_fft_pass1(Pass1Args a) {
+    pass1_body<L, T, SB, false>(a, CoopArgs{});
 }
 
 struct Pass2Args {
@@ -562,8 +632,10 @@ struct Pass2Args {
 // pass 2: row FFT (length L = M2) of T adjacent rows c1 (T/2 couples); FUSED adds /N,
 // |X|^2, int8 level 0..LT of the pyramid.  L*T/32 threads.
 // TWC: pass-1 tile width when known at compile time (all fill addresses fold), 0: a.TW
-template <int L, int T, bool FUSED, int TWC>
-__global__ __launch_bounds__(L *T / 32) void k_fft_pass2(Pass2Args a) {
+// COOP: second phase of a single launch (CoopArgs): tiles by chip-wide tickets only, Y through
+// sc1 loads, a tile's frame must have all its pass-1 tiles published before it is loaded
+template <int L, int T, bool FUSED, int TWC, bool COOP>
+__device__ __forceinline__ void pass2_body(const Pass2Args &a, const CoopArgs &co) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *tile = reinterpret_cast<float4 *>(smem);
     cf *tile_cf = reinterpret_cast<cf *>(smem);
@@ -591,32 +663,86 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2(Pass2Args a) {
     const int lc = log2TW + (31 - __builtin_clz((unsigned)T));  // log2(chunk)
     float4 r[NLD];
     const cf *nxt = nullptr;
+    unsigned nxt_bytes = 0;
+    const __amdgpu_buffer_rsrc_t yrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.Y), 0, COOP ? (int)co.y_bytes : 0, 0x00020000);
+    (void)yrs;
     const unsigned lane_off = (unsigned)((size_t)((2 * tid) >> lc) * blk + ((2 * tid) & (chunk - 1)));
     auto point_at = [&](unsigned sidx) {
         const unsigned slot = xcd_slot(sidx, total);
         const unsigned f = slot / a.tiles_per_frame;
         const unsigned tl = slot - f * a.tiles_per_frame;
         nxt = a.Y + (size_t)f * a.yframe + (size_t)(tl * T) * TW;
+        nxt_bytes = (unsigned)(((size_t)f * a.yframe + (size_t)(tl * T) * TW) * sizeof(cf));
     };
     auto issue = [&](auto qc) {
         constexpr int i = decltype(qc)::value;
         // uniform part of idx = 2*i*NT: block (2*i*NT)>>lc, offset (2*i*NT)&(chunk-1)
-        const cf *q = nxt + (size_t)((2 * i * NT) >> lc) * blk + ((2 * i * NT) & (chunk - 1)) + lane_off;
-        r[i] = *reinterpret_cast<const float4 *>(q);
+        if constexpr (COOP) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const unsigned uni = (unsigned)(((size_t)((2 * i * NT) >> lc) * blk + ((2 * i * NT) & (chunk - 1))) * sizeof(cf));
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(yrs, lane_off * (unsigned)sizeof(cf), nxt_bytes + uni, /*sc1*/ 16);
+            r[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        } else {
+            const cf *q = nxt + (size_t)((2 * i * NT) >> lc) * blk + ((2 * i * NT) & (chunk - 1)) + lane_off;
+            r[i] = *reinterpret_cast<const float4 *>(q);
+        }
     };
     __shared__ unsigned s_next[2];
     TileQueue tq;
     // pass 2 has no use for XCD affinity (full-line stores, tile-major records) and the XCDs
     // differ by ~10 % in speed: one chip-wide counter (pass 1 keeps the per-XCD queues: adjacent
     // tiles share the 128-byte lines of the raw rows)
-    tq.init(a.tickets, total, true);
+    tq.init(a.tickets, total, true, COOP);
     unsigned s = blockIdx.x, snext = blockIdx.x + gridDim.x;
-    if (s < total) {
-        point_at(s);
-        static_for<0, NLD>(issue);
+    // COOP: thread 0 knows which frames are complete (frames complete roughly in order; the
+    // counter of a frame beyond `known` is polled a tile before it is needed)
+    unsigned known = 0, polled_f = 0xFFFFFFFFu, polled_v = 0;
+    auto frame_of = [&](unsigned sidx) { return xcd_slot(sidx, total) / a.tiles_per_frame; };
+    auto poll_begin = [&](unsigned sidx) {  // thread 0
+        const unsigned fr = frame_of(sidx);
+        if (fr >= known) {
+            polled_f = fr;
+            polled_v = __hip_atomic_load(co.cnt1 + fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto wait_frame = [&](unsigned sidx) {  // thread 0: returns when the tile's frame is complete
+        const unsigned fr = frame_of(sidx);
+        if (fr < known) return;
+        if (!(polled_f == fr && polled_v >= co.need)) {
+            // bounded (about a second): a lost completion must not hang the device
+            for (unsigned spin = 0; spin < (1u << 21) &&
+                                    __hip_atomic_load(co.cnt1 + fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < co.need;
+                 spin++)
+                __builtin_amdgcn_s_sleep(8);
+        }
+        known = fr + 1;  // (frames below fr were waited for by earlier tiles of this work-group
+                         //  or are older: tickets are handed out in frame order)
+    };
+    if constexpr (COOP) {
+        if (tid == 0) {
+            s_next[0] = tq.draw_now();
+            s_next[1] = tq.draw_now();
+        }
+        for (int i = tid; i < L; i += NT) Wl[i] = a.Wl[i];
+        __syncthreads();
+        s = s_next[0];
+        snext = s_next[1];
+        __syncthreads();
+        if (s < total) {
+            if (tid == 0) wait_frame(s);
+            __syncthreads();
+            point_at(s);
+            static_for<0, NLD>(issue);
+        }
+    } else {
+        if (s < total) {
+            point_at(s);
+            static_for<0, NLD>(issue);
+        }
+        for (int i = tid; i < L; i += NT) Wl[i] = a.Wl[i];  // visible after the loop's first barrier
     }
     tq.draw_begin();
-    for (int i = tid; i < L; i += NT) Wl[i] = a.Wl[i];  // visible after the loop's first barrier
     PSDR_WGTRACE(a.trace, 1);
 
     int it = 0;
@@ -644,11 +770,22 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2(Pass2Args a) {
             tile_cf[2 * (slot0 + H) + (rr & 1)] = make_float2(r[i].z, r[i].w);
         }
         PSDR_SCHED_FENCE();
-        if (more) static_for<0, EARLY>(issue);
+        if constexpr (COOP) {
+            if (tid == 0 && more) wait_frame(snext);  // normally a register compare
+        } else {
+            if (more) static_for<0, EARLY>(issue);
+        }
         PSDR_SCHED_FENCE();
         PSDR_TRACE(a.trace, it, 1);
         __syncthreads();
         PSDR_TRACE(a.trace, it, 2);
+        if constexpr (COOP) {
+            if (more) static_for<0, EARLY>(issue);  // only now: thread 0 has seen the frame complete
+            if (tid == 0) {                          // and look at the tile after that one
+                const unsigned s2t = s_next[it & 1];
+                if (s2t < total) poll_begin(s2t);
+            }
+        }
         // stage-0 input comes from the tile itself: all reads, then a barrier, before any
         // in-place write
         c2 u[16];
@@ -731,6 +868,20 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2(Pass2Args a) {
         snext = s2;
     }
     PSDR_WGTRACE(a.trace, 7);
+}
+
+template <int L, int T, bool FUSED, int TWC>
+__global__ __launch_bounds__(L *T / 32) void k_fft_pass2(Pass2Args a) {
+    pass2_body<L, T, FUSED, TWC, false>(a, CoopArgs{});
+}
+
+// Both passes in one launch: a work-group walks pass-1 tiles while there are any, then pass-2
+// tiles.  No kernel boundary: the ramp, the first-tile latency and the tail of the two passes
+// overlap with the other work-groups' steady state.  Square splits only (both passes L x T).
+template <int L, int T, int SB, bool FUSED, int TWC>
+__global__ __launch_bounds__(L *T / 32) void k_fft_two_phase(Pass1Args a1, Pass2Args a2, CoopArgs co) {
+    pass1_body<L, T, SB, true>(a1, co);
+    pass2_body<L, T, FUSED, TWC, true>(a2, co);
 }
 
 }  // namespace psdr

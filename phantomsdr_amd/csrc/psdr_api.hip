@@ -44,9 +44,10 @@ extern "C" const char *psdr_version(void) { return "phantomsdr_amd 0.1 (gfx950)"
 
 namespace {
 
-enum KernelId { K_PASS1, K_PASS2, K_UNTANGLE, K_TAIL, K_IDFT, K_OLA, K_WFALL, K_POST, K_COUNT };
+enum KernelId { K_PASS1, K_PASS2, K_UNTANGLE, K_TAIL, K_IDFT, K_OLA, K_WFALL, K_POST, K_TWO_PHASE, K_COUNT };
 const char *kKernelNames[K_COUNT] = {"fft_pass1",  "fft_pass2", "untangle_real", "pyramid_tail",
-                                     "demod_idft", "demod_ola", "waterfall_gather", "post_chain"};
+                                     "demod_idft", "demod_ola", "waterfall_gather", "post_chain",
+                                     "fft_two_phase"};
 
 struct PendingEvent {
     hipEvent_t a, b;
@@ -144,6 +145,9 @@ struct psdr_ctx {
     bool y_pending[2] = {false, false};
     // TileQueue counters: a ring of TICKET_SLOTS launches x 8 counters per pass; half the ring is
     // re-zeroed (in stream order) whenever the other half starts being used
+    bool two_phase = false;          // both passes in one launch (2^20-point case)
+    unsigned *d_cnt1 = nullptr;      // ring of TICKET_SLOTS x max_batch completion counters
+    unsigned cnt1_pos = 0;
     unsigned *d_tickets[2] = {nullptr, nullptr};
     unsigned ticket_pos[2] = {0, 0};
     bool static_tiles = false, no_p1_stream = true;  // tuning knobs (PSDR_STATIC_TILES, PSDR_P1_STREAM)
@@ -347,6 +351,35 @@ int launch_pass2_t(psdr_ctx *c, const Pass2Args &a, unsigned blocks) {
     return PSDR_OK;
 }
 
+
+// ---- both passes in one launch (k_fft_two_phase): the 2^20-point case
+template <int SB, bool FUSED>
+int launch_two_phase_t(psdr_ctx *c, const Pass1Args &a1, const Pass2Args &a2, const CoopArgs &co) {
+    constexpr int L = 1024, T = 16;
+    const size_t lds = (size_t)L * T * sizeof(cf) + 2 * (size_t)L * sizeof(cf);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_fft_two_phase<L, T, SB, FUSED, 16>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        attr_set = true;
+    }
+    ProfScope ps(c, K_TWO_PHASE);
+    const unsigned grid = persistent_grid(c, std::max(a1.total_slots, a2.total_slots), lds);
+    hipLaunchKernelGGL((k_fft_two_phase<L, T, SB, FUSED, 16>), dim3(grid), dim3(L * T / 32), lds, c->stream, a1, a2, co);
+    HIPCHK(hipGetLastError());
+    return PSDR_OK;
+}
+int launch_two_phase(psdr_ctx *c, int sb, bool fused, const Pass1Args &a1, const Pass2Args &a2, const CoopArgs &co) {
+    if (fused) {
+        if (sb == 2) return launch_two_phase_t<2, true>(c, a1, a2, co);
+        if (sb == 4) return launch_two_phase_t<4, true>(c, a1, a2, co);
+        return launch_two_phase_t<8, true>(c, a1, a2, co);
+    }
+    if (sb == 2) return launch_two_phase_t<2, false>(c, a1, a2, co);
+    if (sb == 4) return launch_two_phase_t<4, false>(c, a1, a2, co);
+    return launch_two_phase_t<8, false>(c, a1, a2, co);
+}
+
 #define P1CASE(L_, T_)                                                   \
     if (L == L_ && T == T_) {                                            \
         if (sb == 2) return launch_pass1_t<L_, T_, 2>(c, a, blocks);     \
@@ -447,8 +480,11 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
     }
     a1.tiles_per_frame = tiles1;
     a1.total_slots = tiles1 * (unsigned)nframes;
-    int rc = launch_pass1(c, c->M1, c->T1, sb, a1, a1.total_slots);
-    if (rc) return rc;
+    int rc = 0;
+    if (!c->two_phase) {  // (two-phase: pass 1 runs inside the combined launch below)
+        rc = launch_pass1(c, c->M1, c->T1, sb, a1, a1.total_slots);
+        if (rc) return rc;
+    }
     if (piped) {
         HIPCHK(hipEventRecord(c->ev_p1[c->cur_y], c->p1));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_p1[c->cur_y], 0));
@@ -480,15 +516,31 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
     // pass 2 overwrites this result set: its previous consumers (two batches ago) must be done
     if (c->set_pending[c->cur_set] && c->side != c->stream)
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_set_done[c->cur_set], 0));
+    // both passes in one launch, or pass 2 on its own
+    auto run_pass2 = [&](bool fused) -> int {
+        if (!c->two_phase) return launch_pass2(c, c->M2, c->T2, fused, a2, a2.total_slots);
+        // per-frame completion counters from a ring (zeroed in stream order half a ring ahead,
+        // like the tickets)
+        const unsigned slot = c->cnt1_pos % TICKET_SLOTS;
+        if (slot % (TICKET_SLOTS / 2) == 0 && c->cnt1_pos >= TICKET_SLOTS / 2)
+            HIPCHK(hipMemsetAsync(c->d_cnt1 + (size_t)slot * c->max_batch, 0,
+                                  (size_t)(TICKET_SLOTS / 2) * c->max_batch * sizeof(unsigned), c->stream));
+        c->cnt1_pos++;
+        CoopArgs co{};
+        co.cnt1 = c->d_cnt1 + (size_t)slot * c->max_batch;
+        co.need = tiles1;
+        co.y_bytes = (unsigned)((size_t)nframes * a1.yframe * sizeof(cf));
+        return launch_two_phase(c, sb, fused, a1, a2, co);
+    };
     if (!c->is_real) {
         a2.X = c->d_spec;
         a2.spec_stride = c->spec_stride;
-        rc = launch_pass2(c, c->M2, c->T2, true, a2, a2.total_slots);
+        rc = run_pass2(true);
         if (rc) return rc;
     } else {
         a2.X = c->d_Z;
         a2.spec_stride = c->M;
-        rc = launch_pass2(c, c->M2, c->T2, false, a2, a2.total_slots);
+        rc = run_pass2(false);
         if (rc) return rc;
         UntangleArgs u{};
         u.Z = c->d_Z;
@@ -569,6 +621,7 @@ void free_all(psdr_ctx *c) {
     F(c->d_TB);
     F(c->d_UA);
     F(c->d_UB);
+    F(c->d_cnt1);
     F(c->d_tickets[0]);
     F(c->d_tickets[1]);
     F(c->y_pool[0]);
@@ -692,6 +745,12 @@ int build(psdr_ctx *c) {
     // ---- work buffers
     const size_t F = (size_t)c->max_batch;
     if (const char *e = getenv("PSDR_YPAD")) c->ypad = (size_t)atoi(e);
+    c->two_phase = getenv("PSDR_TWO_PHASE") != nullptr && atoi(getenv("PSDR_TWO_PHASE")) != 0 && c->M1 == 1024 && c->M2 == 1024 && c->T1 == 16 && c->T2 == 16 &&
+                   c->no_p1_stream && c->ypad == 0;
+    if (c->two_phase) {
+        HIPCHK(hipMalloc((void **)&c->d_cnt1, (size_t)TICKET_SLOTS * c->max_batch * sizeof(unsigned)));
+        HIPCHK(hipMemset(c->d_cnt1, 0, (size_t)TICKET_SLOTS * c->max_batch * sizeof(unsigned)));
+    }
     for (int i = 0; i < 2; i++) {
         HIPCHK(hipMalloc((void **)&c->d_tickets[i], TICKET_SLOTS * 8 * sizeof(unsigned)));
         HIPCHK(hipMemset(c->d_tickets[i], 0, TICKET_SLOTS * 8 * sizeof(unsigned)));
