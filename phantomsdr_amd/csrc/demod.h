@@ -318,6 +318,213 @@ __global__ __launch_bounds__(64 * PSDR_IDFT_WAVES) void k_demod_idft_wave(DemodA
     }
 }
 
+// ---- compile-time plans for the audio sizes the BASELINE configurations use (n = 360, 720)
+// The generic kernels above spend most of their ~2000 wave instructions per 360-point item on
+// index arithmetic, table look-ups and predication, and with hundreds of clients the
+// demodulation is VALU-issue bound (65 536 items: 227 us on an idle chip, 1.5-2x that beside
+// the FFT passes).  Here n and the radices are template parameters: a lane owns whole radix-R
+// butterflies (R inputs read once, outputs from registers with the R-th roots, conjugate pairs
+// (s, R-s) sharing their sums), every LDS access is base + immediate, the twiddle exponent
+// q*(i%p)*n/(p*R) never wraps, and each stage runs IN PLACE (all reads of a stage precede its
+// first write; LDS operations of one wave execute in order) so four items share 15 KiB.
+template <int N, int R, int PP>
+__device__ __forceinline__ void idft_stage_fixed(cf *buf, const cf *Wn, int lane) {
+    constexpr int TLEN = N / R, ROUNDS = (TLEN + 63) / 64, STEP = N / (PP * R), HR = R / 2;
+    constexpr bool RAGGED = (TLEN % 64) != 0;
+    cf root[HR + 1];  // exp(+2 pi i t/R), t <= R/2
+#pragma unroll
+    for (int t = 0; t <= HR; t++) root[t] = Wn[t * TLEN];
+    cf x[ROUNDS][R];
+    int jo[ROUNDS];
+#pragma unroll
+    for (int rr = 0; rr < ROUNDS; rr++) {
+        const int i = lane + 64 * rr;
+        if (!RAGGED || rr + 1 < ROUNDS || i < TLEN) {
+            const int k = PP == 1 ? 0 : i % PP;
+            jo[rr] = (i - k) * R + k;
+            x[rr][0] = buf[i];
+#pragma unroll
+            for (int q = 1; q < R; q++) {
+                const cf v = buf[i + q * TLEN];
+                if (PP > 1) {
+                    const cf w = Wn[q * k * STEP];
+                    x[rr][q] = make_float2(fmaf(v.x, w.x, -v.y * w.y), fmaf(v.x, w.y, v.y * w.x));
+                } else {
+                    x[rr][q] = v;
+                }
+            }
+        }
+    }
+    // Compiler barrier, no hardware wait: the LDS executes a wave's operations in order, but the
+    // compiler reasons per lane - with compile-time indices it can prove that a lane's own
+    // loads and stores never overlap and sink the later rounds' loads below the first stores,
+    // which other LANES' stores then clobber (seen as 0.4 % errors in 40 outputs of n = 360).
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int rr = 0; rr < ROUNDS; rr++) {
+        const int i = lane + 64 * rr;
+        if (!RAGGED || rr + 1 < ROUNDS || i < TLEN) {
+            cf *o = buf + jo[rr];
+            const cf *xr = x[rr];
+            {  // s = 0
+                float ar = xr[0].x, ai = xr[0].y;
+#pragma unroll
+                for (int q = 1; q < R; q++) {
+                    ar += xr[q].x;
+                    ai += xr[q].y;
+                }
+                o[0] = make_float2(ar, ai);
+            }
+            if constexpr (R % 2 == 0) {  // s = R/2: alternating sum
+                float ar = xr[0].x, ai = xr[0].y;
+#pragma unroll
+                for (int q = 1; q < R; q++) {
+                    ar += (q & 1) ? -xr[q].x : xr[q].x;
+                    ai += (q & 1) ? -xr[q].y : xr[q].y;
+                }
+                o[HR * PP] = make_float2(ar, ai);
+            }
+            // pairs (s, R-s): out = C +- i*D, C = sum x_q cos, D = sum x_q sin
+#pragma unroll
+            for (int s = 1; 2 * s < R; s++) {
+                float cx = xr[0].x, cy = xr[0].y, dx = 0.f, dy = 0.f;
+#pragma unroll
+                for (int q = 1; q < R; q++) {
+                    const int t = (q * s) % R;
+                    if (t == 0) {
+                        cx += xr[q].x;
+                        cy += xr[q].y;
+                    } else if (2 * t == R) {
+                        cx -= xr[q].x;
+                        cy -= xr[q].y;
+                    } else {
+                        const int tt = t <= HR ? t : R - t;
+                        const float c = root[tt].x;
+                        const float sn = t <= HR ? root[tt].y : -root[tt].y;
+                        cx = fmaf(xr[q].x, c, cx);
+                        cy = fmaf(xr[q].y, c, cy);
+                        dx = fmaf(xr[q].x, sn, dx);
+                        dy = fmaf(xr[q].y, sn, dy);
+                    }
+                }
+                o[s * PP] = make_float2(cx - dy, cy + dx);
+                o[(R - s) * PP] = make_float2(cx + dy, cy - dx);
+            }
+        }
+    }
+}
+
+//   grid = ceil(nact * nframes / W), W = blockDim.x / 64 items per work-group;
+//   dynamic LDS = (1 + W) * N * 8 bytes
+template <int N, int R0, int R1, int R2>
+__global__ __launch_bounds__(256, 5) void k_demod_idft_fixed(DemodArgs a, int nact) {
+    static_assert(R0 * R1 * R2 == N, "plan");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, W = blockDim.x >> 6;
+    cf *Wn = reinterpret_cast<cf *>(smem);
+    for (int i = threadIdx.x; i < N; i += blockDim.x) Wn[i] = a.Wn[i];
+    __syncthreads();  // the only work-group barrier: the shared twiddle table
+    // everything about the item is wave-uniform: keep it in scalar registers (the mode
+    // branches become scalar branches, the range tests compare against scalars)
+    const int item = __builtin_amdgcn_readfirstlane((int)blockIdx.x * W + wv);
+    if (item >= nact * a.nframes) return;
+    const int ci = item / a.nframes, f = item - ci * a.nframes;
+    ClientParams cp = a.clients[ci];
+    cp.l = __builtin_amdgcn_readfirstlane(cp.l);
+    cp.r = __builtin_amdgcn_readfirstlane(cp.r);
+    cp.m_floor = __builtin_amdgcn_readfirstlane(cp.m_floor);
+    cp.mode = __builtin_amdgcn_readfirstlane(cp.mode);
+    cp.slot = __builtin_amdgcn_readfirstlane(cp.slot);
+    const unsigned long long frame_num = a.first_frame_num + (unsigned long long)f;
+    cf *buf = Wn + N + (size_t)wv * N;
+
+    const int len = cp.r - cp.l;
+    const int m = cp.m_floor - cp.l;  // audio_m
+    const cf *S = a.spec + (size_t)f * a.spec_stride + cp.l;
+    constexpr int NR = (N + 63) / 64;
+    cf sv[NR];  // the slice (at most n bins, src/signal.cpp:309-311): loads first, LDS after
+#pragma unroll
+    for (int u = 0; u < NR; u++) {
+        const int t = lane + 64 * u;
+        sv[u] = t < len ? S[t] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < NR; u++) {
+        const int i = lane + 64 * u;
+        if (i < N) buf[i] = make_float2(0.f, 0.f);
+    }
+    asm volatile("" ::: "memory");  // zero-fill before any lane's scatter (compiler order, see above)
+    float pw = 0.f;
+#pragma unroll
+    for (int u = 0; u < NR; u++) {
+        const int t = lane + 64 * u;
+        if (t < len) {
+            const cf v = sv[u];
+            pw += fmaf(v.x, v.x, v.y * v.y);
+            if (cp.mode == 0) {  // USB :125-137
+                if (t >= m && t < m + N) buf[t - m] = v;
+            } else if (cp.mode == 1) {  // LSB :139-153
+                if (t >= m - N + 1 && t < m + 1) buf[m - t] = v;
+            } else {  // AM/FM :175-198
+                if (t >= m && t < m + N / 2) buf[t - m] = v;
+                if (t >= m - N / 2 + 1 && t < m) buf[N - m + t] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) pw += __shfl_xor(pw, d, 64);
+    if (lane == 0) a.pwr[(size_t)cp.slot * a.max_batch + f] = pw;
+    if (cp.mode < 2) {  // c2r semantics, see k_demod_idft
+        wave_lds_sync();
+#pragma unroll
+        for (int u = 0; u < (N / 2 + 63) / 64; u++) {
+            const int k = lane + 1 + 64 * u;
+            if (k < N / 2) {
+                const cf v = buf[k];
+                buf[N - k] = make_float2(v.x, -v.y);
+            }
+        }
+        if (lane == 0) {
+            buf[0].y = 0.f;
+            buf[N / 2].y = 0.f;
+        }
+    }
+    wave_lds_sync();
+    idft_stage_fixed<N, R0, 1>(buf, Wn, lane);
+    wave_lds_sync();
+    idft_stage_fixed<N, R1, R0>(buf, Wn, lane);
+    wave_lds_sync();
+    if constexpr (R2 > 1) {
+        idft_stage_fixed<N, R2, R0 * R1>(buf, Wn, lane);
+        wave_lds_sync();
+    }
+    const bool flip = flip_frame(frame_num, cp.m_floor, a.is_real);
+    const float sg = flip ? -1.f : 1.f;
+    cf *yp = a.ypost + ((size_t)cp.slot * a.max_batch + f) * N;
+    // (mode is a scalar: one plain loop per mode.  The single unrolled loop with the three-way
+    // per-lane select inside was miscompiled by this toolchain - the real part of the last,
+    // partial round was read through a stale address register in the complex modes.)
+    if (cp.mode == 0) {
+#pragma unroll
+        for (int u = 0; u < NR; u++) {
+            const int jx = lane + 64 * u;
+            if (jx < N) yp[jx] = make_float2(buf[jx].x * sg, 0.f);
+        }
+    } else if (cp.mode == 1) {
+#pragma unroll
+        for (int u = 0; u < NR; u++) {
+            const int jx = lane + 64 * u;
+            if (jx < N) yp[jx] = make_float2(buf[N - 1 - jx].x * sg, 0.f);  // std::reverse :155
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < NR; u++) {
+            const int jx = lane + 64 * u;
+            if (jx < N) yp[jx] = make_float2(buf[jx].x * sg, buf[jx].y * sg);
+        }
+    }
+}
+
 // one WAVE per (client, frame): no shared memory, no barrier (NaN flag by wave vote);
 // grid = ceil(nact * nframes / 4) work-groups of 256 threads
 __global__ __launch_bounds__(256) void k_demod_ola(DemodArgs a, int nact) {

@@ -197,6 +197,7 @@ struct psdr_ctx {
     size_t idft_lds = 0;
     int4 *d_stage_tab = nullptr;
     int idft_threads = 256;
+    bool idft_generic = false;  // tuning (PSDR_IDFT_GENERIC=1): never the compile-time plans
     bool idft_block = false;  // tuning (PSDR_IDFT_BLOCK=1): force the one-work-group-per-item kernel
     cf *d_Wn = nullptr, *d_ypost = nullptr, *d_gscratch = nullptr, *d_bb_tail = nullptr,
        *d_bb_last = nullptr;
@@ -844,6 +845,7 @@ int build(psdr_ctx *c) {
             if (rc) return rc;
             c->idft_threads = n <= 512 ? 128 : 256;
             c->idft_block = getenv("PSDR_IDFT_BLOCK") != nullptr;
+            c->idft_generic = getenv("PSDR_IDFT_GENERIC") != nullptr;
         }
         const size_t S = (size_t)std::max(1, g.max_clients);
         c->aslots.resize(S);
@@ -1259,7 +1261,20 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     a.slots = (int)c->aslots.size();
     {
         ProfScope ps(c, K_IDFT, c->side);
-        if (c->n <= 512 && !c->idft_block) {
+        const bool fixed_plan = (c->n == 360 || c->n == 720) && !c->idft_block && !c->idft_generic;
+        if (fixed_plan) {
+            // compile-time plans (demod.h): 360 = 8*9*5, 720 = 8*9*10; W items per work-group in
+            // the 15 KiB of LDS an FFT pass leaves free on a CU
+            const unsigned items = (unsigned)nact * (unsigned)nframes;
+            const unsigned W = c->n == 360 ? 4u : 1u;
+            const size_t lds = (size_t)(1 + W) * c->n * sizeof(cf);
+            if (c->n == 360)
+                hipLaunchKernelGGL((k_demod_idft_fixed<360, 8, 9, 5>), dim3((items + W - 1) / W), dim3(64 * W), lds,
+                                   c->side, a, nact);
+            else
+                hipLaunchKernelGGL((k_demod_idft_fixed<720, 8, 9, 10>), dim3((items + W - 1) / W), dim3(64 * W), lds,
+                                   c->side, a, nact);
+        } else if (c->n <= 512 && !c->idft_block) {
             // one wave per (client, frame), no work-group barriers (demod.h)
             const unsigned items = (unsigned)nact * (unsigned)nframes;
             const size_t lds = (size_t)(2 * PSDR_IDFT_WAVES + 1) * c->n * sizeof(cf);
