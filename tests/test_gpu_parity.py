@@ -246,6 +246,23 @@ def test_demod_audio_fft_sizes(n):
     run_demod_case(N, 0, n, clients, nbatches=2, F=2, seed=41)
 
 
+@pytest.mark.parametrize("n,is_real", [(360, 0), (720, 1), (720, 0)])
+def test_demod_fixed_plans_all_modes(n, is_real):
+    """the compile-time-plan inverse DFTs (n = 360: 8*9*5, n = 720: 8*9*10): every mode, odd and
+    fractional mids (frame flips), slices at the spectrum edges, 5-frame batches (the last
+    work-group of a launch is partly empty)."""
+    N = 1 << 16
+    R = N // 2 if is_real else N
+    c = int(tone_bin(N, is_real, 0.13))
+    w3, w5 = n // 4, n // 2 - 3
+    clients = [("USB", c, float(c), c + w3), ("USB", c + 1, c + 1.5, c + 1 + w3), ("LSB", c - w3, float(c), c),
+               ("LSB", c - w3 + 1, c + 1.25, c + 1), ("AM", c - w5, float(c), c + w5),
+               ("AM", c - w5 + 1, c + 1.0, c + 1 + w5), ("FM", c - w5, float(c), c + w5),
+               ("FM", c - w5 + 1, c + 1.75, c + w5), ("USB", 0, 0.0, w3), ("LSB", R - 1 - w3, float(R - 1), R - 1),
+               ("AM", 40, 300.0, 60), ("USB", 200, 200.0, 200 + n), ("AM", c - 20, float(c), c + 31)]
+    run_demod_case(N, is_real, n, clients, nbatches=2, F=5, seed=77 + n + is_real)
+
+
 def test_baseline_cfg1_shape():
     """BASELINE.json configs[0]: 3.2 MSPS IQ u8 (rtl_sdr), 2^16-point FFT, one audio client
     (n = ceil(12000 * 2^16 / 3.2e6 / 4) * 4 = 248) - the reference's own CPU-runnable case,
