@@ -389,8 +389,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=0,
-                    help="frames per step (F); default 64: every launch of the persistent passes costs "
-                         "~20 us of ramp/prologue/tail whatever F is (DESIGN.md, batch-size table)")
+                    help="frames per step (F); default 256: a step of the two persistent passes has ~90 us of "
+                         "fixed cost (ramp, prologue, tail, launch gaps) whatever F is (DESIGN.md, batch-size table)")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ring-mib", type=int, default=512)
@@ -406,7 +406,7 @@ def main():
     if world != args.gpus and world > 1:
         args.gpus = world
     if args.batch <= 0:
-        args.batch = 64
+        args.batch = 256
 
     import torch
     if not torch.cuda.is_available():

@@ -105,6 +105,55 @@ def test_two_phase_launch_is_bit_identical(N, is_real, monkeypatch):
         assert np.array_equal(a[2][ci].view(np.uint32), b[2][ci].view(np.uint32)), f"audio of client {ci}"
 
 
+def test_bench_batch_size_matches_small_batches():
+    """the bench's batch size (256 frames per launch at 2^20 points) gives the same bits as four
+    launches of 64: per-frame CRCs of spectrum and pyramid, and the clients' audio."""
+    import zlib
+    from phantomsdr_amd import AudioClient, Context
+    N, n, nframes = 1 << 20, 360, 256
+    x = synth_stream((nframes + 1) * (N // 2), False, seed=21, fft_size=N)
+    raw = quantize_raw(x, "s16", False)
+    rng = np.random.default_rng(5)
+    clients = []
+    for mode in ["USB", "LSB", "AM", "FM"]:
+        m = int(rng.uniform(0.1 * N, 0.9 * N))
+        l, r = (m, m + 90) if mode == "USB" else (m - 90, m) if mode == "LSB" else (m - 90, m + 90)
+        clients.append((mode, l, float(m) + 0.5, r))
+
+    def run(splits):
+        ctx = Context(N, False, levels_for(N), additional_size=n, audio_fft_size=n, audio_rate=12000,
+                      input_format="s16", max_batch=max(splits), max_clients=len(clients))
+        try:
+            d = ctx.dev_alloc(raw.nbytes)
+            ctx.h2d(d, raw)
+            gcl = []
+            for mode, l, mid, r in clients:
+                g = AudioClient(ctx)
+                g.set_audio_demodulation(mode)
+                g.set_audio_range(l, mid, r)
+                gcl.append(g)
+            hb = ctx.half_frame_bytes()
+            crcs, audio, frame = [], [[] for _ in clients], 0
+            for nf in splits:
+                ctx.process_batch(d, nf, offset_bytes=frame * hb)
+                ctx.demod_batch(frame)
+                for ci, g in enumerate(gcl):
+                    audio[ci].append(g.read_audio(nf)[0].copy())
+                for f in range(0, nf, 5):  # every fifth frame: 8 MiB of spectrum each
+                    crcs.append((zlib.crc32(ctx.read_spectrum(f).tobytes()), zlib.crc32(ctx.read_quantized(f).tobytes())))
+                frame += nf
+            ctx.dev_free(d)
+            return crcs, [np.concatenate(a) for a in audio]
+        finally:
+            ctx.close()
+
+    a = run([256])
+    b = run([60, 60, 60, 60, 16])  # multiples of 5 keep the sampled frames aligned
+    assert a[0] == b[0]
+    for ci in range(len(clients)):
+        assert np.array_equal(a[1][ci].view(np.uint32), b[1][ci].view(np.uint32)), f"audio of client {ci}"
+
+
 def test_parseval_linearity_and_tone_bin_at_2_20():
     from phantomsdr_amd import Context
     N = 1 << 20
