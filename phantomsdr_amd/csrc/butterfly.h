@@ -38,6 +38,22 @@ __device__ __forceinline__ cf cmul(cf a, cf b) {
         : "v"(to_v2f(a)), "v"(to_v2f(b)), "v"(t));
     return from_v2f(r);
 }
+// two independent products, interleaved: mul1, mul2, fma1, fma2.  A v_pk_fma_f32 right behind
+// the v_pk_mul_f32 it depends on costs a wait state (the compiler puts an s_nop between two asm
+// statements; ~8 % of pass 2's instructions were such nops); with the other product's
+// instruction in between there is none.  (early clobbers: outputs are written while inputs are
+// still to be read)
+__device__ __forceinline__ void cmul_pair(cf &r1, cf a1, cf b1, cf &r2, cf a2, cf b2) {
+    v2f t1, t2, o1, o2;
+    asm("v_pk_mul_f32 %0, %4, %5 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %6, %7 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+        "v_pk_fma_f32 %2, %4, %5, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %3, %6, %7, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]"
+        : "=&v"(t1), "=&v"(t2), "=&v"(o1), "=&v"(o2)
+        : "v"(to_v2f(a1)), "v"(to_v2f(b1)), "v"(to_v2f(a2)), "v"(to_v2f(b2)));
+    r1 = from_v2f(o1);
+    r2 = from_v2f(o2);
+}
 __device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
 // a + (-i)*d = (a.x + d.y, a.y - d.x)
@@ -82,7 +98,11 @@ __device__ __forceinline__ cf mul_w8_3(cf a) {  // (-1 - i)/sqrt2 * a = (-i)(1 -
 }
 
 // the same operations on a column couple; w is shared by the two columns
-__device__ __forceinline__ c2 cmul(c2 v, cf w) { return c2{cmul(v.a, w), cmul(v.b, w)}; }
+__device__ __forceinline__ c2 cmul(c2 v, cf w) {
+    c2 r;
+    cmul_pair(r.a, v.a, w, r.b, v.b, w);
+    return r;
+}
 __device__ __forceinline__ c2 cadd(c2 u, c2 v) { return c2{cadd(u.a, v.a), cadd(u.b, v.b)}; }
 __device__ __forceinline__ c2 csub(c2 u, c2 v) { return c2{csub(u.a, v.a), csub(u.b, v.b)}; }
 __device__ __forceinline__ c2 add_mi(c2 u, c2 v) { return c2{add_mi(u.a, v.a), add_mi(u.b, v.b)}; }

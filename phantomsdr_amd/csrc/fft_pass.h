@@ -380,6 +380,10 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
     // to it, so a per-tile twiddle look-up costs two LDS reads, no L2 round trip.
     cf *ldsTB = Wl + L;
     auto tw = [&](unsigned e) -> cf { return cmul(Wl[e >> a.log2M2], ldsTB[e & (unsigned)(M2 - 1)]); };
+    auto tw2 = [&](unsigned eA, unsigned eB, cf &rA, cf &rB) {  // two look-ups, products interleaved
+        cmul_pair(rA, Wl[eA >> a.log2M2], ldsTB[eA & (unsigned)(M2 - 1)], rB, Wl[eB >> a.log2M2],
+                  ldsTB[eB & (unsigned)(M2 - 1)]);
+    };
 
     // chunk i*NT + tid of the image = row (i*NT + tid)/LPR, byte (tid % LPR)*16 of that row.
     // global: frame f starts at complex sample f*M/2; row r is M2 samples further.
@@ -465,7 +469,8 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
         const unsigned nA = tl * T + 2u * (unsigned)p, nB = nA + 1u;  // n2 of the two columns
         c2 u[16];
         {
-            const cf wbA = tw(nA), wbB = tw(nB);  // W_M^{n2}: window angle of the columns
+            cf wbA, wbB;  // W_M^{n2}: window angle of the columns
+            tw2(nA, nB, wbA, wbB);
             if (a.is_real) {
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
@@ -527,37 +532,44 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
             // base * stepB^b * stepS^s (three table look-ups per column); client order
             // carries (-1)^{n2}: nothing for the even column, a sign for the odd one
             [&]() {
-                tbA[0] = tw(nA * (unsigned)i0);
-                tbB[0] = tw(nB * (unsigned)i0);
+                tw2(nA * (unsigned)i0, nB * (unsigned)i0, tbA[0], tbB[0]);
                 if (a.rot) tbB[0] = make_float2(-tbB[0].x, -tbB[0].y);
-                const cf sbA = tw(nA * (unsigned)L16), sbB = tw(nB * (unsigned)L16);
-                const cf ssA = tw(nA * (unsigned)PL), ssB = tw(nB * (unsigned)PL);
+                cf sbA, sbB, ssA, ssB;
+                tw2(nA * (unsigned)L16, nB * (unsigned)L16, sbA, sbB);
+                tw2(nA * (unsigned)PL, nB * (unsigned)PL, ssA, ssB);
 #pragma unroll
                 for (int b = 1; b < NBL; b++) {
-                    tbA[b] = cmul(tbA[b - 1], sbA);
-                    tbB[b] = cmul(tbB[b - 1], sbB);
+                    cmul_pair(tbA[b], tbA[b - 1], sbA, tbB[b], tbB[b - 1], sbB);
                 }
                 tsA[0] = tsB[0] = make_float2(1.f, 0.f);
 #pragma unroll
                 for (int q = 1; q < RL; q++) {
-                    tsA[q] = q == 1 ? ssA : cmul(tsA[q - 1], ssA);
-                    tsB[q] = q == 1 ? ssB : cmul(tsB[q - 1], ssB);
+                    if (q == 1) {
+                        tsA[q] = ssA;
+                        tsB[q] = ssB;
+                    } else {
+                        cmul_pair(tsA[q], tsA[q - 1], ssA, tsB[q], tsB[q - 1], ssB);
+                    }
                 }
                 // output (b=0,s=0) of the thread with i0 = 0 is bin k1 = 0: in client order
                 // it goes to row M1-1 with W_M^{n2*M1}
                 w00A = tbA[0];
                 w00B = tbB[0];
                 if (a.rot && i0 == 0) {
-                    w00A = tw(nA * (unsigned)L);
-                    w00B = tw(nB * (unsigned)L);
+                    tw2(nA * (unsigned)L, nB * (unsigned)L, w00A, w00B);
                     w00B = make_float2(-w00B.x, -w00B.y);
                 }
             },
             [&](int b, int sidx, int k1, c2 x) {
-                const cf wA = (sidx == 0) ? (b == 0 ? w00A : tbA[b]) : cmul(tbA[b], tsA[sidx]);
-                const cf wB = (sidx == 0) ? (b == 0 ? w00B : tbB[b]) : cmul(tbB[b], tsB[sidx]);
+                cf wA, wB, yA, yB;
+                if (sidx == 0) {
+                    wA = b == 0 ? w00A : tbA[b];
+                    wB = b == 0 ? w00B : tbB[b];
+                } else {
+                    cmul_pair(wA, tbA[b], tsA[sidx], wB, tbB[b], tsB[sidx]);
+                }
                 const int c1 = a.rot ? ((k1 - 1) & (L - 1)) : k1;
-                const cf yA = cmul(x.a, wA), yB = cmul(x.b, wB);
+                cmul_pair(yA, x.a, wA, yB, x.b, wB);
                 if constexpr (COOP) {
                     const u32x4 v = {__float_as_uint(yA.x), __float_as_uint(yA.y), __float_as_uint(yB.x),
                                      __float_as_uint(yB.y)};

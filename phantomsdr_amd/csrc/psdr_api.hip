@@ -151,6 +151,7 @@ struct psdr_ctx {
     unsigned *d_tickets[2] = {nullptr, nullptr};
     unsigned ticket_pos[2] = {0, 0};
     bool static_tiles = false, no_p1_stream = true;  // tuning knobs (PSDR_STATIC_TILES, PSDR_P1_STREAM)
+    unsigned p1_grid = 0, p2_grid = 0;  // PSDR_P1_GRID / PSDR_P2_GRID: work-groups of each pass (0: all CUs)
     bool input_on_main = false;  // level-1 H2D staging was enqueued on the main stream
     hipEvent_t ev_in = nullptr, ev_p1[2] = {nullptr, nullptr}, ev_p2[2] = {nullptr, nullptr};
     hipEvent_t ev_fft_done = nullptr, ev_side_done = nullptr;
@@ -331,7 +332,8 @@ int launch_pass1_t(psdr_ctx *c, const Pass1Args &a, unsigned blocks) {
     }
     ProfScope ps(c, K_PASS1, c->p1);
     // persistent: as many work-groups per CU as their LDS admits (a 128 KiB tile: one)
-    const unsigned grid = persistent_grid(c, blocks, lds);
+    unsigned grid = persistent_grid(c, blocks, lds);
+    if (c->p1_grid && c->p1_grid < grid) grid = c->p1_grid;
     hipLaunchKernelGGL((k_fft_pass1<L, T, SB>), dim3(grid), dim3(L * T / 32), lds, c->p1, a);
     HIPCHK(hipGetLastError());
     return PSDR_OK;
@@ -346,7 +348,8 @@ int launch_pass2_t(psdr_ctx *c, const Pass2Args &a, unsigned blocks) {
         attr_set = true;
     }
     ProfScope ps(c, K_PASS2);
-    const unsigned grid = persistent_grid(c, blocks, lds);
+    unsigned grid = persistent_grid(c, blocks, lds);
+    if (c->p2_grid && c->p2_grid < grid) grid = c->p2_grid;
     hipLaunchKernelGGL((k_fft_pass2<L, T, FUSED, TWC>), dim3(grid), dim3(L * T / 32), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return PSDR_OK;
@@ -699,6 +702,8 @@ int build(psdr_ctx *c) {
     // both batches' intermediates fit the 256 MiB MALL together (measured: F=16 2^20-point frames
     // lose 12 %, F>=32 gain nothing), so it is opt-in
     c->no_p1_stream = getenv("PSDR_P1_STREAM") == nullptr;
+    if (const char *e = getenv("PSDR_P1_GRID")) c->p1_grid = (unsigned)atoi(e) & ~7u;
+    if (const char *e = getenv("PSDR_P2_GRID")) c->p2_grid = (unsigned)atoi(e) & ~7u;
     c->p1 = c->no_p1_stream ? c->own_stream : c->own_p1;
     HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {
