@@ -323,16 +323,15 @@ template <int SB, bool SCALED>
 __device__ __forceinline__ c2 image_to_c2(const unsigned char *img, int elem, int fmt) {
     if constexpr (SB == 2) {
         unsigned w = reinterpret_cast<const unsigned *>(img)[elem >> 1];
-        if (fmt == 0) w ^= 0x80808080u;
+        w ^= fmt == 0 ? 0x80808080u : 0u;  // (a scalar select, then one xor: no per-lane select)
         const float k = SCALED ? 1.0f / 128.0f : 1.0f;
         return c2{make_float2((float)(int8_t)(w & 0xFFu) * k, (float)(int8_t)((w >> 8) & 0xFFu) * k),
                   make_float2((float)(int8_t)((w >> 16) & 0xFFu) * k, (float)(int8_t)(w >> 24) * k)};
     } else if constexpr (SB == 4) {
         uint2 w = reinterpret_cast<const uint2 *>(img)[elem >> 1];
-        if (fmt == 2) {
-            w.x ^= 0x80008000u;
-            w.y ^= 0x80008000u;
-        }
+        const unsigned flip = fmt == 2 ? 0x80008000u : 0u;
+        w.x ^= flip;
+        w.y ^= flip;
         const float k = SCALED ? 1.0f / 32768.0f : 1.0f;
         return c2{make_float2((float)(int16_t)(w.x & 0xFFFFu) * k, (float)(int16_t)(w.x >> 16) * k),
                   make_float2((float)(int16_t)(w.y & 0xFFFFu) * k, (float)(int16_t)(w.y >> 16) * k)};
