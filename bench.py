@@ -393,6 +393,9 @@ def main():
                          "fixed cost (ramp, prologue, tail, launch gaps) whatever F is (DESIGN.md, batch-size table)")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-post-chain", action="store_true",
+                    help="skip the separate post-demodulation-chain measurement (used for the rocprofv3 kernel stats: "
+                         "its passes overlap the long chain kernels and would skew the per-kernel averages)")
     ap.add_argument("--ring-mib", type=int, default=512)
     ap.add_argument("--shard", default="time", choices=["time", "clients"],
                     help="N > 1: shard the stream (default) or the clients (spectrum broadcast)")
@@ -474,7 +477,7 @@ def main():
     # SURVEY 8f-2 (widened row): the optional post-demodulation chain (DC blocker + AGC + int16),
     # measured separately - it is NOT part of `value` (the metric's clients end at float audio)
     post = None
-    if clients:
+    if clients and not args.no_post_chain:
         try:
             eng.ctx.set_post_chain(True)
             psteps = 6

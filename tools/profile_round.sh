@@ -8,18 +8,18 @@ TAG=${1:-r01}; WL=${2:-cfg2}; shift; shift
 R=$(pwd); O=$R/gpurun_out/$TAG; mkdir -p $O/profiles
 python bench.py --workload $WL "$@" > $O/profiles/${TAG}_${WL}_bench.json 2> $O/bench.err
 cd /tmp; export TMPDIR=/tmp
-B="python $R/bench.py --workload $WL --steps 30 --warmup 10 --no-cpu-baseline $*"
+B="python $R/bench.py --workload $WL --steps 30 --warmup 10 --no-cpu-baseline --no-post-chain $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- $B > $O/stats.log 2>&1
 # counter passes: the torch-free driver of the same library calls (rocprofv3's counter
 # collection crashes on torch's own ring-generation kernels), same N / F / clients as the bench
 case $WL in
-  cfg3) K="python $R/tools/kernel_times.py --fft 21 --real --clients 64 --batch 64 --steps 6";;
-  *)    K="python $R/tools/kernel_times.py --fft 20 --clients 16 --batch 64 --steps 6";;
+  cfg3) K="python $R/tools/kernel_times.py --fft 21 --real --clients 64 --batch 256 --steps 4";;
+  *)    K="python $R/tools/kernel_times.py --fft 20 --clients 16 --batch 256 --steps 4";;
 esac
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- $K > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- $K > $O/pmc_write.log 2>&1
 cd $R
 cp $O/stats/p_kernel_stats.csv $O/profiles/${TAG}_${WL}_kernel_stats.csv 2>/dev/null
-python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $WL $O/profiles/${TAG}_${WL}_pmc.json $O/profiles/traffic.json 64
+python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $WL $O/profiles/${TAG}_${WL}_pmc.json $O/profiles/traffic.json 256
 cat $O/profiles/${TAG}_${WL}_bench.json
 head -8 $O/profiles/${TAG}_${WL}_kernel_stats.csv | cut -c1-200
