@@ -561,13 +561,13 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
             },
             [&](int b, int sidx, int k1, c2 x) {
                 cf wA, wB, yA, yB;
+                const int c1 = a.rot ? ((k1 - 1) & (L - 1)) : k1;
                 if (sidx == 0) {
                     wA = b == 0 ? w00A : tbA[b];
                     wB = b == 0 ? w00B : tbB[b];
                 } else {
                     cmul_pair(wA, tbA[b], tsA[sidx], wB, tbB[b], tsB[sidx]);
                 }
-                const int c1 = a.rot ? ((k1 - 1) & (L - 1)) : k1;
                 cmul_pair(yA, x.a, wA, yB, x.b, wB);
                 if constexpr (COOP) {
                     const u32x4 v = {__float_as_uint(yA.x), __float_as_uint(yA.y), __float_as_uint(yB.x),
