@@ -125,11 +125,16 @@ __global__ __launch_bounds__(256) void k_untangle_real(UntangleArgs a) {
         const size_t k0 = 4 * j;
         const float4 f0 = reinterpret_cast<const float4 *>(Zf)[2 * j];      // Z[k0], Z[k0+1]
         const float4 f1 = reinterpret_cast<const float4 *>(Zf)[2 * j + 1];  // Z[k0+2], Z[k0+3]
-        const cf zx = Zf[k0 + 4];                                            // k0+4 <= M/2
         const size_t mb = (M - k0 - 4) / 2;
         const float4 g0 = reinterpret_cast<const float4 *>(Zf)[mb];      // Z[M-k0-4], Z[M-k0-3]
         const float4 g1 = reinterpret_cast<const float4 *>(Zf)[mb + 1];  // Z[M-k0-2], Z[M-k0-1]
-        const cf m0 = Zf[(M - k0) & (M - 1)];
+        // Z[k0+4] is the next lane's Z[k0] and Z[M-k0] the previous lane's Z[M-k0'-4]: two lane
+        // shifts instead of two more 8-byte loads per lane (only the edge lanes load)
+        const int lane = threadIdx.x & 63;
+        cf zx = make_float2(__shfl_down(f0.x, 1, 64), __shfl_down(f0.y, 1, 64));
+        cf m0 = make_float2(__shfl_up(g0.x, 1, 64), __shfl_up(g0.y, 1, 64));
+        if (lane == 63 || j + 1 >= M / 8) zx = Zf[k0 + 4];  // k0+4 <= M/2 (the next lane may be past the end)
+        if (lane == 0) m0 = Zf[(M - k0) & (M - 1)];
         // fwd[i] = Z[k0+i], mir[i] = Z[M-k0-i], i = 0..4
         const cf fwd[5] = {make_float2(f0.x, f0.y), make_float2(f0.z, f0.w), make_float2(f1.x, f1.y),
                            make_float2(f1.z, f1.w), zx};
