@@ -339,6 +339,25 @@ __device__ __forceinline__ c2 image_to_c2(const unsigned char *img, int elem, in
         return unpack_c2(reinterpret_cast<const float4 *>(img)[elem >> 1]);
     }
 }
+// the same conversion from the raw words of one (row, couple) held in registers
+template <int SB, bool SCALED>
+__device__ __forceinline__ c2 words_to_c2(const unsigned (&w)[SB / 2], int fmt) {
+    if constexpr (SB == 2) {
+        const unsigned v = w[0] ^ (fmt == 0 ? 0x80808080u : 0u);
+        const float k = SCALED ? 1.0f / 128.0f : 1.0f;
+        return c2{make_float2((float)(int8_t)(v & 0xFFu) * k, (float)(int8_t)((v >> 8) & 0xFFu) * k),
+                  make_float2((float)(int8_t)((v >> 16) & 0xFFu) * k, (float)(int8_t)(v >> 24) * k)};
+    } else if constexpr (SB == 4) {
+        const unsigned flip = fmt == 2 ? 0x80008000u : 0u;
+        const unsigned x = w[0] ^ flip, y = w[1] ^ flip;
+        const float k = SCALED ? 1.0f / 32768.0f : 1.0f;
+        return c2{make_float2((float)(int16_t)(x & 0xFFFFu) * k, (float)(int16_t)(x >> 16) * k),
+                  make_float2((float)(int16_t)(y & 0xFFFFu) * k, (float)(int16_t)(y >> 16) * k)};
+    } else {
+        return c2{make_float2(__uint_as_float(w[0]), __uint_as_float(w[1])),
+                  make_float2(__uint_as_float(w[2]), __uint_as_float(w[3]))};
+    }
+}
 // the integer formats' 2^-(bits-1) (a power of two: folding it into the window weight
 // instead of the sample changes no bit of the product)
 template <int SB>
@@ -359,10 +378,13 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
     constexpr int NT = (L / 16) * H;
     constexpr int L16 = L / 16;
     constexpr int RL = LastStage<L>::R, PL = LastStage<L>::Pp, NBL = 16 / RL;
-    constexpr int ROWB = T * SB;                            // bytes of one image row
-    constexpr int LPR = ROWB / 16;                          // 16-byte chunks (lanes) per row
-    constexpr int NCHK = (L * T * SB) / (16 * NT);          // chunks per thread (= 2*SB)
-    static_assert(ROWB >= 16 && (L * T * SB) % (16 * NT) == 0 && NT % LPR == 0, "tile shape");
+    // The raw samples go straight from HBM into the registers of the thread that converts them:
+    // one load per row of the thread (16 rows x one couple = 2*SB bytes each: 4 / 8 / 16), eight
+    // lanes = one 64-byte (s16) row segment, eight rows per wave instruction.  (Round 1 staged a
+    // linear image of the tile through LDS with 16-byte loads: 8 more ds_write_b128, 16 more
+    // ds_read_b64 and two more barriers per tile for the same lines touched.)
+    constexpr int WPL = SB / 2;                             // 32-bit words per load
+    constexpr int NCHK = 16;                                // loads per thread and tile
     constexpr int NTICK = 2 * (Plan<L>::NS - 1);            // ticks that carry loads
     constexpr int EARLY = NCHK / 4;                         // loads issued right after the image write
     constexpr int LPT = (NCHK - EARLY + NTICK - 1) / NTICK;
@@ -388,10 +410,10 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
     // global: frame f starts at complex sample f*M/2; row r is M2 samples further.
     const unsigned gsb = fmt == 5 ? 16u : (unsigned)SB;  // bytes per complex sample in HBM
     const size_t g_row = (size_t)M2 * gsb;
-    const size_t g_step = (size_t)(NT / LPR) * g_row;  // between a thread's consecutive chunks
-    const size_t g_lane = (size_t)(tid / LPR) * g_row + (size_t)(tid % LPR) * (16 / SB) * gsb;
+    const size_t g_step = (size_t)L16 * g_row;  // between a thread's consecutive rows
+    const size_t g_lane = (size_t)i0_ * g_row + (size_t)(2 * p_) * gsb;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // plain vector: SROA keeps it in VGPRs
-    u32x4 rq[NCHK];
+    unsigned rq[NCHK][WPL];
     const unsigned char *nxt = nullptr;
     auto point_at = [&](unsigned sidx) {
         const unsigned slot = xcd_slot(sidx, total);
@@ -402,13 +424,23 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
     auto issue = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const unsigned char *q = nxt + (size_t)i * g_step;
-        if (SB == 8 && fmt == 5) {  // f64: two samples = 32 bytes, narrowed to f32 here
-            const double2 s0 = reinterpret_cast<const double2 *>(q)[0];
-            const double2 s1 = reinterpret_cast<const double2 *>(q)[1];
-            rq[i] = u32x4{__float_as_uint((float)s0.x), __float_as_uint((float)s0.y),
-                          __float_as_uint((float)s1.x), __float_as_uint((float)s1.y)};
+        if constexpr (SB == 8) {
+            if (fmt == 5) {  // f64: two samples = 32 bytes, narrowed to f32 here
+                const double2 s0 = reinterpret_cast<const double2 *>(q)[0];
+                const double2 s1 = reinterpret_cast<const double2 *>(q)[1];
+                rq[i][0] = __float_as_uint((float)s0.x);
+                rq[i][1] = __float_as_uint((float)s0.y);
+                rq[i][2] = __float_as_uint((float)s1.x);
+                rq[i][3] = __float_as_uint((float)s1.y);
+            } else {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(q);
+                rq[i][0] = v.x, rq[i][1] = v.y, rq[i][2] = v.z, rq[i][3] = v.w;
+            }
+        } else if constexpr (SB == 4) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(q);
+            rq[i][0] = v.x, rq[i][1] = v.y;
         } else {
-            rq[i] = *reinterpret_cast<const u32x4 *>(q);
+            rq[i][0] = *reinterpret_cast<const unsigned *>(q);
         }
     };
     __shared__ unsigned s_next[2];
@@ -449,20 +481,12 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
         int i0 = i0_, p = p_, tidx = tid;
         asm volatile("" : "+v"(i0), "+v"(p), "+v"(tidx));
 
-        // ---- raw image into LDS (linear, 16 bytes per lane)
-        static_for<0, NCHK>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            reinterpret_cast<u32x4 *>(smem)[i * NT + tidx] = rq[i];
-        });
-        PSDR_SCHED_FENCE();
-        if (more) static_for<0, EARLY>(issue);
-        PSDR_SCHED_FENCE();
+        (void)tidx;
         PSDR_TRACE(a.trace, it, 1);
-        __syncthreads();
         PSDR_TRACE(a.trace, it, 2);
 
-        // ---- stage-0 input: convert (src/samplereader.cpp:29-40) + Hann window; the image
-        // shares the tile's LDS, so every thread reads before anyone writes.
+        // ---- stage-0 input: convert (src/samplereader.cpp:29-40) + Hann window, from the
+        // registers the prefetch left the raw words in.
         // periodic Hann (src/utils/dsp.cpp:6-11) from the twiddle tables:
         // exp(-i*2*pi*n/M) = W_M1^{n1} * W_M^{n2}
         const unsigned nA = tl * T + 2u * (unsigned)p, nB = nA + 1u;  // n2 of the two columns
@@ -474,7 +498,7 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
                     const int row = i0 + e * L16;
-                    u[e] = image_to_c2<SB, true>(smem, row * T + 2 * p, fmt);
+                    u[e] = words_to_c2<SB, true>(rq[e], fmt);
                     const cf wl = Wl[row];
                     const cf zA = cmul(wl, wbA), zB = cmul(wl, wbB);
                     u[e].a.x *= fmaf(-0.5f, zA.x, 0.5f);
@@ -490,7 +514,7 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
                     const int row = i0 + e * L16;
-                    const c2 x = image_to_c2<SB, false>(smem, row * T + 2 * p, fmt);
+                    const c2 x = words_to_c2<SB, false>(rq[e], fmt);
                     const cf wl = Wl[row];
                     v2f t, t2;
                     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t) : "v"(to_v2f(wl)), "v"(wy));
@@ -503,6 +527,9 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
                 }
             }
         }
+        PSDR_SCHED_FENCE();
+        if (more) static_for<0, EARLY>(issue);  // the raw registers are free again
+        PSDR_SCHED_FENCE();
         if constexpr (COOP) {
             // drain point for the PREVIOUS tile's Y stores: only the EARLY loads of the next
             // tile are younger (wave 0 also has the ticket atomic in flight: it waits for all)
@@ -512,10 +539,9 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
                 else
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EARLY) : "memory");
             }
+            __syncthreads();
         }
-        __syncthreads();
         PSDR_TRACE(a.trace, it, 3);
-        const unsigned s2 = s_next[it & 1];
         if constexpr (COOP) {
             if (have_prev && tid == 0) {
                 __hip_atomic_fetch_add(co.cnt1 + prev_f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -596,6 +622,8 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
             [&](int k) { PSDR_TRACE(a.trace, it, k); });
         PSDR_TRACE(a.trace, it, 10);
         PSDR_WGTRACE(a.trace, 2 + it);
+        // (published by thread 0 before the stages' barriers)
+        const unsigned s2 = s_next[it & 1];
         s = snext;
         snext = s2;
     }
