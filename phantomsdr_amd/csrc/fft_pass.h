@@ -316,30 +316,9 @@ struct Pass1Args {
     unsigned long long *trace;
 };
 
-// two adjacent complex samples (columns 2p, 2p+1 of one row) of the LDS raw image -> c2
+// the raw words of two adjacent complex samples (columns 2p, 2p+1 of one row) -> c2
 // (src/samplereader.cpp:29-40): unsigned formats flip the MSB, integers are divided by
-// 2^(bits-1) (exact: multiply by the reciprocal).  `elem` is the even sample's index.
-template <int SB, bool SCALED>
-__device__ __forceinline__ c2 image_to_c2(const unsigned char *img, int elem, int fmt) {
-    if constexpr (SB == 2) {
-        unsigned w = reinterpret_cast<const unsigned *>(img)[elem >> 1];
-        w ^= fmt == 0 ? 0x80808080u : 0u;  // (a scalar select, then one xor: no per-lane select)
-        const float k = SCALED ? 1.0f / 128.0f : 1.0f;
-        return c2{make_float2((float)(int8_t)(w & 0xFFu) * k, (float)(int8_t)((w >> 8) & 0xFFu) * k),
-                  make_float2((float)(int8_t)((w >> 16) & 0xFFu) * k, (float)(int8_t)(w >> 24) * k)};
-    } else if constexpr (SB == 4) {
-        uint2 w = reinterpret_cast<const uint2 *>(img)[elem >> 1];
-        const unsigned flip = fmt == 2 ? 0x80008000u : 0u;
-        w.x ^= flip;
-        w.y ^= flip;
-        const float k = SCALED ? 1.0f / 32768.0f : 1.0f;
-        return c2{make_float2((float)(int16_t)(w.x & 0xFFFFu) * k, (float)(int16_t)(w.x >> 16) * k),
-                  make_float2((float)(int16_t)(w.y & 0xFFFFu) * k, (float)(int16_t)(w.y >> 16) * k)};
-    } else {
-        return unpack_c2(reinterpret_cast<const float4 *>(img)[elem >> 1]);
-    }
-}
-// the same conversion from the raw words of one (row, couple) held in registers
+// 2^(bits-1) (exact: multiply by the reciprocal).
 template <int SB, bool SCALED>
 __device__ __forceinline__ c2 words_to_c2(const unsigned (&w)[SB / 2], int fmt) {
     if constexpr (SB == 2) {
