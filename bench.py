@@ -271,8 +271,12 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     time_mode = args.shard == "time"
     wl = WORKLOADS[args.workload or ("cfg2" if time_mode else "cfg4")]
-    F, N = args.batch, wl["fft_size"]
+    N = wl["fft_size"]
     warm = TimeShardedRunner.WARMUP if time_mode else 0
+    # time mode: a launch carries --batch frames INCLUDING the two warm-up frames, so its tile
+    # count stays a multiple of the work-group count (258 frames would leave half the
+    # work-groups one tile short: +20 us of tail per step); F = the NEW frames per step
+    F = args.batch - warm
     per_gpu = wl["audio"]
     eng = SpectrumEngine(wl["sps"], N, wl["is_real"], input_format=wl["fmt"], max_batch=F + warm,
                          max_clients=max(per_gpu, 1), max_waterfall_clients=max(wl["waterfall"], 1),
