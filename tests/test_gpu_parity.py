@@ -263,6 +263,22 @@ def test_demod_fixed_plans_all_modes(n, is_real):
     run_demod_case(N, is_real, n, clients, nbatches=2, F=5, seed=77 + n + is_real)
 
 
+def test_demod_many_clients():
+    """257 clients (mixed modes, random slices) x 3-frame batches: the demodulation kernels'
+    grids are ragged in every dimension (items per work-group, clients per wave in the post
+    chain's layout); every client of every frame against the oracle."""
+    N, n = 1 << 14, 360
+    rng = np.random.default_rng(123)
+    clients = []
+    for i in range(257):
+        mode = ("USB", "LSB", "AM", "FM")[i % 4]
+        m = int(rng.integers(200, N - 200))
+        w = int(rng.integers(10, n // 2 - 2))
+        l, r = (m, m + w) if mode == "USB" else (m - w, m) if mode == "LSB" else (m - w, m + w)
+        clients.append((mode, l, m + float(rng.integers(0, 4)) * 0.25, r))
+    run_demod_case(N, 0, n, clients, nbatches=2, F=3, seed=5)
+
+
 def test_baseline_cfg1_shape():
     """BASELINE.json configs[0]: 3.2 MSPS IQ u8 (rtl_sdr), 2^16-point FFT, one audio client
     (n = ceil(12000 * 2^16 / 3.2e6 / 4) * 4 = 248) - the reference's own CPU-runnable case,
