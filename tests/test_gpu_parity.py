@@ -412,6 +412,46 @@ def test_post_chain_bit_exact():
         ctx.close()
 
 
+def test_post_chain_many_clients():
+    """70 clients (more than the 64 lanes of one wave of the chain's client-per-lane kernels),
+    n = 360 (h = 180 is not a multiple of the kernels' 32-sample blocks), three batches."""
+    from phantomsdr_amd import AudioClient, Context
+    N, n, F, nb = 1 << 14, 360, 6, 3
+    x = synth_stream((nb * F + 1) * (N // 2), False, seed=78, fft_size=N)
+    raw = quantize_raw(x, "s16", False)
+    ctx = Context(N, False, levels_for(N), additional_size=n, audio_fft_size=n, audio_rate=12000,
+                  input_format="s16", max_batch=F, max_clients=70)
+    try:
+        ctx.set_post_chain(True)
+        d = ctx.dev_alloc(raw.nbytes)
+        ctx.h2d(d, raw)
+        rng = np.random.default_rng(9)
+        gcl, chains = [], []
+        for i in range(70):
+            mode = ("USB", "LSB", "AM", "FM")[i % 4]
+            m = int(rng.integers(300, N - 300))
+            l, r = (m, m + 100) if mode == "USB" else (m - 100, m) if mode == "LSB" else (m - 100, m + 100)
+            g = AudioClient(ctx)
+            g.set_audio_demodulation(mode)
+            g.set_audio_range(l, float(m), r)
+            gcl.append(g)
+            chains.append(O.PostChain(12000))
+        hb = ctx.half_frame_bytes()
+        for b in range(nb):
+            ctx.process_batch(d, F, offset_bytes=b * F * hb)
+            ctx.demod_batch(b * F)
+            for ci, (g, ch) in enumerate(zip(gcl, chains)):
+                audio, _, nan = g.read_audio(F)
+                pcm = g.read_pcm(F)
+                assert not nan.any()
+                for f in range(F):
+                    want = ch.process(audio[f])
+                    assert np.array_equal(pcm[f], want), f"client {ci} batch {b} frame {f}"
+        ctx.dev_free(d)
+    finally:
+        ctx.close()
+
+
 def test_post_chain_skips_nan_frames():
     """A frame whose audio contains a NaN is dropped by the reference before the chain
     (src/signal.cpp:266-271): the chain's state must advance only over the surviving frames."""
