@@ -331,6 +331,45 @@ def test_waterfall_batch():
         ctx.close()
 
 
+@pytest.mark.parametrize("is_real", [0, 1])
+def test_waterfall_many_clients(is_real):
+    """64 waterfall clients (BASELINE.json configs[4]: zoomed waterfalls) at random levels and
+    ranges, IQ (tile-major records for the low levels) and real input (level-major buffer): the
+    gathered rows equal the corresponding slices of the frame's int8 pyramid."""
+    from phantomsdr_amd import Context, WaterfallClient
+    N, F = 1 << 16, 5
+    R = N // 2 if is_real else N
+    levels = levels_for(R)
+    x = synth_stream((F + 1) * (N // 2), bool(is_real), seed=6, fft_size=N)
+    raw = quantize_raw(x, "s16", bool(is_real))
+    ctx = Context(N, is_real, levels, input_format="s16", max_batch=F, max_waterfall_clients=64, skip_num=1)
+    try:
+        d = ctx.dev_alloc(raw.nbytes)
+        ctx.h2d(d, raw)
+        rng = np.random.default_rng(31)
+        ws = []
+        for i in range(64):
+            w = WaterfallClient(ctx)
+            lv = int(rng.integers(0, levels))
+            span = R >> lv
+            width = int(rng.integers(1, min(span, 3000) + 1))
+            l = int(rng.integers(0, span - width + 1))
+            w.set_waterfall_range(lv, l, l + width)
+            ws.append(w)
+        ctx.process_batch(d, F)
+        ctx.waterfall_batch(0)
+        qs = [ctx.read_quantized(f) for f in range(F)]
+        for w in ws:
+            got, label = w.read_waterfall()
+            assert got.shape == (F, w.r - w.l)
+            assert label == (w.l << w.level, w.r << w.level)
+            for f in range(F):
+                assert np.array_equal(got[f], ctx.quantized_level(qs[f], w.level)[w.l:w.r]), (w.level, w.l, w.r, f)
+        ctx.dev_free(d)
+    finally:
+        ctx.close()
+
+
 def test_error_paths():
     from phantomsdr_amd import AudioClient, Context, PsdrError
     with pytest.raises(PsdrError):
