@@ -4,11 +4,27 @@
  *   gcc -Iinclude examples/level1_demo.c -Lphantomsdr_amd -lpsdr_hip -Wl,-rpath,$PWD/phantomsdr_amd */
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "psdr.h"
 
-int main(void) {
+/* optional argv[1] = directory: the input half-frames and, per frame, the spectrum and the int8
+ * pyramid are dumped there so a test can compare them with the CPU oracle */
+static void dump(const char *dir, const char *name, int f, const void *p, size_t bytes) {
+    char path[1024];
+    if (!dir) return;
+    snprintf(path, sizeof path, "%s/%s%d.bin", dir, name, f);
+    FILE *fp = fopen(path, "wb");
+    if (!fp || fwrite(p, 1, bytes, fp) != bytes) {
+        fprintf(stderr, "cannot write %s\n", path);
+        exit(5);
+    }
+    fclose(fp);
+}
+
+int main(int argc, char **argv) {
+    const char *dir = argc > 1 ? argv[1] : NULL;
     psdr_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.struct_size = sizeof cfg;
@@ -37,6 +53,7 @@ int main(void) {
             buf[h][2 * i] = (float)(0.01 * cos(ph));
             buf[h][2 * i + 1] = (float)(0.01 * sin(ph));
         }
+    for (int h = 0; h < 3; h++) dump(dir, "half", h, buf[h], N * sizeof(float));
     for (int f = 0; f < 2; f++) {
         psdr_load_complex_input(ctx, buf[f], buf[f + 1]);
         if (psdr_execute(ctx) != PSDR_OK) {
@@ -47,6 +64,12 @@ int main(void) {
         int8_t *q;
         psdr_get_output_buffer(ctx, &X);
         psdr_get_quantized_buffer(ctx, &q);
+        dump(dir, "spec", f, X, (N + (size_t)cfg.additional_size) * 2 * sizeof(float));
+        {
+            size_t qlen = 0;
+            for (int i = 0; i < cfg.downsample_levels; i++) qlen += N >> i;
+            dump(dir, "q", f, q, qlen);
+        }
         size_t kmax = 0;
         for (size_t k = 1; k < N; k++)
             if (hypotf(X[2 * k], X[2 * k + 1]) > hypotf(X[2 * kmax], X[2 * kmax + 1])) kmax = k;
