@@ -33,6 +33,8 @@ sharding and the exchange are covered by world_size-2 gloo tests on CPU
 (tests/test_distributed_cpu.py) with the oracle as compute stand-in, and by the HIP
 back-end on the GPUs.
 """
+import contextlib
+
 import numpy as np
 
 
@@ -57,13 +59,17 @@ class ShardedRunner:
         self.bytes_broadcast = 0
 
     def step(self, i):
-        if self.rank == self.root:
-            self.backend.forward(i)
-        if self.world > 1:
-            t = self.backend.spectrum_tensor()
-            self.dist.broadcast(t, src=self.root)
-            self.bytes_broadcast += t.numel() * t.element_size()
-        self.backend.demod(self.frame_num)
+        # the forward kernels, the collective and the demodulation are ordered on ONE stream
+        # (the back-end's; a CPU back-end has none)
+        ctx = getattr(self.backend, "stream_context", None)
+        with (ctx() if ctx else contextlib.nullcontext()):
+            if self.rank == self.root:
+                self.backend.forward(i)
+            if self.world > 1:
+                t = self.backend.spectrum_tensor()
+                self.dist.broadcast(t, src=self.root)
+                self.bytes_broadcast += t.numel() * t.element_size()
+            self.backend.demod(self.frame_num)
         self.frame_num += self.F
 
 
@@ -135,14 +141,26 @@ class HipBackend:
         self.torch, self.ctx, self.F = torch, ctx, frames_per_step
         self.ring_ptr, self.nbatches = ring_ptr, nbatches
         self.hb = ctx.half_frame_bytes()
-        p, nb = C.c_void_p(), C.c_size_t()
         from ._lib import check
+        # ONE stream for the kernels and the collective's ordering.  It must be a stream of its own:
+        # torch's default stream has handle 0, which psdr_set_stream() reads as "restore the
+        # context's own streams" - the context would then alternate between its two result sets
+        # while the broadcast keeps sending set 0 (found by tests/test_gpu_fullsize.py).
+        self.stream = torch.cuda.Stream(device=device)
+        assert self.stream.cuda_stream != 0
+        check(ctx.lib.psdr_set_stream(ctx.h, C.c_void_p(self.stream.cuda_stream)))
+        # (after psdr_set_stream: on a caller's stream the context keeps to ONE result set)
+        p, nb = C.c_void_p(), C.c_size_t()
         check(ctx.lib.psdr_spectrum_device_ptr(ctx.h, 0, C.byref(p), C.byref(nb)))
         self.spec_ptr = p.value
         self.stride_bins = ctx.N if not ctx.is_real else ctx.N // 2 + 2
         self.spec = alias_device_f32(torch, self.spec_ptr, self.F * self.stride_bins * 2, device)
-        # one stream for the kernels and the collective's ordering
-        check(ctx.lib.psdr_set_stream(ctx.h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def stream_context(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def synchronize(self):
+        self.stream.synchronize()
 
     def forward(self, i):
         b = i % self.nbatches
