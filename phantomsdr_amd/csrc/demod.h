@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "butterfly.h"
+#include "quantize.h"
 
 namespace psdr {
 
@@ -41,8 +42,9 @@ struct ClientParams {
 };
 
 struct DemodArgs {
-    const cf *spec;  // [nframes][spec_stride]; IQ: client order, real: k order
+    const cf *spec;  // [nframes][spec_stride]; IQ: client order, real: k order, through `lay`
     size_t spec_stride;
+    SpecLayout lay;  // where bin c of a frame sits (quantize.h); natural order unless the fused real path
     int is_real;
     int n;  // audio_fft_size
     int nframes;
@@ -151,14 +153,14 @@ __global__ __launch_bounds__(256) void k_demod_idft(DemodArgs a) {
 
     const int len = cp.r - cp.l;
     const int m = cp.m_floor - cp.l;  // audio_m
-    const cf *S = a.spec + (size_t)f * a.spec_stride + cp.l;
+    const cf *S = a.spec + (size_t)f * a.spec_stride;  // slice bin t at lay.pos(cp.l + t)
 
     for (int i = tid; i < n; i += NT) bufA[i] = make_float2(0.f, 0.f);
     __syncthreads();
 
     float pw = 0.f;
     for (int t = tid; t < len; t += NT) {
-        const cf v = S[t];
+        const cf v = S[a.lay.pos(cp.l + t)];
         pw += fmaf(v.x, v.x, v.y * v.y);
         if (cp.mode == 0) {  // USB :125-137
             if (t >= m && t < m + n) bufA[t - m] = v;
@@ -255,12 +257,12 @@ __global__ __launch_bounds__(64 * PSDR_IDFT_WAVES) void k_demod_idft_wave(DemodA
 
     const int len = cp.r - cp.l;
     const int m = cp.m_floor - cp.l;  // audio_m
-    const cf *S = a.spec + (size_t)f * a.spec_stride + cp.l;
+    const cf *S = a.spec + (size_t)f * a.spec_stride;  // slice bin t at lay.pos(cp.l + t)
     for (int i = lane; i < n; i += 64) bufA[i] = make_float2(0.f, 0.f);
     wave_lds_sync();
     float pw = 0.f;
     for (int t = lane; t < len; t += 64) {
-        const cf v = S[t];
+        const cf v = S[a.lay.pos(cp.l + t)];
         pw += fmaf(v.x, v.x, v.y * v.y);
         if (cp.mode == 0) {  // USB :125-137
             if (t >= m && t < m + n) bufA[t - m] = v;
@@ -440,13 +442,13 @@ __global__ __launch_bounds__(256, 5) void k_demod_idft_fixed(DemodArgs a, int na
 
     const int len = cp.r - cp.l;
     const int m = cp.m_floor - cp.l;  // audio_m
-    const cf *S = a.spec + (size_t)f * a.spec_stride + cp.l;
+    const cf *S = a.spec + (size_t)f * a.spec_stride;  // slice bin t at lay.pos(cp.l + t)
     constexpr int NR = (N + 63) / 64;
     cf sv[NR];  // the slice (at most n bins, src/signal.cpp:309-311): loads first, LDS after
 #pragma unroll
     for (int u = 0; u < NR; u++) {
         const int t = lane + 64 * u;
-        sv[u] = t < len ? S[t] : make_float2(0.f, 0.f);
+        sv[u] = t < len ? S[a.lay.pos(cp.l + t)] : make_float2(0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < NR; u++) {

@@ -76,6 +76,120 @@ __global__ __launch_bounds__(256) void k_pyramid_tail(TailArgs a) {
     if (valid && (threadIdx.x & 63) == 0 && a.Pout) a.Pout[(size_t)f * a.out_stride + (j >> 6)] = top;
 }
 
+// ---- column tail: the levels a fused pass 2 leaves open, one THREAD per output row ---------------
+// The fused epilogues leave the level-LT sums in tile-major order (RecMap): the groups of one output
+// row c2 (M1 adjacent bins = NG groups) sit L floats (or octet pairs) apart, so the generic tail above
+// reads every 4-byte value from a different line (it took 220 us per 256 frames of cfg2 and 460 us for
+// the fused real path, on the side stream, in the way of the next batch's passes).  Here lane = row
+// c2: every load is contiguous across the wave, the pair-sum tree of a row runs in registers
+// (half_and_quantize, src/fft_impl.cpp:45-61), and levels LT+1 .. LT+log2(NG) go straight to the
+// level-major int8 buffer.  Pout gets the row sums (level LT+log2 NG, natural order) for
+// k_pyramid_tail to finish the few levels above.
+struct ColTailArgs {
+    const float *Pin;  // [nframes][in_stride]
+    size_t in_stride;
+    int mode;  // RecMap::mapped: 1 = IQ tiles of 16 rows (group i of row c at i*L + c),
+               // 2 = fused real: octet pairs (low octet of tile g, mirror octet of tile g) at (g*L + c)*2
+    int L, l2L;
+    int lvl_in, nlevels, size_log2;
+    int8_t *Q;
+    size_t q_stride;
+    size_t R;
+    float *Pout;
+    size_t out_stride;
+};
+// levels +1..+4 of 16 consecutive groups (chunk `ch` of row c); returns their sum
+template <int NG>
+__device__ __forceinline__ float col_chunk16(float (&v)[16], int ch, int c, const ColTailArgs &a, int8_t *Qf,
+                                             const size_t (&qoff)[12]) {
+#pragma unroll
+    for (int d = 1; d <= 4; d++) {
+        const int cnt = 16 >> d;
+#pragma unroll
+        for (int i = 0; i < cnt; i++) v[i] = __fadd_rn(v[2 * i], v[2 * i + 1]);
+        const int lv = a.lvl_in + d;
+        if (lv < a.nlevels) {
+            int8_t *dst = Qf + qoff[d] + (size_t)c * (NG >> d) + ch * cnt;
+            if (d == 1)
+                store_q<8>(dst, v, a.size_log2 - lv);
+            else if (d == 2)
+                store_q<4>(dst, v, a.size_log2 - lv);
+            else if (d == 3)
+                store_q<2>(dst, v, a.size_log2 - lv);
+            else
+                store_q<1>(dst, v, a.size_log2 - lv);
+        }
+    }
+    return v[0];
+}
+template <int NG>
+__global__ __launch_bounds__(64) void k_col_tail(ColTailArgs a) {
+    static_assert(NG % 32 == 0 && NG <= 256, "groups per row");
+    constexpr int NC = NG / 16, LOGNG = NG == 64 ? 6 : (NG == 128 ? 7 : 8);
+    const int c = blockIdx.x * 64 + threadIdx.x, f = blockIdx.y;
+    if (c >= a.L) return;
+    const float *Pf = a.Pin + (size_t)f * a.in_stride;
+    int8_t *Qf = a.Q + (size_t)f * a.q_stride;
+    size_t qoff[12];  // byte offset of level lvl_in + d
+    {
+        size_t o = 0;
+        for (int i = 0; i <= a.lvl_in; i++) o += a.R >> i;
+#pragma unroll
+        for (int d = 1; d < 12; d++) {
+            qoff[d] = o;
+            o += a.R >> (a.lvl_in + d);
+        }
+        qoff[0] = 0;
+    }
+    float cs[NC];
+    if (a.mode == 1) {
+#pragma unroll
+        for (int ch = 0; ch < NC; ch++) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = Pf[((size_t)(16 * ch + i) << a.l2L) + c];
+            cs[ch] = col_chunk16<NG>(v, ch, c, a, Qf, qoff);
+        }
+    } else {
+        // one 8-byte load gives the low octet of tile g (group g) and its mirror octet (group NG-1-g)
+#pragma unroll
+        for (int ch = 0; ch < NC / 2; ch++) {
+            float lo[16], hi[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const float2 t = reinterpret_cast<const float2 *>(Pf)[((size_t)(16 * ch + i) << a.l2L) + c];
+                lo[i] = t.x;
+                hi[15 - i] = t.y;
+            }
+            cs[ch] = col_chunk16<NG>(lo, ch, c, a, Qf, qoff);
+            cs[NC - 1 - ch] = col_chunk16<NG>(hi, NC - 1 - ch, c, a, Qf, qoff);
+        }
+    }
+    // levels +5 .. +log2(NG) over the chunk sums
+#pragma unroll
+    for (int d = 5; d <= LOGNG; d++) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int cnt = NG >> d;
+#pragma unroll
+        for (int i = 0; i < NC / 2; i++)
+            if (i < cnt) cs[i] = __fadd_rn(cs[2 * i], cs[2 * i + 1]);
+        const int lv = a.lvl_in + d;
+        if (lv < a.nlevels) {
+            int8_t *dst = Qf + qoff[d] + (size_t)c * cnt;
+            if (cnt >= 8)
+                store_q<8>(dst, cs, a.size_log2 - lv);
+            else if (cnt == 4)
+                store_q<4>(dst, cs, a.size_log2 - lv);
+            else if (cnt == 2)
+                store_q<2>(dst, cs, a.size_log2 - lv);
+            else
+                store_q<1>(dst, cs, a.size_log2 - lv);
+        }
+    }
+    if (a.Pout) a.Pout[(size_t)f * a.out_stride + c] = cs[0];
+}
+
 struct UntangleArgs {
     const cf *Z;  // [nframes][M] unnormalised N/2-point transform of the packed input
     cf *X;        // [nframes][spec_stride] (spec_stride >= M+1): k order
@@ -198,6 +312,45 @@ __global__ __launch_bounds__(256) void k_untangle_real(UntangleArgs a) {
         a.Pscr[(size_t)f * a.p_stride + (gF >> 6)] = topF;
         a.Pscr[(size_t)f * a.p_stride + (gM >> 6)] = topM;
     }
+}
+
+// ---- fused real-input path (k_fft_pass2_real, fft_pass.h) -------------------------------------
+// Completes the high octets a segment's first tile could not finish: element 0 of the octet comes
+// from the carry-out of the segment above (the LAST segment's from tile 0: row M1/2), elements
+// 1..7 from the tile's own partial rows.  grid = (segments per frame, nframes).
+struct SeamArgs {
+    const float *seamP;  // [nframes][S][L][8]: elements 1..7 of the octet at [0..7)
+    const float *seamC;  // [nframes][S][L]
+    int S, SL, L;        // segments per frame, tiles per segment, row length (M2)
+    int size_log2;
+    int8_t *Qt;
+    size_t qt_stride;
+    float *Pscr;
+    size_t p_stride;
+};
+__global__ __launch_bounds__(256) void k_real_seam(SeamArgs a) {
+    const int si = blockIdx.x, f = blockIdx.y;
+    const int g = (si + 1) * a.SL - 1;  // the segment's first tile
+    const float *P = a.seamP + ((size_t)f * a.S + si) * a.L * 8;
+    const float *Cc = a.seamC + ((size_t)f * a.S + (si + 1) % a.S) * a.L;
+    int8_t *Qf = a.Qt + (size_t)f * a.qt_stride;
+    float *Pf = a.Pscr + (size_t)f * a.p_stride;
+    for (int c = threadIdx.x; c < a.L; c += blockDim.x) {
+        const float4 v0 = reinterpret_cast<const float4 *>(P)[2 * c], v1 = reinterpret_cast<const float4 *>(P)[2 * c + 1];
+        float pw[8] = {Cc[c], v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z};  // elements 1..7 at [0..7)
+        const size_t rp = ((size_t)g * a.L + c) * 2 + 1;
+        uint4 rec;
+        pyr_record8(pw, a.size_log2, rec);
+        *reinterpret_cast<uint4 *>(Qf + rp * 16) = rec;
+        Pf[rp] = pw[0];
+    }
+}
+
+// device layout of the fused real path (SpecLayout) -> the reference's k order (one frame, M+1 bins)
+__global__ __launch_bounds__(256) void k_real_unpermute(const cf *X, cf *out, size_t M, SpecLayout lay) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > M) return;
+    out[k] = k == M ? X[M] : X[lay.pos((int)k)];
 }
 
 struct WfClient {

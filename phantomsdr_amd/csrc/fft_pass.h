@@ -182,9 +182,10 @@ __device__ __forceinline__ void tile_read(c2 (&u)[16], const float4 *tile, int i
 //                 read-back (odd k): the caller issues a slice of the next tile's global
 //                 loads there, so they trickle through the compute phases instead of
 //                 blocking the memory pipe in one burst
-template <int L, int T, bool SWZ, typename PreLast, typename EmitLast, typename Tick, typename Mark>
-__device__ __forceinline__ void run_stages(float4 *tile, const cf *Wl, int i0, int p, c2 (&u)[16],
-                                           PreLast pre_last, EmitLast emit_last, Tick tick, Mark mark) {
+// every stage but the last (the last stage's outputs go to the caller's emit)
+template <int L, int T, bool SWZ, typename Tick, typename Mark>
+__device__ __forceinline__ void run_front_stages(float4 *tile, const cf *Wl, int i0, int p, c2 (&u)[16], Tick tick,
+                                                 Mark mark) {
     using P = Plan<L>;
     constexpr int H = T / 2;
     stage_compute<L, P::R0, 1>(u, i0, Wl,
@@ -217,9 +218,18 @@ __device__ __forceinline__ void run_stages(float4 *tile, const cf *Wl, int i0, i
         tick(3);
         PSDR_SCHED_FENCE();
     }
-    pre_last();
+}
+template <int L, typename EmitLast>
+__device__ __forceinline__ void run_last_stage(const cf *Wl, int i0, c2 (&u)[16], EmitLast emit_last) {
     stage_compute<L, LastStage<L>::R, LastStage<L>::Pp>(
         u, i0, Wl, [&](int b, int s, int pos, c2 x) { emit_last(b, s, pos, x); });
+}
+template <int L, int T, bool SWZ, typename PreLast, typename EmitLast, typename Tick, typename Mark>
+__device__ __forceinline__ void run_stages(float4 *tile, const cf *Wl, int i0, int p, c2 (&u)[16],
+                                           PreLast pre_last, EmitLast emit_last, Tick tick, Mark mark) {
+    run_front_stages<L, T, SWZ>(tile, Wl, i0, p, u, tick, mark);
+    pre_last();
+    run_last_stage<L>(Wl, i0, u, emit_last);
 }
 
 // XCD-aware slot mapping: work-group b runs on XCD b%8 (observed; used for speed only).
@@ -348,7 +358,15 @@ __device__ __forceinline__ constexpr float image_scale() {
 //   T columns per tile (T/2 couples), SB bytes per complex sample of the raw image
 //   (u8/s8: 2, u16/s16: 4, f32 and f64-narrowed-to-f32: 8).  L*T/32 threads.
 // COOP: part of a single launch with pass 2 (CoopArgs): sc1 stores of Y, completion counters
-template <int L, int T, int SB, bool COOP>
+// PAIR: real input feeding the fused pass 2 (k_fft_pass2_real).  The packed N/2-point transform Z is
+// untangled into the real signal's spectrum from the pairs (Z[k], conj Z[M-k]); bin k = c1 + M1*c2
+// pairs with row M1-c1, column M2-1-c2.  Two changes make that pairing thread-local in pass 2:
+//   * rows are stored interleaved, row c1 < M1/2 at slot 2*c1, its mirror M1-c1 at slot 2*c1+1
+//     (row M1/2 at slot 1, beside row 0): a pass-2 couple is a (row, mirror row) pair;
+//   * mirror rows (c1 > M1/2) are stored as conj(Y[c1][n2]) * W_M2^{n2}: the plain forward row
+//     transform of that sequence is G[c2] = conj(Z[c1][M2-1-c2]), exactly the partner of the
+//     couple's other half at the same output index c2.
+template <int L, int T, int SB, bool COOP, bool PAIR = false>
 __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &co) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *tile = reinterpret_cast<float4 *>(smem);
@@ -530,6 +548,7 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
         }
 
         cf tbA[NBL], tbB[NBL], tsA[RL], tsB[RL], w00A, w00B;  // inter-pass twiddles
+        cf cWA = make_float2(1.f, 0.f), cWB = cWA;             // PAIR: W_M2^{n2} of the two columns
         run_stages<L, T, false>(
             tile, Wl, i0, p, u,
             // ---- inter-pass twiddle W_M^{n2*kappa}, kappa = i0 + b*L/16 + s*P, as
@@ -563,10 +582,15 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
                     tw2(nA * (unsigned)L, nB * (unsigned)L, w00A, w00B);
                     w00B = make_float2(-w00B.x, -w00B.y);
                 }
+                if constexpr (PAIR) tw2(nA * (unsigned)L, nB * (unsigned)L, cWA, cWB);  // W_M^{n2*M1}
             },
             [&](int b, int sidx, int k1, c2 x) {
                 cf wA, wB, yA, yB;
-                const int c1 = a.rot ? ((k1 - 1) & (L - 1)) : k1;
+                int c1 = a.rot ? ((k1 - 1) & (L - 1)) : k1;
+                if constexpr (PAIR) c1 = k1 < L / 2 ? 2 * k1 : ((2 * (L - k1) + 1) & (L - 1));
+#ifdef PSDR_ABL_P1SLOT
+                c1 = k1;
+#endif
                 if (sidx == 0) {
                     wA = b == 0 ? w00A : tbA[b];
                     wB = b == 0 ? w00B : tbB[b];
@@ -574,6 +598,15 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
                     cmul_pair(wA, tbA[b], tsA[sidx], wB, tbB[b], tsB[sidx]);
                 }
                 cmul_pair(yA, x.a, wA, yB, x.b, wB);
+                if constexpr (PAIR) {
+                    if (sidx >= RL / 2) {  // k1 >= L/2 (compile time): mirror form, except row L/2 itself
+                        cf mA, mB;
+                        cmul_pair(mA, make_float2(yA.x, -yA.y), cWA, mB, make_float2(yB.x, -yB.y), cWB);
+                        const bool natural = sidx == RL / 2 && b == 0 && i0 == 0;  // k1 == L/2
+                        yA = natural ? yA : mA;
+                        yB = natural ? yB : mB;
+                    }
+                }
                 if constexpr (COOP) {
                     const u32x4 v = {__float_as_uint(yA.x), __float_as_uint(yA.y), __float_as_uint(yB.x),
                                      __float_as_uint(yB.y)};
@@ -618,9 +651,9 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
     }
     PSDR_WGTRACE(a.trace, 7);
 }
-template <int L, int T, int SB>
+template <int L, int T, int SB, bool PAIR = false>
 __global__ __launch_bounds__(L *T / 32) void k_fft_pass1(Pass1Args a) {
-    pass1_body<L, T, SB, false>(a, CoopArgs{});
+    pass1_body<L, T, SB, false, PAIR>(a, CoopArgs{});
 }
 
 struct Pass2Args {
@@ -645,6 +678,12 @@ struct Pass2Args {
     unsigned total_slots;
     unsigned *tickets;  // TileQueue counters of this launch (8, zeroed)
     unsigned long long *trace;
+    // fused real-input epilogue (k_fft_pass2_real)
+    const cf *UA, *UB;  // W_N^{h << log2UB}, W_N^{l}: untangle twiddles
+    int log2UB;
+    int seg_len;        // tiles of one frame a work-group walks in a chain (divides tiles_per_frame)
+    float *seamP;       // [nframes][segs][L][8]: partial octets of every segment's first tile
+    float *seamC;       // [nframes][segs][L]: carry-out of every segment's last tile
 };
 
 // pass 2: row FFT (length L = M2) of T adjacent rows c1 (T/2 couples); FUSED adds /N,
@@ -891,6 +930,334 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, const CoopArgs &c
 template <int L, int T, bool FUSED, int TWC>
 __global__ __launch_bounds__(L *T / 32) void k_fft_pass2(Pass2Args a) {
     pass2_body<L, T, FUSED, TWC, false>(a, CoopArgs{});
+}
+
+// ---- pass 2 for REAL input, fused with the Hermitian untangle, /N, |X|^2 and pyramid levels 0..3 ----
+// (replaces cufftExecR2C / fftwf r2c + power_and_quantize + the first half_and_quantize calls,
+//  src/fft_impl.cpp:104-117,144-172; round 1 ran a third full pass over the spectrum for this)
+//
+// Pass 1 (PAIR) left the rows of Y as (row c1, mirror row M1-c1) couples, mirror rows pre-conjugated,
+// so after the row transform a thread holds, for each of its 16 output indices c2,
+//     a = Z[c1 + M1*c2]            b = conj(Z[M - (c1 + M1*c2)])
+// and both real-signal bins of the pair come out of its own registers:
+//     X[k]   = (a+b)/2 + W_N^k * (-i)(a-b)/2          X[M-k] = conj((a+b)/2 - W_N^k * (-i)(a-b)/2)
+// Tile g = couples (8g+p, M1-8g-p), p = 0..7.  The self-paired rows 0 and M1/2 share couple 0 of
+// tile 0 (their partners sit in OTHER threads' registers: one LDS exchange, that tile only).
+//
+// Output of tile g at column c2: rows 8g..8g+7 (from the couples' first halves) and, at column
+// L-1-c2, rows M1-8g-7..M1-8g (second halves).  In the reference's k order these are two 64-byte
+// pieces 8 KiB away from the next column's - and the neighbouring rows belong to tiles another
+// work-group writes at an unrelated time: stored like that, the spectrum stores cost more than the
+// whole rest of the tile (measured 1035 of 1940 us per 256 frames, with 8- or 16-byte stores alike).
+// So the frame is laid out in HBM as 128-byte lines [ low octet of column c | mirror octet of tile g
+// of column L-1-c ], tile-major (SpecLayout, quantize.h): the lane pair (p, p^1) swaps one bin per
+// output (DPP), even lanes store the low-side pairs, odd lanes the mirror-side pairs, ONE
+// 16-byte-per-lane store instruction writes eight adjacent whole lines, and a tile's output is one
+// contiguous 128 KiB block.  Consumers index through SpecLayout::pos (demodulation slices) or ask
+// for k order (psdr_read_spectrum).
+//
+// Pyramid: octets in TRUE k order.  The low octet [8g, 8g+8) is complete in the tile.  The high
+// octet [M1-8g-8, M1-8g) has seven rows here and its first row (M1-8g-8) in tile g+1 (couple 0), so
+// a work-group walks a SEGMENT of seg_len consecutive tiles of one frame in DEcreasing g and carries
+// that one row of powers (4 KiB of LDS) to the next tile.  The first tile of a segment has no
+// carry-in: it leaves the seven partial rows in seamP; the last tile leaves its carry-out in seamC;
+// k_real_seam (epilogue.h) completes those octets (tile 0's carry-out is row M1/2, which closes the
+// ring at octet [M1/2, M1/2+8) of the LAST tile).  Records: [tile g][c2][low, high] x 16 bytes
+// (RecMap mode 2), level-3 sums in the same order for the tail kernel.
+// W_32^t = exp(-2 pi i t/32), t < 16: a thread's 16 outputs are c2 = i0 + (L/16)*t, and
+// W_N^{M1*c2} = W_{2L}^{c2} = W_{2L}^{i0} * W_32^t
+__device__ __forceinline__ cf w32(int t) {
+    constexpr float C[16] = {1.f,
+                             0.98078528040323044913f,
+                             0.92387953251128675613f,
+                             0.83146961230254523708f,
+                             0.70710678118654752440f,
+                             0.55557023301960222474f,
+                             0.38268343236508977173f,
+                             0.19509032201612826785f,
+                             0.f,
+                             -0.19509032201612826785f,
+                             -0.38268343236508977173f,
+                             -0.55557023301960222474f,
+                             -0.70710678118654752440f,
+                             -0.83146961230254523708f,
+                             -0.92387953251128675613f,
+                             -0.98078528040323044913f};
+    // sin(2 pi t/32) = C[(t + 24) & 31] for the full circle; t < 16: sin >= 0 = C[|8 - t|]
+    const int u = t <= 8 ? 8 - t : t - 8;
+    return make_float2(C[t], -C[u]);
+}
+// the two bins of a pair from a = Z[k], b = conj(Z[M-k]); w = W_N^k; h = 0.5/N (a power of two:
+// scaling last changes no bit).  xm is X[M-k].
+__device__ __forceinline__ void untangle_pair(cf a, cf b, cf w, float h, cf &xk, cf &xm) {
+    const cf s = cadd(a, b), d = csub(a, b);
+    const cf wo = cmul(w, make_float2(d.y, -d.x));  // W_N^k * (-i)(a-b)
+    xk = make_float2((s.x + wo.x) * h, (s.y + wo.y) * h);
+    xm = make_float2((s.x - wo.x) * h, (wo.y - s.y) * h);
+}
+__device__ __forceinline__ float bin_power(cf x) { return fmaf(x.x, x.x, x.y * x.y); }  // src/fft_impl.cpp:36-38
+
+template <int L, int T, int TWC>
+__global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
+    static_assert(T == 16, "eight (row, mirror) couples per tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *tile = reinterpret_cast<float4 *>(smem);
+    cf *tile_cf = reinterpret_cast<cf *>(smem);
+    cf *Wl = tile_cf + L * T;
+    float *carry = reinterpret_cast<float *>(Wl + L);  // [2][L]
+    constexpr int H = T / 2;
+    constexpr int NT = (L / 16) * H;
+    constexpr int L16 = L / 16;
+    constexpr int NLD = 16;
+    constexpr int NTICK = 2 * (Plan<L>::NS - 1);
+    constexpr int EARLY = 4;
+    constexpr int LPT = (NLD - EARLY + NTICK - 1) / NTICK;
+    constexpr int NBL = 16 / LastStage<L>::R;
+    const int tid = threadIdx.x;
+    const int p_ = tid % H, i0_ = tid / H;
+    const int M1 = a.M1;
+    const unsigned total = a.total_slots;  // segments
+    const int TW = TWC;
+    constexpr int log2TW = TWC == 16 ? 4 : 3;
+    static_assert(TWC == 16 || TWC == 8, "pass-1 tile width");
+    const int chunk = T * TW;
+    const size_t blk = a.yblk;
+    const int lc = log2TW + 4;  // log2(chunk)
+    const int SL = a.seg_len;
+    const unsigned S = a.tiles_per_frame / (unsigned)SL;  // segments per frame
+    float4 r[NLD];
+    const cf *nxt = nullptr;
+    const unsigned lane_off = (unsigned)((size_t)((2 * tid) >> lc) * blk + ((2 * tid) & (chunk - 1)));
+    // tile j of segment sg: frame sg / S, g = (sg % S + 1) * SL - 1 - j
+    auto tile_of = [&](unsigned sg, int j, unsigned &f, int &g) {
+        f = sg / S;
+        g = (int)((sg - f * S + 1u) * (unsigned)SL) - 1 - j;
+    };
+    auto point_at = [&](unsigned sg, int j) {
+        unsigned f;
+        int g;
+        tile_of(sg, j, f, g);
+        nxt = a.Y + (size_t)f * a.yframe + (size_t)(g * T) * TW;
+    };
+    auto issue = [&](auto qc) {
+        constexpr int i = decltype(qc)::value;
+        const cf *q = nxt + (size_t)((2 * i * NT) >> lc) * blk + ((2 * i * NT) & (chunk - 1)) + lane_off;
+        r[i] = *reinterpret_cast<const float4 *>(q);
+    };
+    __shared__ unsigned s_next[2];
+    TileQueue tq;
+    tq.init(a.tickets, total, true, false);
+    unsigned s = blockIdx.x, snext = blockIdx.x + gridDim.x;
+    if (s < total) {
+        point_at(s, 0);
+        static_for<0, NLD>(issue);
+    }
+    for (int i = tid; i < L; i += NT) Wl[i] = a.Wl[i];  // visible after the loop's first barrier
+    tq.draw_begin();
+
+    const float hscale = 0.5f * a.inv_n;
+    const unsigned ubm = (1u << a.log2UB) - 1u;
+    int j = 0, segit = 0;
+    for (int it = 0; s < total; it++) {
+        unsigned f;
+        int g;
+        tile_of(s, j, f, g);
+        const bool seg_first = j == 0, seg_last = j == SL - 1;
+        const unsigned si = s - f * S;
+        bool more;
+        if (!seg_last) {
+            more = true;
+            point_at(s, j + 1);
+        } else {
+            more = snext < total;
+            if (more) point_at(snext, 0);
+        }
+        if (seg_first) {
+            tq.draw_end(&s_next[segit & 1], s);
+            tq.draw_begin();
+        }
+        int i0 = i0_, p = p_, tidx = tid;  // opaque copies (see pass 1)
+        asm volatile("" : "+v"(i0), "+v"(p), "+v"(tidx));
+        // untangle twiddle of the thread's first output: W_N^{c1 + M1*i0}
+        const int c1 = 8 * g + p;
+        const unsigned e0 = (unsigned)c1 + (unsigned)M1 * (unsigned)i0;
+        const cf ua = a.UA[e0 >> a.log2UB], ub = a.UB[e0 & ubm];
+        // transposing fill (as pass2_body)
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+            const int w = ((2 * i * NT) & (chunk - 1)) + ((2 * tidx) & (chunk - 1));
+            const int rr = w >> log2TW, cc = w & (TW - 1);
+            const int n2 = (((2 * i * NT) >> lc) + ((2 * tidx) >> lc)) * TW + cc;  // even
+            const int slot0 = lds_slot<H, true>(n2, rr >> 1);
+            tile_cf[2 * slot0 + (rr & 1)] = make_float2(r[i].x, r[i].y);
+            tile_cf[2 * (slot0 + H) + (rr & 1)] = make_float2(r[i].z, r[i].w);
+        }
+        PSDR_SCHED_FENCE();
+        if (more) static_for<0, EARLY>(issue);
+        PSDR_SCHED_FENCE();
+        __syncthreads();
+        c2 u[16];
+        tile_read<L, H, true>(u, tile, i0, p);
+        __syncthreads();
+
+        cf *Xf = a.X + (size_t)f * a.spec_stride;
+        float *Pst = reinterpret_cast<float *>(smem);             // [L][16]: low octet, high octet
+        cf *exA = tile_cf + (size_t)L * 8, *exB = exA + L;        // tile 0: rows 0 and M1/2 (beyond Pst)
+        float *carry_w = carry + (it & 1) * L, *carry_r = carry + ((it & 1) ^ 1) * L;
+        float *seamC = a.seamC + ((size_t)f * S + si) * L;
+        run_front_stages<L, T, true>(
+            tile, Wl, i0, p, u,
+            [&](int k) {
+                if (more)
+                    static_switch<0, NTICK>(k, [&](auto kc) {
+                        constexpr int K = decltype(kc)::value;
+                        constexpr int lo = EARLY + K * LPT < NLD ? EARLY + K * LPT : NLD;
+                        constexpr int hi = lo + LPT < NLD ? lo + LPT : NLD;
+                        static_for<lo, hi>(issue);
+                    });
+            },
+            [&](int) {});
+        const cf w0 = cmul(ua, ub);
+        cf *Xt = Xf + (size_t)g * (16 * L);  // line (g, c) of the frame starts at Xt + 16 * c
+        // Octet staging Pst[c2][16]: [0..8) the low octet of column c2; [8..15) elements 1..7 of the
+        // high octet of column c2 (its element 0 is the carried row).
+        // Tile 0 only (couple 0 is special there): 8 bytes per lane.
+        auto emit_pair = [&](int t, int c2i, c2 x) {
+            cf xk, xm;
+            untangle_pair(x.a, x.b, cmul(w0, w32(t)), hscale, xk, xm);
+            const int cm = L - 1 - c2i;
+#ifndef PSDR_ABL_NOX
+            Xt[16 * c2i + p] = xk;
+            Xt[16 * c2i + 15 - p] = xm;  // mirror row M1-p: element 7-p of the mirror octet
+#endif
+            Pst[c2i * 16 + p] = bin_power(xk);
+            Pst[cm * 16 + 15 - p] = bin_power(xm);  // (p >= 1 here: element 8-p at [7+8-p])
+        };
+        // Every other tile: two outputs (A, B) per call.  Lane pair (2q, 2q+1): the even lane ends up
+        // with rows 8g+2q, 8g+2q+1 of both outputs, the odd lane with the mirror rows M1-8g-2q-1,
+        // M1-8g-2q of both (one DPP swap per value), so that lanes 0..7 of an i0 write one whole line.
+        cf skA = make_float2(0.f, 0.f), smA = skA;
+        int cA = 0;
+        auto swap1 = [](float v) {
+            return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+        };
+        auto emit_two = [&](int cB, cf xkB, cf xmB) {
+            const bool ev = (p & 1) == 0;
+            const cf mineA = ev ? skA : smA, mineB = ev ? xkB : xmB;
+            const cf sendA = ev ? smA : skA, sendB = ev ? xmB : xkB;
+            const cf recvA = make_float2(swap1(sendA.x), swap1(sendA.y)), recvB = make_float2(swap1(sendB.x), swap1(sendB.y));
+            const int q2 = p & ~1;
+            const int off = ev ? q2 : 14 - q2;  // bin inside the line; odd: (own row M1-8g-2q-1, partner's M1-8g-2q)
+#ifndef PSDR_ABL_NOX
+            *reinterpret_cast<float4 *>(Xt + 16 * cA + off) = make_float4(mineA.x, mineA.y, recvA.x, recvA.y);
+            *reinterpret_cast<float4 *>(Xt + 16 * cB + off) = make_float4(mineB.x, mineB.y, recvB.x, recvB.y);
+#endif
+            // the mirror-side values of output column c belong to column L-1-c
+            const int sA = ev ? cA : L - 1 - cA, sB = ev ? cB : L - 1 - cB;
+            const float prA = bin_power(recvA), prB = bin_power(recvB);
+            *reinterpret_cast<float2 *>(Pst + sA * 16 + off) = make_float2(bin_power(mineA), prA);
+            *reinterpret_cast<float2 *>(Pst + sB * 16 + off) = make_float2(bin_power(mineB), prB);
+            if (p == 1) {  // partner's row M1-8g: element 0 of the next octet up, the carry to tile g-1
+                carry_w[sA] = prA;
+                carry_w[sB] = prB;
+                if (seg_last) {
+                    seamC[sA] = prA;
+                    seamC[sB] = prB;
+                }
+            }
+        };
+        if (g != 0) {
+            run_last_stage<L>(Wl, i0, u, [&](int b, int sidx, int c2i, c2 x) {
+                cf xk, xm;
+                untangle_pair(x.a, x.b, cmul(w0, w32(b + NBL * sidx)), hscale, xk, xm);
+                if ((sidx & 1) == 0) {
+                    skA = xk;
+                    smA = xm;
+                    cA = c2i;
+                } else {
+                    emit_two(c2i, xk, xm);
+                }
+            });
+        } else {
+            run_last_stage<L>(Wl, i0, u, [&](int b, int sidx, int c2i, c2 x) {
+                if (p == 0) {  // rows 0 and M1/2: the partners are in other threads
+                    exA[c2i] = x.a;
+                    exB[c2i] = x.b;
+                } else {
+                    emit_pair(b + NBL * sidx, c2i, x);
+                }
+            });
+            __syncthreads();
+            if (p == 0) {
+                // row 0: k = M1*c2 pairs with M1*(L-c2) (same row, column (L-c2) mod L);
+                // row M1/2: k = M1/2 + M1*c2 pairs with column L-1-c2 of the same row
+                const cf w0z = cmul(a.UA[((unsigned)M1 * (unsigned)i0) >> a.log2UB], a.UB[((unsigned)M1 * (unsigned)i0) & ubm]);
+                const unsigned eh = (unsigned)(M1 >> 1) + (unsigned)M1 * (unsigned)i0;
+                const cf w0h = cmul(a.UA[eh >> a.log2UB], a.UB[eh & ubm]);
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    const int c2i = i0 + L16 * t;
+                    cf xk, xm;
+                    const cf pz = exA[(L - c2i) & (L - 1)];
+                    untangle_pair(exA[c2i], make_float2(pz.x, -pz.y), cmul(w0z, w32(t)), hscale, xk, xm);
+                    Xf[16 * c2i] = xk;  // line (0, c2), bin 0
+                    Pst[c2i * 16] = bin_power(xk);
+                    // bin N/2 is never normalised by the reference (src/fft_impl.cpp:156-160 visits
+                    // k < N/2 only): X[N/2] = Re Z[0] - Im Z[0]
+                    if (c2i == 0) Xf[(size_t)L << a.log2M1] = make_float2(exA[0].x - exA[0].y, 0.f);  // after the M bins
+                    const cf ph = exB[L - 1 - c2i];
+                    untangle_pair(exB[c2i], make_float2(ph.x, -ph.y), cmul(w0h, w32(t)), hscale, xk, xm);
+                    Xf[16 * (L - 1 - c2i) + 15] = xk;  // row M1/2 closes tile 0's mirror octet, line (0, L-1-c2)
+                    seamC[c2i] = bin_power(xk);  // element 0 of the octet [M1/2, M1/2+8) at column c2
+                }
+            }
+        }
+        __syncthreads();  // octet staging (and the carry) complete
+        {
+            int8_t *Qf = a.Qt + (size_t)f * a.qt_stride;
+            float *Pf = a.Pscr + (size_t)f * a.p_stride;
+            float *seamP = a.seamP + ((size_t)f * S + si) * L * 8;
+            constexpr int NG = 2 * L / NT;  // octets per thread: chunk q = 2*c2 + side
+#ifdef PSDR_ABL_NOREC
+            if (tidx >= 0) goto skip_rec;
+#endif
+#pragma unroll
+            for (int k = 0; k < NG; k++) {
+                const int q = k * NT + tidx;
+                const int side = q & 1, c2i = q >> 1;
+                const float4 v0 = reinterpret_cast<const float4 *>(Pst)[2 * q], v1 = reinterpret_cast<const float4 *>(Pst)[2 * q + 1];
+                float pw[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                if (side) {  // high octet: element 0 is the carried row, 1..7 sit at [0..7)
+                    pw[0] = carry_r[c2i];
+                    pw[1] = v0.x, pw[2] = v0.y, pw[3] = v0.z, pw[4] = v0.w, pw[5] = v1.x, pw[6] = v1.y, pw[7] = v1.z;
+                }
+                if (side && seg_first) {  // no carry-in: the octet is completed by k_real_seam
+                    reinterpret_cast<float4 *>(seamP)[2 * c2i] = v0;
+                    reinterpret_cast<float4 *>(seamP)[2 * c2i + 1] = v1;
+                } else {
+                    const size_t rp = (size_t)g * (2 * L) + q;  // RecMap mode 2
+                    uint4 rec;
+                    pyr_record8(pw, a.size_log2, rec);
+                    *reinterpret_cast<uint4 *>(Qf + rp * 16) = rec;
+                    Pf[rp] = pw[0];
+                }
+                PSDR_SCHED_FENCE();
+            }
+#ifdef PSDR_ABL_NOREC
+        skip_rec:;
+#endif
+        }
+        __syncthreads();  // the tile is free again
+        if (seg_last) {
+            const unsigned s2 = s_next[segit & 1];
+            s = snext;
+            snext = s2;
+            j = 0;
+            segit++;
+        } else {
+            j++;
+        }
+    }
 }
 
 // Both passes in one launch: a work-group walks pass-1 tiles while there are any, then pass-2

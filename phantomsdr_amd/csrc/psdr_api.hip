@@ -44,10 +44,10 @@ extern "C" const char *psdr_version(void) { return "phantomsdr_amd 0.1 (gfx950)"
 
 namespace {
 
-enum KernelId { K_PASS1, K_PASS2, K_UNTANGLE, K_TAIL, K_IDFT, K_OLA, K_WFALL, K_POST, K_TWO_PHASE, K_COUNT };
+enum KernelId { K_PASS1, K_PASS2, K_UNTANGLE, K_TAIL, K_IDFT, K_OLA, K_WFALL, K_POST, K_TWO_PHASE, K_SEAM, K_COUNT };
 const char *kKernelNames[K_COUNT] = {"fft_pass1",  "fft_pass2", "untangle_real", "pyramid_tail",
                                      "demod_idft", "demod_ola", "waterfall_gather", "post_chain",
-                                     "fft_two_phase"};
+                                     "fft_two_phase", "real_seam"};
 
 struct PendingEvent {
     hipEvent_t a, b;
@@ -124,6 +124,14 @@ struct psdr_ctx {
     int M1 = 0, M2 = 0, log2M1 = 0, log2M2 = 0;
     int T1 = 0, T2 = 0;
     bool is_real = false;
+    // real input, N/2 = 1024*1024 or 2048*1024 points: pass 2 untangles, normalises, takes the power
+    // and builds pyramid levels 0..3 itself (k_fft_pass2_real); smaller real transforms keep the
+    // three-pass form (pass 1, pass 2, k_untangle_real)
+    bool real_fused = false;
+    SpecLayout lay{};                // device layout of the spectrum (natural unless real_fused)
+    int seg_len_env = 0;             // PSDR_SEG_LEN (tuning): tiles per chain segment
+    float *d_seamP = nullptr, *d_seamC = nullptr;
+    size_t seam_cap = 0;             // segments the seam buffers hold
     int size_log2 = 0;
     int levels = 0;
     size_t spec_stride = 0;  // complex elements per frame
@@ -320,13 +328,13 @@ unsigned persistent_grid(psdr_ctx *c, unsigned blocks, size_t lds) {
     return blocks <= cap ? blocks : std::max(cap, 8u);
 }
 
-template <int L, int T, int SB>
+template <int L, int T, int SB, bool PAIR = false>
 int launch_pass1_t(psdr_ctx *c, const Pass1Args &a, unsigned blocks) {
     // tile + W_L (= first twiddle factor) + second twiddle factor (M2 entries)
     const size_t lds = (size_t)L * T * sizeof(cf) + (size_t)L * sizeof(cf) + (size_t)a.M2 * sizeof(cf);
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass1<L, T, SB>,
+        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass1<L, T, SB, PAIR>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         attr_set = true;
     }
@@ -334,7 +342,7 @@ int launch_pass1_t(psdr_ctx *c, const Pass1Args &a, unsigned blocks) {
     // persistent: as many work-groups per CU as their LDS admits (a 128 KiB tile: one)
     unsigned grid = persistent_grid(c, blocks, lds);
     if (c->p1_grid && c->p1_grid < grid) grid = c->p1_grid;
-    hipLaunchKernelGGL((k_fft_pass1<L, T, SB>), dim3(grid), dim3(L * T / 32), lds, c->p1, a);
+    hipLaunchKernelGGL((k_fft_pass1<L, T, SB, PAIR>), dim3(grid), dim3(L * T / 32), lds, c->p1, a);
     HIPCHK(hipGetLastError());
     return PSDR_OK;
 }
@@ -390,7 +398,18 @@ int launch_two_phase(psdr_ctx *c, int sb, bool fused, const Pass1Args &a1, const
         if (sb == 4) return launch_pass1_t<L_, T_, 4>(c, a, blocks);     \
         return launch_pass1_t<L_, T_, 8>(c, a, blocks);                  \
     }
-int launch_pass1(psdr_ctx *c, int L, int T, int sb, const Pass1Args &a, unsigned blocks) {
+#define P1PAIR(L_, T_)                                                         \
+    if (L == L_ && T == T_) {                                                  \
+        if (sb == 2) return launch_pass1_t<L_, T_, 2, true>(c, a, blocks);     \
+        if (sb == 4) return launch_pass1_t<L_, T_, 4, true>(c, a, blocks);     \
+        return launch_pass1_t<L_, T_, 8, true>(c, a, blocks);                  \
+    }
+int launch_pass1(psdr_ctx *c, int L, int T, int sb, const Pass1Args &a, unsigned blocks, bool pair = false) {
+    if (pair) {
+        P1PAIR(1024, 16)
+        P1PAIR(2048, 8)
+        return fail(PSDR_ERR_UNSUPPORTED, "no paired pass-1 kernel for L=%d T=%d", L, T);
+    }
     P1CASE(64, 64)
     P1CASE(128, 64)
     P1CASE(128, 128)
@@ -419,6 +438,40 @@ int launch_pass2(psdr_ctx *c, int L, int T, bool fused, const Pass2Args &a, unsi
     P2CASE(1024, 16)
     P2CASE(2048, 8)
     return fail(PSDR_ERR_UNSUPPORTED, "no pass-2 kernel for L=%d T=%d", L, T);
+}
+
+// fused real-input pass 2 (TWC = pass-1 tile width: 16 for 1024 x 1024, 8 for 2048 x 1024)
+template <int TWC>
+int launch_pass2_real_t(psdr_ctx *c, const Pass2Args &a) {
+    constexpr int L = 1024, T = 16;
+    constexpr size_t lds = (size_t)L * T * sizeof(cf) + (size_t)L * sizeof(cf) + 2 * (size_t)L * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass2_real<L, T, TWC>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    ProfScope ps(c, K_PASS2);
+    unsigned grid = persistent_grid(c, a.total_slots, lds);
+    if (c->p2_grid && c->p2_grid < grid) grid = c->p2_grid;
+    hipLaunchKernelGGL((k_fft_pass2_real<L, T, TWC>), dim3(grid), dim3(L * T / 32), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return PSDR_OK;
+}
+// Tiles of one frame a work-group walks in a chain: long chains carry the mirror-side octets in LDS
+// (nothing extra in HBM), short chains give the persistent grid enough independent segments.  Aim
+// for about four segments per work-group.
+int real_seg_len(const psdr_ctx *c, int nframes) {
+    const int G = c->M1 / 16;
+    if (c->seg_len_env > 0) {
+        int sl = 1;
+        while (sl * 2 <= c->seg_len_env && sl * 2 <= G) sl *= 2;
+        return sl;
+    }
+    const long long want = (long long)G * nframes / (4LL * std::max(c->num_cus, 1));
+    int sl = 1;
+    while (sl * 2 <= want && sl * 2 <= G) sl *= 2;
+    return sl;
 }
 
 size_t fmt_bytes(int fmt) {
@@ -486,7 +539,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
     a1.total_slots = tiles1 * (unsigned)nframes;
     int rc = 0;
     if (!c->two_phase) {  // (two-phase: pass 1 runs inside the combined launch below)
-        rc = launch_pass1(c, c->M1, c->T1, sb, a1, a1.total_slots);
+        rc = launch_pass1(c, c->M1, c->T1, sb, a1, a1.total_slots, c->real_fused);
         if (rc) return rc;
     }
     if (piped) {
@@ -541,6 +594,35 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
         a2.spec_stride = c->spec_stride;
         rc = run_pass2(true);
         if (rc) return rc;
+    } else if (c->real_fused) {
+        a2.X = c->d_spec;
+        a2.spec_stride = c->spec_stride;
+        a2.UA = c->d_UA;
+        a2.UB = c->d_UB;
+        a2.log2UB = c->log2UB;
+        a2.seg_len = real_seg_len(c, nframes);
+        const unsigned S = tiles2 / (unsigned)a2.seg_len;
+        if ((size_t)nframes * S > c->seam_cap)
+            return fail(PSDR_ERR_STATE, "seam buffers too small (%zu segments, %zu allocated)", (size_t)nframes * S, c->seam_cap);
+        a2.seamP = c->d_seamP;
+        a2.seamC = c->d_seamC;
+        a2.total_slots = S * (unsigned)nframes;
+        rc = c->M1 == 1024 ? launch_pass2_real_t<16>(c, a2) : launch_pass2_real_t<8>(c, a2);
+        if (rc) return rc;
+        SeamArgs sa{};
+        sa.seamP = c->d_seamP;
+        sa.seamC = c->d_seamC;
+        sa.S = (int)S;
+        sa.SL = a2.seg_len;
+        sa.L = c->M2;
+        sa.size_log2 = c->size_log2;
+        sa.Qt = c->d_qt;
+        sa.qt_stride = c->qt_stride;
+        sa.Pscr = c->d_pscr[0];
+        sa.p_stride = c->p_stride;
+        ProfScope ps(c, K_SEAM);
+        hipLaunchKernelGGL(k_real_seam, dim3(S, nframes), dim3(256), 0, c->stream, sa);
+        HIPCHK(hipGetLastError());
     } else {
         a2.X = c->d_Z;
         a2.spec_stride = c->M;
@@ -579,6 +661,40 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
     int lvl = c->LT;
     size_t len = c->R >> lvl;
     int cur = 0;
+    // tile-major sums of a fused pass 2 (rows of 1024 outputs): one thread per output row takes the
+    // levels inside a row (k_col_tail), the generic kernel the few above
+    const int ng = (int)(len >> c->log2M2);  // groups per output row
+    const bool col_tail = c->recmap.mapped && c->M2 == 1024 && c->recmap.l2gpt == 0 && (ng == 64 || ng == 128 || ng == 256) &&
+                          getenv("PSDR_NO_COL_TAIL") == nullptr;
+    if (col_tail && lvl + 1 < c->levels) {
+        ColTailArgs t{};
+        t.Pin = c->d_pscr[0];
+        t.in_stride = c->p_stride;
+        t.mode = c->recmap.mapped;
+        t.L = c->M2;
+        t.l2L = c->log2M2;
+        t.lvl_in = lvl;
+        t.nlevels = c->levels;
+        t.size_log2 = c->size_log2;
+        t.Q = c->d_q;
+        t.q_stride = c->q_stride;
+        t.R = c->R;
+        t.Pout = c->d_pscr[1];
+        t.out_stride = c->p_stride;
+        ProfScope ps(c, K_TAIL, c->side);
+        const dim3 grid((unsigned)(c->M2 / 64), (unsigned)nframes);
+        if (ng == 64)
+            hipLaunchKernelGGL(k_col_tail<64>, grid, dim3(64), 0, c->side, t);
+        else if (ng == 128)
+            hipLaunchKernelGGL(k_col_tail<128>, grid, dim3(64), 0, c->side, t);
+        else
+            hipLaunchKernelGGL(k_col_tail<256>, grid, dim3(64), 0, c->side, t);
+        HIPCHK(hipGetLastError());
+        lvl += ilog2((size_t)ng);
+        len = (size_t)c->M2;
+        cur = 1;
+    }
+    const int lvl_mapped = col_tail ? -1 : c->LT;  // the level whose sums are still in RecMap order
     while (lvl + 1 < c->levels && len >= 2) {
         TailArgs t{};
         t.Pin = c->d_pscr[cur];
@@ -593,7 +709,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
         t.Pout = c->d_pscr[cur ^ 1];
         t.out_stride = c->p_stride;
         t.map = c->recmap;
-        if (cur != 0 || lvl != c->LT) t.map.mapped = 0;  // only pass 2's own output is tile-major
+        if (lvl != lvl_mapped) t.map.mapped = 0;  // only pass 2's own output is tile-major
         ProfScope ps(c, K_TAIL, c->side);
         const unsigned nb = (unsigned)((len / 2 + 255) / 256);
         hipLaunchKernelGGL(k_pyramid_tail, dim3(nb, nframes), dim3(256), 0, c->side, t);
@@ -626,6 +742,8 @@ void free_all(psdr_ctx *c) {
     F(c->d_UA);
     F(c->d_UB);
     F(c->d_cnt1);
+    F(c->d_seamP);
+    F(c->d_seamC);
     F(c->d_tickets[0]);
     F(c->d_tickets[1]);
     F(c->y_pool[0]);
@@ -752,7 +870,7 @@ int build(psdr_ctx *c) {
     const size_t F = (size_t)c->max_batch;
     if (const char *e = getenv("PSDR_YPAD")) c->ypad = (size_t)atoi(e);
     c->two_phase = getenv("PSDR_TWO_PHASE") != nullptr && atoi(getenv("PSDR_TWO_PHASE")) != 0 && c->M1 == 1024 && c->M2 == 1024 && c->T1 == 16 && c->T2 == 16 &&
-                   c->no_p1_stream && c->ypad == 0;
+                   c->no_p1_stream && c->ypad == 0 && !c->real_fused;
     if (c->two_phase) {
         HIPCHK(hipMalloc((void **)&c->d_cnt1, (size_t)TICKET_SLOTS * c->max_batch * sizeof(unsigned)));
         HIPCHK(hipMemset(c->d_cnt1, 0, (size_t)TICKET_SLOTS * c->max_batch * sizeof(unsigned)));
@@ -764,7 +882,18 @@ int build(psdr_ctx *c) {
     // the second Y buffer only exists when pass 1 runs on its own stream (PSDR_P1_STREAM)
     for (int i = 0; i < (c->no_p1_stream ? 1 : 2); i++)
         HIPCHK(hipMalloc((void **)&c->y_pool[i], F * (c->M + c->ypad * (size_t)(c->M2 / c->T1)) * sizeof(cf)));
-    if (c->is_real) HIPCHK(hipMalloc((void **)&c->d_Z, F * c->M * sizeof(cf)));
+    if (c->is_real && !c->real_fused) HIPCHK(hipMalloc((void **)&c->d_Z, F * c->M * sizeof(cf)));
+    if (c->real_fused) {
+        // one frame of k-order staging for psdr_read_spectrum / psdr_get_output_buffer
+        HIPCHK(hipMalloc((void **)&c->d_Z, (c->M + 2) * sizeof(cf)));
+        if (const char *e = getenv("PSDR_SEG_LEN")) c->seg_len_env = atoi(e);
+        size_t cap = 0;
+        for (int nf = 1; nf <= c->max_batch; nf++)
+            cap = std::max(cap, (size_t)nf * (size_t)((c->M1 / 16) / real_seg_len(c, nf)));
+        c->seam_cap = cap;
+        HIPCHK(hipMalloc((void **)&c->d_seamP, cap * (size_t)c->M2 * 8 * sizeof(float)));
+        HIPCHK(hipMalloc((void **)&c->d_seamC, cap * (size_t)c->M2 * sizeof(float)));
+    }
     for (int s = 0; s < 2; s++) {
         HIPCHK(hipMalloc((void **)&c->spec_pool[s], F * c->spec_stride * sizeof(cf)));
         HIPCHK(hipMemset(c->spec_pool[s], 0, F * c->spec_stride * sizeof(cf)));
@@ -935,7 +1064,22 @@ extern "C" int psdr_create(const psdr_config *cfg, psdr_ctx **out) {
     c->q_len = 0;
     for (int i = 0; i < c->levels; i++) c->q_len += c->R >> i;
     c->q_stride = (c->q_len + 127) & ~(size_t)127;
-    if (is_real) {
+    c->real_fused = is_real && c->M2 == 1024 && c->T2 == 16 && (c->M1 == 1024 || c->M1 == 2048) &&
+                    getenv("PSDR_REAL_3PASS") == nullptr;
+    if (c->real_fused) {
+        c->tile_ch = 8;  // octet records, levels 0..3 (quantize.h, RecMap mode 2)
+        c->LT = 3;
+        c->tiled_lt = 3;
+        c->recmap.l2tpr = ilog2((size_t)(c->M1 / 8));
+        c->recmap.l2gpt = 0;
+        c->recmap.l2rows = c->log2M2;
+        c->recmap.mapped = 2;
+        c->qt_stride = 2 * c->R;
+        c->lay.m1 = c->M1;
+        c->lay.l2m1 = c->log2M1;
+        c->lay.L = c->M2;
+        c->lay.l2L = c->log2M2;
+    } else if (is_real) {
         c->LT = 8;  // the untangle kernel finishes levels 0..8 (4 bins per lane, 64 lanes)
         c->tiled_lt = -1;
     } else {
@@ -1036,7 +1180,13 @@ static int copy_spectrum_k_order(psdr_ctx *c, int frame, cf *dst) {
         int rc = drain(c);
         if (rc) return rc;
     }
-    if (c->is_real) {
+    if (c->real_fused) {
+        // the device keeps the rows of every M1-block permuted (fft_pass.h): k order via staging
+        hipLaunchKernelGGL(k_real_unpermute, dim3((unsigned)((c->M + 1 + 255) / 256)), dim3(256), 0, c->stream, src, c->d_Z,
+                           c->M, c->lay);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(dst, c->d_Z, (c->N / 2 + 1) * sizeof(cf), hipMemcpyDeviceToHost, c->stream));
+    } else if (c->is_real) {
         HIPCHK(hipMemcpyAsync(dst, src, (c->N / 2 + 1) * sizeof(cf), hipMemcpyDeviceToHost,
                               c->stream));
     } else {
@@ -1245,6 +1395,7 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     a.spec = spec;
     a.spec_stride = spec_stride;
     a.is_real = c->is_real ? 1 : 0;
+    a.lay = c->lay;
     a.n = c->n;
     a.nframes = nframes;
     a.max_batch = c->max_batch;

@@ -168,12 +168,45 @@ __device__ __forceinline__ void pyr_levels(float (&p)[CH], int8_t *Qf, size_t qo
 // (tpr = M1/CH groups per output row, gpt = T/CH groups per tile and row, rows = M2).
 struct RecMap {
     int l2tpr, l2gpt, l2rows;
-    int mapped;  // 0: identity (level-major producers: the real-input untangle kernel)
+    int mapped;  // 0: identity (level-major producers: the three-pass real-input path)
+                 // 1: IQ tile-major (above)
+                 // 2: fused real-input pass 2 (k_fft_pass2_real): octet o = k / 8 of bin k lives in
+                 //    row c2 = o / tpr (tpr = M1/8 octets per row); the lower half of a row's octets
+                 //    belongs to tile g = o % tpr as its LOW octet, the upper half to tile
+                 //    g = tpr - 1 - o % tpr as its HIGH octet: pos = (g * rows + c2) * 2 + side
     __host__ __device__ __forceinline__ size_t pos(size_t g) const {
         if (!mapped) return g;
         const size_t row = g >> l2tpr, gc = g & (((size_t)1 << l2tpr) - 1);
+        if (mapped == 2) {
+            const size_t tpr = (size_t)1 << l2tpr;
+            const size_t side = gc >= (tpr >> 1) ? 1 : 0;
+            const size_t tl = side ? tpr - 1 - gc : gc;
+            return (((tl << l2rows) + row) << 1) + side;
+        }
         const size_t tl = gc >> l2gpt, k = gc & (((size_t)1 << l2gpt) - 1);
         return (((tl << l2rows) + row) << l2gpt) + k;
+    }
+};
+
+// Device layout of the spectrum.  m1 = 0: natural order (IQ: client order, real three-pass: k order).
+// Fused real-input path (k_fft_pass2_real, fft_pass.h), bin k = c1 + M1*c2 (c1 < M1 row, c2 < L column):
+// the frame is a sequence of 128-byte LINES of 16 bins, TILE-MAJOR: line (g, c) = g * L + c holds
+//   [ rows 8g..8g+7 of column c | the mirror octet of tile g of column L-1-c ]
+// where the mirror octet of tile g is rows M1-8g-7..M1-8g in ascending order (for g = 0 its last
+// element is row M1/2 instead of "row M1").  The two halves of a line are the two real-signal bins
+// a (row, mirror row) couple produces together, so one pass-2 store instruction writes whole lines,
+// and the 1024 lines of a tile are one contiguous 128 KiB block: a work-group streams its output
+// linearly (lines of one column but different tiles are written at unrelated times by different
+// work-groups: scattered over the frame they cost twice the whole rest of the tile, measured).
+struct SpecLayout {
+    int m1, l2m1, L, l2L;
+    __host__ __device__ __forceinline__ size_t pos(int k) const {
+        if (!m1) return (size_t)k;
+        const int c1 = k & (m1 - 1), c2 = k >> l2m1;
+        if (c1 < (m1 >> 1)) return ((((size_t)(c1 >> 3) << l2L) + c2) << 4) + (c1 & 7);
+        const int hp = c1 == (m1 >> 1) ? m1 - 1 : c1 - 1;  // rows above M1/2 shift down, M1/2 goes last
+        const int g = (m1 - 1 - hp) >> 3;
+        return ((((size_t)g << l2L) + (L - 1 - c2)) << 4) + 8 + (hp & 7);
     }
 };
 

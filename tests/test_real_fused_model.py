@@ -1,0 +1,144 @@
+"""CPU model of the fused real-input pass 2 (phantomsdr_amd/csrc/fft_pass.h, k_fft_pass2_real):
+the index algebra the kernel relies on, restated in numpy at small sizes and checked against
+numpy.fft.rfft.  This is host-side logic (no GPU): it pins
+
+  * the row pairing of pass 1's PAIR mode: row c1 at slot 2*c1, mirror row M1-c1 at slot 2*c1+1 stored
+    as conj(Y)*W_M2^{n2}, row M1/2 beside row 0;
+  * the thread-local untangle X[k] = (a+b)/2 + W_N^k(-i)(a-b)/2, X[M-k] = conj((a+b)/2 - ...), with
+    a = Z[k], b = conj(Z[M-k]) = the mirror row's plain forward transform at the same output index;
+  * the self-paired rows 0 and M1/2 (couple 0 of tile 0) and the un-normalised bin N/2
+    (src/fft_impl.cpp:156-160 never visits it);
+  * the line layout of the spectrum (SpecLayout): the two bins a couple produces together share a
+    128-byte line, so one store instruction writes whole lines;
+  * the octet pyramid bookkeeping: low octets complete per tile, high octets through the carried row of
+    the chain (decreasing g), the seam buffers at segment boundaries and the ring closure through row
+    M1/2, and the record order (RecMap mode 2).
+"""
+import numpy as np
+import pytest
+
+
+def spec_layout_pos(k, M1, M2):
+    """SpecLayout::pos (quantize.h): 128-byte lines [low octet of column c | mirror octet of column L-1-c],
+    tile-major (line (g, c) = g*L + c)"""
+    c1, c2 = k % M1, k // M1
+    if c1 < M1 // 2:
+        return ((c1 // 8) * M2 + c2) * 16 + c1 % 8
+    hp = M1 - 1 if c1 == M1 // 2 else c1 - 1
+    g = (M1 - 1 - hp) // 8
+    return (g * M2 + (M2 - 1 - c2)) * 16 + 8 + hp % 8
+
+
+def recmap2_pos(o, M1, M2):
+    tpr = M1 // 8
+    row, gc = o // tpr, o % tpr
+    side = 1 if gc >= tpr // 2 else 0
+    tl = tpr - 1 - gc if side else gc
+    return ((tl * M2) + row) * 2 + side
+
+
+def pass1_pair(z, M1, M2):
+    """Y slots [M1][M2] as pass 1 stores them in PAIR mode"""
+    M = M1 * M2
+    zz = z.reshape(M1, M2)                       # z[M2*n1 + n2]
+    col = np.fft.fft(zz, axis=0)                 # over n1 -> [c1][n2]
+    n2 = np.arange(M2)
+    Y = col * np.exp(-2j * np.pi * np.outer(np.arange(M1), n2) / M)
+    slots = np.zeros((M1, M2), complex)
+    cW = np.exp(-2j * np.pi * n2 / M2)
+    for c1 in range(M1):
+        if c1 < M1 // 2:
+            slots[2 * c1] = Y[c1]
+        elif c1 == M1 // 2:
+            slots[1] = Y[c1]                     # natural form, beside row 0
+        else:
+            slots[2 * (M1 - c1) + 1] = np.conj(Y[c1]) * cW
+    return slots
+
+
+def untangle_pair(a, b, w, h):
+    s, d = a + b, a - b
+    wo = w * (-1j * d)
+    return (s + wo) * h, np.conj((s - wo) * h)
+
+
+def fused_pass2(slots, M1, M2, seg_len):
+    """returns (permuted spectrum [M+1], records dict pos -> 8 powers, level-3 sums dict)"""
+    M, N = M1 * M2, 2 * M1 * M2
+    G = M1 // 16
+    S = G // seg_len
+    h = 0.5 / N
+    X = np.zeros(M + 1, complex)
+    rec, seamP, seamC = {}, {}, {}
+    c2 = np.arange(M2)
+    for si in range(S):
+        carry = None
+        for j in range(seg_len):
+            g = (si + 1) * seg_len - 1 - j
+            low = np.zeros((M2, 8))
+            high = np.zeros((M2, 8))
+            carry_w = np.zeros(M2)
+            for p in range(8):
+                a = np.fft.fft(slots[16 * g + 2 * p])
+                b = np.fft.fft(slots[16 * g + 2 * p + 1])
+                c1 = 8 * g + p
+                if g == 0 and p == 0:
+                    # row 0 <-> itself at column (M2-c2) % M2; row M1/2 <-> itself at column M2-1-c2
+                    w = np.exp(-2j * np.pi * (M1 * c2) / N)
+                    xk, _ = untangle_pair(a, np.conj(a[(M2 - c2) % M2]), w, h)
+                    X[16 * c2] = xk                       # line (0, c2), bin 0
+                    low[:, 0] = np.abs(xk) ** 2
+                    X[M] = a[0].real - a[0].imag
+                    w = np.exp(-2j * np.pi * (M1 // 2 + M1 * c2) / N)
+                    xk, _ = untangle_pair(b, np.conj(b[M2 - 1 - c2]), w, h)
+                    X[16 * (M2 - 1 - c2) + 15] = xk       # row M1/2 closes tile 0's mirror octet
+                    seamC[si] = np.abs(xk) ** 2
+                    continue
+                w = np.exp(-2j * np.pi * (c1 + M1 * c2) / N)
+                xk, xm = untangle_pair(a, b, w, h)
+                cm = M2 - 1 - c2
+                X[(g * M2 + c2) * 16 + p] = xk            # both halves of line (g, c2)
+                X[(g * M2 + c2) * 16 + 15 - p] = xm
+                low[:, p] = np.abs(xk) ** 2
+                if p:
+                    high[cm, 8 - p] = np.abs(xm) ** 2
+                else:
+                    carry_w[cm] = np.abs(xm) ** 2
+                    if j == seg_len - 1:
+                        seamC[si] = carry_w.copy()
+            for c in range(M2):
+                rec[(g * M2 + c) * 2] = low[c].copy()
+                if j == 0:
+                    seamP[si] = high.copy() if c == 0 else seamP[si]
+                else:
+                    pw = high[c].copy()
+                    pw[0] = carry[c]
+                    rec[(g * M2 + c) * 2 + 1] = pw
+            carry = carry_w
+    for si in range(S):                          # k_real_seam
+        g = (si + 1) * seg_len - 1
+        for c in range(M2):
+            pw = seamP[si][c].copy()
+            pw[0] = seamC[(si + 1) % S][c]
+            rec[(g * M2 + c) * 2 + 1] = pw
+    return X, rec
+
+
+@pytest.mark.parametrize("M1,M2,seg_len", [(32, 16, 1), (32, 16, 2), (64, 8, 2), (64, 8, 4), (16, 16, 1)])
+def test_fused_real_pass2_model_matches_rfft(M1, M2, seg_len):
+    M, N = M1 * M2, 2 * M1 * M2
+    rng = np.random.default_rng(M1 + seg_len)
+    x = rng.standard_normal(N)
+    z = x[0::2] + 1j * x[1::2]
+    Xp, rec = fused_pass2(pass1_pair(z, M1, M2), M1, M2, seg_len)
+    ref = np.fft.rfft(x) / N
+    ref[M] *= N                                   # bin N/2 stays un-normalised
+    pos = np.array([spec_layout_pos(int(k), M1, M2) for k in range(M)])
+    assert sorted(pos) == list(range(M))          # a permutation: every line written exactly once
+    got = np.concatenate([Xp[pos], Xp[M:]])
+    assert np.abs(got - ref).max() < 1e-12 * np.abs(ref).max() * N
+    # octet records in true k order through RecMap mode 2
+    P = np.abs(ref[:M]) ** 2
+    assert len(rec) == M // 8
+    for o in range(M // 8):
+        assert np.allclose(rec[recmap2_pos(o, M1, M2)], P[8 * o: 8 * o + 8], rtol=1e-9, atol=0), o
