@@ -225,8 +225,6 @@ def kernel_roofline(ctx, step, first_step, nsteps, wl, wl_name, params, clients,
     per_kernel_bytes = {
         "fft_pass1": ab["input"] * Fl,
         "fft_pass2": (ab["spectrum"] + (ab["pyramid"] if not wl["is_real"] else 0)) * Fl,
-        # PSDR_TWO_PHASE=1: both passes in one launch
-        "fft_two_phase": (ab["input"] + ab["spectrum"] + (ab["pyramid"] if not wl["is_real"] else 0)) * Fl,
         "untangle_real": (ab["spectrum"] + ab["pyramid"]) * Fl if wl["is_real"] else 0,
         "demod_idft": ab["clients"] * Fl,
     }

@@ -346,11 +346,18 @@ __global__ __launch_bounds__(256) void k_real_seam(SeamArgs a) {
     }
 }
 
-// device layout of the fused real path (SpecLayout) -> the reference's k order (one frame, M+1 bins)
-__global__ __launch_bounds__(256) void k_real_unpermute(const cf *X, cf *out, size_t M, SpecLayout lay) {
+// device layout (SpecLayout) -> the reference's k order, one frame: `nbins` bins (+ the un-normalised
+// bin N/2 of real input, kept after the M laid-out bins).  IQ: bin k is client-order bin
+// c = (k - N/2 - 1) mod N (src/fft_impl.cpp:149-160).
+__global__ __launch_bounds__(256) void k_spec_k_order(const cf *X, cf *out, size_t M, int is_real, SpecLayout lay) {
     const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k > M) return;
-    out[k] = k == M ? X[M] : X[lay.pos((int)k)];
+    if (is_real) {
+        if (k > M) return;
+        out[k] = k == M ? X[M] : X[lay.pos((int)k)];
+    } else {
+        if (k >= M) return;
+        out[k] = X[lay.pos((int)((k + M - (M / 2 + 1)) & (M - 1)))];
+    }
 }
 
 struct WfClient {

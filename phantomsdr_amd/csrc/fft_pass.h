@@ -295,21 +295,9 @@ struct TileQueue {
     }
 };
 
-// Single-launch operation (k_fft_two_phase): pass 2 starts inside the same launch as soon as a
-// work-group runs out of pass-1 tiles.  Y crosses XCDs (non-coherent L2s) inside one kernel:
-// pass 1 stores it write-through (sc1), every wave drains its stores (counted wait at the next
-// tile's second barrier), one lane bumps the frame's counter with a relaxed agent-scope atomic;
-// pass 2 reads Y with sc1 loads after a relaxed poll of the counter
-// (cdna_hip_programming.md, "in-launch combine", sc1 form).
-struct CoopArgs {
-    unsigned *cnt1;     // [nframes] pass-1 tiles completed per frame, zeroed
-    unsigned need;      // pass-1 tiles per frame
-    unsigned y_bytes;   // size of Y (buffer descriptor range)
-};
-
 struct Pass1Args {
     const void *raw;  // nframes+1 raw half-frames, contiguous
-    cf *Y;            // blocked: [nframes][tile][M1][T]
+    cf *Y;            // !PAIR: [nframes][pass-1 tile][M1][T]; PAIR: [nframes][pass-2 tile][pass-1 tile][row in tile][T]
     const cf *Wl;     // W_L^j, j < L (L = M1)
     const cf *TB;     // W_M^l, l < M2
     cf wdelta;        // W_N^1 (real input: window angle of the odd sample)
@@ -318,7 +306,9 @@ struct Pass1Args {
     int fmt;
     int is_real;  // window pairs (w[2n], w[2n+1]) instead of (w[n], w[n])
     int rot;      // IQ: produce client order
-    size_t yblk;  // elements between consecutive blocks of Y (>= L*T)
+    size_t yblk;    // !PAIR: elements of one pass-1 tile's block (M1 * T)
+    int l2t2;       // PAIR: log2 of the rows per pass-2 tile
+    size_t ytile;   // PAIR: elements of one pass-2 tile's block (M2 * rows per tile)
     size_t yframe;  // elements between frames of Y
     unsigned tiles_per_frame;
     unsigned total_slots;
@@ -357,7 +347,14 @@ __device__ __forceinline__ constexpr float image_scale() {
 // pass 1: convert + window + column FFT (length L = M1) + inter-pass twiddle.
 //   T columns per tile (T/2 couples), SB bytes per complex sample of the raw image
 //   (u8/s8: 2, u16/s16: 4, f32 and f64-narrowed-to-f32: 8).  L*T/32 threads.
-// COOP: part of a single launch with pass 2 (CoopArgs): sc1 stores of Y, completion counters
+// Y layout.  Plain (IQ, small real transforms): one linear block per PASS-1 tile, [c1][T]; pass 2
+// gathers 2 KiB pieces (16 rows x T) from the 64 blocks of a frame - efficient because the 64 pass-2
+// work-groups of a frame read neighbouring pieces at about the same time.  PAIR (fused real input):
+// PASS-2-TILE-MAJOR - a pass-1 tile contributes one (rows per pass-2 tile) x T chunk to every pass-2
+// tile's block, so that pass 2 reads its tile as ONE contiguous 128 KiB block: its work-groups walk
+// chains of tiles of different frames and have no neighbours in time (measured on cfg3: gathered
+// reads 1092 us, linear reads 960 us per 256 frames; the scattered 2 KiB writes cost pass 1 28 us,
+// which is why the IQ path, whose pass 2 gains only 5 us, keeps the linear pass-1 blocks).
 // PAIR: real input feeding the fused pass 2 (k_fft_pass2_real).  The packed N/2-point transform Z is
 // untangled into the real signal's spectrum from the pairs (Z[k], conj Z[M-k]); bin k = c1 + M1*c2
 // pairs with row M1-c1, column M2-1-c2.  Two changes make that pairing thread-local in pass 2:
@@ -366,8 +363,8 @@ __device__ __forceinline__ constexpr float image_scale() {
 //   * mirror rows (c1 > M1/2) are stored as conj(Y[c1][n2]) * W_M2^{n2}: the plain forward row
 //     transform of that sequence is G[c2] = conj(Z[c1][M2-1-c2]), exactly the partner of the
 //     couple's other half at the same output index c2.
-template <int L, int T, int SB, bool COOP, bool PAIR = false>
-__device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &co) {
+template <int L, int T, int SB, bool PAIR = false>
+__device__ __forceinline__ void pass1_body(const Pass1Args &a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *tile = reinterpret_cast<float4 *>(smem);
     cf *Wl = reinterpret_cast<cf *>(smem) + L * T;
@@ -443,10 +440,6 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
     __shared__ unsigned s_next[2];
     TileQueue tq;
     tq.init(a.tickets, total);
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, COOP ? (int)co.y_bytes : 0, 0x00020000);
-    (void)yrs;
-    bool have_prev = false;  // COOP: the previous tile's completion is not published yet
-    unsigned prev_f = 0;
     unsigned s = blockIdx.x, snext = blockIdx.x + gridDim.x;
     if (s < total) {
         point_at(s);
@@ -465,9 +458,9 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
         const unsigned slot = xcd_slot(s, total);
         const unsigned f = slot / a.tiles_per_frame;
         const unsigned tl = slot - f * a.tiles_per_frame;
-        cf *Yb = a.Y + (size_t)f * a.yframe + (size_t)tl * a.yblk;  // this tile's block
-        const unsigned yb_bytes = (unsigned)(((size_t)f * a.yframe + (size_t)tl * a.yblk) * sizeof(cf));
-        (void)yb_bytes;
+        const int T2 = 1 << a.l2t2;
+        // this tile's block (plain) / its chunk of pass-2 tile 0 (PAIR)
+        cf *Yb = a.Y + (size_t)f * a.yframe + (PAIR ? (size_t)tl * (T2 * T) : (size_t)tl * a.yblk);
         const bool more = snext < total;
         if (more) point_at(snext);
         // the index after `snext`: drawn one tile ago, published now, read after the barrier
@@ -527,25 +520,7 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
         PSDR_SCHED_FENCE();
         if (more) static_for<0, EARLY>(issue);  // the raw registers are free again
         PSDR_SCHED_FENCE();
-        if constexpr (COOP) {
-            // drain point for the PREVIOUS tile's Y stores: only the EARLY loads of the next
-            // tile are younger (wave 0 also has the ticket atomic in flight: it waits for all)
-            if (have_prev) {
-                if (!more || tid < 64)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EARLY) : "memory");
-            }
-            __syncthreads();
-        }
         PSDR_TRACE(a.trace, it, 3);
-        if constexpr (COOP) {
-            if (have_prev && tid == 0) {
-                __hip_atomic_fetch_add(co.cnt1 + prev_f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            have_prev = true;
-            prev_f = f;
-        }
 
         cf tbA[NBL], tbB[NBL], tsA[RL], tsB[RL], w00A, w00B;  // inter-pass twiddles
         cf cWA = make_float2(1.f, 0.f), cWB = cWA;             // PAIR: W_M2^{n2} of the two columns
@@ -607,19 +582,8 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
                         yB = natural ? yB : mB;
                     }
                 }
-                if constexpr (COOP) {
-                    const u32x4 v = {__float_as_uint(yA.x), __float_as_uint(yA.y), __float_as_uint(yB.x),
-                                     __float_as_uint(yB.y)};
-                    // sc1: write through, the reader is on another XCD.  The whole offset goes in
-                    // the VGPR (soffset = 0): with an SGPR soffset the compiler puts no wait state
-                    // between a 128-bit buffer store and a VALU write of its data registers (its
-                    // hazard recogniser assumes none is needed in that form), and on gfx950 the
-                    // butterflies that follow then corrupt the stored rows (measured: the even
-                    // rows of some tiles, deterministically; gone with soffset = 0).
-                    __builtin_amdgcn_raw_buffer_store_b128(v, yrs, yb_bytes + (unsigned)((c1 * T + 2 * p) * (int)sizeof(cf)), 0, 16);
-                } else {
-                    *reinterpret_cast<float4 *>(Yb + (size_t)c1 * T + 2 * p) = make_float4(yA.x, yA.y, yB.x, yB.y);
-                }
+                cf *dst = PAIR ? Yb + (size_t)(c1 >> a.l2t2) * a.ytile + (c1 & (T2 - 1)) * T + 2 * p : Yb + (size_t)c1 * T + 2 * p;
+                *reinterpret_cast<float4 *>(dst) = make_float4(yA.x, yA.y, yB.x, yB.y);
             },
             // ---- trickle the rest of the next tile's loads through the stages
             [&](int k) {
@@ -639,25 +603,15 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, const CoopArgs &c
         s = snext;
         snext = s2;
     }
-    if constexpr (COOP) {
-        if (have_prev) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                __hip_atomic_fetch_add(co.cnt1 + prev_f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        __syncthreads();  // the LDS is about to change hands
-    }
     PSDR_WGTRACE(a.trace, 7);
 }
 template <int L, int T, int SB, bool PAIR = false>
 __global__ __launch_bounds__(L *T / 32) void k_fft_pass1(Pass1Args a) {
-    pass1_body<L, T, SB, false, PAIR>(a, CoopArgs{});
+    pass1_body<L, T, SB, PAIR>(a);
 }
 
 struct Pass2Args {
-    const cf *Y;   // blocked: [nframes][tiles1][M1][TW]
+    const cf *Y;   // k_fft_pass2: [nframes][tiles1][M1][TW]; k_fft_pass2_real: [nframes][pass-2 tile][tiles1][rows][TW]
     cf *X;         // [nframes][spec_stride]: bin c1 + M1*c2
     size_t spec_stride;
     const cf *Wl;  // W_L^j, L = M2
@@ -665,7 +619,7 @@ struct Pass2Args {
     int log2M1;
     int TW;       // pass-1 tile width (columns per block of Y)
     int log2TW;
-    size_t yblk, yframe;  // block / frame strides of Y in elements
+    size_t yblk, ytile, yframe;  // pass-1 block (k_fft_pass2) / pass-2 tile block (k_fft_pass2_real) / frame strides, elements
     // fused IQ epilogue
     float inv_n;
     int size_log2;
@@ -680,6 +634,7 @@ struct Pass2Args {
     unsigned long long *trace;
     // fused real-input epilogue (k_fft_pass2_real)
     const cf *UA, *UB;  // W_N^{h << log2UB}, W_N^{l}: untangle twiddles
+    const cf *UG;       // W_N^{8g}, g < M1/16: the tile's factor of the untangle twiddle
     int log2UB;
     int seg_len;        // tiles of one frame a work-group walks in a chain (divides tiles_per_frame)
     float *seamP;       // [nframes][segs][L][8]: partial octets of every segment's first tile
@@ -689,10 +644,8 @@ struct Pass2Args {
 // pass 2: row FFT (length L = M2) of T adjacent rows c1 (T/2 couples); FUSED adds /N,
 // |X|^2, int8 level 0..LT of the pyramid.  L*T/32 threads.
 // TWC: pass-1 tile width when known at compile time (all fill addresses fold), 0: a.TW
-// COOP: second phase of a single launch (CoopArgs): tiles by chip-wide tickets only, Y through
-// sc1 loads, a tile's frame must have all its pass-1 tiles published before it is loaded
-template <int L, int T, bool FUSED, int TWC, bool COOP>
-__device__ __forceinline__ void pass2_body(const Pass2Args &a, const CoopArgs &co) {
+template <int L, int T, bool FUSED, int TWC>
+__device__ __forceinline__ void pass2_body(const Pass2Args &a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *tile = reinterpret_cast<float4 *>(smem);
     cf *tile_cf = reinterpret_cast<cf *>(smem);
@@ -710,95 +663,41 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, const CoopArgs &c
     const unsigned total = a.total_slots;
     const int TW = TWC ? TWC : a.TW;
     const int log2TW = TWC ? 31 - __builtin_clz((unsigned)(TWC ? TWC : 1)) : a.log2TW;
-    const int chunk = T * TW;  // contiguous elements of one pass-1 block that belong to this tile
-    const size_t blk = a.yblk;
+    const int chunk = T * TW;  // elements one pass-1 tile contributes to this tile
 
     // Element idx of the tile is (block j, row rr, column cc) with idx = j*chunk + rr*TW + cc:
     // Y block j, row c1base + rr, column cc, and n2 = j*TW + cc.  A thread loads 16 bytes =
     // elements idx, idx+1 with idx = 2*(i*NT + tid), i < 16: the address is a uniform per-i
     // part plus ONE per-lane offset.
     const int lc = log2TW + (31 - __builtin_clz((unsigned)T));  // log2(chunk)
+    const size_t blk = a.yblk;
     float4 r[NLD];
     const cf *nxt = nullptr;
-    unsigned nxt_bytes = 0;
-    const __amdgpu_buffer_rsrc_t yrs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.Y), 0, COOP ? (int)co.y_bytes : 0, 0x00020000);
-    (void)yrs;
     const unsigned lane_off = (unsigned)((size_t)((2 * tid) >> lc) * blk + ((2 * tid) & (chunk - 1)));
     auto point_at = [&](unsigned sidx) {
         const unsigned slot = xcd_slot(sidx, total);
         const unsigned f = slot / a.tiles_per_frame;
         const unsigned tl = slot - f * a.tiles_per_frame;
         nxt = a.Y + (size_t)f * a.yframe + (size_t)(tl * T) * TW;
-        nxt_bytes = (unsigned)(((size_t)f * a.yframe + (size_t)(tl * T) * TW) * sizeof(cf));
     };
     auto issue = [&](auto qc) {
         constexpr int i = decltype(qc)::value;
         // uniform part of idx = 2*i*NT: block (2*i*NT)>>lc, offset (2*i*NT)&(chunk-1)
-        if constexpr (COOP) {
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            const unsigned uni = (unsigned)(((size_t)((2 * i * NT) >> lc) * blk + ((2 * i * NT) & (chunk - 1))) * sizeof(cf));
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(yrs, lane_off * (unsigned)sizeof(cf), nxt_bytes + uni, /*sc1*/ 16);
-            r[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-        } else {
-            const cf *q = nxt + (size_t)((2 * i * NT) >> lc) * blk + ((2 * i * NT) & (chunk - 1)) + lane_off;
-            r[i] = *reinterpret_cast<const float4 *>(q);
-        }
+        const cf *q = nxt + (size_t)((2 * i * NT) >> lc) * blk + ((2 * i * NT) & (chunk - 1)) + lane_off;
+        r[i] = *reinterpret_cast<const float4 *>(q);
     };
     __shared__ unsigned s_next[2];
     TileQueue tq;
     // pass 2 has no use for XCD affinity (full-line stores, tile-major records) and the XCDs
     // differ by ~10 % in speed: one chip-wide counter (pass 1 keeps the per-XCD queues: adjacent
     // tiles share the 128-byte lines of the raw rows)
-    tq.init(a.tickets, total, true, COOP);
+    tq.init(a.tickets, total, true, false);
     unsigned s = blockIdx.x, snext = blockIdx.x + gridDim.x;
-    // COOP: thread 0 knows which frames are complete (frames complete roughly in order; the
-    // counter of a frame beyond `known` is polled a tile before it is needed)
-    unsigned known = 0, polled_f = 0xFFFFFFFFu, polled_v = 0;
-    auto frame_of = [&](unsigned sidx) { return xcd_slot(sidx, total) / a.tiles_per_frame; };
-    auto poll_begin = [&](unsigned sidx) {  // thread 0
-        const unsigned fr = frame_of(sidx);
-        if (fr >= known) {
-            polled_f = fr;
-            polled_v = __hip_atomic_load(co.cnt1 + fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-    auto wait_frame = [&](unsigned sidx) {  // thread 0: returns when the tile's frame is complete
-        const unsigned fr = frame_of(sidx);
-        if (fr < known) return;
-        if (!(polled_f == fr && polled_v >= co.need)) {
-            // bounded (about a second): a lost completion must not hang the device
-            for (unsigned spin = 0; spin < (1u << 21) &&
-                                    __hip_atomic_load(co.cnt1 + fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < co.need;
-                 spin++)
-                __builtin_amdgcn_s_sleep(8);
-        }
-        known = fr + 1;  // (frames below fr were waited for by earlier tiles of this work-group
-                         //  or are older: tickets are handed out in frame order)
-    };
-    if constexpr (COOP) {
-        if (tid == 0) {
-            s_next[0] = tq.draw_now();
-            s_next[1] = tq.draw_now();
-        }
-        for (int i = tid; i < L; i += NT) Wl[i] = a.Wl[i];
-        __syncthreads();
-        s = s_next[0];
-        snext = s_next[1];
-        __syncthreads();
-        if (s < total) {
-            if (tid == 0) wait_frame(s);
-            __syncthreads();
-            point_at(s);
-            static_for<0, NLD>(issue);
-        }
-    } else {
-        if (s < total) {
-            point_at(s);
-            static_for<0, NLD>(issue);
-        }
-        for (int i = tid; i < L; i += NT) Wl[i] = a.Wl[i];  // visible after the loop's first barrier
+    if (s < total) {
+        point_at(s);
+        static_for<0, NLD>(issue);
     }
+    for (int i = tid; i < L; i += NT) Wl[i] = a.Wl[i];  // visible after the loop's first barrier
     tq.draw_begin();
     PSDR_WGTRACE(a.trace, 1);
 
@@ -827,22 +726,11 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, const CoopArgs &c
             tile_cf[2 * (slot0 + H) + (rr & 1)] = make_float2(r[i].z, r[i].w);
         }
         PSDR_SCHED_FENCE();
-        if constexpr (COOP) {
-            if (tid == 0 && more) wait_frame(snext);  // normally a register compare
-        } else {
-            if (more) static_for<0, EARLY>(issue);
-        }
+        if (more) static_for<0, EARLY>(issue);
         PSDR_SCHED_FENCE();
         PSDR_TRACE(a.trace, it, 1);
         __syncthreads();
         PSDR_TRACE(a.trace, it, 2);
-        if constexpr (COOP) {
-            if (more) static_for<0, EARLY>(issue);  // only now: thread 0 has seen the frame complete
-            if (tid == 0) {                          // and look at the tile after that one
-                const unsigned s2t = s_next[it & 1];
-                if (s2t < total) poll_begin(s2t);
-            }
-        }
         // stage-0 input comes from the tile itself: all reads, then a barrier, before any
         // in-place write
         c2 u[16];
@@ -852,6 +740,8 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, const CoopArgs &c
         const unsigned s2 = s_next[it & 1];
 
         cf *Xf = a.X + (size_t)f * a.spec_stride;
+        cf *Xt = Xf + (size_t)tl * (L * T);  // the tile's block of a tile-major frame
+        (void)Xt;
         float *Pst = reinterpret_cast<float *>(smem);  // reuses the (dead) tile after the last read
         run_stages<L, T, true>(
             tile, Wl, i0, p, u, [&]() {},
@@ -865,7 +755,11 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, const CoopArgs &c
                     *reinterpret_cast<float2 *>(Pst + c2i * T + 2 * p) =
                         make_float2(fmaf(x.a.x, x.a.x, x.a.y * x.a.y), fmaf(x.b.x, x.b.x, x.b.y * x.b.y));
                 }
-                *reinterpret_cast<float4 *>(Xf + ((size_t)c2i << a.log2M1) + c1base + 2 * p) = pack_c2(x);
+                // FUSED (IQ) tiles of 1024-point rows: tile-major lines (SpecLayout mode 1, quantize.h)
+                if constexpr (FUSED && L == 1024 && T == 16)
+                    *reinterpret_cast<float4 *>(Xt + c2i * T + 2 * p) = pack_c2(x);
+                else
+                    *reinterpret_cast<float4 *>(Xf + ((size_t)c2i << a.log2M1) + c1base + 2 * p) = pack_c2(x);
             },
             [&](int k) {  // trickle the rest of the next tile's loads through the stages
                 if (more)
@@ -929,7 +823,7 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, const CoopArgs &c
 
 template <int L, int T, bool FUSED, int TWC>
 __global__ __launch_bounds__(L *T / 32) void k_fft_pass2(Pass2Args a) {
-    pass2_body<L, T, FUSED, TWC, false>(a, CoopArgs{});
+    pass2_body<L, T, FUSED, TWC>(a);
 }
 
 // ---- pass 2 for REAL input, fused with the Hermitian untangle, /N, |X|^2 and pyramid levels 0..3 ----
@@ -995,7 +889,15 @@ __device__ __forceinline__ void untangle_pair(cf a, cf b, cf w, float h, cf &xk,
     xk = make_float2((s.x + wo.x) * h, (s.y + wo.y) * h);
     xm = make_float2((s.x - wo.x) * h, (wo.y - s.y) * h);
 }
-__device__ __forceinline__ float bin_power(cf x) { return fmaf(x.x, x.x, x.y * x.y); }  // src/fft_impl.cpp:36-38
+// |x|^2 as the reference rounds it (src/fft_impl.cpp:36-38: fma(re, re, im*im)).  Two plain VALU
+// instructions: left to itself the compiler packs two of these into v_pk_mul/v_pk_fma and pays four
+// v_mov to gather the operands (a packed f32 op costs two plain ones: nothing gained, moves lost).
+__device__ __forceinline__ float bin_power(cf x) {
+    float t, p;
+    asm("v_mul_f32 %0, %1, %1" : "=v"(t) : "v"(x.y));
+    asm("v_fma_f32 %0, %1, %1, %2" : "=v"(p) : "v"(x.x), "v"(t));
+    return p;
+}
 
 template <int L, int T, int TWC>
 __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
@@ -1021,28 +923,28 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
     constexpr int log2TW = TWC == 16 ? 4 : 3;
     static_assert(TWC == 16 || TWC == 8, "pass-1 tile width");
     const int chunk = T * TW;
-    const size_t blk = a.yblk;
     const int lc = log2TW + 4;  // log2(chunk)
     const int SL = a.seg_len;
     const unsigned S = a.tiles_per_frame / (unsigned)SL;  // segments per frame
     float4 r[NLD];
-    const cf *nxt = nullptr;
-    const unsigned lane_off = (unsigned)((size_t)((2 * tid) >> lc) * blk + ((2 * tid) & (chunk - 1)));
-    // tile j of segment sg: frame sg / S, g = (sg % S + 1) * SL - 1 - j
+    const float4 *nxt = nullptr;
+    // tile j of segment sg: frame sg / S, g = (sg % S + 1) * SL - 1 - j (S, SL powers of two; the
+    // segment index is wave-uniform: keep the tile's coordinates and addresses in scalar registers)
+    const int l2S = 31 - __builtin_clz(S);
     auto tile_of = [&](unsigned sg, int j, unsigned &f, int &g) {
-        f = sg / S;
-        g = (int)((sg - f * S + 1u) * (unsigned)SL) - 1 - j;
+        sg = __builtin_amdgcn_readfirstlane(sg);
+        f = sg >> l2S;
+        g = (int)((sg - (f << l2S) + 1u) * (unsigned)SL) - 1 - j;
     };
     auto point_at = [&](unsigned sg, int j) {
         unsigned f;
         int g;
         tile_of(sg, j, f, g);
-        nxt = a.Y + (size_t)f * a.yframe + (size_t)(g * T) * TW;
+        nxt = reinterpret_cast<const float4 *>(a.Y + (size_t)f * a.yframe + (size_t)g * a.ytile) + tid;  // one linear block
     };
     auto issue = [&](auto qc) {
         constexpr int i = decltype(qc)::value;
-        const cf *q = nxt + (size_t)((2 * i * NT) >> lc) * blk + ((2 * i * NT) & (chunk - 1)) + lane_off;
-        r[i] = *reinterpret_cast<const float4 *>(q);
+        r[i] = nxt[i * NT];
     };
     __shared__ unsigned s_next[2];
     TileQueue tq;
@@ -1057,6 +959,26 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
 
     const float hscale = 0.5f * a.inv_n;
     const unsigned ubm = (1u << a.log2UB) - 1u;
+    // Untangle twiddle of the thread's first output: W_N^{c1 + M1*i0}, c1 = 8g + p.  The (p, i0) part
+    // is a per-thread constant; the tile's part W_N^{8g} is wave-uniform and comes through the
+    // SCALAR cache: a vector load here would sit behind the previous tile's ~40 stores in the
+    // in-order vmcnt queue and waiting for it drains them all, once per tile.
+    // Lane roles of the pair exchange below: even lanes keep the low-side bin X[k] ("mine") and pass
+    // the mirror-side bin X[M-k] on ("send"), odd lanes the other way round.  With sigma = +1 / -1:
+    //   mine = (s + sigma*wo) * (h, sigma*h)      send = (s - sigma*wo) * (h, -sigma*h)
+    // (s = a+b, wo = W_N^k * (-i)(a-b); the signed second component is the conjugation of X[M-k]),
+    // so the roles cost no select: sigma rides in the thread's twiddle constant and in two
+    // per-thread scale pairs.
+    const bool ev_ = (p_ & 1) == 0;
+    cf wc;
+    {
+        const unsigned e = (unsigned)p_ + (unsigned)M1 * (unsigned)i0_;
+        wc = cmul(a.UA[e >> a.log2UB], a.UB[e & ubm]);
+        if (!ev_) wc = make_float2(-wc.x, -wc.y);
+    }
+    const v2f hm = {hscale, ev_ ? hscale : -hscale}, hs = {hscale, ev_ ? -hscale : hscale};
+    const int off_ = ev_ ? (p_ & ~1) : 14 - (p_ & ~1);  // bin of the lane's pair inside the 16-bin line
+    const int xflip_ = ev_ ? 0 : L - 1;                 // mirror-side values of column c belong to column L-1-c
     int j = 0, segit = 0;
     for (int it = 0; s < total; it++) {
         unsigned f;
@@ -1078,10 +1000,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         }
         int i0 = i0_, p = p_, tidx = tid;  // opaque copies (see pass 1)
         asm volatile("" : "+v"(i0), "+v"(p), "+v"(tidx));
-        // untangle twiddle of the thread's first output: W_N^{c1 + M1*i0}
-        const int c1 = 8 * g + p;
-        const unsigned e0 = (unsigned)c1 + (unsigned)M1 * (unsigned)i0;
-        const cf ua = a.UA[e0 >> a.log2UB], ub = a.UB[e0 & ubm];
+        const cf wg = a.UG[__builtin_amdgcn_readfirstlane(g)];
         // transposing fill (as pass2_body)
 #pragma unroll
         for (int i = 0; i < NLD; i++) {
@@ -1117,14 +1036,15 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                     });
             },
             [&](int) {});
-        const cf w0 = cmul(ua, ub);
+        const cf w0 = cmul(wc, wg);
         cf *Xt = Xf + (size_t)g * (16 * L);  // line (g, c) of the frame starts at Xt + 16 * c
         // Octet staging Pst[c2][16]: [0..8) the low octet of column c2; [8..15) elements 1..7 of the
         // high octet of column c2 (its element 0 is the carried row).
         // Tile 0 only (couple 0 is special there): 8 bytes per lane.
         auto emit_pair = [&](int t, int c2i, c2 x) {
             cf xk, xm;
-            untangle_pair(x.a, x.b, cmul(w0, w32(t)), hscale, xk, xm);
+            const cf w0p = (p & 1) ? make_float2(-w0.x, -w0.y) : w0;  // (w0 carries the lane's sigma)
+            untangle_pair(x.a, x.b, cmul(w0p, w32(t)), hscale, xk, xm);
             const int cm = L - 1 - c2i;
 #ifndef PSDR_ABL_NOX
             Xt[16 * c2i + p] = xk;
@@ -1136,46 +1056,53 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         // Every other tile: two outputs (A, B) per call.  Lane pair (2q, 2q+1): the even lane ends up
         // with rows 8g+2q, 8g+2q+1 of both outputs, the odd lane with the mirror rows M1-8g-2q-1,
         // M1-8g-2q of both (one DPP swap per value), so that lanes 0..7 of an i0 write one whole line.
-        cf skA = make_float2(0.f, 0.f), smA = skA;
-        int cA = 0;
+        // (The carried row - the odd lane's partner value at q = 0 - lands in slot 15 of the staging
+        // row and is picked up from there by the octet loop.)
+        cf mineA = make_float2(0.f, 0.f), sendA = mineA;
+        // Addresses: output t of the thread is column c = i0 + (L/16)*t.  Global: the tile's block
+        // (scalar) + t * 8 KiB (scalar) + one per-thread byte offset.  Staging: the even lane writes
+        // row c, the odd lane row L-1-c = (L/16-1-i0) + (L/16)*(15-t): per-thread base and +-4 KiB
+        // stride.  (Opaque copies: see the loop-invariant-address note in pass 1.)
+        unsigned gofs = (unsigned)((i0_ * 16 + off_) * (int)sizeof(cf));
+        int lbase = ((ev_ ? i0_ : (L16 - 1 - i0_) + 15 * L16) * 16 + off_) * (int)sizeof(float);
+        int lstride = (ev_ ? L16 : -L16) * 16 * (int)sizeof(float);
+        asm volatile("" : "+v"(gofs), "+v"(lbase), "+v"(lstride));
+        char *Xtb = reinterpret_cast<char *>(Xt);
+        char *Pstb = reinterpret_cast<char *>(Pst);
         auto swap1 = [](float v) {
             return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
         };
-        auto emit_two = [&](int cB, cf xkB, cf xmB) {
-            const bool ev = (p & 1) == 0;
-            const cf mineA = ev ? skA : smA, mineB = ev ? xkB : xmB;
-            const cf sendA = ev ? smA : skA, sendB = ev ? xmB : xkB;
+        auto emit_two = [&](int tA, int tB, cf mineB, cf sendB) {
             const cf recvA = make_float2(swap1(sendA.x), swap1(sendA.y)), recvB = make_float2(swap1(sendB.x), swap1(sendB.y));
-            const int q2 = p & ~1;
-            const int off = ev ? q2 : 14 - q2;  // bin inside the line; odd: (own row M1-8g-2q-1, partner's M1-8g-2q)
 #ifndef PSDR_ABL_NOX
-            *reinterpret_cast<float4 *>(Xt + 16 * cA + off) = make_float4(mineA.x, mineA.y, recvA.x, recvA.y);
-            *reinterpret_cast<float4 *>(Xt + 16 * cB + off) = make_float4(mineB.x, mineB.y, recvB.x, recvB.y);
+            // scalar base + 32-bit lane offset: the store's own address mode, no vector address math
+            typedef __attribute__((address_space(1))) char gchar;
+            typedef float gf4 __attribute__((ext_vector_type(4)));
+            gchar *bA = (gchar *)(Xtb + (size_t)tA * (L16 * 16 * sizeof(cf))), *bB = (gchar *)(Xtb + (size_t)tB * (L16 * 16 * sizeof(cf)));
+            asm volatile("" : "+s"(bA), "+s"(bB));
+            *(__attribute__((address_space(1))) gf4 *)(bA + gofs) = gf4{mineA.x, mineA.y, recvA.x, recvA.y};
+            *(__attribute__((address_space(1))) gf4 *)(bB + gofs) = gf4{mineB.x, mineB.y, recvB.x, recvB.y};
 #endif
-            // the mirror-side values of output column c belong to column L-1-c
-            const int sA = ev ? cA : L - 1 - cA, sB = ev ? cB : L - 1 - cB;
-            const float prA = bin_power(recvA), prB = bin_power(recvB);
-            *reinterpret_cast<float2 *>(Pst + sA * 16 + off) = make_float2(bin_power(mineA), prA);
-            *reinterpret_cast<float2 *>(Pst + sB * 16 + off) = make_float2(bin_power(mineB), prB);
-            if (p == 1) {  // partner's row M1-8g: element 0 of the next octet up, the carry to tile g-1
-                carry_w[sA] = prA;
-                carry_w[sB] = prB;
-                if (seg_last) {
-                    seamC[sA] = prA;
-                    seamC[sB] = prB;
-                }
-            }
+            *reinterpret_cast<float2 *>(Pstb + lbase + tA * lstride) = make_float2(bin_power(mineA), bin_power(recvA));
+            *reinterpret_cast<float2 *>(Pstb + lbase + tB * lstride) = make_float2(bin_power(mineB), bin_power(recvB));
         };
+        int tA = 0;
+#ifdef PSDR_ABL_NOG0
+        if (true) {
+#else
         if (g != 0) {
+#endif
             run_last_stage<L>(Wl, i0, u, [&](int b, int sidx, int c2i, c2 x) {
-                cf xk, xm;
-                untangle_pair(x.a, x.b, cmul(w0, w32(b + NBL * sidx)), hscale, xk, xm);
+                const cf sm = cadd(x.a, x.b), d = csub(x.a, x.b);
+                const cf wo = cmul(cmul(w0, w32(b + NBL * sidx)), make_float2(d.y, -d.x));  // sigma * W_N^k * (-i)(a-b)
+                const v2f mine = (to_v2f(sm) + to_v2f(wo)) * hm, send = (to_v2f(sm) - to_v2f(wo)) * hs;
+                (void)c2i;  // = i0 + (L/16) * (b + NBL * sidx)
                 if ((sidx & 1) == 0) {
-                    skA = xk;
-                    smA = xm;
-                    cA = c2i;
+                    mineA = from_v2f(mine);
+                    sendA = from_v2f(send);
+                    tA = b + NBL * sidx;
                 } else {
-                    emit_two(c2i, xk, xm);
+                    emit_two(tA, b + NBL * sidx, from_v2f(mine), from_v2f(send));
                 }
             });
         } else {
@@ -1227,7 +1154,10 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                 const int side = q & 1, c2i = q >> 1;
                 const float4 v0 = reinterpret_cast<const float4 *>(Pst)[2 * q], v1 = reinterpret_cast<const float4 *>(Pst)[2 * q + 1];
                 float pw[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                if (side) {  // high octet: element 0 is the carried row, 1..7 sit at [0..7)
+                if (side) {  // high octet: element 0 is the carried row, 1..7 sit at [0..7), and slot 7
+                             // holds this tile's own carry-out (row M1-8g of column c2i)
+                    carry_w[c2i] = v1.w;
+                    if (seg_last && g != 0) seamC[c2i] = v1.w;
                     pw[0] = carry_r[c2i];
                     pw[1] = v0.x, pw[2] = v0.y, pw[3] = v0.z, pw[4] = v0.w, pw[5] = v1.x, pw[6] = v1.y, pw[7] = v1.z;
                 }
@@ -1258,15 +1188,6 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             j++;
         }
     }
-}
-
-// Both passes in one launch: a work-group walks pass-1 tiles while there are any, then pass-2
-// tiles.  No kernel boundary: the ramp, the first-tile latency and the tail of the two passes
-// overlap with the other work-groups' steady state.  Square splits only (both passes L x T).
-template <int L, int T, int SB, bool FUSED, int TWC>
-__global__ __launch_bounds__(L *T / 32) void k_fft_two_phase(Pass1Args a1, Pass2Args a2, CoopArgs co) {
-    pass1_body<L, T, SB, true>(a1, co);
-    pass2_body<L, T, FUSED, TWC, true>(a2, co);
 }
 
 }  // namespace psdr

@@ -44,10 +44,10 @@ extern "C" const char *psdr_version(void) { return "phantomsdr_amd 0.1 (gfx950)"
 
 namespace {
 
-enum KernelId { K_PASS1, K_PASS2, K_UNTANGLE, K_TAIL, K_IDFT, K_OLA, K_WFALL, K_POST, K_TWO_PHASE, K_SEAM, K_COUNT };
+enum KernelId { K_PASS1, K_PASS2, K_UNTANGLE, K_TAIL, K_IDFT, K_OLA, K_WFALL, K_POST, K_SEAM, K_COUNT };
 const char *kKernelNames[K_COUNT] = {"fft_pass1",  "fft_pass2", "untangle_real", "pyramid_tail",
                                      "demod_idft", "demod_ola", "waterfall_gather", "post_chain",
-                                     "fft_two_phase", "real_seam"};
+                                     "real_seam"};
 
 struct PendingEvent {
     hipEvent_t a, b;
@@ -119,7 +119,6 @@ struct psdr_ctx {
     psdr_config cfg;
     int device = 0;
     int num_cus = 256;
-    size_t ypad = 0;  // elements of padding between blocks of Y
     size_t N = 0, M = 0, R = 0;
     int M1 = 0, M2 = 0, log2M1 = 0, log2M2 = 0;
     int T1 = 0, T2 = 0;
@@ -153,9 +152,6 @@ struct psdr_ctx {
     bool y_pending[2] = {false, false};
     // TileQueue counters: a ring of TICKET_SLOTS launches x 8 counters per pass; half the ring is
     // re-zeroed (in stream order) whenever the other half starts being used
-    bool two_phase = false;          // both passes in one launch (2^20-point case)
-    unsigned *d_cnt1 = nullptr;      // ring of TICKET_SLOTS x max_batch completion counters
-    unsigned cnt1_pos = 0;
     unsigned *d_tickets[2] = {nullptr, nullptr};
     unsigned ticket_pos[2] = {0, 0};
     bool static_tiles = false, no_p1_stream = true;  // tuning knobs (PSDR_STATIC_TILES, PSDR_P1_STREAM)
@@ -176,7 +172,7 @@ struct psdr_ctx {
     bool set_pending[2] = {false, false};
 
     cf *d_Wl1 = nullptr, *d_Wl2 = nullptr, *d_TA = nullptr, *d_TB = nullptr;
-    cf *d_UA = nullptr, *d_UB = nullptr;
+    cf *d_UA = nullptr, *d_UB = nullptr, *d_UG = nullptr;
     cf wdelta = {1.f, 0.f};  // W_N^1
     unsigned long long *d_trace = nullptr;  // PSDR_TRACE tuning builds: per pass [8][16] phase stamps + [256][8] work-group timeline
     int log2B = 0, log2UB = 0;
@@ -364,34 +360,6 @@ int launch_pass2_t(psdr_ctx *c, const Pass2Args &a, unsigned blocks) {
 }
 
 
-// ---- both passes in one launch (k_fft_two_phase): the 2^20-point case
-template <int SB, bool FUSED>
-int launch_two_phase_t(psdr_ctx *c, const Pass1Args &a1, const Pass2Args &a2, const CoopArgs &co) {
-    constexpr int L = 1024, T = 16;
-    const size_t lds = (size_t)L * T * sizeof(cf) + 2 * (size_t)L * sizeof(cf);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_fft_two_phase<L, T, SB, FUSED, 16>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        attr_set = true;
-    }
-    ProfScope ps(c, K_TWO_PHASE);
-    const unsigned grid = persistent_grid(c, std::max(a1.total_slots, a2.total_slots), lds);
-    hipLaunchKernelGGL((k_fft_two_phase<L, T, SB, FUSED, 16>), dim3(grid), dim3(L * T / 32), lds, c->stream, a1, a2, co);
-    HIPCHK(hipGetLastError());
-    return PSDR_OK;
-}
-int launch_two_phase(psdr_ctx *c, int sb, bool fused, const Pass1Args &a1, const Pass2Args &a2, const CoopArgs &co) {
-    if (fused) {
-        if (sb == 2) return launch_two_phase_t<2, true>(c, a1, a2, co);
-        if (sb == 4) return launch_two_phase_t<4, true>(c, a1, a2, co);
-        return launch_two_phase_t<8, true>(c, a1, a2, co);
-    }
-    if (sb == 2) return launch_two_phase_t<2, false>(c, a1, a2, co);
-    if (sb == 4) return launch_two_phase_t<4, false>(c, a1, a2, co);
-    return launch_two_phase_t<8, false>(c, a1, a2, co);
-}
-
 #define P1CASE(L_, T_)                                                   \
     if (L == L_ && T == T_) {                                            \
         if (sb == 2) return launch_pass1_t<L_, T_, 2>(c, a, blocks);     \
@@ -522,8 +490,10 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
     a1.Y = Y;
     a1.Wl = c->d_Wl1;
     a1.TB = c->d_TB;
-    a1.yblk = (size_t)c->M1 * (c->T1 * cols) + c->ypad;
-    a1.yframe = a1.yblk * tiles1;
+    a1.yblk = (size_t)c->M1 * (c->T1 * cols);  // plain: one linear block per pass-1 tile
+    a1.l2t2 = ilog2((size_t)c->T2);
+    a1.ytile = (size_t)c->M2 * c->T2;  // fused real: pass-2-tile-major (fft_pass.h, "Y layout")
+    a1.yframe = c->M;
     a1.wdelta = c->wdelta;
     a1.M2 = c->M2;
     a1.log2M2 = c->log2M2;
@@ -537,11 +507,8 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
     }
     a1.tiles_per_frame = tiles1;
     a1.total_slots = tiles1 * (unsigned)nframes;
-    int rc = 0;
-    if (!c->two_phase) {  // (two-phase: pass 1 runs inside the combined launch below)
-        rc = launch_pass1(c, c->M1, c->T1, sb, a1, a1.total_slots, c->real_fused);
-        if (rc) return rc;
-    }
+    int rc = launch_pass1(c, c->M1, c->T1, sb, a1, a1.total_slots, c->real_fused);
+    if (rc) return rc;
     if (piped) {
         HIPCHK(hipEventRecord(c->ev_p1[c->cur_y], c->p1));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_p1[c->cur_y], 0));
@@ -554,6 +521,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
     a2.log2M1 = c->log2M1;
     a2.TW = c->T1 * cols;
     a2.yblk = a1.yblk;
+    a2.ytile = a1.ytile;
     a2.yframe = a1.yframe;
     a2.log2TW = ilog2((size_t)(c->T1 * cols));
     a2.inv_n = 1.0f / (float)c->N;
@@ -573,22 +541,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
     // pass 2 overwrites this result set: its previous consumers (two batches ago) must be done
     if (c->set_pending[c->cur_set] && c->side != c->stream)
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_set_done[c->cur_set], 0));
-    // both passes in one launch, or pass 2 on its own
-    auto run_pass2 = [&](bool fused) -> int {
-        if (!c->two_phase) return launch_pass2(c, c->M2, c->T2, fused, a2, a2.total_slots);
-        // per-frame completion counters from a ring (zeroed in stream order half a ring ahead,
-        // like the tickets)
-        const unsigned slot = c->cnt1_pos % TICKET_SLOTS;
-        if (slot % (TICKET_SLOTS / 2) == 0 && c->cnt1_pos >= TICKET_SLOTS / 2)
-            HIPCHK(hipMemsetAsync(c->d_cnt1 + (size_t)slot * c->max_batch, 0,
-                                  (size_t)(TICKET_SLOTS / 2) * c->max_batch * sizeof(unsigned), c->stream));
-        c->cnt1_pos++;
-        CoopArgs co{};
-        co.cnt1 = c->d_cnt1 + (size_t)slot * c->max_batch;
-        co.need = tiles1;
-        co.y_bytes = (unsigned)((size_t)nframes * a1.yframe * sizeof(cf));
-        return launch_two_phase(c, sb, fused, a1, a2, co);
-    };
+    auto run_pass2 = [&](bool fused) -> int { return launch_pass2(c, c->M2, c->T2, fused, a2, a2.total_slots); };
     if (!c->is_real) {
         a2.X = c->d_spec;
         a2.spec_stride = c->spec_stride;
@@ -599,6 +552,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
         a2.spec_stride = c->spec_stride;
         a2.UA = c->d_UA;
         a2.UB = c->d_UB;
+        a2.UG = c->d_UG;
         a2.log2UB = c->log2UB;
         a2.seg_len = real_seg_len(c, nframes);
         const unsigned S = tiles2 / (unsigned)a2.seg_len;
@@ -741,7 +695,7 @@ void free_all(psdr_ctx *c) {
     F(c->d_TB);
     F(c->d_UA);
     F(c->d_UB);
-    F(c->d_cnt1);
+    F(c->d_UG);
     F(c->d_seamP);
     F(c->d_seamC);
     F(c->d_tickets[0]);
@@ -860,6 +814,10 @@ int build(psdr_ctx *c) {
             if (rc) return rc;
             rc = upload(&c->d_UB, make_twiddles(UB, 1, c->N, -1));
             if (rc) return rc;
+            if (c->real_fused) {
+                rc = upload(&c->d_UG, make_twiddles((size_t)(c->M1 / 16), 8, c->N, -1));
+                if (rc) return rc;
+            }
         }
     }
 #ifdef PSDR_TRACE_ON
@@ -868,21 +826,15 @@ int build(psdr_ctx *c) {
 #endif
     // ---- work buffers
     const size_t F = (size_t)c->max_batch;
-    if (const char *e = getenv("PSDR_YPAD")) c->ypad = (size_t)atoi(e);
-    c->two_phase = getenv("PSDR_TWO_PHASE") != nullptr && atoi(getenv("PSDR_TWO_PHASE")) != 0 && c->M1 == 1024 && c->M2 == 1024 && c->T1 == 16 && c->T2 == 16 &&
-                   c->no_p1_stream && c->ypad == 0 && !c->real_fused;
-    if (c->two_phase) {
-        HIPCHK(hipMalloc((void **)&c->d_cnt1, (size_t)TICKET_SLOTS * c->max_batch * sizeof(unsigned)));
-        HIPCHK(hipMemset(c->d_cnt1, 0, (size_t)TICKET_SLOTS * c->max_batch * sizeof(unsigned)));
-    }
     for (int i = 0; i < 2; i++) {
         HIPCHK(hipMalloc((void **)&c->d_tickets[i], TICKET_SLOTS * 8 * sizeof(unsigned)));
         HIPCHK(hipMemset(c->d_tickets[i], 0, TICKET_SLOTS * 8 * sizeof(unsigned)));
     }
     // the second Y buffer only exists when pass 1 runs on its own stream (PSDR_P1_STREAM)
     for (int i = 0; i < (c->no_p1_stream ? 1 : 2); i++)
-        HIPCHK(hipMalloc((void **)&c->y_pool[i], F * (c->M + c->ypad * (size_t)(c->M2 / c->T1)) * sizeof(cf)));
+        HIPCHK(hipMalloc((void **)&c->y_pool[i], F * c->M * sizeof(cf)));
     if (c->is_real && !c->real_fused) HIPCHK(hipMalloc((void **)&c->d_Z, F * c->M * sizeof(cf)));
+    if (!c->is_real && c->lay.mode) HIPCHK(hipMalloc((void **)&c->d_Z, (c->M + 2) * sizeof(cf)));  // k-order staging
     if (c->real_fused) {
         // one frame of k-order staging for psdr_read_spectrum / psdr_get_output_buffer
         HIPCHK(hipMalloc((void **)&c->d_Z, (c->M + 2) * sizeof(cf)));
@@ -1075,6 +1027,7 @@ extern "C" int psdr_create(const psdr_config *cfg, psdr_ctx **out) {
         c->recmap.l2rows = c->log2M2;
         c->recmap.mapped = 2;
         c->qt_stride = 2 * c->R;
+        c->lay.mode = 2;
         c->lay.m1 = c->M1;
         c->lay.l2m1 = c->log2M1;
         c->lay.L = c->M2;
@@ -1091,6 +1044,13 @@ extern "C" int psdr_create(const psdr_config *cfg, psdr_ctx **out) {
         c->recmap.l2rows = c->log2M2;
         c->recmap.mapped = 1;
         c->qt_stride = 2 * c->R;  // R/CH records of 2*CH bytes
+        if (c->M2 == 1024 && c->T2 == 16) {  // k_fft_pass2<1024, 16, true, *> writes tile-major lines
+            c->lay.mode = 1;
+            c->lay.m1 = c->M1;
+            c->lay.l2m1 = c->log2M1;
+            c->lay.L = c->M2;
+            c->lay.l2L = c->log2M2;
+        }
     }
     c->p_stride = std::max<size_t>(c->R >> c->LT, 64);
     if (cfg->skip_num < 1) c->cfg.skip_num = 1;
@@ -1180,12 +1140,12 @@ static int copy_spectrum_k_order(psdr_ctx *c, int frame, cf *dst) {
         int rc = drain(c);
         if (rc) return rc;
     }
-    if (c->real_fused) {
-        // the device keeps the rows of every M1-block permuted (fft_pass.h): k order via staging
-        hipLaunchKernelGGL(k_real_unpermute, dim3((unsigned)((c->M + 1 + 255) / 256)), dim3(256), 0, c->stream, src, c->d_Z,
-                           c->M, c->lay);
+    if (c->lay.mode) {
+        // the device keeps the frame in tile-major lines (SpecLayout): k order through one frame of staging
+        hipLaunchKernelGGL(k_spec_k_order, dim3((unsigned)((c->M + 1 + 255) / 256)), dim3(256), 0, c->stream, src, c->d_Z,
+                           c->M, c->is_real ? 1 : 0, c->lay);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(dst, c->d_Z, (c->N / 2 + 1) * sizeof(cf), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(dst, c->d_Z, (c->is_real ? c->N / 2 + 1 : c->N) * sizeof(cf), hipMemcpyDeviceToHost, c->stream));
     } else if (c->is_real) {
         HIPCHK(hipMemcpyAsync(dst, src, (c->N / 2 + 1) * sizeof(cf), hipMemcpyDeviceToHost,
                               c->stream));

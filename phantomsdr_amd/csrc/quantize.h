@@ -188,21 +188,27 @@ struct RecMap {
     }
 };
 
-// Device layout of the spectrum.  m1 = 0: natural order (IQ: client order, real three-pass: k order).
-// Fused real-input path (k_fft_pass2_real, fft_pass.h), bin k = c1 + M1*c2 (c1 < M1 row, c2 < L column):
-// the frame is a sequence of 128-byte LINES of 16 bins, TILE-MAJOR: line (g, c) = g * L + c holds
-//   [ rows 8g..8g+7 of column c | the mirror octet of tile g of column L-1-c ]
-// where the mirror octet of tile g is rows M1-8g-7..M1-8g in ascending order (for g = 0 its last
-// element is row M1/2 instead of "row M1").  The two halves of a line are the two real-signal bins
-// a (row, mirror row) couple produces together, so one pass-2 store instruction writes whole lines,
-// and the 1024 lines of a tile are one contiguous 128 KiB block: a work-group streams its output
-// linearly (lines of one column but different tiles are written at unrelated times by different
-// work-groups: scattered over the frame they cost twice the whole rest of the tile, measured).
+// Device layout of the spectrum of one frame: where bin c (IQ: client order, real: k order) sits.
+// The passes whose row transform has 1024 points keep the spectrum in 128-byte LINES of 16 bins,
+// TILE-MAJOR: a pass-2 work-group owns 16 rows c1 of the (c1, c2) output grid (bin = c1 + M1*c2) and
+// writes the 1024 lines of its tile as one contiguous 128 KiB block (a wave's store instruction
+// covers 8 adjacent lines).  In the natural order the same lines are 8 KiB apart and their
+// neighbours belong to tiles written by other work-groups at other times; measured on the fused
+// real path that cost twice the whole rest of the tile.
+//   mode 0  natural order
+//   mode 1  IQ, tiles of 16 adjacent rows: line (tl, c2) = tl * L + c2 = rows 16tl..16tl+15 of column c2
+//   mode 2  fused real input (k_fft_pass2_real, fft_pass.h): line (g, c) = g * L + c =
+//           [ rows 8g..8g+7 of column c | the mirror octet of tile g of column L-1-c ]; the mirror
+//           octet of tile g is rows M1-8g-7..M1-8g ascending (g = 0: its last element is row M1/2
+//           instead of "row M1").  The halves of a line are the two real-signal bins a
+//           (row, mirror row) couple produces together.
+// Consumers index through pos() (demodulation slices) or ask for k order (psdr_read_spectrum).
 struct SpecLayout {
-    int m1, l2m1, L, l2L;
+    int mode, m1, l2m1, L, l2L;
     __host__ __device__ __forceinline__ size_t pos(int k) const {
-        if (!m1) return (size_t)k;
+        if (!mode) return (size_t)k;
         const int c1 = k & (m1 - 1), c2 = k >> l2m1;
+        if (mode == 1) return ((((size_t)(c1 >> 4) << l2L) + c2) << 4) + (c1 & 15);
         if (c1 < (m1 >> 1)) return ((((size_t)(c1 >> 3) << l2L) + c2) << 4) + (c1 & 7);
         const int hp = c1 == (m1 >> 1) ? m1 - 1 : c1 - 1;  // rows above M1/2 shift down, M1/2 goes last
         const int g = (m1 - 1 - hp) >> 3;

@@ -80,31 +80,6 @@ def test_batch_split_is_bit_invariant(N, is_real):
         assert np.array_equal(a[2][ci].view(np.uint32), b[2][ci].view(np.uint32)), f"audio of client {ci}"
 
 
-@pytest.mark.parametrize("N,is_real", [(1 << 20, 0), (1 << 21, 1)])
-def test_two_phase_launch_is_bit_identical(N, is_real, monkeypatch):
-    """PSDR_TWO_PHASE=1 (both FFT passes in one launch, in-kernel hand-off of the inter-pass
-    data across XCDs) gives the same bits as the default two launches: spectrum, pyramid, audio."""
-    R = N // 2 if is_real else N
-    nframes = 40
-    x = synth_stream((nframes + 1) * (N // 2), bool(is_real), seed=9, fft_size=N)
-    raw = quantize_raw(x, "s16", bool(is_real))
-    rng = np.random.default_rng(13)
-    clients = []
-    for i, mode in enumerate(["USB", "LSB", "AM", "FM"]):
-        m = int(rng.uniform(0.1 * R, 0.9 * R))
-        l, r = (m, m + 90) if mode == "USB" else (m - 90, m) if mode == "LSB" else (m - 90, m + 90)
-        clients.append((mode, l, float(m), r))
-    monkeypatch.delenv("PSDR_TWO_PHASE", raising=False)
-    a = _run(N, is_real, raw, [24, 16], clients)
-    monkeypatch.setenv("PSDR_TWO_PHASE", "1")
-    b = _run(N, is_real, raw, [24, 16], clients)
-    for f in range(nframes):
-        assert np.array_equal(a[0][f].view(np.uint32), b[0][f].view(np.uint32)), f"spectrum of frame {f}"
-        assert np.array_equal(a[1][f], b[1][f]), f"pyramid of frame {f}"
-    for ci in range(len(clients)):
-        assert np.array_equal(a[2][ci].view(np.uint32), b[2][ci].view(np.uint32)), f"audio of client {ci}"
-
-
 def test_bench_batch_size_matches_small_batches():
     """the bench's batch size (256 frames per launch at 2^20 points) gives the same bits as four
     launches of 64: per-frame CRCs of spectrum and pyramid, and the clients' audio."""
