@@ -71,6 +71,10 @@ typedef struct psdr_config {
     int32_t max_clients;         /* audio client slots */
     int32_t max_waterfall_clients;
     int32_t skip_num;            /* waterfall sent when frame_num % skip_num == 0 (src/fft.cpp:33,102) */
+    int32_t waterfall_size;      /* min_waterfall_fft = input.waterfall_size (src/spectrumserver.cpp:56): default
+                                    width of a new waterfall client (src/websocket.cpp:198) and target of the
+                                    level search (src/waterfall.cpp:62-79).  0 = R >> (downsample_levels-1),
+                                    which equals it whenever waterfall_size is a power of two */
 } psdr_config;
 
 const char *psdr_last_error(void);
@@ -110,6 +114,21 @@ int psdr_synchronize(psdr_ctx *ctx);
 /* bytes of one raw half-frame in cfg.input_format (N/2 samples, x2 components for IQ) */
 size_t psdr_half_frame_bytes(const psdr_ctx *ctx);
 
+/* ---- streaming ingest: the sample reader's double buffering (src/fft.cpp:56-67 reads half k+2
+ * while frame (k, k+1) is transformed; src/samplereader.cpp:42-70) on the device ------------------
+ * The context owns a ring of `nhalves` raw half-frames in HBM.  psdr_ring_write_async() copies one
+ * half-frame from (pinned) host memory into slot `half_index % nhalves` on a dedicated COPY stream and
+ * returns at once; psdr_process_ring() transforms frames first_half .. first_half+nframes-1 (frame f
+ * = halves f, f+1; the window may wrap around the ring) after waiting, on the device, for the copies
+ * of exactly the halves it reads - so the PCIe transfer of later halves overlaps the transform of
+ * earlier ones.  A slot may be rewritten as soon as the psdr_process_ring() call that read it has
+ * been issued (the copy waits for that batch on the device).  The source buffer must stay valid
+ * until psdr_ring_wait(ctx, half_index) (or any synchronising call) returns. */
+int psdr_ring_create(psdr_ctx *ctx, int nhalves);
+int psdr_ring_write_async(psdr_ctx *ctx, uint64_t half_index, const void *host_half);
+int psdr_ring_wait(psdr_ctx *ctx, uint64_t half_index);
+int psdr_process_ring(psdr_ctx *ctx, uint64_t first_half, int nframes);
+
 /* ---- Level 2: batched frames ------------------------------------------------------ */
 /* Frame loop body, src/fft.cpp:47-105, for nframes consecutive frames at once.
  * d_halves: device pointer to nframes+1 consecutive raw half-frames (cfg.input_format);
@@ -131,16 +150,20 @@ int psdr_client_set_audio_demodulation(psdr_ctx *ctx, int id, int mode);
  * active client over the frames of the last psdr_process_batch.  first_frame_num is the
  * server's frame counter of the first frame (flip parity, src/signal.cpp:160-168,223). */
 int psdr_demod_batch(psdr_ctx *ctx, uint64_t first_frame_num);
-/* same, but reading nframes spectra from a caller-supplied device buffer (client order for
- * IQ, k order for real; frame_stride_bins complex bins between frames): used when the
- * spectrum was produced on another GPU and received over xGMI. */
+/* same, but reading nframes spectra from a caller-supplied device buffer in the device layout of
+ * psdr_spectrum_device_ptr() of an identically configured context (frame_stride_bins complex bins
+ * between frames): used when the spectrum was produced on another GPU and received over xGMI
+ * (SURVEY 8e). */
 int psdr_demod_batch_from(psdr_ctx *ctx, const float *d_spec, size_t frame_stride_bins,
                           int nframes, uint64_t first_frame_num);
 /* results of the last demod batch for one client: audio [nframes][n/2] floats (the
  * demodulated, overlap-added samples handed to the DC blocker at src/signal.cpp:278),
  * pwr [nframes] (average_power, src/signal.cpp:117-119), nan_flags [nframes] (1 = the
  * reference would have dropped the frame, src/signal.cpp:266-271).  Any may be NULL. */
-int psdr_read_audio(psdr_ctx *ctx, int id, float *audio, float *pwr, int32_t *nan_flags);
+/* nframes = rows the caller's buffers hold; it must be >= the frames of the last demod batch
+ * (PSDR_ERR_INVALID otherwise, nothing is written); *nframes_out (may be NULL) = rows written. */
+int psdr_read_audio(psdr_ctx *ctx, int id, int nframes, float *audio, float *pwr, int32_t *nan_flags,
+                    int *nframes_out);
 /* device-resident results (no copy): audio of client slot `id` */
 int psdr_audio_device_ptr(psdr_ctx *ctx, int id, const float **d_audio, const float **d_pwr);
 
@@ -153,8 +176,8 @@ int psdr_audio_device_ptr(psdr_ctx *ctx, int id, const float **d_audio, const fl
  * hands to its audio encoder.  Frames whose NaN flag is set are skipped by the chain (the
  * reference drops them before it, src/signal.cpp:266-271); their PCM rows are zero. */
 int psdr_set_post_chain(psdr_ctx *ctx, int enable);
-/* pcm: [frames of the last demod_batch][audio_fft_size/2] */
-int psdr_read_pcm(psdr_ctx *ctx, int id, int32_t *pcm);
+/* pcm: [frames of the last demod_batch][audio_fft_size/2]; nframes = rows pcm holds (as psdr_read_audio) */
+int psdr_read_pcm(psdr_ctx *ctx, int id, int nframes, int32_t *pcm, int *nframes_out);
 
 /* waterfall clients: WaterfallClient (src/waterfall.h) */
 int psdr_waterfall_add(psdr_ctx *ctx, int *id_out);
@@ -169,12 +192,22 @@ int psdr_waterfall_on_window_message(psdr_ctx *ctx, int id, int l, int r, int *l
  * gathers q_level[l..r) of every waterfall client for every frame f of the last batch
  * with (first_frame_num+f) % skip_num == 0. */
 int psdr_waterfall_batch(psdr_ctx *ctx, uint64_t first_frame_num);
-/* bytes [nsent][r-l] for one client; *nsent_out = number of sent frames in the batch */
-int psdr_read_waterfall(psdr_ctx *ctx, int id, int8_t *out, size_t out_cap, int *nsent_out);
+/* bytes [nsent][r-l] for one client, with the range the rows were GATHERED with: the window may
+ * have been changed by another thread since psdr_waterfall_batch, so level/l/r of that batch are
+ * returned (any of the out pointers may be NULL).  *nsent_out = number of sent frames in the batch;
+ * out == NULL only queries. */
+int psdr_read_waterfall(psdr_ctx *ctx, int id, int8_t *out, size_t out_cap, int *nsent_out, int *level_out,
+                        int *l_out, int *r_out);
 
 /* last batch, raw device-side results (for consumers that stay on the GPU, and tests) */
-/* spectrum of frame f: IQ: N complex bins in CLIENT order c (bin k = (c+N/2+1) mod N);
- * real: N/2+1 bins in k order.  Normalised by 1/N exactly like src/fft_impl.cpp:34-35. */
+/* spectrum of frame f, normalised by 1/N exactly like src/fft_impl.cpp:34-35.  IQ: N complex bins
+ * indexed by the CLIENT coordinate c (bin k = (c+N/2+1) mod N); real: N/2+1 bins indexed by k.
+ * The DEVICE LAYOUT is opaque: transforms whose row pass has 1024 points (2^20/2^21-point IQ,
+ * 2^21/2^22-point real) keep a frame in tile-major 128-byte lines (phantomsdr_amd/csrc/quantize.h,
+ * SpecLayout); psdr_demod_batch_from() on a context created with the same configuration understands
+ * it (that is what the spectrum broadcast between GPUs ships), psdr_read_spectrum() delivers the
+ * reference's k order.  nbins complex values per frame; frames are spec_stride apart:
+ * N (IQ) or N/2+2 (real) bins. */
 int psdr_spectrum_device_ptr(psdr_ctx *ctx, int frame, const float **d_spec, size_t *nbins);
 /* (level-major layout as in the reference; materialised on demand from the device's tiled
  * records, so this call synchronises) */

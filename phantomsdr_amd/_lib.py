@@ -21,7 +21,7 @@ class psdr_config(C.Structure):
         ("additional_size", C.c_int32), ("audio_fft_size", C.c_int32),
         ("audio_rate", C.c_int32), ("input_format", C.c_int32), ("device", C.c_int32),
         ("max_batch", C.c_int32), ("max_clients", C.c_int32),
-        ("max_waterfall_clients", C.c_int32), ("skip_num", C.c_int32),
+        ("max_waterfall_clients", C.c_int32), ("skip_num", C.c_int32), ("waterfall_size", C.c_int32),
     ]
 
 
@@ -46,6 +46,10 @@ SYMBOLS = [
     ("psdr_memcpy_d2h", _i, [_vp, _vp, _vp, _sz]),
     ("psdr_synchronize", _i, [_vp]),
     ("psdr_half_frame_bytes", _sz, [_vp]),
+    ("psdr_ring_create", _i, [_vp, _i]),
+    ("psdr_ring_write_async", _i, [_vp, _u64, _vp]),
+    ("psdr_ring_wait", _i, [_vp, _u64]),
+    ("psdr_process_ring", _i, [_vp, _u64, _i]),
     ("psdr_process_batch", _i, [_vp, _vp, _i]),
     ("psdr_client_add", _i, [_vp, C.POINTER(_i)]),
     ("psdr_client_remove", _i, [_vp, _i]),
@@ -54,17 +58,17 @@ SYMBOLS = [
     ("psdr_client_set_audio_demodulation", _i, [_vp, _i, _i]),
     ("psdr_demod_batch", _i, [_vp, _u64]),
     ("psdr_demod_batch_from", _i, [_vp, _vp, _sz, _i, _u64]),
-    ("psdr_read_audio", _i, [_vp, _i, _vp, _vp, _vp]),
+    ("psdr_read_audio", _i, [_vp, _i, _i, _vp, _vp, _vp, C.POINTER(_i)]),
     ("psdr_audio_device_ptr", _i, [_vp, _i, _pp, _pp]),
     ("psdr_set_post_chain", _i, [_vp, _i]),
-    ("psdr_read_pcm", _i, [_vp, _i, _vp]),
+    ("psdr_read_pcm", _i, [_vp, _i, _i, _vp, C.POINTER(_i)]),
     ("psdr_waterfall_add", _i, [_vp, C.POINTER(_i)]),
     ("psdr_waterfall_remove", _i, [_vp, _i]),
     ("psdr_waterfall_set_range", _i, [_vp, _i, _i, _i, _i]),
     ("psdr_waterfall_on_window_message", _i,
      [_vp, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     ("psdr_waterfall_batch", _i, [_vp, _u64]),
-    ("psdr_read_waterfall", _i, [_vp, _i, _vp, _sz, C.POINTER(_i)]),
+    ("psdr_read_waterfall", _i, [_vp, _i, _vp, _sz, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     ("psdr_spectrum_device_ptr", _i, [_vp, _i, _pp, C.POINTER(_sz)]),
     ("psdr_quantized_device_ptr", _i, [_vp, _i, _pp, C.POINTER(_sz)]),
     ("psdr_read_spectrum", _i, [_vp, _i, _vp]),

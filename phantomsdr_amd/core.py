@@ -49,7 +49,7 @@ class Context:
 
     def __init__(self, fft_size, is_real, downsample_levels, brightness_offset=0,
                  additional_size=0, audio_fft_size=0, audio_rate=12000, input_format="f32",
-                 device=0, max_batch=1, max_clients=1, max_waterfall_clients=1, skip_num=1):
+                 device=0, max_batch=1, max_clients=1, max_waterfall_clients=1, skip_num=1, waterfall_size=0):
         self.lib = _lib.load()
         cfg = psdr_config()
         cfg.struct_size = C.sizeof(psdr_config)
@@ -66,6 +66,7 @@ class Context:
         cfg.max_clients = max_clients
         cfg.max_waterfall_clients = max_waterfall_clients
         cfg.skip_num = skip_num
+        cfg.waterfall_size = waterfall_size
         self.cfg = cfg
         self.h = C.c_void_p()
         check(self.lib.psdr_create(C.byref(cfg), C.byref(self.h)))
@@ -78,10 +79,14 @@ class Context:
         self.q_len = sum(self.R >> i for i in range(downsample_levels))
         self.nbins = fft_size // 2 + 1 if is_real else fft_size
         self.last_nframes = 0
+        self.last_demod_frames = 0
         self.input_format = input_format
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
+            for p in getattr(self, "_pinned", []):
+                self.lib.psdr_host_free(self.h, p)
+            self._pinned = []
             self.lib.psdr_destroy(self.h)
             self.h = None
 
@@ -126,6 +131,33 @@ class Context:
 
     def demod_batch(self, first_frame_num):
         check(self.lib.psdr_demod_batch(self.h, first_frame_num))
+        self.last_demod_frames = self.last_nframes
+
+    # --- streaming ingest (psdr_ring_*): pinned host half-frames -> HBM ring on a copy stream -----
+    def ring_create(self, nhalves):
+        check(self.lib.psdr_ring_create(self.h, int(nhalves)))
+
+    def ring_write_async(self, half_index, host_half):
+        """host_half: numpy array of one raw half-frame (ideally from pinned_array()); it must stay
+        alive and unchanged until ring_wait(half_index) or a synchronising call returns."""
+        assert host_half.nbytes == self.half_frame_bytes()
+        check(self.lib.psdr_ring_write_async(self.h, int(half_index), _ptr(host_half)))
+
+    def ring_wait(self, half_index):
+        check(self.lib.psdr_ring_wait(self.h, int(half_index)))
+
+    def process_ring(self, first_half, nframes):
+        check(self.lib.psdr_process_ring(self.h, int(first_half), int(nframes)))
+        self.last_nframes = nframes
+
+    def pinned_array(self, nbytes, dtype=np.uint8):
+        """numpy view of pinned host memory from psdr_host_alloc (freed with the context)"""
+        p = C.c_void_p()
+        nfl = (nbytes + 3) // 4
+        check(self.lib.psdr_host_alloc(self.h, nfl, C.byref(p)))
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p.value)).view(dtype)
 
     def waterfall_batch(self, first_frame_num):
         check(self.lib.psdr_waterfall_batch(self.h, first_frame_num))
@@ -294,23 +326,26 @@ class AudioClient:
             self.set_audio_demodulation(demodulation)
 
     def read_audio(self, nframes=None):
-        """(audio[nframes][n/2], pwr[nframes], nan[nframes]) of the last demod batch."""
-        F = nframes or self.ctx.last_nframes
+        """(audio[F][n/2], pwr[F], nan[F]) of the last demod batch (F = its frame count; `nframes`,
+        if given, is the number of rows to allocate and must not be smaller)."""
+        F = nframes or self.ctx.last_demod_frames or self.ctx.last_nframes
         h = self.ctx.n // 2
         audio = np.empty((F, h), np.float32)
         pwr = np.empty(F, np.float32)
         nan = np.empty(F, np.int32)
-        check(self.ctx.lib.psdr_read_audio(self.ctx.h, self.id, _ptr(audio), _ptr(pwr), _ptr(nan)))
-        return audio, pwr, nan
+        got = C.c_int(0)
+        check(self.ctx.lib.psdr_read_audio(self.ctx.h, self.id, F, _ptr(audio), _ptr(pwr), _ptr(nan), C.byref(got)))
+        return audio[:got.value], pwr[:got.value], nan[:got.value]
 
     def read_pcm(self, nframes=None):
         """int16 PCM (in int32, like the reference's buffer) of the last demod batch after the
         DC blocker / AGC / int16 conversion (src/signal.cpp:277-284); needs
         Context.set_post_chain(True)."""
-        F = nframes or self.ctx.last_nframes
+        F = nframes or self.ctx.last_demod_frames or self.ctx.last_nframes
         pcm = np.empty((F, self.ctx.n // 2), np.int32)
-        check(self.ctx.lib.psdr_read_pcm(self.ctx.h, self.id, _ptr(pcm)))
-        return pcm
+        got = C.c_int(0)
+        check(self.ctx.lib.psdr_read_pcm(self.ctx.h, self.id, F, _ptr(pcm), C.byref(got)))
+        return pcm[:got.value]
 
     def on_close(self):
         if self.id >= 0 and self.ctx.h:
@@ -327,7 +362,8 @@ class WaterfallClient:
         check(ctx.lib.psdr_waterfall_add(ctx.h, C.byref(wid)))
         self.id = wid.value
         self.level = ctx.levels - 1
-        self.l, self.r = 0, ctx.R >> self.level
+        mwf = ctx.cfg.waterfall_size or (ctx.R >> self.level)
+        self.l, self.r = 0, min(mwf, ctx.R >> self.level)
 
     def set_waterfall_range(self, level, l, r):
         check(self.ctx.lib.psdr_waterfall_set_range(self.ctx.h, self.id, int(level), int(l), int(r)))
@@ -346,13 +382,17 @@ class WaterfallClient:
 
     def read_waterfall(self):
         """int8[nsent][r-l] for the frames of the last waterfall batch that were sent, plus
-        the (l << level, r << level) labels of send_waterfall (src/waterfall.cpp:47)."""
-        ln = self.r - self.l
-        cap = max(1, self.ctx.max_batch * ln)
+        the (l << level, r << level) labels of send_waterfall (src/waterfall.cpp:47).  Row length
+        and labels are those of the BATCH (the window may have moved since)."""
+        ns, lv, l, r = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        lib, h = self.ctx.lib, self.ctx.h
+        check(lib.psdr_read_waterfall(h, self.id, None, 0, C.byref(ns), C.byref(lv), C.byref(l), C.byref(r)))
+        ln = r.value - l.value
+        cap = max(1, ns.value * ln)
         out = np.empty(cap, np.int8)
-        ns = C.c_int(0)
-        check(self.ctx.lib.psdr_read_waterfall(self.ctx.h, self.id, _ptr(out), cap, C.byref(ns)))
-        return out[: ns.value * ln].reshape(ns.value, ln), (self.l << self.level, self.r << self.level)
+        check(lib.psdr_read_waterfall(h, self.id, _ptr(out), cap, C.byref(ns), C.byref(lv), C.byref(l), C.byref(r)))
+        ln = r.value - l.value
+        return out[: ns.value * ln].reshape(ns.value, ln), (l.value << lv.value, r.value << lv.value)
 
     def on_close(self):
         if self.id >= 0 and self.ctx.h:
@@ -376,7 +416,8 @@ class SpectrumEngine:
                            additional_size=p["audio_fft_size"], audio_fft_size=p["audio_fft_size"],
                            audio_rate=audio_sps, input_format=input_format, device=device,
                            max_batch=max_batch, max_clients=max_clients,
-                           max_waterfall_clients=max_waterfall_clients, skip_num=p["skip_num"])
+                           max_waterfall_clients=max_waterfall_clients, skip_num=p["skip_num"],
+                           waterfall_size=waterfall_size)
         self.frame_num = 0
         self.audio_clients = []
         self.waterfall_clients = []

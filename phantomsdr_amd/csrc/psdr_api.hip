@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -65,8 +66,11 @@ struct AudioSlot {
 struct WfSlot {
     bool active = false;
     int level = 0, l = 0, r = 0;
+    // the last psdr_waterfall_batch: what was gathered, and with which window (set_range may run
+    // on another thread between the batch and psdr_read_waterfall)
     size_t out_off = 0;
     int nsent = 0;
+    int b_level = 0, b_l = 0, b_r = 0;
 };
 
 // Small host->device parameter blocks (client lists) are double-buffered K deep so a new
@@ -93,17 +97,18 @@ struct ParamRing {
             if (ev[i]) hipEventDestroy(ev[i]);
         h = d = nullptr;
     }
-    // returns the slot to fill (waits only if the ring wrapped onto a still-busy slot)
+    // returns the slot to fill (waits only if the ring wrapped onto a still-busy slot); -1: HIP error
     int acquire() {
         idx = (idx + 1) % K;
-        if (used[idx]) hipEventSynchronize(ev[idx]);
+        if (used[idx] && hipEventSynchronize(ev[idx]) != hipSuccess) return -1;
         return idx;
     }
     void *host(int i) { return h + slot_bytes * i; }
     void *dev(int i) { return d + slot_bytes * i; }
-    void release(int i, hipStream_t s) {
-        hipEventRecord(ev[i], s);
-        used[i] = true;
+    hipError_t release(int i, hipStream_t s) {
+        const hipError_t e = hipEventRecord(ev[i], s);
+        used[i] = e == hipSuccess;
+        return e;
     }
 };
 
@@ -138,6 +143,8 @@ struct psdr_ctx {
     int LT = 0;  // pyramid levels finished inside the fused kernel
     size_t p_stride = 0;
     int max_batch = 1;
+    int min_waterfall_fft = 0;  // input.waterfall_size (src/spectrumserver.cpp:56)
+    std::set<const void *> lds_attr_done;  // kernels whose dynamic-LDS limit was raised on this device
     // Two streams: the FFT passes run on `stream`; everything that only consumes a finished
     // batch (pyramid tail, demodulation, waterfall gather) runs on `side`, so it overlaps
     // the next batch's pass 1 (its work-groups fit next to the persistent FFT work-groups).
@@ -222,6 +229,20 @@ struct psdr_ctx {
     int8_t *d_wfout = nullptr;
     size_t wfout_cap = 0;
 
+    // streaming ingest ring (psdr_ring_*)
+    struct IngestRing {
+        static constexpr int NEV = 16;
+        unsigned char *d = nullptr;  // nhalves + 1 slots (the last mirrors slot 0: a frame window may end there)
+        int nhalves = 0;
+        size_t hb = 0;
+        hipStream_t copy = nullptr;
+        std::vector<hipEvent_t> ev_written;   // per slot: its last H2D copy
+        std::vector<char> ever_written;
+        std::vector<uint64_t> reader_seq;     // per slot: the last psdr_process_ring call that read it
+        hipEvent_t ev_read[NEV] = {};         // pass 1 of process call seq % NEV has consumed its halves
+        uint64_t seq = 0;
+    } ring;
+
     // instrumentation
     bool profiling = false;
     std::vector<PendingEvent> pending;
@@ -245,19 +266,27 @@ struct ProfScope {
             if (!c->pool.empty()) {
                 e = c->pool.back();
                 c->pool.pop_back();
-            } else {
-                hipEventCreate(&e);
+            } else if (hipEventCreate(&e) != hipSuccess) {
+                e = nullptr;
             }
             return e;
         };
         a = get();
         b = get();
-        hipEventRecord(a, st);
+        if (!a || !b || hipEventRecord(a, st) != hipSuccess) {  // no timing for this launch
+            if (a) c->pool.push_back(a);
+            if (b) c->pool.push_back(b);
+            a = b = nullptr;
+        }
     }
     ~ProfScope() {
-        if (!c->profiling) return;
-        hipEventRecord(b, st);
-        c->pending.push_back({a, b, kid});
+        if (!c->profiling || !a) return;
+        if (hipEventRecord(b, st) == hipSuccess) {
+            c->pending.push_back({a, b, kid});
+        } else {
+            c->pool.push_back(a);
+            c->pool.push_back(b);
+        }
     }
 };
 
@@ -328,12 +357,9 @@ template <int L, int T, int SB, bool PAIR = false>
 int launch_pass1_t(psdr_ctx *c, const Pass1Args &a, unsigned blocks) {
     // tile + W_L (= first twiddle factor) + second twiddle factor (M2 entries)
     const size_t lds = (size_t)L * T * sizeof(cf) + (size_t)L * sizeof(cf) + (size_t)a.M2 * sizeof(cf);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass1<L, T, SB, PAIR>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        attr_set = true;
-    }
+    // (per context = per device: the attribute is a property of the function ON a device)
+    if (c->lds_attr_done.insert((const void *)k_fft_pass1<L, T, SB, PAIR>).second)
+        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass1<L, T, SB, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     ProfScope ps(c, K_PASS1, c->p1);
     // persistent: as many work-groups per CU as their LDS admits (a 128 KiB tile: one)
     unsigned grid = persistent_grid(c, blocks, lds);
@@ -345,12 +371,9 @@ int launch_pass1_t(psdr_ctx *c, const Pass1Args &a, unsigned blocks) {
 template <int L, int T, bool FUSED, int TWC>
 int launch_pass2_t(psdr_ctx *c, const Pass2Args &a, unsigned blocks) {
     constexpr size_t lds = (size_t)L * T * sizeof(cf) + (size_t)L * sizeof(cf);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass2<L, T, FUSED, TWC>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    // (per context = per device: the attribute is a property of the function ON a device)
+    if (c->lds_attr_done.insert((const void *)k_fft_pass2<L, T, FUSED, TWC>).second)
+        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass2<L, T, FUSED, TWC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope ps(c, K_PASS2);
     unsigned grid = persistent_grid(c, blocks, lds);
     if (c->p2_grid && c->p2_grid < grid) grid = c->p2_grid;
@@ -413,12 +436,9 @@ template <int TWC>
 int launch_pass2_real_t(psdr_ctx *c, const Pass2Args &a) {
     constexpr int L = 1024, T = 16;
     constexpr size_t lds = (size_t)L * T * sizeof(cf) + (size_t)L * sizeof(cf) + 2 * (size_t)L * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass2_real<L, T, TWC>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    // (per context = per device: the attribute is a property of the function ON a device)
+    if (c->lds_attr_done.insert((const void *)k_fft_pass2_real<L, T, TWC>).second)
+        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass2_real<L, T, TWC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope ps(c, K_PASS2);
     unsigned grid = persistent_grid(c, a.total_slots, lds);
     if (c->p2_grid && c->p2_grid < grid) grid = c->p2_grid;
@@ -467,7 +487,7 @@ void select_set(psdr_ctx *c, int set) {
     c->d_pscr[1] = c->pscr_pool[set][1];
 }
 
-int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
+int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipEvent_t ev_raw_consumed = nullptr) {
     // alternate the result set when the consumers run on their own stream
     if (c->side != c->stream) select_set(c, c->cur_set ^ 1);
     const int cols = 1;
@@ -509,6 +529,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt) {
     a1.total_slots = tiles1 * (unsigned)nframes;
     int rc = launch_pass1(c, c->M1, c->T1, sb, a1, a1.total_slots, c->real_fused);
     if (rc) return rc;
+    if (ev_raw_consumed) HIPCHK(hipEventRecord(ev_raw_consumed, c->p1));  // pass 1 is the only reader of the raw halves
     if (piped) {
         HIPCHK(hipEventRecord(c->ev_p1[c->cur_y], c->p1));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_p1[c->cur_y], 0));
@@ -696,6 +717,12 @@ void free_all(psdr_ctx *c) {
     F(c->d_UA);
     F(c->d_UB);
     F(c->d_UG);
+    F(c->ring.d);
+    for (auto e : c->ring.ev_written)
+        if (e) hipEventDestroy(e);
+    for (auto e : c->ring.ev_read)
+        if (e) hipEventDestroy(e);
+    if (c->ring.copy) hipStreamDestroy(c->ring.copy);
     F(c->d_seamP);
     F(c->d_seamC);
     F(c->d_tickets[0]);
@@ -1054,6 +1081,11 @@ extern "C" int psdr_create(const psdr_config *cfg, psdr_ctx **out) {
     }
     c->p_stride = std::max<size_t>(c->R >> c->LT, 64);
     if (cfg->skip_num < 1) c->cfg.skip_num = 1;
+    if (cfg->waterfall_size < 0) {
+        delete c;
+        return fail(PSDR_ERR_INVALID, "waterfall_size must be >= 0");
+    }
+    c->min_waterfall_fft = cfg->waterfall_size > 0 ? cfg->waterfall_size : (int)(c->R >> (c->levels - 1));
 
     int rc = build(c);
     if (rc) {
@@ -1241,7 +1273,83 @@ extern "C" int psdr_process_batch(psdr_ctx *c, const void *d_halves, int nframes
     return process_frames(c, d_halves, nframes, c->cfg.input_format);
 }
 
+// ---- streaming ingest (src/fft.cpp:56-67, src/samplereader.cpp:42-70 on the device) -----------------
+extern "C" int psdr_ring_create(psdr_ctx *c, int nhalves) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    if (nhalves < 2) return fail(PSDR_ERR_INVALID, "a ring needs at least 2 half-frames");
+    if (c->ring.d) return fail(PSDR_ERR_STATE, "the context already has an ingest ring");
+    HIPCHK(hipSetDevice(c->device));
+    auto &r = c->ring;
+    r.hb = psdr_half_frame_bytes(c);
+    r.nhalves = nhalves;
+    HIPCHK(hipMalloc((void **)&r.d, (size_t)(nhalves + 1) * r.hb));
+    HIPCHK(hipMemset(r.d, 0, (size_t)(nhalves + 1) * r.hb));
+    HIPCHK(hipStreamCreateWithFlags(&r.copy, hipStreamNonBlocking));
+    r.ev_written.assign(nhalves, nullptr);
+    r.ever_written.assign(nhalves, 0);
+    r.reader_seq.assign(nhalves, 0);
+    for (auto &e : r.ev_written) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : r.ev_read) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return PSDR_OK;
+}
+extern "C" int psdr_ring_write_async(psdr_ctx *c, uint64_t half_index, const void *host_half) {
+    if (!c || !host_half) return fail(PSDR_ERR_INVALID, "null argument");
+    auto &r = c->ring;
+    if (!r.d) return fail(PSDR_ERR_STATE, "psdr_ring_create() first");
+    HIPCHK(hipSetDevice(c->device));
+    const int slot = (int)(half_index % (uint64_t)r.nhalves);
+    // the slot's previous content may still be waiting for its reader (a process call issued at
+    // most NEV calls ago: older ones were waited for when their event was reused)
+    const uint64_t rs = r.reader_seq[slot];
+    if (rs && r.seq - rs < (uint64_t)psdr_ctx::IngestRing::NEV)
+        HIPCHK(hipStreamWaitEvent(r.copy, r.ev_read[rs % psdr_ctx::IngestRing::NEV], 0));
+    if (slot == 0 && r.reader_seq[r.nhalves - 1]) {  // the mirror of slot 0 is read with the LAST slot's frame
+        const uint64_t rl = r.reader_seq[r.nhalves - 1];
+        if (r.seq - rl < (uint64_t)psdr_ctx::IngestRing::NEV)
+            HIPCHK(hipStreamWaitEvent(r.copy, r.ev_read[rl % psdr_ctx::IngestRing::NEV], 0));
+    }
+    HIPCHK(hipMemcpyAsync(r.d + (size_t)slot * r.hb, host_half, r.hb, hipMemcpyHostToDevice, r.copy));
+    if (slot == 0)
+        HIPCHK(hipMemcpyAsync(r.d + (size_t)r.nhalves * r.hb, host_half, r.hb, hipMemcpyHostToDevice, r.copy));
+    HIPCHK(hipEventRecord(r.ev_written[slot], r.copy));
+    r.ever_written[slot] = 1;
+    return PSDR_OK;
+}
+extern "C" int psdr_ring_wait(psdr_ctx *c, uint64_t half_index) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    auto &r = c->ring;
+    if (!r.d) return fail(PSDR_ERR_STATE, "psdr_ring_create() first");
+    const int slot = (int)(half_index % (uint64_t)r.nhalves);
+    if (r.ever_written[slot]) HIPCHK(hipEventSynchronize(r.ev_written[slot]));
+    return PSDR_OK;
+}
+extern "C" int psdr_process_ring(psdr_ctx *c, uint64_t first_half, int nframes) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    auto &r = c->ring;
+    if (!r.d) return fail(PSDR_ERR_STATE, "psdr_ring_create() first");
+    if (nframes < 1 || nframes > c->max_batch)
+        return fail(PSDR_ERR_INVALID, "nframes %d outside [1, max_batch=%d]", nframes, c->max_batch);
+    const int s0 = (int)(first_half % (uint64_t)r.nhalves);
+    if (s0 + nframes > r.nhalves)
+        return fail(PSDR_ERR_INVALID, "frames %d..%d cross the end of the %d-half ring (one guard half-frame): split the batch",
+                    s0, s0 + nframes - 1, r.nhalves);
+    HIPCHK(hipSetDevice(c->device));
+    for (int i = 0; i <= nframes; i++) {  // halves s0 .. s0+nframes (the last may be the mirror of slot 0)
+        const int slot = (s0 + i) % r.nhalves;
+        if (!r.ever_written[slot]) return fail(PSDR_ERR_STATE, "half-frame slot %d was never written", slot);
+        HIPCHK(hipStreamWaitEvent(c->p1, r.ev_written[slot], 0));
+    }
+    r.seq++;
+    hipEvent_t ev = r.ev_read[r.seq % psdr_ctx::IngestRing::NEV];
+    HIPCHK(hipEventSynchronize(ev));  // the call that used it NEV calls ago (no-op if never recorded)
+    int rc = process_frames(c, r.d + (size_t)s0 * r.hb, nframes, c->cfg.input_format, ev);
+    if (rc) return rc;
+    for (int i = 0; i <= nframes; i++) r.reader_seq[(s0 + i) % r.nhalves] = r.seq;
+    return PSDR_OK;
+}
+
 static int drain(psdr_ctx *c) {
+    if (c->ring.copy) HIPCHK(hipStreamSynchronize(c->ring.copy));
     if (c->p1 != c->stream) HIPCHK(hipStreamSynchronize(c->p1));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->side != c->stream) HIPCHK(hipStreamSynchronize(c->side));
@@ -1328,6 +1436,7 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     HIPCHK(hipSetDevice(c->device));
     int nact = 0;
     const int ring = c->client_ring.acquire();
+    if (ring < 0) return fail(PSDR_ERR_HIP, "client parameter ring: event wait failed");
     ClientParams *h_clients = (ClientParams *)c->client_ring.host(ring);
     ClientParams *d_clients = (ClientParams *)c->client_ring.dev(ring);
     {
@@ -1436,7 +1545,7 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
         hipLaunchKernelGGL(k_pc_scatter, dim3(cb, nframes, jb), dim3(256), 0, c->side, pa);
         HIPCHK(hipGetLastError());
     }
-    c->client_ring.release(ring, c->side);
+    HIPCHK(c->client_ring.release(ring, c->side));
     if (c->side != c->stream) {
         HIPCHK(hipEventRecord(c->ev_side_done, c->side));
         c->side_pending = true;
@@ -1505,7 +1614,7 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
     c->post_on = true;
     return PSDR_OK;
 }
-extern "C" int psdr_read_pcm(psdr_ctx *c, int id, int32_t *pcm) {
+extern "C" int psdr_read_pcm(psdr_ctx *c, int id, int nframes, int32_t *pcm, int *nframes_out) {
     if (!c || !pcm) return fail(PSDR_ERR_INVALID, "null argument");
     {
         std::lock_guard<std::mutex> lk(c->mtx);
@@ -1516,11 +1625,13 @@ extern "C" int psdr_read_pcm(psdr_ctx *c, int id, int32_t *pcm) {
     HIPCHK(hipSetDevice(c->device));
     const size_t F = (size_t)c->last_demod_frames, h = (size_t)c->n / 2, mb = (size_t)c->max_batch;
     if (F == 0) return fail(PSDR_ERR_STATE, "no demodulated batch to read");
+    if (nframes < (int)F) return fail(PSDR_ERR_INVALID, "buffer holds %d frames, the last batch has %zu", nframes, F);
     {
         int rc = drain(c);
         if (rc) return rc;
     }
     HIPCHK(hipMemcpy(pcm, c->post.pcm + (size_t)id * mb * h, F * h * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (nframes_out) *nframes_out = (int)F;
     return PSDR_OK;
 }
 
@@ -1539,7 +1650,8 @@ extern "C" int psdr_demod_batch_from(psdr_ctx *c, const float *d_spec, size_t fr
     return demod_impl(c, (const cf *)d_spec, frame_stride_bins, nframes, first_frame_num);
 }
 
-extern "C" int psdr_read_audio(psdr_ctx *c, int id, float *audio, float *pwr, int32_t *nan_flags) {
+extern "C" int psdr_read_audio(psdr_ctx *c, int id, int nframes, float *audio, float *pwr, int32_t *nan_flags,
+                               int *nframes_out) {
     if (!c) return fail(PSDR_ERR_INVALID, "null argument");
     {
         std::lock_guard<std::mutex> lk(c->mtx);
@@ -1549,6 +1661,8 @@ extern "C" int psdr_read_audio(psdr_ctx *c, int id, float *audio, float *pwr, in
     HIPCHK(hipSetDevice(c->device));
     const size_t F = (size_t)c->last_demod_frames, h = (size_t)c->n / 2, mb = (size_t)c->max_batch;
     if (F == 0) return fail(PSDR_ERR_STATE, "no demodulated batch to read");
+    if (nframes < (int)F) return fail(PSDR_ERR_INVALID, "buffers hold %d frames, the last batch has %zu", nframes, F);
+    if (nframes_out) *nframes_out = (int)F;
     {
         int rc = drain(c);
         if (rc) return rc;
@@ -1591,7 +1705,7 @@ extern "C" int psdr_waterfall_add(psdr_ctx *c, int *id_out) {
             // default = whole spectrum at the coarsest level (src/websocket.cpp:198)
             s.level = c->levels - 1;
             s.l = 0;
-            s.r = (int)(c->R >> s.level);
+            s.r = std::min(c->min_waterfall_fft, (int)(c->R >> s.level));  // set_waterfall_range(levels-1, 0, min_waterfall_fft)
             *id_out = (int)i;
             return PSDR_OK;
         }
@@ -1626,7 +1740,7 @@ extern "C" int psdr_waterfall_on_window_message(psdr_ctx *c, int id, int new_l, 
     if (!c) return fail(PSDR_ERR_INVALID, "null argument");
     // src/waterfall.cpp:53-79
     if (new_l < 0 || new_r < 0 || new_l >= new_r) return fail(PSDR_ERR_INVALID, "window rejected");
-    const int mwf = (int)(c->R >> (c->levels - 1));  // min_waterfall_fft
+    const int mwf = c->min_waterfall_fft;
     float new_l_f = (float)new_l, new_r_f = (float)new_r;
     int new_level = c->levels - 1;
     float best = (float)(mwf * 2);
@@ -1655,6 +1769,7 @@ extern "C" int psdr_waterfall_batch(psdr_ctx *c, uint64_t first_frame_num) {
     HIPCHK(hipSetDevice(c->device));
     std::lock_guard<std::mutex> lk(c->mtx);
     const int ring = c->wf_ring.acquire();
+    if (ring < 0) return fail(PSDR_ERR_HIP, "waterfall parameter ring: event wait failed");
     WfClient *h_wf = (WfClient *)c->wf_ring.host(ring);
     WfClient *d_wf = (WfClient *)c->wf_ring.dev(ring);
     int *h_sent = (int *)((unsigned char *)c->wf_ring.host(ring) + c->wf_sent_off);
@@ -1676,6 +1791,9 @@ extern "C" int psdr_waterfall_batch(psdr_ctx *c, uint64_t first_frame_num) {
         w.out_off = total;
         s.out_off = total;
         s.nsent = s.active ? nsent : 0;
+        s.b_level = s.level;
+        s.b_l = s.l;
+        s.b_r = s.r;
         if (s.active) {
             total += (size_t)nsent * (size_t)(s.r - s.l);
             total = (total + 15) & ~(size_t)15;
@@ -1700,7 +1818,7 @@ extern "C" int psdr_waterfall_batch(psdr_ctx *c, uint64_t first_frame_num) {
                            c->d_wfout);
         HIPCHK(hipGetLastError());
     }
-    c->wf_ring.release(ring, c->side);
+    HIPCHK(c->wf_ring.release(ring, c->side));
     if (c->side != c->stream) {
         HIPCHK(hipEventRecord(c->ev_side_done, c->side));
         c->side_pending = true;
@@ -1709,15 +1827,20 @@ extern "C" int psdr_waterfall_batch(psdr_ctx *c, uint64_t first_frame_num) {
     }
     return PSDR_OK;
 }
-extern "C" int psdr_read_waterfall(psdr_ctx *c, int id, int8_t *out, size_t out_cap, int *nsent_out) {
+extern "C" int psdr_read_waterfall(psdr_ctx *c, int id, int8_t *out, size_t out_cap, int *nsent_out, int *level_out,
+                                   int *l_out, int *r_out) {
     if (!c) return fail(PSDR_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(c->mtx);
     int rc = check_wslot(c, id);
     if (rc) return rc;
     HIPCHK(hipSetDevice(c->device));
     const WfSlot &s = c->wslots[id];
-    const size_t bytes = (size_t)s.nsent * (size_t)(s.r - s.l);
+    // the window of the BATCH, not the live one (it may have changed since)
+    const size_t bytes = (size_t)s.nsent * (size_t)(s.b_r - s.b_l);
     if (nsent_out) *nsent_out = s.nsent;
+    if (level_out) *level_out = s.b_level;
+    if (l_out) *l_out = s.b_l;
+    if (r_out) *r_out = s.b_r;
     if (bytes == 0 || !out) return PSDR_OK;
     if (bytes > out_cap) return fail(PSDR_ERR_INVALID, "output buffer too small (%zu > %zu)", bytes, out_cap);
     {

@@ -174,7 +174,7 @@ class HipBackend:
         from ._lib import check
         check(self.ctx.lib.psdr_demod_batch_from(self.ctx.h, C.c_void_p(self.spec_ptr),
                                                  self.stride_bins, self.F, first_frame_num))
-        self.ctx.last_nframes = self.F
+        self.ctx.last_nframes = self.ctx.last_demod_frames = self.F
 
 
 def gather_audio_to_root(dist, rank, world, local_ids, local_audio, nclients, root=0):

@@ -80,6 +80,7 @@ class hipFFT : public FFT {
         cfg.max_clients = 1;
         cfg.max_waterfall_clients = 1;
         cfg.skip_num = 1;
+        cfg.waterfall_size = 0;  // Level 1 serves no waterfall clients itself
         if (psdr_create(&cfg, &ctx) != PSDR_OK) throw std::runtime_error(psdr_last_error());
     }
     static int chk(int rc) {
