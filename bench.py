@@ -119,13 +119,16 @@ def gen_ring_torch(torch, device, nhalves, N, is_real, seed):
     return ring
 
 
-def cpu_baseline(wl, params, clients, waterfalls, budget_s=15.0):
+def cpu_baseline(wl, params, clients, waterfalls, budget_s=16.0, fft_library=None):
     """The oracle ("port") timed on this host's cores over a bounded sample of the same workload.
-    Frames are independent for everything but the clients' overlap-add tails, so the CPU gets
-    the same deal as the GPU's batches: W workers (threads; the oracle's C calls release the GIL),
-    each a single-threaded pipeline - forward FFT + pyramid + every client's send_audio +
-    the waterfall slices - on its own frames; `value` is the aggregate, `cores` = W (the best of
-    a short probe over worker counts: the pipelines are memory-bound long before 256 threads)."""
+    The big forward transform runs through the first library found with the FFTW3 API - libfftw3f.so.3,
+    then MKL's wrappers (libmkl_rt.so) - i.e. the kind of FFT the reference's FFTW back-end calls
+    (src/fft_impl.cpp:89-117,145); if none loads, through the oracle's own radix-4 transform.  Which
+    one is stated in `fft`.  Frames are independent for everything but the clients' overlap-add tails,
+    so the CPU gets the same deal as the GPU's batches: W workers (threads; the oracle's C calls
+    release the GIL), each a single-threaded pipeline - forward FFT + pyramid + every client's
+    send_audio + the waterfall slices - on its own frames.  Reported: one thread, and the best
+    aggregate over worker counts up to all host threads (`value`, `cores`)."""
     import threading
     from oracle import oracle as O
     N, is_real = wl["fft_size"], wl["is_real"]
@@ -138,7 +141,12 @@ def cpu_baseline(wl, params, clients, waterfalls, budget_s=15.0):
     else:
         halves = ((rng.standard_normal((nh, N // 2)) + 1j * rng.standard_normal((nh, N // 2))) * 2.0 ** -9).astype(np.complex64)
     O.set_threads(1)
+    libname = O.use_fft_library(fft_library) if fft_library != "" else ""
     ncpu = os.cpu_count() or 1
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
 
     class Worker:
         def __init__(self):
@@ -179,19 +187,45 @@ def cpu_baseline(wl, params, clients, waterfalls, budget_s=15.0):
         dt = time.perf_counter() - t0
         return sum(w.frames for w in workers), dt
 
-    cand = sorted({c for c in (8, 32, 64, 128, ncpu) if c <= ncpu} | {min(ncpu, 8)})
+    cand = sorted({c for c in (1, 8, 32, 64, 128, ncpu) if c <= ncpu} | {1, min(ncpu, 8)})
     pool = [Worker() for _ in range(max(cand))]
-    best_rate, cores = 0.0, cand[0]
+    rates = {}
     probe_s = min(2.0, budget_s / (2 * len(cand)))
     for c in cand:
         fr, dt = measure(pool[:c], probe_s)
-        if fr / dt > best_rate:
-            best_rate, cores = fr / dt, c
-    frames, dt = measure(pool[:cores], budget_s / 2)
+        rates[c] = fr / dt
+    cores = max(rates, key=rates.get)
+    frames, dt = measure(pool[:cores], budget_s / 3)
+    fr1, dt1 = measure(pool[:1], budget_s / 6)
     msps = frames * (N // 2) / dt / 1e6
-    return {"value": round(msps, 3), "unit": "MSamples/s", "cores": cores, "kind": "port",
+    fft = (os.path.basename(libname) + " through the FFTW3 API (fftwf_plan_dft_1d / fftwf_execute, ESTIMATE, 1 thread per plan)"
+           if libname else "built-in radix-4 (oracle/psdr_oracle.c): no FFTW3-API library could be loaded")
+    return {"value": round(msps, 3), "unit": "MSamples/s", "cores": cores, "kind": "port", "fft": fft,
+            "one_thread_MSamples_per_s": round(fr1 * (N // 2) / dt1 / 1e6, 3),
+            "host_threads_available": ncpu,
+            "MSamples_per_s_by_workers": {str(k): round(v * (N // 2) / 1e6, 1) for k, v in sorted(rates.items())},
             "sample": f"{frames} frames of the same workload in {dt:.1f} s: {cores} single-threaded pipelines "
-                      f"(oracle/psdr_oracle.c) side by side on {ncpu} host threads, best worker count of a probe"}
+                      f"(oracle/psdr_oracle.c, forward FFT as stated in 'fft') side by side on {ncpu} usable host "
+                      f"threads, best worker count of a probe; one pipeline alone: {fr1} frames in {dt1:.1f} s"}
+
+
+def cpu_baseline_subprocess(wl_name, timeout_s=240):
+    """runs cpu_baseline() in a child process (a third-party FFT library is dlopen()ed there: keep it
+    away from the process that owns the GPU context) and falls back to the built-in transform"""
+    import subprocess
+    for lib in (None, ""):
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", wl_name]
+        if lib == "":
+            cmd.append("--cpu-builtin-fft")
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and line:
+                return json.loads(line[-1])
+            err = (r.stderr or "")[-300:]
+        except Exception as e:  # timeout or a crash inside the library
+            err = repr(e)
+    return {"error": err}
 
 
 def emit(out):
@@ -252,130 +286,157 @@ def kernel_roofline(ctx, step, first_step, nsteps, wl, wl_name, params, clients,
 
 
 def run_sharded_bench(args, torch, rank, world, local_rank):
-    """N > 1.  Default (--shard time): the STREAM is sharded - batch g goes to rank g mod G
-    with a two-frame warm-up instead of any exchange (phantomsdr_amd/distributed.py); every
-    rank serves all the clients of its frames; weak scaling (per-GPU work fixed), no data-path
-    collective.  --shard clients: BASELINE.json configs[3] shape - audio clients sharded over
-    the ranks, rank 0 FFTs and broadcasts each spectrum batch over RCCL/xGMI."""
+    """N > 1, one process per GPU over RCCL.  Three ways to shard the path are measured in the same run;
+    `value` is the one --shard names (default: BASELINE.json configs[3]):
+
+      clients  audio clients sharded over the ranks (client i -> rank i mod G); rank 0 FFTs and
+               broadcasts each spectrum batch (8N bytes per frame) over RCCL/xGMI
+      raw      the same sharding, but rank 0 broadcasts the RAW new half-frames (cs16: 2N bytes per
+               frame, 4x fewer) and every rank runs the forward FFT itself (SURVEY 8e variant i)
+      time     the STREAM is sharded - batch g goes to rank g mod G with a two-frame warm-up instead of
+               any exchange; every rank serves all the clients of its frames; no data-path collective
+    """
     import torch.distributed as dist
     from phantomsdr_amd import SpectrumEngine
-    from phantomsdr_amd.distributed import (HipBackend, HipTimeBackend, ShardedRunner, TimeShardedRunner,
-                                            assign_clients)
+    from phantomsdr_amd.distributed import (HipBackend, HipRawBackend, HipTimeBackend, RawShardedRunner, ShardedRunner,
+                                            TimeShardedRunner, assign_clients)
 
     device = torch.device("cuda", local_rank)
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    time_mode = args.shard == "time"
-    wl = WORKLOADS[args.workload or ("cfg2" if time_mode else "cfg4")]
-    N = wl["fft_size"]
-    warm = TimeShardedRunner.WARMUP if time_mode else 0
-    # time mode: a launch carries --batch frames INCLUDING the two warm-up frames, so its tile
-    # count stays a multiple of the work-group count (258 frames would leave half the
-    # work-groups one tile short: +20 us of tail per step); F = the NEW frames per step
-    F = args.batch - warm
-    per_gpu = wl["audio"]
-    eng = SpectrumEngine(wl["sps"], N, wl["is_real"], input_format=wl["fmt"], max_batch=F + warm,
-                         max_clients=max(per_gpu, 1), max_waterfall_clients=max(wl["waterfall"], 1),
-                         device=local_rank)
-    params = eng.params
-    hb = eng.ctx.half_frame_bytes()
-    nbatches = max(2, (args.ring_mib * (1 << 20)) // (hb * F))
-    ring = None
-    ring_ptr = 0
-    if time_mode or rank == 0:
-        ring = gen_ring_torch(torch, device, nbatches * F + 1, N, wl["is_real"], seed=0x5D5D0004)
-        ring_ptr = ring.data_ptr()
-    torch.cuda.synchronize()
 
-    if time_mode:
-        clients = make_clients(wl, params, seed=0x5D5D0002)
-        waterfalls = make_waterfalls(wl, params, seed=0x5D5D0002)
-        for mode, l, m, r in clients:
-            eng.add_audio_client(l, m, r, mode)
-        for lv, l, r in waterfalls:
-            eng.add_waterfall_client(lv, l, r)
-        backend = HipTimeBackend(eng.ctx, ring_ptr, nbatches * F + 1, F + warm)
-        runner = TimeShardedRunner(backend, rank, world, F)
-
-        def step(i):
-            first, skip = runner.step(i)
-            if waterfalls:
-                eng.ctx.waterfall_batch(first - skip)
-        nclients_total, par = len(clients), (
-            f"stream sharded over {world} GPUs: batch g -> rank g mod G, 2-frame warm-up, no data-path collective")
-        bytes_bcast = None
-    else:
-        all_clients = make_clients(wl, params, seed=0x5D5D0004, count=per_gpu * world)
-        mine = assign_clients(len(all_clients), world)[rank]
-        clients = [all_clients[c] for c in mine]
-        waterfalls = []
-        for mode, l, m, r in clients:
-            eng.add_audio_client(l, m, r, mode)
+    def measure(mode, steps, warmup):
+        time_mode = mode == "time"
+        wl_name = args.workload or ("cfg2" if time_mode else "cfg4")
+        wl = WORKLOADS[wl_name]
+        N = wl["fft_size"]
+        warm = TimeShardedRunner.WARMUP if time_mode else 0
+        # time mode: a launch carries --batch frames INCLUDING the two warm-up frames, so its tile
+        # count stays a multiple of the work-group count; F = the NEW frames per step
+        F = args.batch - warm
+        per_gpu = wl["audio"]
+        eng = SpectrumEngine(wl["sps"], N, wl["is_real"], input_format=wl["fmt"], max_batch=F + warm,
+                             max_clients=max(per_gpu, 1), max_waterfall_clients=max(wl["waterfall"], 1),
+                             device=local_rank)
+        params = eng.params
+        hb = eng.ctx.half_frame_bytes()
+        nbatches = max(2, (args.ring_mib * (1 << 20)) // (hb * F))
+        ring = None
+        if time_mode or rank == 0:
+            ring = gen_ring_torch(torch, device, nbatches * F + 1, N, wl["is_real"], seed=0x5D5D0004)
         torch.cuda.synchronize()
-        backend = HipBackend(torch, eng.ctx, device, ring_ptr, nbatches, F)
-        runner = ShardedRunner(backend, dist, rank, world, F)
-        step = runner.step
-        nclients_total, par = per_gpu * world, (
-            f"clients sharded over {world} GPUs (client i -> rank i mod G); rank 0 FFT + RCCL broadcast "
-            "of the spectrum batch")
+        waterfalls = []
+        if time_mode:
+            clients = make_clients(wl, params, seed=0x5D5D0002)
+            waterfalls = make_waterfalls(wl, params, seed=0x5D5D0002)
+            for mode_, l, m, r in clients:
+                eng.add_audio_client(l, m, r, mode_)
+            for lv, l, r in waterfalls:
+                eng.add_waterfall_client(lv, l, r)
+            backend = HipTimeBackend(eng.ctx, ring.data_ptr(), nbatches * F + 1, F + warm)
+            runner = TimeShardedRunner(backend, rank, world, F)
 
-    for i in range(args.warmup):
-        step(i)
-    eng.ctx.synchronize()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    if not time_mode:
-        runner.bytes_broadcast = 0
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    eng.ctx.synchronize()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+            def step(i):
+                first, skip = runner.step(i)
+                if waterfalls:
+                    eng.ctx.waterfall_batch(first - skip)
+            nclients_total = len(clients)
+            par = f"stream sharded over {world} GPUs: batch g -> rank g mod G, 2-frame warm-up, no data-path collective"
+            bytes_per_frame = 0
+        else:
+            all_clients = make_clients(wl, params, seed=0x5D5D0004, count=per_gpu * world)
+            mine = assign_clients(len(all_clients), world)[rank]
+            clients = [all_clients[c] for c in mine]
+            for mode_, l, m, r in clients:
+                eng.add_audio_client(l, m, r, mode_)
+            torch.cuda.synchronize()
+            if mode == "raw":
+                backend = HipRawBackend(torch, eng.ctx, device, ring.view(nbatches * F + 1, -1) if ring is not None else None,
+                                        nbatches, F)
+                runner = RawShardedRunner(backend, dist, rank, world, F)
+                par = (f"clients sharded over {world} GPUs (client i -> rank i mod G); rank 0 broadcasts the RAW new "
+                       "half-frames over RCCL, every rank runs the forward FFT")
+                bytes_per_frame = hb
+            else:
+                backend = HipBackend(torch, eng.ctx, device, ring.data_ptr() if ring is not None else 0, nbatches, F)
+                runner = ShardedRunner(backend, dist, rank, world, F)
+                par = (f"clients sharded over {world} GPUs (client i -> rank i mod G); rank 0 FFT + RCCL broadcast "
+                       "of the spectrum batch")
+                bytes_per_frame = 8 * N
+            step = runner.step
+            nclients_total = per_gpu * world
 
-    # time mode: every rank ingests its own F new frames per step; client mode: one stream
-    frames = args.steps * F * (world if time_mode else 1)
-    msps = frames * (N // 2) / dt / 1e6
-    # roofline of the dominant kernel on rank 0's GPU (all ranks replay: client mode broadcasts)
-    wl_name_s = args.workload or ("cfg2" if time_mode else "cfg4")
-    roofline, kernels, _ = kernel_roofline(eng.ctx, step, args.warmup + args.steps, min(args.steps, 20), wl,
-                                           wl_name_s, params, clients, waterfalls, F + warm)
-    eng.ctx.synchronize()
-    torch.cuda.synchronize()
-    dist.barrier()
-    if rank == 0:
+        def fence():
+            eng.ctx.synchronize()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+        for i in range(warmup):
+            step(i)
+        fence()
+        if not time_mode:
+            runner.bytes_broadcast = 0
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        fence()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        # time mode: every rank ingests its own F new frames per step; client modes: one stream
+        frames = steps * F * (world if time_mode else 1)
+        msps = frames * (N // 2) / dt / 1e6
+        roofline, kernels, _ = kernel_roofline(eng.ctx, step, warmup + steps, min(steps, 20), wl, wl_name, params,
+                                               clients, waterfalls, F + warm)
+        fence()
         ab = algorithmic_bytes_per_frame(wl, params, clients, waterfalls)
+        res = {"value": round(msps, 2), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+               "workload": wl_name + ": " + wl["desc"], "frames_per_step": F, "fft_size": N,
+               "audio_clients": nclients_total, "waterfall_clients": len(waterfalls), "parallelism": par,
+               "realtime_factor": round(msps * 1e6 / wl["sps"], 1), "roofline": roofline,
+               "path": {"algorithmic_bytes_per_frame": int(ab["total"]), "frames_per_s": round(frames / dt, 1),
+                        "kernels": kernels,
+                        "frac_of_hbm_peak_per_gpu": round(ab["total"] * frames / dt / HBM_PEAK / (world if time_mode else 1), 4)},
+               "xgmi": None if time_mode else {
+                   "broadcast_bytes_per_frame": bytes_per_frame,
+                   "GB_per_s_per_link": round(runner.bytes_broadcast / dt / 1e9, 2) if world > 1 else None,
+                   "link_peak_GB_per_s": 153.0,
+                   "ingest_ceiling_MSamples_per_s": round(153.0e9 / bytes_per_frame * (N // 2) / 1e6, 1)}}
+        eng.close()
+        del ring
+        torch.cuda.empty_cache()
+        return res
+
+    main_mode = args.shard
+    results = {main_mode: measure(main_mode, args.steps, args.warmup)}
+    for m in ("clients", "raw", "time"):
+        if m not in results:
+            try:
+                results[m] = measure(m, min(args.steps, 30), min(args.warmup, 5))
+            except Exception as e:
+                results[m] = {"error": repr(e)}
+    if rank == 0:
+        r = results[main_mode]
         out = {
             "metric": "ingest MSamples/s + concurrent audio clients at 2^20-pt FFT",
-            "value": round(msps, 2), "unit": "MSamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "value": r["value"], "unit": "MSamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": (args.workload or ("cfg2" if time_mode else "cfg4")) + ": " + wl["desc"],
-                       "frames_per_step": F, "fft_size": N, "audio_clients": nclients_total,
-                       "waterfall_clients": len(waterfalls), "parallelism": par,
-                       "realtime_factor": round(msps * 1e6 / wl["sps"], 1)},
-            "roofline": roofline,
-            "path": {"algorithmic_bytes_per_frame": int(ab["total"]),
-                     "frames_per_s": round(frames / dt, 1), "kernels": kernels,
-                     "frac_of_hbm_peak_per_gpu": round(ab["total"] * frames / dt / HBM_PEAK / (world if time_mode else 1), 4)},
-            "xgmi": None if time_mode else {
-                "broadcast_bytes_per_frame": 8 * N,
-                "GB_per_s_per_link": round(runner.bytes_broadcast / dt / 1e9, 2) if world > 1 else None,
-                "link_peak_GB_per_s": 153.0},
+            "config": {k: r[k] for k in ("workload", "frames_per_step", "fft_size", "audio_clients", "waterfall_clients",
+                                         "parallelism", "realtime_factor")},
+            "roofline": r["roofline"], "path": r["path"], "xgmi": r["xgmi"],
+            "sharding": {m: {k: v for k, v in results[m].items() if k in ("value", "ms_per_step", "steps", "audio_clients",
+                                                                           "parallelism", "xgmi", "error", "workload")}
+                         for m in results},
             "cpu_baseline": None,
         }
     else:
         out = None
-    eng.close()
     if dist.is_initialized():
         emit(None)  # every rank flushes what RCCL wrote through C stdio ...
         dist.barrier()
@@ -385,25 +446,113 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
     emit(out)
 
 
+class SingleGpuRun:
+    """One workload on one GPU: engine + device-resident ring + the bench's clients."""
+
+    def __init__(self, torch, device, local_rank, wl_name, wl, F, ring_mib, nclients=None):
+        from phantomsdr_amd import SpectrumEngine
+        self.torch, self.wl_name, self.wl, self.F = torch, wl_name, wl, F
+        nc = wl["audio"] if nclients is None else nclients
+        self.eng = eng = SpectrumEngine(wl["sps"], wl["fft_size"], wl["is_real"], input_format=wl["fmt"],
+                                        max_batch=F, max_clients=max(nc, 1),
+                                        max_waterfall_clients=max(wl["waterfall"], 1), device=local_rank)
+        self.params = eng.params
+        self.N = wl["fft_size"]
+        self.hb = eng.ctx.half_frame_bytes()
+        # ring > 256 MiB Infinity Cache; a whole number of batches (+1 trailing half)
+        self.nbatches = max(1, (ring_mib * (1 << 20)) // (self.hb * F))
+        self.nhalves = self.nbatches * F + 1
+        self.ring = gen_ring_torch(torch, device, self.nhalves, self.N, wl["is_real"], seed=0x5D5D0002)
+        torch.cuda.synchronize()
+        self.ring_ptr = self.ring.data_ptr()
+        self.clients = make_clients(dict(wl, audio=nc), self.params, seed=0x5D5D0002)
+        self.waterfalls = make_waterfalls(wl, self.params, seed=0x5D5D0002)
+        for mode, l, m, r in self.clients:
+            eng.add_audio_client(l, m, r, mode)
+        for lv, l, r in self.waterfalls:
+            eng.add_waterfall_client(lv, l, r)
+
+    def step(self, i):
+        eng = self.eng
+        eng.ctx.process_batch(self.ring_ptr, self.F, offset_bytes=(i % self.nbatches) * self.F * self.hb)
+        if self.clients:
+            eng.ctx.demod_batch(eng.frame_num)
+        if self.waterfalls:
+            eng.ctx.waterfall_batch(eng.frame_num)
+        eng.frame_num += self.F
+
+    def sync(self):
+        self.eng.ctx.synchronize()
+        self.torch.cuda.synchronize()
+
+    def timed(self, steps, warmup, min_reps=5, min_total_s=1.0, max_reps=40):
+        """`warmup` untimed steps, then repetitions of EXACTLY `steps` steps, each bracketed by a full
+        synchronisation; at least `min_reps` and until `min_total_s` of timed work.  Returns the
+        per-repetition wall times (seconds)."""
+        for i in range(warmup):
+            self.step(i)
+        self.sync()
+        times, k = [], warmup
+        while len(times) < min_reps or (sum(times) < min_total_s and len(times) < max_reps):
+            self.sync()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                self.step(k + i)
+            self.sync()
+            times.append(time.perf_counter() - t0)
+            k += steps
+        self.next_step = k
+        return times
+
+    def summary(self, times, steps):
+        med = float(np.median(times))
+        frames = steps * self.F
+        ab = algorithmic_bytes_per_frame(self.wl, self.params, self.clients, self.waterfalls)
+        return {"value": round(frames * (self.N // 2) / med / 1e6, 2), "ms_per_step": round(med / steps * 1e3, 4),
+                "frames_per_s": round(frames / med, 1), "frac_of_hbm_peak": round(ab["total"] * frames / med / HBM_PEAK, 4),
+                "algorithmic_bytes_per_frame": int(ab["total"]), "repetitions": len(times),
+                "ms_per_step_min_max": [round(min(times) / steps * 1e3, 4), round(max(times) / steps * 1e3, 4)],
+                "timed_s": round(sum(times), 3)}
+
+    def close(self):
+        self.eng.close()
+        self.ring = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=0,
-                    help="frames per step (F); default 256: a step of the two persistent passes has ~90 us of "
+                    help="frames per step (F); default 256: a step of the two persistent passes has ~60 us of "
                          "fixed cost (ramp, prologue, tail, launch gaps) whatever F is (DESIGN.md, batch-size table)")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-post-chain", action="store_true",
                     help="skip the separate post-demodulation-chain measurement (used for the rocprofv3 kernel stats: "
                          "its passes overlap the long chain kernels and would skew the per-kernel averages)")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the clients256 / cfg3 sub-objects (profiling runs of one workload)")
     ap.add_argument("--ring-mib", type=int, default=512)
-    ap.add_argument("--shard", default="time", choices=["time", "clients"],
-                    help="N > 1: shard the stream (default) or the clients (spectrum broadcast)")
+    ap.add_argument("--shard", default="clients", choices=["clients", "time", "raw"],
+                    help="N > 1: shard the clients with a spectrum broadcast (BASELINE.json configs[3], default), "
+                         "the clients with a RAW half-frame broadcast + replicated FFT, or the stream (no collective)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path even with one rank (testing)")
+    ap.add_argument("--cpu-baseline-only", default=None, metavar="WORKLOAD",
+                    help="(internal) run only the CPU baseline leg of a workload and print its JSON")
+    ap.add_argument("--cpu-builtin-fft", action="store_true", help="(internal) CPU leg with the oracle's own FFT")
     args = ap.parse_args()
+
+    if args.cpu_baseline_only:
+        from phantomsdr_amd.core import derived_params
+        wl = WORKLOADS[args.cpu_baseline_only]
+        p = derived_params(wl["sps"], wl["fft_size"], wl["is_real"])
+        cl = make_clients(wl, p, seed=0x5D5D0002)
+        wf = make_waterfalls(wl, p, seed=0x5D5D0002)
+        print(json.dumps(cpu_baseline(wl, p, cl, wf, fft_library="" if args.cpu_builtin_fft else None)), flush=True)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -422,59 +571,17 @@ def main():
     if world > 1 or args.force_sharded:
         return run_sharded_bench(args, torch, rank, world, local_rank)
 
-    from phantomsdr_amd import SpectrumEngine
     wl_name = args.workload or "cfg2"
     wl = WORKLOADS[wl_name]
     F = args.batch
-    eng = SpectrumEngine(wl["sps"], wl["fft_size"], wl["is_real"], input_format=wl["fmt"],
-                         max_batch=F, max_clients=max(wl["audio"], 1),
-                         max_waterfall_clients=max(wl["waterfall"], 1), device=local_rank)
-    params = eng.params
-    N = wl["fft_size"]
-    hb = eng.ctx.half_frame_bytes()
-    # ring > 256 MiB Infinity Cache; a whole number of batches (+1 trailing half)
-    nbatches = max(1, (args.ring_mib * (1 << 20)) // (hb * F))
-    nhalves = nbatches * F + 1
-    ring = gen_ring_torch(torch, device, nhalves, N, wl["is_real"], seed=0x5D5D0002)
-    torch.cuda.synchronize()
-    eng.ring = None
-    ring_ptr = ring.data_ptr()
+    run = SingleGpuRun(torch, device, local_rank, wl_name, wl, F, args.ring_mib)
+    eng, params, clients, waterfalls, N = run.eng, run.params, run.clients, run.waterfalls, run.N
+    times = run.timed(args.steps, args.warmup)
+    head = run.summary(times, args.steps)
 
-    clients = make_clients(wl, params, seed=0x5D5D0002)
-    waterfalls = make_waterfalls(wl, params, seed=0x5D5D0002)
-    for mode, l, m, r in clients:
-        eng.add_audio_client(l, m, r, mode)
-    for lv, l, r in waterfalls:
-        eng.add_waterfall_client(lv, l, r)
-
-    def step(i):
-        b = i % nbatches
-        eng.ctx.process_batch(ring_ptr, F, offset_bytes=b * F * hb)
-        if clients:
-            eng.ctx.demod_batch(eng.frame_num)
-        if waterfalls:
-            eng.ctx.waterfall_batch(eng.frame_num)
-        eng.frame_num += F
-
-    for i in range(args.warmup):
-        step(i)
-    eng.ctx.synchronize()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    eng.ctx.synchronize()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-
-    frames = args.steps * F
-    msps = frames * (N // 2) / dt / 1e6
-    ms_per_step = dt / args.steps * 1e3
-
-    # per-kernel durations: second, profiled replay of the same steps (the events do not perturb `value`)
-    roofline, kernels, ab = kernel_roofline(eng.ctx, step, args.warmup, min(args.steps, 50), wl, wl_name, params,
+    # per-kernel durations: profiled replay of the same steps (the events do not perturb `value`)
+    roofline, kernels, ab = kernel_roofline(eng.ctx, run.step, run.next_step, min(args.steps, 50), wl, wl_name, params,
                                             clients, waterfalls, F)
-    path_frac = ab["total"] * (frames / dt) / HBM_PEAK
 
     # SURVEY 8f-2 (widened row): the optional post-demodulation chain (DC blocker + AGC + int16),
     # measured separately - it is NOT part of `value` (the metric's clients end at float audio)
@@ -482,16 +589,9 @@ def main():
     if clients and not args.no_post_chain:
         try:
             eng.ctx.set_post_chain(True)
-            psteps = 6
-            for i in range(2):
-                step(i)
-            eng.ctx.synchronize()
-            t0 = time.perf_counter()
-            for i in range(psteps):
-                step(2 + i)
-            eng.ctx.synchronize()
-            pdt = (time.perf_counter() - t0) / psteps
+            pt = run.timed(10, 3, min_reps=3, min_total_s=0.1)
             eng.ctx.set_post_chain(False)
+            pdt = float(np.median(pt)) / 10
             h = params["audio_fft_size"] // 2
             post = {"ms_per_step": round(pdt * 1e3, 3), "MSamples_per_s_ingest": round(F * (N // 2) / pdt / 1e6, 1),
                     "audio_samples_per_s": round(len(clients) * F * h / pdt, 1),
@@ -499,30 +599,54 @@ def main():
                     "note": "whole step with psdr_set_post_chain(1): f32 recurrences, sequential per client"}
         except Exception as e:
             post = {"error": repr(e)}
+    nhalves, hb = run.nhalves, run.hb
+    run.close()
+    del run
+
+    # more of BASELINE.json's single-GPU shapes, each with its own value and whole-path fraction:
+    # the target's own wording (256 concurrent audio clients on one MI355X) and configs[2]
+    extra = {}
+    if not args.no_extra and wl_name == "cfg2":
+        for key, name, nc in (("clients256", "cfg2", 256), ("cfg3", "cfg3", None)):
+            try:
+                w2 = WORKLOADS[name] if nc is None else dict(WORKLOADS[name], modes=("USB", "LSB", "AM", "FM"))
+                r2 = SingleGpuRun(torch, device, local_rank, name, w2, F, args.ring_mib, nclients=nc)
+                st = min(args.steps, 50)
+                sm = r2.summary(r2.timed(st, min(args.warmup, 5), min_reps=3, min_total_s=0.3), st)
+                sm.update({"workload": (name + ": " + w2["desc"]) if nc is None else
+                           f"cfg2 shape with {nc} mixed USB/LSB/AM/FM audio clients + {w2['waterfall']} waterfall clients on one GPU",
+                           "audio_clients": len(r2.clients), "steps": st,
+                           "realtime_factor": round(sm["value"] * 1e6 / w2["sps"], 1)})
+                extra[key] = sm
+                r2.close()
+                del r2
+            except Exception as e:
+                extra[key] = {"error": repr(e)}
 
     cpu = None
     if not args.no_cpu_baseline:
-        try:
-            cpu = cpu_baseline(wl, params, clients, waterfalls)
-        except Exception as e:  # the oracle is optional for the measured value
-            cpu = {"error": repr(e)}
+        cpu = cpu_baseline_subprocess(wl_name)
 
     out = {
         "metric": "ingest MSamples/s + concurrent audio clients at 2^20-pt FFT",
-        "value": round(msps, 2), "unit": "MSamples/s", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "value": head["value"], "unit": "MSamples/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl_name + ": " + wl["desc"], "frames_per_step": F,
                    "fft_size": N, "audio_clients": len(clients), "waterfall_clients": len(waterfalls),
                    "audio_fft_size": params["audio_fft_size"], "ring_MiB": round(nhalves * hb / 2 ** 20, 1),
-                   "realtime_factor": round(msps * 1e6 / wl["sps"], 1)},
+                   "realtime_factor": round(head["value"] * 1e6 / wl["sps"], 1),
+                   "timing": f"median of {head['repetitions']} repetitions of exactly {args.steps} steps "
+                             f"({head['timed_s']} s timed), each bracketed by a full synchronisation"},
         "roofline": roofline,
-        "path": {"algorithmic_bytes_per_frame": int(ab["total"]), "frames_per_s": round(frames / dt, 1),
-                 "frac_of_hbm_peak": round(path_frac, 4), "kernels": kernels},
+        "path": {"algorithmic_bytes_per_frame": head["algorithmic_bytes_per_frame"], "frames_per_s": head["frames_per_s"],
+                 "frac_of_hbm_peak": head["frac_of_hbm_peak"], "ms_per_step_min_max": head["ms_per_step_min_max"],
+                 "kernels": kernels},
+        "clients256": extra.get("clients256"),
+        "cfg3": extra.get("cfg3"),
         "post_chain": post,
         "cpu_baseline": cpu,
     }
-    eng.close()
     emit(out)
 
 

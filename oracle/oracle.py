@@ -51,6 +51,9 @@ def lib():
         L.orc_dft_c2c.argtypes = [vp, vp, sz, i32]
         L.orc_dft_r2c.argtypes = [vp, vp, sz]
         L.orc_dft_c2r.argtypes = [vp, vp, sz]
+        L.orc_fft_use_library.argtypes = [C.c_char_p]
+        L.orc_fft_use_library.restype = i32
+        L.orc_fft_library.restype = C.c_char_p
         L.orc_fft_create.argtypes = [sz, i32, i32, i32, i32]
         L.orc_fft_create.restype = vp
         L.orc_fft_destroy.argtypes = [vp]
@@ -138,6 +141,32 @@ def _p(a):
 
 def set_threads(n):
     lib().orc_set_threads(int(n))
+
+
+FFT_LIBRARY_CANDIDATES = ("libfftw3f.so.3", "libfftw3f.so", "libmkl_rt.so.2", "libmkl_rt.so.1", "libmkl_rt.so",
+                          "/opt/conda/lib/libmkl_rt.so")
+
+
+def use_fft_library(path=None):
+    """Make FFT objects created from now on run their big forward transform through a library with
+    the FFTW3 API (what the reference's FFTW back-end calls, src/fft_impl.cpp:89-117,145).
+    path=None probes FFT_LIBRARY_CANDIDATES in order; "" switches back to the built-in transform.
+    Returns the name in use ("" = built-in).  MKL is run single-threaded (its threads are the
+    caller's business: bench.py runs one pipeline per core)."""
+    os.environ.setdefault("MKL_THREADING_LAYER", "SEQUENTIAL")
+    os.environ.setdefault("MKL_NUM_THREADS", "1")
+    L = lib()
+    if path == "":
+        L.orc_fft_use_library(b"")
+        return ""
+    for cand in ([path] if path else FFT_LIBRARY_CANDIDATES):
+        if L.orc_fft_use_library(cand.encode()) == 0:
+            return cand
+    return ""
+
+
+def fft_library():
+    return lib().orc_fft_library().decode()
 
 
 def convert(raw, fmt):

@@ -16,7 +16,9 @@
  */
 #include "psdr_oracle.h"
 
+#include <dlfcn.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -448,7 +450,56 @@ struct orc_fft {
     int8_t *quantizedbuf;
     size_t quantized_len;
     cf32 *W, *Whalf, *scr1, *scr2;
+    void *lib_plan; /* FFTW3-API plan bound to inbuf/outbuf (orc_fft_use_library), or NULL */
 };
+
+/* ------------------------------------------------------------------------------------
+ * Optional FFT library for the big forward transform.  The reference's FFTW back-end calls
+ * fftwf_plan_dft_1d / fftwf_plan_dft_r2c_1d + fftwf_execute (src/fft_impl.cpp:89-117,145).
+ * FFTW itself is not in this image; any library that exports the FFTW3 single-precision API
+ * (libfftw3f.so.3, or MKL's wrappers in libmkl_rt.so) can be dlopen()ed here so that the CPU
+ * baseline of bench.py times the kind of FFT the reference would run, and so that the
+ * built-in transform can be cross-checked against an independent production FFT.  Parity
+ * tests use the built-in transform (deterministic, same bits everywhere).
+ * ---------------------------------------------------------------------------------- */
+typedef void *(*fn_plan_c2c)(int, void *, void *, int, unsigned);
+typedef void *(*fn_plan_r2c)(int, float *, void *, unsigned);
+typedef void (*fn_execute)(void *);
+typedef void (*fn_destroy)(void *);
+static struct {
+    void *handle;
+    fn_plan_c2c plan_c2c;
+    fn_plan_r2c plan_r2c;
+    fn_execute execute;
+    fn_destroy destroy;
+    char name[256];
+} g_fftlib;
+static pthread_mutex_t g_plan_mtx = PTHREAD_MUTEX_INITIALIZER; /* FFTW planners are not thread-safe */
+
+int orc_fft_use_library(const char *path) {
+    if (!path || !*path) { /* back to the built-in transform (existing plans keep theirs) */
+        memset(&g_fftlib, 0, sizeof g_fftlib);
+        return 0;
+    }
+    void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return -1;
+    fn_plan_c2c pc = (fn_plan_c2c)dlsym(h, "fftwf_plan_dft_1d");
+    fn_plan_r2c pr = (fn_plan_r2c)dlsym(h, "fftwf_plan_dft_r2c_1d");
+    fn_execute ex = (fn_execute)dlsym(h, "fftwf_execute");
+    fn_destroy de = (fn_destroy)dlsym(h, "fftwf_destroy_plan");
+    if (!pc || !pr || !ex || !de) {
+        dlclose(h);
+        return -2;
+    }
+    g_fftlib.handle = h;
+    g_fftlib.plan_c2c = pc;
+    g_fftlib.plan_r2c = pr;
+    g_fftlib.execute = ex;
+    g_fftlib.destroy = de;
+    strncpy(g_fftlib.name, path, sizeof g_fftlib.name - 1);
+    return 0;
+}
+const char *orc_fft_library(void) { return g_fftlib.handle ? g_fftlib.name : ""; }
 
 /* FFT::FFT src/fft_impl.cpp:63-70 + FFTW::plan_c2c :89-103 / plan_r2c :104-117 */
 orc_fft *orc_fft_create(size_t size, int is_real, int downsample_levels,
@@ -482,10 +533,21 @@ orc_fft *orc_fft_create(size_t size, int is_real, int downsample_levels,
         f->scr1 = (cf32 *)xaligned(sizeof(cf32) * (size / 2 + 1));
         f->scr2 = (cf32 *)xaligned(sizeof(cf32) * (size / 2 + 1));
     }
+    if (g_fftlib.handle) { /* FFTW_FORWARD = -1, FFTW_ESTIMATE = 1 << 6 (src/fft_impl.cpp:89-117) */
+        pthread_mutex_lock(&g_plan_mtx);
+        f->lib_plan = is_real ? g_fftlib.plan_r2c((int)size, f->inbuf, f->outbuf, 1u << 6)
+                              : g_fftlib.plan_c2c((int)size, f->inbuf, f->outbuf, -1, 1u << 6);
+        pthread_mutex_unlock(&g_plan_mtx);
+    }
     return f;
 }
 void orc_fft_destroy(orc_fft *f) {
     if (!f) return;
+    if (f->lib_plan && g_fftlib.destroy) {
+        pthread_mutex_lock(&g_plan_mtx);
+        g_fftlib.destroy(f->lib_plan);
+        pthread_mutex_unlock(&g_plan_mtx);
+    }
     free(f->windowbuf);
     free(f->inbuf);
     free(f->outbuf);
@@ -555,7 +617,9 @@ static void half_and_quantize(const float *powerbuf, float *halfbuf, int8_t *qua
  * src/fft.cpp:91-98 (memcpy(&X[R], &X[0], A bins)). */
 void orc_fft_execute(orc_fft *f) {
     size_t N = f->size;
-    if (!f->is_real) {
+    if (f->lib_plan) {
+        g_fftlib.execute(f->lib_plan); /* fftwf_execute(p), src/fft_impl.cpp:145 */
+    } else if (!f->is_real) {
         /* out-of-place so inbuf survives (FFTW_DESTROY_INPUT makes that unobservable) */
         fft_pow2_f32((const cf32 *)f->inbuf, (cf32 *)f->outbuf, f->scr1, N, -1, f->W);
     } else {

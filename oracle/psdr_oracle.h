@@ -61,6 +61,10 @@ void orc_dft_c2r(const float *in, float *out, size_t n);           /* reads in[0
 
 /* class FFTW, src/fft_impl.cpp:63-174 (+ the IQ wrap copy of src/fft.cpp:91-98) */
 typedef struct orc_fft orc_fft;
+/* dlopen() a library with the FFTW3 single-precision API (libfftw3f.so.3, libmkl_rt.so) for the big
+ * forward transform of FFT objects created afterwards; NULL/"" = the built-in transform.  0 = ok. */
+int orc_fft_use_library(const char *path);
+const char *orc_fft_library(void);
 orc_fft *orc_fft_create(size_t size, int is_real, int downsample_levels,
                         int brightness_offset, int additional_size);
 void orc_fft_destroy(orc_fft *f);

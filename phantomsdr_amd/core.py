@@ -128,6 +128,7 @@ class Context:
     def set_post_chain(self, enable=True):
         """batched DC blocker + AGC + int16 conversion after every demod_batch"""
         check(self.lib.psdr_set_post_chain(self.h, 1 if enable else 0))
+        self.post_chain_on = bool(enable)
 
     def demod_batch(self, first_frame_num):
         check(self.lib.psdr_demod_batch(self.h, first_frame_num))

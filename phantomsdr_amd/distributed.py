@@ -73,6 +73,47 @@ class ShardedRunner:
         self.frame_num += self.F
 
 
+class RawShardedRunner:
+    """SURVEY 8e variant (i): clients sharded as in ShardedRunner, but what crosses xGMI is the RAW
+    new half-frames (cs16: 2.1 MB per 2^20-point frame, 4x fewer bytes than the 8.39 MB spectrum)
+    and every rank runs the forward FFT itself.  The broadcast's per-link ceiling moves from
+    ~9.5 to ~38 GS/s of ingest; the price is G redundant forward transforms, i.e. per-GPU compute
+    stays that of a single GPU and only the clients scale.
+
+    backend must provide:
+      raw_tensor()                 torch tensor of the batch's F+1 raw half-frames (same shape on
+                                   every rank); row 0 is the last half of the previous batch
+      load_raw(step_index)         root only: fill rows 1..F (and row 0 at step 0) from the ring
+      roll()                       every rank, before the next step: row F -> row 0
+      forward_local()              forward FFT (+ pyramid) of the F frames in raw_tensor()
+      demod(first_frame_num)       demodulate this rank's clients
+    """
+
+    def __init__(self, backend, dist, rank, world, frames_per_step, root=0):
+        self.backend, self.dist = backend, dist
+        self.rank, self.world, self.F, self.root = rank, world, frames_per_step, root
+        self.frame_num = 0
+        self.bytes_broadcast = 0
+        self.first = True
+
+    def step(self, i):
+        ctx = getattr(self.backend, "stream_context", None)
+        with (ctx() if ctx else contextlib.nullcontext()):
+            if not self.first:
+                self.backend.roll()
+            if self.rank == self.root:
+                self.backend.load_raw(i)
+            if self.world > 1:
+                t = self.backend.raw_tensor()
+                t = t if self.first else t[1:]   # row 0 is already everywhere after the first step
+                self.dist.broadcast(t, src=self.root)
+                self.bytes_broadcast += t.numel() * t.element_size()
+            self.backend.forward_local()
+            self.backend.demod(self.frame_num)
+        self.first = False
+        self.frame_num += self.F
+
+
 class TimeShardedRunner:
     """Batch g of the stream -> rank g mod G, with a two-frame warm-up instead of any
     exchange.  backend must provide
@@ -84,6 +125,13 @@ class TimeShardedRunner:
     WARMUP = 2
 
     def __init__(self, backend, rank, world, frames_per_step):
+        # The two-frame warm-up rebuilds the overlap-add tails and FM's last sample exactly, nothing
+        # more: the post-demodulation chain (DC blocker sums, 200 ms AGC look-ahead and gain) has
+        # seconds of memory and the NaN guard can drop warm-up frames - time sharding would
+        # silently change the PCM there, so it is refused.
+        if getattr(backend, "post_chain", False):
+            raise ValueError("time sharding is exact only up to the float audio: disable the post-demodulation "
+                             "chain (psdr_set_post_chain) or shard the clients instead")
         self.backend, self.rank, self.world, self.F = backend, rank, world, frames_per_step
         self.step_index = 0
 
@@ -110,6 +158,7 @@ class HipTimeBackend:
         self.hb = ctx.half_frame_bytes()
         self.max_frames = max_frames
         self.last = (0, 0)
+        self.post_chain = bool(getattr(ctx, "post_chain_on", False))
 
     def run(self, first_half, nframes, first_frame_num):
         span = nframes + 1
@@ -175,6 +224,44 @@ class HipBackend:
         check(self.ctx.lib.psdr_demod_batch_from(self.ctx.h, C.c_void_p(self.spec_ptr),
                                                  self.stride_bins, self.F, first_frame_num))
         self.ctx.last_nframes = self.ctx.last_demod_frames = self.F
+
+
+class HipRawBackend:
+    """RawShardedRunner back-end on the HIP library: every rank owns a Context and a device buffer of
+    F+1 raw half-frames; the broadcast lands in that buffer, psdr_process_batch reads it."""
+
+    def __init__(self, torch, ctx, device, ring, nbatches, frames_per_step):
+        import ctypes as C
+        from ._lib import check
+        self.torch, self.ctx, self.F = torch, ctx, frames_per_step
+        self.ring, self.nbatches = ring, nbatches  # ring: torch int16 tensor [halves][samples] on the root, else None
+        self.hb = ctx.half_frame_bytes()
+        self.stream = torch.cuda.Stream(device=device)
+        check(ctx.lib.psdr_set_stream(ctx.h, C.c_void_p(self.stream.cuda_stream)))
+        self.raw = torch.zeros((self.F + 1, self.hb // 2), dtype=torch.int16, device=device)
+
+    def stream_context(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def raw_tensor(self):
+        return self.raw
+
+    def load_raw(self, i):
+        b = i % self.nbatches
+        src = self.ring[b * self.F: b * self.F + self.F + 1]
+        if i == 0:
+            self.raw.copy_(src)
+        else:
+            self.raw[1:].copy_(src[1:])
+
+    def roll(self):
+        self.raw[0].copy_(self.raw[self.F])
+
+    def forward_local(self):
+        self.ctx.process_batch(self.raw.data_ptr(), self.F)
+
+    def demod(self, first_frame_num):
+        self.ctx.demod_batch(first_frame_num)
 
 
 def gather_audio_to_root(dist, rank, world, local_ids, local_audio, nclients, root=0):

@@ -139,6 +139,112 @@ def test_two_rank_sharding_matches_single_process():
 
 
 # ---------------------------------------------------------------------------------------
+# raw-half broadcast (SURVEY 8e variant i): the new half-frames cross the wire, every rank transforms
+# ---------------------------------------------------------------------------------------
+class OracleRawBackend:
+    def __init__(self, torch, halves, my_clients, is_root):
+        from oracle import oracle as O
+        self.O, self.torch = O, torch
+        self.halves = halves if is_root else None
+        self.fo = O.FFT(N, False, 3, 0, NAUD)
+        self.raw = torch.zeros((F + 1, N // 2), dtype=torch.complex64)
+        self.specs = None
+        self.clients = []
+        for mode, l, m, r in my_clients:
+            c = O.AudioClient(False, NAUD, 12000, N)
+            c.set_audio_demodulation(mode)
+            c.set_audio_range(l, m, r)
+            self.clients.append(c)
+        self.audio = [[] for _ in my_clients]
+
+    def raw_tensor(self):
+        return self.raw
+
+    def load_raw(self, i):
+        src = self.torch.from_numpy(self.halves[i * F: i * F + F + 1].copy())
+        if i == 0:
+            self.raw.copy_(src)
+        else:
+            self.raw[1:].copy_(src[1:])
+
+    def roll(self):
+        self.raw[0].copy_(self.raw[F])
+
+    def forward_local(self):
+        self.specs = []
+        h = self.raw.numpy()
+        for f in range(F):
+            self.fo.load(h[f], h[f + 1])
+            self.fo.execute()
+            self.specs.append(self.fo.output().copy())
+
+    def demod(self, first_frame_num):
+        for f in range(F):
+            for ci, c in enumerate(self.clients):
+                a, _, _, _ = c.send_audio(self.specs[f], first_frame_num + f, fft=self.fo)
+                self.audio[ci].append(a)
+
+
+def _raw_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from phantomsdr_amd.distributed import RawShardedRunner, assign_clients, gather_audio_to_root
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        allc = _clients()
+        mine = assign_clients(len(allc), world)[rank]
+        be = OracleRawBackend(torch, _halves(), [allc[i] for i in mine], rank == 0)
+        runner = RawShardedRunner(be, dist, rank, world, F)
+        for i in range(NBATCH):
+            runner.step(i)
+        merged = gather_audio_to_root(dist, rank, world, mine, [np.stack(a) for a in be.audio], len(allc))
+        if rank == 0:
+            q.put((merged, runner.bytes_broadcast))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_raw_broadcast_matches_single_process():
+    """only rank 0 ever sees the sample ring; the other rank's clients hear exactly the same audio"""
+    import torch
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    allc = _clients()
+    be = OracleBackend(torch, _halves(), allc)
+    from phantomsdr_amd.distributed import ShardedRunner
+    r1 = ShardedRunner(be, None, 0, 1, F)
+    for i in range(NBATCH):
+        r1.step(i)
+    ref = [np.stack(a) for a in be.audio]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_raw_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    merged, nbytes = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert nbytes == (NBATCH * F + 1) * (N // 2) * 8       # every half-frame crosses the wire once
+    for a, b in zip(merged, ref):
+        assert np.array_equal(a, b)
+
+
+def test_time_sharding_refuses_the_post_chain():
+    from phantomsdr_amd.distributed import TimeShardedRunner
+
+    class _B:
+        post_chain = True
+
+    with pytest.raises(ValueError):
+        TimeShardedRunner(_B(), 0, 2, 4)
+
+
+# ---------------------------------------------------------------------------------------
 # time sharding: batch g -> rank g mod G with a two-frame warm-up and NO exchange
 # ---------------------------------------------------------------------------------------
 TF, TSTEPS = 4, 3     # frames per batch, steps per rank (world 2 -> 24 frames in total)

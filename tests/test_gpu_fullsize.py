@@ -162,11 +162,14 @@ def test_cfg4_share_demod_from_matches_unsharded_and_oracle():
       C  a context that never runs an FFT: A's spectrum batch is copied device-to-device into a
          foreign buffer with a padded frame stride (the stand-in for the RCCL broadcast's receive
          buffer) and demodulated with psdr_demod_batch_from on a caller-owned stream.
-    B and C must equal A bit for bit; A is checked against the oracle."""
+      D  HipRawBackend + RawShardedRunner, world = 1: the raw half-frames go through the broadcast
+         buffer (row F carried over to row 0 between steps) and the FFT runs from there.
+    B, C and D must equal A bit for bit; A is checked against the oracle."""
     import torch
     from phantomsdr_amd import SpectrumEngine
     from phantomsdr_amd._lib import check
-    from phantomsdr_amd.distributed import HipBackend, ShardedRunner, alias_device_f32, assign_clients
+    from phantomsdr_amd.distributed import (HipBackend, HipRawBackend, RawShardedRunner, ShardedRunner,
+                                            alias_device_f32, assign_clients)
     B = _bench()
     wl = B.WORKLOADS["cfg4"]
     N, F, world, nb_ = wl["fft_size"], 3, 8, 2
@@ -178,17 +181,18 @@ def test_cfg4_share_demod_from_matches_unsharded_and_oracle():
     torch.cuda.synchronize()
     mk = lambda: SpectrumEngine(wl["sps"], N, False, input_format="s16", max_batch=F, max_clients=wl["audio"],
                                 max_waterfall_clients=1)
-    engA, engB, engC = mk(), mk(), mk()
+    engA, engB, engC, engD = mk(), mk(), mk(), mk()
     try:
         p = engA.params
         n, levels, R = p["audio_fft_size"], p["downsample_levels"], p["fft_result_size"]
         all_clients = B.make_clients(wl, p, seed=0x5D5D0004, count=wl["audio"] * world)
         mine = [all_clients[c] for c in assign_clients(len(all_clients), world)[3]]
         assert len(mine) == wl["audio"]
-        gA, gB, gC = ([e.add_audio_client(l, m, r, mode) for mode, l, m, r in mine] for e in (engA, engB, engC))
+        gA, gB, gC, gD = ([e.add_audio_client(l, m, r, mode) for mode, l, m, r in mine] for e in (engA, engB, engC, engD))
         hb = engA.ctx.half_frame_bytes()
         backend = HipBackend(torch, engB.ctx, dev, ring.data_ptr(), nb_, F)
         runner = ShardedRunner(backend, None, 0, 1, F)
+        raw_runner = RawShardedRunner(HipRawBackend(torch, engD.ctx, dev, ring.view(nb_ * F + 1, -1), nb_, F), None, 0, 1, F)
         stride = N + 64
         foreign = torch.zeros(F * stride * 2, dtype=torch.float32, device=dev)
         side = torch.cuda.Stream(device=dev)
@@ -201,6 +205,7 @@ def test_cfg4_share_demod_from_matches_unsharded_and_oracle():
             engA.ctx.demod_batch(b * F)
             engA.ctx.synchronize()
             runner.step(b)
+            raw_runner.step(b)
             src, nbins = C.c_void_p(), C.c_size_t()
             check(engA.ctx.lib.psdr_spectrum_device_ptr(engA.ctx.h, 0, C.byref(src), C.byref(nbins)))
             t_src = alias_device_f32(torch, src.value, F * N * 2, dev).view(F, N * 2)
@@ -210,7 +215,7 @@ def test_cfg4_share_demod_from_matches_unsharded_and_oracle():
             torch.cuda.synchronize()
             got = [g.read_audio(F) for g in gA]
             for ci in range(len(mine)):
-                for name, gx in (("HipBackend", gB), ("foreign buffer", gC)):
+                for name, gx in (("HipBackend", gB), ("foreign buffer", gC), ("HipRawBackend", gD)):
                     a2, p2, n2 = gx[ci].read_audio(F)
                     assert np.array_equal(got[ci][0].view(np.uint32), a2.view(np.uint32)), f"{name}: batch {b} client {ci} audio"
                     assert np.array_equal(got[ci][1].view(np.uint32), p2.view(np.uint32)), f"{name}: batch {b} client {ci} pwr"
@@ -225,7 +230,7 @@ def test_cfg4_share_demod_from_matches_unsharded_and_oracle():
                     _check_audio(f"frame {fr} client {ci} {mine[ci]}", o.mode, got[ci][0][f], got[ci][1][f],
                                  got[ci][2][f], a_o, p_o, dropped)
     finally:
-        for e in (engB, engC):
+        for e in (engB, engC, engD):
             check(e.ctx.lib.psdr_set_stream(e.ctx.h, None))
-        for e in (engA, engB, engC):
+        for e in (engA, engB, engC, engD):
             e.close()
