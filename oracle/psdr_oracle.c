@@ -163,7 +163,7 @@ static void fft_pow2_f32(const cf32 *in, cf32 *out, cf32 *scratch, size_t n, int
         size_t t = n / 4, tw = n / (4 * p);
         long long nb = (long long)t;
         long long i;
-#pragma omp parallel for schedule(static) if (n >= 16384)
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (n >= 16384)
         for (i = 0; i < nb; i++) {
             size_t k = (size_t)i & (p - 1);
             size_t j = (((size_t)i - k) << 2) + k;
@@ -217,7 +217,7 @@ static void fft_pow2_f32(const cf32 *in, cf32 *out, cf32 *scratch, size_t n, int
         size_t t = n / 2, tw = n / (2 * p);
         long long nb = (long long)t;
         long long i;
-#pragma omp parallel for schedule(static) if (n >= 16384)
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (n >= 16384)
         for (i = 0; i < nb; i++) {
             size_t k = (size_t)i & (p - 1);
             size_t j = (((size_t)i - k) << 1) + k;
@@ -377,7 +377,7 @@ static void r2c_pow2_f32(const float *in, cf32 *out, size_t n, const cf32 *Whalf
     fft_pow2_f32((const cf32 *)in, scr1, scr2, M, -1, Whalf);
     const cf32 *Z = scr1;
     long long k;
-#pragma omp parallel for schedule(static) if (n >= 16384)
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (n >= 16384)
     for (k = 0; k <= (long long)M; k++) {
         cf32 a = Z[(size_t)k % M];
         cf32 b = Z[(M - (size_t)k) % M];
@@ -590,7 +590,7 @@ void orc_fft_load_complex_input(orc_fft *f, const float *a1, const float *a2) {
 static void power_and_quantize(float *complexbuf, float *powerbuf, int8_t *quantizedbuf,
                                float normalize, size_t len, int power_offset) {
     long long i;
-#pragma omp parallel for schedule(static) if (len >= 16384)
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (len >= 16384)
     for (i = 0; i < (long long)len; i++) {
         complexbuf[i * 2] /= normalize;
         complexbuf[i * 2 + 1] /= normalize;
@@ -605,7 +605,7 @@ static void power_and_quantize(float *complexbuf, float *powerbuf, int8_t *quant
 static void half_and_quantize(const float *powerbuf, float *halfbuf, int8_t *quantizedbuf,
                               size_t len, int power_offset) {
     long long i;
-#pragma omp parallel for schedule(static) if (len >= 16384)
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (len >= 16384)
     for (i = 0; i < (long long)len; i++) {
         float power = powerbuf[i * 2] + powerbuf[i * 2 + 1];
         halfbuf[i] = power;
@@ -656,7 +656,7 @@ void orc_pyramid_from_spectrum(const float *spec, size_t size, int is_real, int 
     for (int i = 0; i < downsample_levels; i++) total += L >> i;
     float *pw = power ? power : (float *)xaligned(sizeof(float) * (total + L));
     long long i;
-#pragma omp parallel for schedule(static) if (L >= 16384)
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (L >= 16384)
     for (i = 0; i < (long long)L; i++) {
         size_t k = is_real ? (size_t)i : ((size_t)i + base_idx) % size;
         float re = spec[2 * k], im = spec[2 * k + 1];

@@ -9,45 +9,56 @@
 // Three f32 recurrences run along time and are bit-exact only in the reference's order:
 //   s1_t = (s1_{t-1} - x_{t-D}) + x_t            first moving average  (m1 = s1 / D)
 //   s2_t = (s2_{t-1} - m1_{t-D}) + m1_t          second moving average (out = x_{t-D+1} - s2 / D)
-//   g_t  = fma(-a, g - w_t, g) or fma(r, w_t - g, g)        AGC attack / release
-// Everything else is a pure function of the streams and runs fully parallel.  The streams are
-// time-major [t][slot] with the history they need kept IN FRONT of the new samples (D rows for
-// the averages, L-1 rows for the AGC look-ahead), so there are no rings: a lane owns a client,
-// a wave walks time, every step is a few coalesced row accesses fetched a block ahead, and the
-// loop bodies are just the recurrences.
-//   k_pc_gather   audio[slot][frame][j] -> X[D + t][slot], frames with the NaN flag skipped
-//   k_pc_ma<0|1>  the two running sums                                     (sequential)
+//   g_t  = g + (w_t < g ? attack : release) * (w_t - g)           AGC attack / release
+// Everything else is a pure function of the streams and runs fully parallel.
+//
+// Layout (round 2): every stream is CLIENT-MAJOR, [slot][row], with the history it needs kept IN
+// FRONT of the new samples (D rows for the averages, L-1 rows for the AGC look-ahead) - no rings.
+// A lane of a sequential kernel owns a client and walks its stream with 16-byte loads and stores
+// (four samples per memory instruction, a whole 16-step block = four loads, prefetched three
+// blocks ahead); the parallel kernels put their lanes along time.  Round 1 kept the streams
+// time-major with one 4-byte access per sample and one block of prefetch: with a single wave per 64
+// clients the two recurrence loops were bound by memory latency (43 and 32 ns per sample, 2.0 and
+// 1.5 ms per 256-frame batch) rather than by their 7 and 3 arithmetic operations per sample.
+//   k_pc_index    stream offset of every frame of every client (NaN-flagged frames dropped)
+//   k_pc_gather   audio[slot][frame][j] -> X[slot][D + t]
+//   k_pc_ma2      both running sums in one loop (D = 32)          (sequential)
+//   k_pc_ma<0|1>  the two running sums, any D                      (sequential, fallback)
 //   k_pc_scan     AGC look-ahead peak: sliding maximum of |x| over L samples (the reference's
 //                 monotonic deque) as van Herk prefix / suffix maxima of blocks of L (sequential,
 //                 but over (client, block) pairs)
-//   k_pc_want     w_t = desired / (peak_t + 1e-10)                          (parallel)
-//   k_pc_gain     the gain recurrence                                       (sequential)
-//   k_pc_out      delayed sample * gain, int16 conversion                   (parallel)
+//   k_pc_want     w_t = desired / (peak_t + 1e-10)                 (parallel)
+//   k_pc_gain     the gain recurrence                              (sequential)
+//   k_pc_out      delayed sample * gain, int16 conversion, straight into pcm[slot][frame][j]
 //   k_pc_history  the last D / L-1 rows become the next batch's history
-//   k_pc_scatter  pcm[t][slot] -> pcm[slot][frame][j]
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "demod.h"
 
 namespace psdr {
 
 struct PostArgs {
-    const ClientParams *clients;  // active clients (compact), .slot = column
+    const ClientParams *clients;  // active clients (compact), .slot = row block
     int nact, nframes, max_batch, h;  // h = n/2 samples per frame
-    int slots;                        // row pitch of the time-major arrays
+    int slots;
     int D, L;                         // DC delay, AGC look-ahead (samples)
     float desired, attack, release;   // AGC
     const float *audio;               // [slots][max_batch][h]
     const int *nan_flags;             // [slots][max_batch]
     int *fstart;                      // [slots][max_batch] stream offset of a frame, -1 = dropped
     int *len;                         // [slots] samples of this batch's stream
-    float *X;                         // [D + max_batch*h][slots]: demodulated audio, rows < D history
-    float *M1;                        // [D + max_batch*h][slots]: first moving average, rows < D history
-    float *V1;                        // [L-1 + max_batch*h][slots]: DC-blocked stream, rows < L-1 history
+    size_t px, pv;                    // row pitches (floats per client) of X/M1 and of V1/P/S, multiples of 4
+    int vo;                           // V1 only: leading pad so that its NEW rows (from row L-1) are 16-byte aligned
+    float *X;                         // [slots][px]: demodulated audio, rows < D history          (D + T + pad)
+    float *M1;                        // [slots][px]: first moving average, rows < D history
+    float *V1;                        // [slots][pv]: DC-blocked stream, rows < L-1 history         (L-1 + T + pad)
+    float *V1n;                       // the NEXT batch's V1 (double-buffered: k_pc_history moves the tail there)
+    int hist_sel;                     // k_pc_history: 0 = X and M1, 1 = V1 -> V1n
     float *P, *S;                     // like V1: prefix / suffix maxima; then S = w_t, P = g_t
-    int *pcm_t;                       // [max_batch*h][slots]
     int32_t *pcm;                     // [slots][max_batch][h]
     // carried state
     float *dc_s1, *dc_s2;             // [slots] running sums
@@ -56,49 +67,44 @@ struct PostArgs {
     int ma_fused;  // k_pc_ma2 keeps M1's history itself (k_pc_history leaves M1 alone)
 };
 
-__device__ __forceinline__ unsigned pc_at(const PostArgs &a, int row, int slot) {
-    return (unsigned)row * (unsigned)a.slots + (unsigned)slot;
+typedef float pc_f4 __attribute__((ext_vector_type(4)));
+
+// one wave per client: where each surviving frame starts in the client's stream (a ballot per 64
+// frames: the count of surviving frames below a lane is a popcount)
+__global__ __launch_bounds__(64) void k_pc_index(PostArgs a) {
+    const int lane = threadIdx.x;
+    const ClientParams cp = a.clients[blockIdx.x];
+    const int slot = cp.slot;
+    const int *nf = a.nan_flags + (size_t)slot * a.max_batch;
+    int *fs = a.fstart + (size_t)slot * a.max_batch;
+    int cnt = 0;
+    for (int f0 = 0; f0 < a.nframes; f0 += 64) {
+        const int f = f0 + lane;
+        const bool alive = f < a.nframes && nf[f] == 0;
+        const unsigned long long m = __ballot(alive);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (f < a.nframes) fs[f] = alive ? (cnt + before) * a.h : -1;
+        cnt += __popcll(m);
+    }
+    if (lane == 0) a.len[slot] = cnt * a.h;
+    if (cp.agc_reset == 2) {  // a new client in this slot starts from zero history (sums: see k_pc_ma*)
+        float *x = a.X + (size_t)slot * a.px, *m1 = a.M1 + (size_t)slot * a.px;
+        for (int r = lane; r < a.D; r += 64) x[r] = m1[r] = 0.f;
+    }
 }
 
-// tile of 64 clients x 32 samples of one frame through LDS (both accesses coalesced)
+// grid (client, frame): one frame of audio to its place in the stream (contiguous both sides)
 __global__ __launch_bounds__(256) void k_pc_gather(PostArgs a) {
-    __shared__ float tile[32][65];
-    const int c0 = blockIdx.x * 64, f = blockIdx.y, j0 = blockIdx.z * 32;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    // stream offset of frame f for client c0 + lane (count of surviving frames before f)
-    int pos = -1, slot = 0;
-    if (c0 + tx < a.nact) {
-        slot = a.clients[c0 + tx].slot;
-        const int *nf = a.nan_flags + (size_t)slot * a.max_batch;
-        int cnt = 0;
-        for (int g = 0; g < f; g++) cnt += nf[g] ? 0 : 1;
-        pos = nf[f] ? -1 : cnt * a.h;
-        if (blockIdx.z == 0 && ty == 0) {
-            a.fstart[(size_t)slot * a.max_batch + f] = pos;
-            if (f == a.nframes - 1) a.len[slot] = (cnt + (nf[f] ? 0 : 1)) * a.h;
-            // a new client in this slot starts from zero history (the sums are reset in k_pc_ma)
-            if (f == 0 && a.clients[c0 + tx].agc_reset == 2)
-                for (int r = 0; r < a.D; r++) {
-                    a.X[pc_at(a, r, slot)] = 0.f;
-                    a.M1[pc_at(a, r, slot)] = 0.f;
-                }
-        }
-    }
-    for (int r = ty; r < 64; r += 4) {  // load: lanes along j
-        const int ci = c0 + r;
-        const int j = j0 + (tx & 31);
-        if ((tx < 32) && ci < a.nact && j < a.h) {
-            const int sl = a.clients[ci].slot;
-            tile[tx & 31][r] = a.audio[((size_t)sl * a.max_batch + f) * a.h + j];
-        }
-    }
-    __syncthreads();
-    if (pos >= 0)
-        for (int jj = ty; jj < 32; jj += 4)
-            if (j0 + jj < a.h) a.X[pc_at(a, a.D + pos + j0 + jj, slot)] = tile[jj][tx];
+    const int slot = a.clients[blockIdx.x].slot, f = blockIdx.y;
+    const int pos = a.fstart[(size_t)slot * a.max_batch + f];
+    if (pos < 0) return;
+    const float *src = a.audio + ((size_t)slot * a.max_batch + f) * a.h;
+    float *dst = a.X + (size_t)slot * a.px + a.D + pos;
+    for (int j = threadIdx.x; j < a.h; j += blockDim.x) dst[j] = src[j];
 }
 
-// One moving average (MovingAverage::insert, src/utils.h:84-93: sum -= oldest; push; sum += val).
+// One moving average (MovingAverage::insert, src/utils.h:84-93: sum -= oldest; push; sum += val),
+// any delay D (the fused kernel below covers the reference's D = 32).
 //   SECOND = false: in = X,  sum = s1, writes M1[D + t] = s1 / D
 //   SECOND = true : in = M1, sum = s2, writes V1[L-1 + t] = X[t + 1] - s2 / D
 //                   (getLatest(delay - 1) = x_{t-D+1}, src/utils.h:160-166)
@@ -110,208 +116,186 @@ __global__ __launch_bounds__(64) void k_pc_ma(PostArgs a) {
     if (ci >= a.nact) return;
     const ClientParams cp = a.clients[ci];
     const int slot = cp.slot, D = a.D;
-    const bool fresh = cp.agc_reset == 2;  // a new client in this slot: zero sums (k_pc_gather zeroed the history)
+    const bool fresh = cp.agc_reset == 2;  // a new client in this slot: zero sums (k_pc_index zeroed the history)
     const int T = a.len[slot];
-    const float *__restrict__ in = SECOND ? a.M1 : a.X;
-    const float *__restrict__ X = a.X;
-    float *__restrict__ out = SECOND ? a.V1 : a.M1;
-    const int orow = SECOND ? a.L - 1 : D;
+    const float *__restrict__ in = (SECOND ? a.M1 : a.X) + (size_t)slot * a.px;
+    const float *__restrict__ X = a.X + (size_t)slot * a.px;
+    float *__restrict__ out = SECOND ? a.V1 + (size_t)slot * a.pv + a.vo + (a.L - 1) : a.M1 + (size_t)slot * a.px + D;
     float s = fresh ? 0.f : (SECOND ? a.dc_s2 : a.dc_s1)[slot];
     const float fD = (float)D, rD = 1.0f / fD;
-    constexpr int KB = 16;
-    auto fetch = [&](float (&ev)[KB], float (&nw)[KB], float (&xd)[KB], int t0) {
-#pragma unroll
-        for (int i = 0; i < KB; i++) {
-            const int t = t0 + i;
-            ev[i] = in[pc_at(a, t, slot)];
-            nw[i] = in[pc_at(a, D + t, slot)];
-            if (SECOND) xd[i] = X[pc_at(a, t + 1, slot)];
-        }
-    };
-    auto block = [&](const float (&ev)[KB], const float (&nw)[KB], const float (&xd)[KB], int t0) {
-        float o[KB];
-#pragma unroll
-        for (int i = 0; i < KB; i++) {
-            s = __fadd_rn(s, -ev[i]);
-            s = __fadd_rn(s, nw[i]);
-            const float m = POW2 ? __fmul_rn(s, rD) : __fdiv_rn(s, fD);
-            o[i] = SECOND ? __fsub_rn(xd[i], m) : m;
-        }
-#pragma unroll
-        for (int i = 0; i < KB; i++) out[pc_at(a, orow + t0 + i, slot)] = o[i];
-    };
-    const int nblk = T / KB;
-    if (nblk > 0) {  // the loads of block b+1 in flight while block b runs (two register sets)
-        float ea[KB], na[KB], xa[KB], eb[KB], nb[KB], xb[KB];
-        fetch(ea, na, xa, 0);
-        int b = 0;
-        for (; b + 1 < nblk; b += 2) {
-            fetch(eb, nb, xb, (b + 1) * KB);
-            block(ea, na, xa, b * KB);
-            if (b + 2 < nblk) fetch(ea, na, xa, (b + 2) * KB);
-            block(eb, nb, xb, (b + 1) * KB);
-        }
-        if (b < nblk) block(ea, na, xa, b * KB);
-    }
-    for (int t = nblk * KB; t < T; t++) {
-        s = __fadd_rn(s, -in[pc_at(a, t, slot)]);
-        s = __fadd_rn(s, in[pc_at(a, D + t, slot)]);
+    for (int t = 0; t < T; t++) {
+        s = __fadd_rn(s, -in[t]);
+        s = __fadd_rn(s, in[D + t]);
         const float m = POW2 ? __fmul_rn(s, rD) : __fdiv_rn(s, fD);
-        if (SECOND) {
-            out[pc_at(a, orow + t, slot)] = __fsub_rn(X[pc_at(a, t + 1, slot)], m);
-        } else {
-            out[pc_at(a, orow + t, slot)] = m;
-        }
+        out[t] = SECOND ? __fsub_rn(X[t + 1], m) : m;
     }
     (SECOND ? a.dc_s2 : a.dc_s1)[slot] = s;
 }
 
-// Both moving averages in one loop for D = 32: the m1 values the second average evicts are
-// the ones this lane produced two 16-step blocks ago - they stay in registers (two alternating
-// sets), M1 only holds the 32 carried values (time order, oldest first).  Two independent
-// recurrences per step instead of one: the same time as a single average.  A stream that is
-// not a whole number of blocks ends with a partial block whose surplus steps are predicated off.
+// Both moving averages in one loop for D = 32.  The x values the first average evicts were
+// inserted two 16-step blocks earlier and the m1 values the second average evicts were produced two
+// blocks earlier: both stay in two alternating register sets, so a 16-step block costs four 16-byte
+// loads (the new x), four 16-byte stores and 16 x 7 arithmetic operations.  M1 only holds the 32
+// carried values between batches (time order, oldest first).  A stream that is not a whole number
+// of blocks ends with a short scalar loop on the in-memory history.
 __global__ __launch_bounds__(64) void k_pc_ma2(PostArgs a) {
     const int lane = threadIdx.x, ci = blockIdx.x * 64 + lane;
     if (ci >= a.nact) return;
     const ClientParams cp = a.clients[ci];
     const int slot = cp.slot;
-    constexpr int KB = 16, D = 32;
-    const bool fresh = cp.agc_reset == 2;  // zero sums (k_pc_gather zeroed the history rows)
+    constexpr int KB = 16, D = 32, AHEAD = 3;
+    // one wave next to the FFT passes' eight issue-bound waves: let it issue first
+    __builtin_amdgcn_s_setprio(3);
+    const bool fresh = cp.agc_reset == 2;  // zero sums (k_pc_index zeroed the history rows)
     const int T = a.len[slot];
     if (T == 0) return;
-    const int nfull = T / KB, rem = T - nfull * KB;
-    const float *__restrict__ X = a.X;
-    float *__restrict__ M1 = a.M1;
-    float *__restrict__ V1 = a.V1;
+    const int nfull = T / KB;
+    float *__restrict__ X = a.X + (size_t)slot * a.px;
+    float *__restrict__ M1 = a.M1 + (size_t)slot * a.px;
+    float *__restrict__ V1 = a.V1 + (size_t)slot * a.pv + a.vo + (a.L - 1);  // 16-byte aligned (vo)
     float s1 = fresh ? 0.f : a.dc_s1[slot], s2 = fresh ? 0.f : a.dc_s2[slot];
     const float rD = 1.0f / 32.0f;
-    const int orow = a.L - 1;
-    float ma[KB], mb[KB];  // m1 of the blocks two and one back (alternating roles)
+    float xs[2][KB], ms[2][KB];  // x / m1 of the blocks two and one back (alternating roles)
 #pragma unroll
     for (int i = 0; i < KB; i++) {
-        ma[i] = M1[pc_at(a, i, slot)];
-        mb[i] = M1[pc_at(a, KB + i, slot)];
+        xs[0][i] = X[i];
+        xs[1][i] = X[KB + i];
+        ms[0][i] = M1[i];
+        ms[1][i] = M1[KB + i];
     }
-    auto fetch = [&](float (&ev)[KB], float (&nw)[KB], float &xlast, int t0) {
+    pc_f4 nw[AHEAD + 1][4];  // the new x of blocks b .. b+AHEAD (a ring of register sets)
+    auto fetch = [&](auto kc, int blk) {
+        constexpr int k = decltype(kc)::value;
+        if (blk < nfull) {
+            const pc_f4 *src = reinterpret_cast<const pc_f4 *>(X + D + blk * KB);  // D, KB, px: multiples of 4
 #pragma unroll
-        for (int i = 0; i < KB; i++) {  // (rows past the stream exist: the arrays are padded)
-            ev[i] = X[pc_at(a, t0 + i, slot)];
-            nw[i] = X[pc_at(a, D + t0 + i, slot)];
+            for (int q = 0; q < 4; q++) nw[k][q] = src[q];
         }
-        xlast = X[pc_at(a, t0 + KB, slot)];  // x_{t-D+1} of the block's last step
     };
-    // m2old: m1 of block b-2 (evicted, then overwritten with block b's m1); valid < KB: only
-    // the first `valid` steps exist
-    auto block = [&](const float (&ev)[KB], const float (&nw)[KB], float xlast, float (&m2old)[KB], int t0,
-                     int valid) {
+    // xold / mold: x and m1 of block b-2 (evicted, then overwritten with block b's); xnext[0] is
+    // x_{t-D+1} of the block's last step (getLatest(delay - 1), src/utils.h:160-166)
+    auto block = [&](const pc_f4 (&nv)[4], float (&xold)[KB], const float (&xnext)[KB], float (&mold)[KB], int t0) {
         float o[KB];
 #pragma unroll
         for (int i = 0; i < KB; i++) {
-            const bool ok = i < valid;
-            const float s1n = __fadd_rn(__fadd_rn(s1, -ev[i]), nw[i]);
-            const float m1 = __fmul_rn(s1n, rD);
-            const float s2n = __fadd_rn(__fadd_rn(s2, -m2old[i]), m1);
-            s1 = ok ? s1n : s1;
-            s2 = ok ? s2n : s2;
-            m2old[i] = ok ? m1 : m2old[i];
-            // getLatest(delay - 1) = x_{t-D+1} = the next step's evictee
-            o[i] = __fsub_rn(i + 1 < KB ? ev[i + 1] : xlast, __fmul_rn(s2n, rD));
+            const float xn = nv[i >> 2][i & 3];
+            s1 = __fadd_rn(__fadd_rn(s1, -xold[i]), xn);
+            const float m1 = __fmul_rn(s1, rD);
+            s2 = __fadd_rn(__fadd_rn(s2, -mold[i]), m1);
+            mold[i] = m1;
+            o[i] = __fsub_rn(i + 1 < KB ? xold[i + 1] : xnext[0], __fmul_rn(s2, rD));
         }
 #pragma unroll
-        for (int i = 0; i < KB; i++)
-            if (i < valid) V1[pc_at(a, orow + t0 + i, slot)] = o[i];
+        for (int i = 0; i < KB; i++) xold[i] = nv[i >> 2][i & 3];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            reinterpret_cast<pc_f4 *>(V1 + t0)[q] = pc_f4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
     };
-    const int nblk = nfull + (rem ? 1 : 0);
-    float ea[KB], na[KB], eb[KB], nb[KB], xa, xb;
-    fetch(ea, na, xa, 0);
+    // software pipeline: blocks b+1 .. b+AHEAD are in flight while block b runs; the ring of register
+    // sets is indexed at compile time (4 blocks per trip)
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    fetch(I0{}, 0);
+    fetch(I1{}, 1);
+    fetch(I2{}, 2);
     int b = 0;
-    for (; b + 1 < nblk; b += 2) {
-        fetch(eb, nb, xb, (b + 1) * KB);
-        block(ea, na, xa, ma, b * KB, KB);
-        if (b + 2 < nblk) fetch(ea, na, xa, (b + 2) * KB);
-        block(eb, nb, xb, mb, (b + 1) * KB, (b + 1 == nblk - 1 && rem) ? rem : KB);
+    for (; b + 4 <= nfull; b += 4) {
+        fetch(I3{}, b + 3);
+        block(nw[0], xs[0], xs[1], ms[0], b * KB);
+        fetch(I0{}, b + 4);
+        block(nw[1], xs[1], xs[0], ms[1], (b + 1) * KB);
+        fetch(I1{}, b + 5);
+        block(nw[2], xs[0], xs[1], ms[0], (b + 2) * KB);
+        fetch(I2{}, b + 6);
+        block(nw[3], xs[1], xs[0], ms[1], (b + 3) * KB);
     }
-    const bool odd = b < nblk;
-    if (odd) block(ea, na, xa, ma, b * KB, rem ? rem : KB);
-    // the last 32 m1 values in time order.  After the loop the set of the LAST block is `ma` if
-    // the block count is odd, else `mb`; with a partial last block (rem steps) that set holds
-    // [new m1 x rem | m1 of three blocks ago x (KB-rem)], the other set the block before.
-    const int r = rem ? rem : KB;  // valid entries of the last block's set
+    // up to three more whole blocks (already fetched into sets 0..2; b is a multiple of 4: set 0 pairs with xs[0])
+    if (b < nfull) {
+        block(nw[0], xs[0], xs[1], ms[0], b * KB);
+        b++;
+    }
+    if (b < nfull) {
+        block(nw[1], xs[1], xs[0], ms[1], b * KB);
+        b++;
+    }
+    if (b < nfull) {
+        block(nw[2], xs[0], xs[1], ms[0], b * KB);
+        b++;
+    }
+    // now (b even) ms[0] is the older set of m1 values, else ms[1]: the window of m1 values in time
+    // order goes to rows t1.. of M1 for the remaining T - nfull*KB (< KB) steps, one by one
+    const int t1 = nfull * KB;
 #pragma unroll
     for (int i = 0; i < KB; i++) {
-        const float lastv = odd ? ma[i] : mb[i], prevv = odd ? mb[i] : ma[i];
-        // time order of the 32 + (KB - r) candidates: [last set's stale tail (i >= r), prev set, last set's head]
-        // rows: stale tail entry i -> row i - r - (KB - r) ... dropped unless it is among the newest 32
-        const int row_prev = KB - r + i;        // prev set entry i
-        const int row_last = 2 * KB - r + i;    // last set entry i (valid for i < r)
-        const int row_stale = i - r;            // last set entry i >= r: m1 of the block before prev
-        if (i < r) M1[pc_at(a, row_last, slot)] = lastv;
-        M1[pc_at(a, row_prev, slot)] = prevv;
-        if (i >= r) M1[pc_at(a, row_stale, slot)] = lastv;
+        M1[t1 + i] = (b & 1) ? ms[1][i] : ms[0][i];
+        M1[t1 + KB + i] = (b & 1) ? ms[0][i] : ms[1][i];
     }
+    for (int t = t1; t < T; t++) {
+        s1 = __fadd_rn(__fadd_rn(s1, -X[t]), X[D + t]);
+        const float m1 = __fmul_rn(s1, rD);
+        s2 = __fadd_rn(__fadd_rn(s2, -M1[t]), m1);
+        M1[D + t] = m1;
+        V1[t] = __fsub_rn(X[t + 1], __fmul_rn(s2, rD));
+    }
+    // the last 32 m1 values in time order become rows 0..31 (X's own history is moved by k_pc_history)
+    float keep[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) keep[i] = M1[T + i];
+#pragma unroll
+    for (int i = 0; i < D; i++) M1[i] = keep[i];
     a.dc_s1[slot] = s1;
     a.dc_s2[slot] = s2;
 }
 
-// blockIdx.y = block k of L rows of V1, blockIdx.z = 0: prefix maxima, 1: suffix maxima
+// grid (client, block k of L rows of V1, 2): z = 0: prefix maxima of |v| inside the block, 1: suffix
+// maxima.  max is associative and exact, so this one IS parallel: the block's rows go through LDS
+// (coalesced both ways), each lane scans a contiguous chunk, the chunk totals are combined by a
+// wave scan.  dynamic LDS: L floats
 __global__ __launch_bounds__(64) void k_pc_scan(PostArgs a) {
-    const int lane = threadIdx.x, ci = blockIdx.x * 64 + lane;
-    if (ci >= a.nact) return;
-    const int slot = a.clients[ci].slot;
+    extern __shared__ float pc_blk[];
+    const int lane = threadIdx.x;
+    const int slot = a.clients[blockIdx.x].slot;
     const int rows = a.L - 1 + a.len[slot];
     const int r0 = blockIdx.y * a.L, r1 = min(r0 + a.L, rows);
     if (r0 >= rows) return;
+    const int n = r1 - r0;
+    const float *__restrict__ v1 = a.V1 + (size_t)slot * a.pv + a.vo + r0;
+    const bool suffix = blockIdx.z != 0;
+    // LDS position i = distance from the scan's start (suffix scans run backwards)
+    for (int i = lane; i < n; i += 64) pc_blk[suffix ? n - 1 - i : i] = fabsf(v1[i]);
+    __syncthreads();
+    const int C = (n + 63) / 64, i0 = lane * C, i1 = min(i0 + C, n);
     float m = 0.f;
-    constexpr int KB = 16;
-    const float *__restrict__ v1 = a.V1;
-    if (blockIdx.z == 0) {
-        float *__restrict__ P = a.P;
-        int r = r0;
-        for (; r + KB <= r1; r += KB) {
-            float x[KB];
+    for (int i = i0; i < i1; i++) m = fmaxf(m, pc_blk[i]);
+    float incl = m;  // inclusive wave scan of the chunk maxima
 #pragma unroll
-            for (int i = 0; i < KB; i++) x[i] = v1[pc_at(a, r + i, slot)];
-#pragma unroll
-            for (int i = 0; i < KB; i++) {
-                m = fmaxf(m, fabsf(x[i]));
-                P[pc_at(a, r + i, slot)] = m;
-            }
-        }
-        for (; r < r1; r++) {
-            m = fmaxf(m, fabsf(v1[pc_at(a, r, slot)]));
-            P[pc_at(a, r, slot)] = m;
-        }
-    } else {
-        float *__restrict__ S = a.S;
-        int r = r1 - 1;
-        for (; r - KB + 1 >= r0; r -= KB) {
-            float x[KB];
-#pragma unroll
-            for (int i = 0; i < KB; i++) x[i] = v1[pc_at(a, r - i, slot)];
-#pragma unroll
-            for (int i = 0; i < KB; i++) {
-                m = fmaxf(m, fabsf(x[i]));
-                S[pc_at(a, r - i, slot)] = m;
-            }
-        }
-        for (; r >= r0; r--) {
-            m = fmaxf(m, fabsf(v1[pc_at(a, r, slot)]));
-            S[pc_at(a, r, slot)] = m;
-        }
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl = fmaxf(incl, o);
     }
+    float run = __shfl_up(incl, 1, 64);  // maximum of all earlier chunks
+    if (lane == 0) run = 0.f;
+    for (int i = i0; i < i1; i++) {
+        run = fmaxf(run, pc_blk[i]);
+        pc_blk[i] = run;
+    }
+    __syncthreads();
+    float *__restrict__ out = (suffix ? a.S : a.P) + (size_t)slot * a.pv + r0;
+    for (int i = lane; i < n; i += 64) out[i] = pc_blk[suffix ? n - 1 - i : i];
 }
 
 // w_t = desired / (peak_t + 1e-10), peak_t = max |V1| over rows [t, t+L-1] = max(S[t], P[t+L-1]);
-// in place into S[t] (only this thread reads S[t]).  256 threads = 4 rows x 64 clients.
+// in place into S[t] (only this thread reads S[t]).  grid (client, blocks of 256 samples)
 __global__ __launch_bounds__(256) void k_pc_want(PostArgs a) {
-    const int ci = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int t = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (ci >= a.nact) return;
-    const int slot = a.clients[ci].slot;
+    const int slot = a.clients[blockIdx.x].slot;
+    const int t = blockIdx.y * 256 + threadIdx.x;
     if (t >= a.len[slot]) return;
-    const float peak = fmaxf(a.S[pc_at(a, t, slot)], a.P[pc_at(a, t + a.L - 1, slot)]);
-    a.S[pc_at(a, t, slot)] = __fdiv_rn(a.desired, __fadd_rn(peak, 1e-10f));
+    float *S = a.S + (size_t)slot * a.pv;
+    const float *P = a.P + (size_t)slot * a.pv;
+    const float peak = fmaxf(S[t], P[t + a.L - 1]);
+    S[t] = __fdiv_rn(a.desired, __fadd_rn(peak, 1e-10f));
 }
 
 // the gain recurrence (src/utils/audioprocessing.cpp:55-66); g_t -> P[t] (0 while the
@@ -329,106 +313,123 @@ __global__ __launch_bounds__(64) void k_pc_gain(PostArgs a) {
         gain = 0.f;
         n0 = 0;
     }
-    constexpr int KB = 16;
-    const float *__restrict__ W = a.S;
-    float *__restrict__ G = a.P;
-    const float natt = -a.attack, rel = a.release;
-    auto fetch = [&](float (&w)[KB], int t0) {
-#pragma unroll
-        for (int i = 0; i < KB; i++) w[i] = W[pc_at(a, t0 + i, slot)];
-    };
-    auto step = [&](float w, int t) -> float {
-        if (n0 + t + 1 < L) return 0.f;  // the look-ahead buffer is not full yet
-        const bool att = w < gain;
-        gain = __fmaf_rn(att ? natt : rel, att ? __fsub_rn(gain, w) : __fsub_rn(w, gain), gain);
+    constexpr int KB = 16, AHEAD = 3;
+    __builtin_amdgcn_s_setprio(3);
+    const float *__restrict__ W = a.S + (size_t)slot * a.pv;
+    float *__restrict__ G = a.P + (size_t)slot * a.pv;
+    const float att = a.attack, rel = a.release;
+    // gain <- gain + (w < gain ? attack : release) * (w - gain): three operations per sample
+    // (fma(-a, g - w, g) and fma(a, w - g, g) are the same value: negating both factors is exact)
+    auto step = [&](float w) -> float {
+        const float d = __fsub_rn(w, gain);
+        gain = __fmaf_rn(d < 0.f ? att : rel, d, gain);
         return gain;
     };
-    auto block = [&](const float (&w)[KB], int t0) {
-        float g[KB];
+    // while the look-ahead buffer is filling (only right after a reset / for a new client) the
+    // reference outputs 0 and leaves the gain alone: those steps, then (once 16-byte aligned) whole
+    // blocks with the loads three blocks ahead, then the rest
+    int t = 0;
+    for (; t < T && n0 + t + 1 < L; t++) G[t] = 0.f;
+    for (; t < T && (t & 3); t++) G[t] = step(W[t]);
+    const int nblk = (T - t) / KB;
+    pc_f4 w[AHEAD + 1][4];
+    auto fetch = [&](auto kc, int blk) {
+        constexpr int k = decltype(kc)::value;
+        if (blk < nblk) {
+            const pc_f4 *src = reinterpret_cast<const pc_f4 *>(W + t + blk * KB);
 #pragma unroll
-        for (int i = 0; i < KB; i++) g[i] = step(w[i], t0 + i);
-#pragma unroll
-        for (int i = 0; i < KB; i++) G[pc_at(a, t0 + i, slot)] = g[i];
-    };
-    const int nblk = T / KB;
-    if (nblk > 0) {
-        float wa[KB], wb[KB];
-        fetch(wa, 0);
-        int b = 0;
-        for (; b + 1 < nblk; b += 2) {
-            fetch(wb, (b + 1) * KB);
-            block(wa, b * KB);
-            if (b + 2 < nblk) fetch(wa, (b + 2) * KB);
-            block(wb, (b + 1) * KB);
+            for (int q = 0; q < 4; q++) w[k][q] = src[q];
         }
-        if (b < nblk) block(wa, b * KB);
+    };
+    auto block = [&](const pc_f4 (&wv)[4], int blk) {
+        pc_f4 g[4];
+#pragma unroll
+        for (int i = 0; i < KB; i++) g[i >> 2][i & 3] = step(wv[i >> 2][i & 3]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) reinterpret_cast<pc_f4 *>(G + t + blk * KB)[q] = g[q];
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    fetch(I0{}, 0);
+    fetch(I1{}, 1);
+    fetch(I2{}, 2);
+    int b = 0;
+    for (; b + 4 <= nblk; b += 4) {
+        fetch(I3{}, b + 3);
+        block(w[0], b);
+        fetch(I0{}, b + 4);
+        block(w[1], b + 1);
+        fetch(I1{}, b + 5);
+        block(w[2], b + 2);
+        fetch(I2{}, b + 6);
+        block(w[3], b + 3);
     }
-    for (int t = nblk * KB; t < T; t++) G[pc_at(a, t, slot)] = step(W[pc_at(a, t, slot)], t);
+    if (b < nblk) {
+        block(w[0], b);
+        b++;
+    }
+    if (b < nblk) {
+        block(w[1], b);
+        b++;
+    }
+    if (b < nblk) {
+        block(w[2], b);
+        b++;
+    }
+    for (t += nblk * KB; t < T; t++) G[t] = step(W[t]);
     a.agc_gain[slot] = gain;
     a.agc_n0[slot] = min(n0 + T, L);
 }
 
 // current_sample * gain (row t of V1 is the oldest sample of the look-ahead window; gain 0 =
-// buffer still filling -> 0) and dsp_float_to_int16 (src/utils/dsp.cpp:152-165)
+// buffer still filling -> 0) and dsp_float_to_int16 (src/utils/dsp.cpp:152-165), written to the
+// frame's place in pcm[slot][frame][j]; rows of dropped frames are zero.  grid (client, frame)
 __global__ __launch_bounds__(256) void k_pc_out(PostArgs a) {
-    const int ci = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int t = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (ci >= a.nact) return;
-    const int slot = a.clients[ci].slot;
-    if (t >= a.len[slot]) return;
-    const float g = a.P[pc_at(a, t, slot)];
-    const float y = g == 0.f ? 0.f : __fmul_rn(a.V1[pc_at(a, t, slot)], g);
-    int v = (int)__fmaf_rn(y, 16384.f, 32768.5f) - 32768;
-    v = v > 32767 ? 32767 : (v < -32768 ? -32768 : v);
-    a.pcm_t[pc_at(a, t, slot)] = v;
+    const int slot = a.clients[blockIdx.x].slot, f = blockIdx.y;
+    const int pos = a.fstart[(size_t)slot * a.max_batch + f];
+    int32_t *dst = a.pcm + ((size_t)slot * a.max_batch + f) * a.h;
+    const float *G = a.P + (size_t)slot * a.pv + pos, *V = a.V1 + (size_t)slot * a.pv + a.vo + pos;
+    for (int j = threadIdx.x; j < a.h; j += blockDim.x) {
+        int v = 0;
+        if (pos >= 0) {
+            const float g = G[j];
+            const float y = g == 0.f ? 0.f : __fmul_rn(V[j], g);
+            v = (int)__fmaf_rn(y, 16384.f, 32768.5f) - 32768;
+            v = v > 32767 ? 32767 : (v < -32768 ? -32768 : v);
+        }
+        dst[j] = v;
+    }
 }
 
 // the last D rows of X / M1 and the last L-1 rows of V1 become the history rows of the next
-// batch (in place, ascending: the reads stay ahead of the writes); blockIdx.y: 0 = X and M1, 1 = V1
-__global__ __launch_bounds__(64) void k_pc_history(PostArgs a) {
-    const int lane = threadIdx.x, ci = blockIdx.x * 64 + lane;
-    if (ci >= a.nact) return;
-    const int slot = a.clients[ci].slot;
+// batch.  grid (client); hist_sel = 0: X and M1, 1: V1 -> V1n.  One work-group per stream: all reads, a
+// barrier, all writes (source and destination overlap when the batch is shorter than the history).
+// dynamic LDS: max(D, L - 1) floats
+__global__ __launch_bounds__(256) void k_pc_history(PostArgs a) {
+    extern __shared__ float pc_hist[];
+    const int slot = a.clients[blockIdx.x].slot;
     const int T = a.len[slot];
-    if (T == 0) return;
-    constexpr int KB = 16;
-    if (blockIdx.y == 0) {
-        for (int r = 0; r < a.D; r++) {  // D is small
-            a.X[pc_at(a, r, slot)] = a.X[pc_at(a, r + T, slot)];
-            if (!a.ma_fused) a.M1[pc_at(a, r, slot)] = a.M1[pc_at(a, r + T, slot)];
+    if (T == 0 && a.hist_sel == 0) return;
+    if (a.hist_sel == 0) {
+        float *x = a.X + (size_t)slot * a.px, *m = a.M1 + (size_t)slot * a.px;
+        for (int r = threadIdx.x; r < a.D; r += blockDim.x) pc_hist[r] = x[r + T];
+        __syncthreads();
+        for (int r = threadIdx.x; r < a.D; r += blockDim.x) x[r] = pc_hist[r];
+        if (!a.ma_fused) {
+            __syncthreads();
+            for (int r = threadIdx.x; r < a.D; r += blockDim.x) pc_hist[r] = m[r + T];
+            __syncthreads();
+            for (int r = threadIdx.x; r < a.D; r += blockDim.x) m[r] = pc_hist[r];
         }
         return;
     }
-    int r = 0;
-    for (; r + KB <= a.L - 1; r += KB) {  // the KB reads of a block happen before its writes
-        float x[KB];
-#pragma unroll
-        for (int i = 0; i < KB; i++) x[i] = a.V1[pc_at(a, r + i + T, slot)];
-#pragma unroll
-        for (int i = 0; i < KB; i++) a.V1[pc_at(a, r + i, slot)] = x[i];
-    }
-    for (; r < a.L - 1; r++) a.V1[pc_at(a, r, slot)] = a.V1[pc_at(a, r + T, slot)];
-}
-
-__global__ __launch_bounds__(256) void k_pc_scatter(PostArgs a) {
-    __shared__ int tile[32][65];
-    const int c0 = blockIdx.x * 64, f = blockIdx.y, j0 = blockIdx.z * 32;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    if (c0 + tx < a.nact) {
-        const int slot = a.clients[c0 + tx].slot;
-        const int pos = a.fstart[(size_t)slot * a.max_batch + f];
-        for (int jj = ty; jj < 32; jj += 4)
-            tile[jj][tx] = (pos >= 0 && j0 + jj < a.h) ? a.pcm_t[pc_at(a, pos + j0 + jj, slot)] : 0;
-    }
+    const float *v = a.V1 + (size_t)slot * a.pv + a.vo;
+    float *vn = a.V1n + (size_t)slot * a.pv + a.vo;
+    for (int r = threadIdx.x; r < a.L - 1; r += blockDim.x) pc_hist[r] = v[r + T];
     __syncthreads();
-    for (int r = ty; r < 64; r += 4) {
-        const int ci = c0 + r;
-        const int j = j0 + (tx & 31);
-        if ((tx < 32) && ci < a.nact && j < a.h) {
-            const int sl = a.clients[ci].slot;
-            a.pcm[((size_t)sl * a.max_batch + f) * a.h + j] = tile[tx & 31][r];
-        }
-    }
+    for (int r = threadIdx.x; r < a.L - 1; r += blockDim.x) vn[r] = pc_hist[r];
 }
 
 }  // namespace psdr

@@ -216,6 +216,15 @@ struct psdr_ctx {
     // post-demodulation chain (postchain.h), allocated by psdr_set_post_chain
     bool post_on = false;
     PostArgs post{};
+    // The chain is a two-stage pipeline across batches: stage 1 (index, gather, moving averages) of
+    // batch b+1 runs on `side` while stage 2 (look-ahead peak, gain, int16) of batch b runs on
+    // `side2`; what the stages share is double-buffered (V1, frame offsets, stream lengths)
+    hipStream_t side2 = nullptr;
+    float *post_v1[2] = {nullptr, nullptr};
+    int *post_fstart[2] = {nullptr, nullptr}, *post_len[2] = {nullptr, nullptr};
+    hipEvent_t ev_s1[2] = {nullptr, nullptr}, ev_s2[2] = {nullptr, nullptr};
+    uint64_t chain_seq = 0;
+    bool side2_pending = false;
     std::vector<void *> post_allocs;
     float *d_pwr = nullptr, *d_audio = nullptr, *d_real_prev = nullptr;
     int *d_nan = nullptr;
@@ -295,6 +304,7 @@ void resolve_pending(psdr_ctx *c) {
     hipStreamSynchronize(c->p1);
     hipStreamSynchronize(c->stream);
     hipStreamSynchronize(c->side);
+    if (c->side2) hipStreamSynchronize(c->side2);
     for (auto &p : c->pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -775,6 +785,11 @@ void free_all(psdr_ctx *c) {
         if (c->ev_p2[i]) hipEventDestroy(c->ev_p2[i]);
     }
     if (c->own_side) hipStreamDestroy(c->own_side);
+    if (c->side2) hipStreamDestroy(c->side2);
+    for (int i = 0; i < 2; i++) {
+        if (c->ev_s1[i]) hipEventDestroy(c->ev_s1[i]);
+        if (c->ev_s2[i]) hipEventDestroy(c->ev_s2[i]);
+    }
 }
 
 int build(psdr_ctx *c) {
@@ -1353,6 +1368,7 @@ static int drain(psdr_ctx *c) {
     if (c->p1 != c->stream) HIPCHK(hipStreamSynchronize(c->p1));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->side != c->stream) HIPCHK(hipStreamSynchronize(c->side));
+    if (c->side2) HIPCHK(hipStreamSynchronize(c->side2));
     return PSDR_OK;
 }
 static int check_slot(psdr_ctx *c, int id) {
@@ -1517,35 +1533,63 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
         hipLaunchKernelGGL(k_demod_ola, dim3((items + 3) / 4), dim3(256), 0, c->side, a, nact);
         HIPCHK(hipGetLastError());
     }
+    hipStream_t last_user = c->side;
     if (c->post_on && nact > 0) {
-        ProfScope ps(c, K_POST, c->side);
+        const int par = (int)(c->chain_seq & 1);
+        const bool piped = c->side != c->stream && c->side2 != nullptr;
+        hipStream_t s2 = piped ? c->side2 : c->side;
         PostArgs pa = c->post;
         pa.clients = d_clients;
         pa.nact = nact;
         pa.nframes = nframes;
-        const unsigned cb = (unsigned)((nact + 63) / 64), jb = (unsigned)((pa.h + 31) / 32);
-        const unsigned nblk = (unsigned)((pa.L - 1 + (size_t)nframes * pa.h + pa.L - 1) / pa.L);
-        const unsigned rb = (unsigned)(((size_t)nframes * pa.h + 3) / 4);
-        hipLaunchKernelGGL(k_pc_gather, dim3(cb, nframes, jb), dim3(256), 0, c->side, pa);
-        pa.ma_fused = pa.D == 32 ? 1 : 0;  // both averages in one loop (postchain.h)
-        if (pa.ma_fused) {
-            hipLaunchKernelGGL(k_pc_ma2, dim3(cb), dim3(64), 0, c->side, pa);
-        } else if ((pa.D & (pa.D - 1)) == 0) {
-            hipLaunchKernelGGL((k_pc_ma<false, true>), dim3(cb), dim3(64), 0, c->side, pa);
-            hipLaunchKernelGGL((k_pc_ma<true, true>), dim3(cb), dim3(64), 0, c->side, pa);
-        } else {
-            hipLaunchKernelGGL((k_pc_ma<false, false>), dim3(cb), dim3(64), 0, c->side, pa);
-            hipLaunchKernelGGL((k_pc_ma<true, false>), dim3(cb), dim3(64), 0, c->side, pa);
+        pa.V1 = c->post_v1[par];
+        pa.V1n = c->post_v1[par ^ 1];
+        pa.fstart = c->post_fstart[par];
+        pa.len = c->post_len[par];
+        const unsigned cb = (unsigned)((nact + 63) / 64);
+        const size_t Tb = (size_t)nframes * pa.h;  // longest possible stream of this batch
+        const unsigned nblk = (unsigned)((pa.L - 1 + Tb + pa.L - 1) / pa.L);
+        {  // ---- stage 1 on `side`
+            if (piped && c->chain_seq >= 2) HIPCHK(hipStreamWaitEvent(c->side, c->ev_s2[par], 0));  // stage 2 of batch b-2 read this set
+            ProfScope ps(c, K_POST, c->side);
+            hipLaunchKernelGGL(k_pc_index, dim3(nact), dim3(64), 0, c->side, pa);
+            hipLaunchKernelGGL(k_pc_gather, dim3(nact, nframes), dim3(256), 0, c->side, pa);
+            pa.ma_fused = pa.D == 32 ? 1 : 0;  // both averages in one loop (postchain.h)
+            if (pa.ma_fused) {
+                hipLaunchKernelGGL(k_pc_ma2, dim3(cb), dim3(64), 0, c->side, pa);
+            } else if ((pa.D & (pa.D - 1)) == 0) {
+                hipLaunchKernelGGL((k_pc_ma<false, true>), dim3(cb), dim3(64), 0, c->side, pa);
+                hipLaunchKernelGGL((k_pc_ma<true, true>), dim3(cb), dim3(64), 0, c->side, pa);
+            } else {
+                hipLaunchKernelGGL((k_pc_ma<false, false>), dim3(cb), dim3(64), 0, c->side, pa);
+                hipLaunchKernelGGL((k_pc_ma<true, false>), dim3(cb), dim3(64), 0, c->side, pa);
+            }
+            pa.hist_sel = 0;
+            hipLaunchKernelGGL(k_pc_history, dim3(nact), dim3(256), (size_t)pa.D * sizeof(float), c->side, pa);
+            HIPCHK(hipGetLastError());
         }
-        hipLaunchKernelGGL(k_pc_scan, dim3(cb, nblk, 2), dim3(64), 0, c->side, pa);
-        hipLaunchKernelGGL(k_pc_want, dim3(cb, rb), dim3(256), 0, c->side, pa);
-        hipLaunchKernelGGL(k_pc_gain, dim3(cb), dim3(64), 0, c->side, pa);
-        hipLaunchKernelGGL(k_pc_out, dim3(cb, rb), dim3(256), 0, c->side, pa);
-        hipLaunchKernelGGL(k_pc_history, dim3(cb, 2), dim3(64), 0, c->side, pa);
-        hipLaunchKernelGGL(k_pc_scatter, dim3(cb, nframes, jb), dim3(256), 0, c->side, pa);
-        HIPCHK(hipGetLastError());
+        if (piped) {
+            HIPCHK(hipEventRecord(c->ev_s1[par], c->side));
+            HIPCHK(hipStreamWaitEvent(s2, c->ev_s1[par], 0));
+        }
+        {  // ---- stage 2
+            ProfScope ps(c, K_POST, s2);
+            hipLaunchKernelGGL(k_pc_scan, dim3(nact, nblk, 2), dim3(64), (size_t)pa.L * sizeof(float), s2, pa);
+            hipLaunchKernelGGL(k_pc_want, dim3(nact, (unsigned)((Tb + 255) / 256)), dim3(256), 0, s2, pa);
+            hipLaunchKernelGGL(k_pc_gain, dim3(cb), dim3(64), 0, s2, pa);
+            hipLaunchKernelGGL(k_pc_out, dim3(nact, nframes), dim3(256), 0, s2, pa);
+            pa.hist_sel = 1;
+            hipLaunchKernelGGL(k_pc_history, dim3(nact), dim3(256), (size_t)(pa.L - 1) * sizeof(float), s2, pa);
+            HIPCHK(hipGetLastError());
+        }
+        if (piped) {
+            HIPCHK(hipEventRecord(c->ev_s2[par], s2));
+            c->side2_pending = true;
+        }
+        c->chain_seq++;
+        last_user = s2;
     }
-    HIPCHK(c->client_ring.release(ring, c->side));
+    HIPCHK(c->client_ring.release(ring, last_user));
     if (c->side != c->stream) {
         HIPCHK(hipEventRecord(c->ev_side_done, c->side));
         c->side_pending = true;
@@ -1592,16 +1636,28 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
             c->post_allocs.push_back(*ptr);
             return PSDR_OK;
         };
-        const size_t rows1 = (size_t)a.L - 1 + Tm;
+        // client-major streams (postchain.h): pitches are multiples of 4 floats, + padding for the
+        // blocked kernels' look-ahead
+        a.px = ((size_t)a.D + Tm + 64 + 3) & ~(size_t)3;
+        a.vo = (4 - ((a.L - 1) & 3)) & 3;
+        a.pv = ((size_t)a.vo + (size_t)a.L - 1 + Tm + 64 + 3) & ~(size_t)3;
         int rc = 0;
-        rc |= alloc((void **)&a.fstart, S * c->max_batch * sizeof(int));
-        rc |= alloc((void **)&a.len, S * sizeof(int));
-        rc |= alloc((void **)&a.X, ((size_t)a.D + Tm + 32) * S * sizeof(float));  // + one block of padding
-        rc |= alloc((void **)&a.M1, ((size_t)a.D + Tm + 32) * S * sizeof(float));
-        rc |= alloc((void **)&a.V1, rows1 * S * sizeof(float));
-        rc |= alloc((void **)&a.P, rows1 * S * sizeof(float));
-        rc |= alloc((void **)&a.S, rows1 * S * sizeof(float));
-        rc |= alloc((void **)&a.pcm_t, Tm * S * sizeof(int));
+        for (int i = 0; i < 2; i++) {
+            rc |= alloc((void **)&c->post_fstart[i], S * c->max_batch * sizeof(int));
+            rc |= alloc((void **)&c->post_len[i], S * sizeof(int));
+            rc |= alloc((void **)&c->post_v1[i], a.pv * S * sizeof(float));
+            if (!c->ev_s1[i]) HIPCHK(hipEventCreateWithFlags(&c->ev_s1[i], hipEventDisableTiming));
+            if (!c->ev_s2[i]) HIPCHK(hipEventCreateWithFlags(&c->ev_s2[i], hipEventDisableTiming));
+        }
+        if (!c->side2) {
+            int lo = 0, hi = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIPCHK(hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, hi));
+        }
+        rc |= alloc((void **)&a.X, a.px * S * sizeof(float));
+        rc |= alloc((void **)&a.M1, a.px * S * sizeof(float));
+        rc |= alloc((void **)&a.P, a.pv * S * sizeof(float));
+        rc |= alloc((void **)&a.S, a.pv * S * sizeof(float));
         rc |= alloc((void **)&a.pcm, S * Tm * sizeof(int32_t));
         rc |= alloc((void **)&a.dc_s1, S * sizeof(float));
         rc |= alloc((void **)&a.dc_s2, S * sizeof(float));
@@ -1938,6 +1994,7 @@ extern "C" int psdr_timer_start(psdr_ctx *c) {
 extern "C" int psdr_timer_stop_ms(psdr_ctx *c, double *ms_out) {
     if (!c || !ms_out) return fail(PSDR_ERR_INVALID, "null argument");
     if (c->side_pending && c->side != c->stream) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_side_done, 0));
+    if (c->side2_pending && c->chain_seq > 0) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_s2[(c->chain_seq - 1) & 1], 0));
     HIPCHK(hipEventRecord(c->t1, c->stream));
     HIPCHK(hipEventSynchronize(c->t1));
     float ms = 0;
