@@ -216,6 +216,27 @@ int psdr_quantized_device_ptr(psdr_ctx *ctx, int frame, const int8_t **d_q, size
 int psdr_read_spectrum(psdr_ctx *ctx, int frame, float *out_k_order);
 int psdr_read_quantized(psdr_ctx *ctx, int frame, int8_t *out);
 
+/* ---- wire formats of the reference's packets (host side) ----------------------- */
+/* The CBOR map nlohmann::json::to_cbor produces in AudioEncoder::send (src/audio.cpp:17-36):
+ * {"data": payload, "frame_num", "l", "m", "pwr", "r"} (keys in std::map order, shortest integer
+ * heads, binary32 floats when exact).  payload = the encoded audio frame (FLAC/Opus bytes: the codecs
+ * stay outside).  out must hold psdr_wire_packet_bound(bytes); *len = bytes written. */
+size_t psdr_wire_packet_bound(size_t payload_bytes);
+int psdr_wire_audio_packet(uint64_t frame_num, int l, double m, int r, double pwr, const void *payload,
+                           size_t bytes, uint8_t *out, size_t cap, size_t *len);
+/* WaterfallEncoder::set_data + the CBOR of ZstdEncoder::send (src/waterfallcompression.cpp:13-31):
+ * {"data": int8 row, "frame_num", "l", "r"}; l, r are the client's range << level (src/waterfall.cpp:47) */
+int psdr_wire_waterfall_packet(uint64_t frame_num, int l, int r, const void *payload, size_t bytes,
+                               uint8_t *out, size_t cap, size_t *len);
+/* ... and its zstd stream: one ZSTD_CStream per waterfall client, every packet flushed with
+ * ZSTD_compressStream2(..., ZSTD_e_flush) (src/waterfallcompression.cpp:32-35).  libzstd is looked up
+ * at run time; PSDR_ERR_UNSUPPORTED if the host has none. */
+typedef struct psdr_zstd psdr_zstd;
+int psdr_wire_zstd_create(psdr_zstd **out);
+void psdr_wire_zstd_destroy(psdr_zstd *zs);
+size_t psdr_wire_zstd_bound(size_t nbytes);
+int psdr_wire_zstd_flush(psdr_zstd *zs, const void *in, size_t nbytes, uint8_t *out, size_t cap, size_t *len);
+
 /* ---- instrumentation --------------------------------------------------------------- */
 /* when enabled, every kernel launch is bracketed by hipEvents on the context's stream */
 int psdr_set_profiling(psdr_ctx *ctx, int enable);

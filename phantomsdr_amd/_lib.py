@@ -46,6 +46,13 @@ SYMBOLS = [
     ("psdr_memcpy_d2h", _i, [_vp, _vp, _vp, _sz]),
     ("psdr_synchronize", _i, [_vp]),
     ("psdr_half_frame_bytes", _sz, [_vp]),
+    ("psdr_wire_packet_bound", _sz, [_sz]),
+    ("psdr_wire_audio_packet", _i, [_u64, _i, C.c_double, _i, C.c_double, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    ("psdr_wire_waterfall_packet", _i, [_u64, _i, _i, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    ("psdr_wire_zstd_create", _i, [_pp]),
+    ("psdr_wire_zstd_destroy", None, [_vp]),
+    ("psdr_wire_zstd_bound", _sz, [_sz]),
+    ("psdr_wire_zstd_flush", _i, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
     ("psdr_ring_create", _i, [_vp, _i]),
     ("psdr_ring_write_async", _i, [_vp, _u64, _vp]),
     ("psdr_ring_wait", _i, [_vp, _u64]),

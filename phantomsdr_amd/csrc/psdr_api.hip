@@ -18,6 +18,7 @@
 #include "epilogue.h"
 #include "fft_pass.h"
 #include "postchain.h"
+#include "wire.h"
 
 using namespace psdr;
 

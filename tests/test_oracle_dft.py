@@ -46,3 +46,37 @@ def test_linearity_and_parseval():
     fa, fb, fab = O.dft_c2c(a, -1), O.dft_c2c(b, -1), O.dft_c2c(a + b, -1)
     assert np.abs(fab - (fa + fb)).max() <= 1e-5 * np.abs(fab).max()
     assert abs(np.sum(np.abs(fa) ** 2) / n - np.sum(np.abs(a) ** 2)) <= 1e-5 * np.sum(np.abs(a) ** 2)
+
+
+@pytest.mark.parametrize("N,is_real", [(1 << 14, 0), (1 << 15, 1), (1 << 20, 0), (1 << 21, 1)])
+def test_builtin_transform_against_an_fftw3_api_library(N, is_real):
+    """the oracle's own forward transform against an independent production FFT reached through the
+    FFTW3 API the reference calls (src/fft_impl.cpp:89-117,145): libfftw3f if installed, else MKL's
+    wrappers.  Same window, same normalisation, same pyramid code - only the transform differs."""
+    import numpy as np
+    from oracle import oracle as O
+    rng = np.random.default_rng(N % 1000 + is_real)
+    if is_real:
+        h = (rng.standard_normal((2, N // 2)) * 1e-2).astype(np.float32)
+    else:
+        h = ((rng.standard_normal((2, N // 2)) + 1j * rng.standard_normal((2, N // 2))) * 1e-2).astype(np.complex64)
+    O.use_fft_library("")
+    f0 = O.FFT(N, is_real, 5, 0, 8)
+    f0.load(h[0], h[1])
+    f0.execute()
+    X0, q0 = f0.output().copy(), f0.quantized().copy()
+    name = O.use_fft_library()
+    try:
+        if not name:
+            pytest.skip("no library with the FFTW3 API on this host")
+        f1 = O.FFT(N, is_real, 5, 0, 8)
+        f1.load(h[0], h[1])
+        f1.execute()
+        X1, q1 = f1.output().copy(), f1.quantized().copy()
+    finally:
+        O.use_fft_library("")
+    nb = N // 2 if is_real else N
+    assert np.abs(X0[:nb] - X1[:nb]).max() <= 2e-6 * np.abs(X1[:nb]).max()
+    assert np.linalg.norm(X0[:nb] - X1[:nb]) <= 1e-6 * np.linalg.norm(X1[:nb])
+    d = np.abs(q0.astype(np.int16) - q1.astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3
