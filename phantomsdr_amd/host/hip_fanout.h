@@ -1,0 +1,137 @@
+// hip_fanout.h — Level 2 of the drop-in: the per-frame fan-out of broadcast_server on the GPU.
+//
+// The reference posts one asio task per client and frame:
+//   signal_loop()     src/websocket.cpp:156-185  -> AudioClient::send_audio      src/signal.cpp:102-298
+//   waterfall_loop()  src/websocket.cpp:207-236  -> WaterfallClient::send_waterfall src/waterfall.cpp:44-51
+// With this class the slice, the small inverse transform, the demodulation (and optionally the DC
+// blocker / AGC / int16 conversion) of ALL audio clients and the byte gather of ALL waterfall clients
+// run as a few kernel launches per frame; what stays per client on the asio pool is the hand-over to the
+// encoder and the socket, exactly the tail of send_audio (src/signal.cpp:277-296) and send_waterfall.
+// The class only forwards to the C-ABI (include/psdr.h); integration/level2.patch shows every line of
+// the server that changes.
+#ifndef PSDR_HIP_FANOUT_H
+#define PSDR_HIP_FANOUT_H
+
+#include <cstdint>
+#include <stdexcept>
+#include <vector>
+
+#include "psdr.h"
+
+class HipFanout {
+  public:
+    // the derived parameters broadcast_server computes in its constructor (src/spectrumserver.cpp:99-105,
+    // :151, :186-190) and fft_task (src/fft.cpp:33)
+    struct Params {
+        uint32_t fft_size;
+        bool is_real;
+        int downsample_levels, brightness_offset, audio_max_fft_size, audio_max_sps, skip_num, min_waterfall_fft;
+        psdr_format input_format;  // input.driver.format, src/spectrumserver.cpp:349-364
+        int max_audio_clients, max_waterfall_clients;
+        bool post_chain;           // DC blocker + AGC + int16 on the GPU too
+        int ring_halves;           // half-frames of raw samples kept in HBM (>= 3)
+    };
+    explicit HipFanout(const Params &p) : ctx{nullptr}, prm{p}, next_half{0} {
+        psdr_config cfg{};
+        cfg.struct_size = sizeof(cfg);
+        cfg.fft_size = p.fft_size;
+        cfg.is_real = p.is_real ? 1 : 0;
+        cfg.downsample_levels = p.downsample_levels;
+        cfg.brightness_offset = p.brightness_offset;
+        cfg.additional_size = p.audio_max_fft_size;
+        cfg.audio_fft_size = p.audio_max_fft_size;
+        cfg.audio_rate = p.audio_max_sps;
+        cfg.input_format = p.input_format;
+        cfg.max_batch = 1;  // a live receiver transforms every frame as it arrives
+        cfg.max_clients = p.max_audio_clients;
+        cfg.max_waterfall_clients = p.max_waterfall_clients;
+        cfg.skip_num = p.skip_num;
+        cfg.waterfall_size = p.min_waterfall_fft;
+        chk(psdr_create(&cfg, &ctx));
+        chk(psdr_ring_create(ctx, p.ring_halves));
+        if (p.post_chain) chk(psdr_set_post_chain(ctx, 1));
+    }
+    ~HipFanout() { psdr_destroy(ctx); }
+    HipFanout(const HipFanout &) = delete;
+    HipFanout &operator=(const HipFanout &) = delete;
+
+    // ---- fft_task (src/fft.cpp:47-105) -------------------------------------------------------------
+    // pinned buffer for reader->read() to fill with RAW samples (no CPU conversion: src/samplereader.cpp:29-40
+    // runs inside the first FFT pass)
+    void *alloc_half() {
+        float *p = nullptr;
+        chk(psdr_host_alloc(ctx, (psdr_half_frame_bytes(ctx) + 3) / 4, &p));
+        return p;
+    }
+    // a new half-frame has been read: its copy to HBM starts at once and overlaps the GPU work on the
+    // previous frame (the reference overlaps the read of half k+2 with the FFT of (k, k+1), src/fft.cpp:56-67)
+    void push_half(const void *raw_half) { chk(psdr_ring_write_async(ctx, next_half++, raw_half)); }
+    // the frame made of the two newest half-frames: FFT + pyramid, then every client (src/fft.cpp:61-105).
+    // frame_num is the server's counter before its increment.
+    void process_frame(uint64_t frame_num) {
+        if (next_half < 2) return;
+        const uint64_t first = next_half - 2;
+        // a frame window must not cross the ring end more than by the guard half-frame
+        chk(psdr_process_ring(ctx, first, 1));
+        chk(psdr_demod_batch(ctx, frame_num));                                         // signal_loop()
+        if (frame_num % (uint64_t)prm.skip_num == 0) chk(psdr_waterfall_batch(ctx, frame_num));  // waterfall_loop()
+    }
+
+    // ---- AudioClient (src/signal.cpp:8-97, 300-336) --------------------------------------------------
+    int add_audio_client() {
+        int id = -1;
+        chk(psdr_client_add(ctx, &id));
+        return id;
+    }
+    void remove_audio_client(int id) { psdr_client_remove(ctx, id); }
+    void set_audio_range(int id, int l, double m, int r) { chk(psdr_client_set_audio_range(ctx, id, l, m, r)); }
+    bool on_audio_window_message(int id, int l, double m, int r) {
+        return psdr_client_on_window_message(ctx, id, l, m, r) == PSDR_OK;  // false: the reference returns silently
+    }
+    void set_audio_demodulation(int id, psdr_mode mode) { chk(psdr_client_set_audio_demodulation(ctx, id, mode)); }
+    // the tail of send_audio for one client (asio pool).  Returns false when the reference would have
+    // dropped the frame (NaN guard, src/signal.cpp:266-271).  audio: audio_max_fft_size/2 floats,
+    // pcm (post_chain only): as many int32.
+    bool fetch_audio(int id, float *audio, int32_t *pcm, float *average_power) {
+        int32_t nan = 0;
+        chk(psdr_read_audio(ctx, id, 1, audio, average_power, &nan, nullptr));
+        if (nan) return false;
+        if (prm.post_chain && pcm) chk(psdr_read_pcm(ctx, id, 1, pcm, nullptr));
+        return true;
+    }
+
+    // ---- WaterfallClient (src/waterfall.cpp:6-99) -----------------------------------------------------
+    int add_waterfall_client() {
+        int id = -1;
+        chk(psdr_waterfall_add(ctx, &id));
+        return id;
+    }
+    void remove_waterfall_client(int id) { psdr_waterfall_remove(ctx, id); }
+    bool on_waterfall_window_message(int id, int l, int r, int *level, int *nl, int *nr) {
+        return psdr_waterfall_on_window_message(ctx, id, l, r, level, nl, nr) == PSDR_OK;
+    }
+    // the bytes send_waterfall hands to the encoder, with the labels (l << level, r << level) of the
+    // batch they were gathered in; empty when this frame was not a waterfall frame
+    bool fetch_waterfall(int id, std::vector<int8_t> &row, int *l_label, int *r_label) {
+        int ns = 0, lv = 0, l = 0, r = 0;
+        chk(psdr_read_waterfall(ctx, id, nullptr, 0, &ns, &lv, &l, &r));
+        if (ns == 0) return false;
+        row.resize((size_t)ns * (size_t)(r - l));
+        chk(psdr_read_waterfall(ctx, id, row.data(), row.size(), &ns, &lv, &l, &r));
+        *l_label = l << lv;
+        *r_label = r << lv;
+        return true;
+    }
+    psdr_ctx *context() { return ctx; }
+    bool post_chain() const { return prm.post_chain; }
+
+  private:
+    psdr_ctx *ctx;
+    Params prm;
+    uint64_t next_half;
+    static void chk(int rc) {
+        if (rc != PSDR_OK) throw std::runtime_error(psdr_last_error());
+    }
+};
+
+#endif

@@ -188,3 +188,45 @@ def test_cpp_adapter_compiles_against_the_reference_header():
                            "-I" + d, "-I/root/reference/src", "-I/opt/rocm/include",
                            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "phantomsdr_amd", "host"),
                            os.path.join(d, "tu.cpp")])
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/src/fft.h"), reason="reference tree absent")
+def test_integration_patches_apply_to_the_reference_tree():
+    """integration/level1.patch and level2.patch (the f1 artefact: every edited line of src/fft.h,
+    src/spectrumserver.cpp, meson.build, src/fft.cpp, src/websocket.cpp, src/signal.*, src/waterfall.*) apply
+    cleanly, one after the other, to a pristine copy of the reference files, add lines only, and are what
+    tools/make_integration_patches.py generates from the tree."""
+    import shutil
+    import subprocess
+    import tempfile
+    d = tempfile.mkdtemp()
+    shutil.copytree("/root/reference/src", os.path.join(d, "src"))
+    shutil.copy("/root/reference/meson.build", d)
+    for name in ("level1.patch", "level2.patch"):
+        txt = open(os.path.join(ROOT, "integration", name)).read()
+        assert not [ln for ln in txt.splitlines() if ln.startswith("-") and not ln.startswith("---")], "additive only"
+        subprocess.check_call(["patch", "-p1", "-s", "-i", os.path.join(ROOT, "integration", name)], cwd=d)
+    patched = open(os.path.join(d, "src", "spectrumserver.cpp")).read()
+    assert "std::make_unique<hipFFT>" in patched and "std::make_unique<HipFanout>" in patched
+    assert "GPU_hipFFT" in open(os.path.join(d, "src", "fft.h")).read()
+    assert "fft_task_hip();" in open(os.path.join(d, "src", "fft.cpp")).read()
+    assert os.path.exists(os.path.join(d, "meson_options.txt"))
+    # the patched src/fft.h still compiles with the adapter on top of it (same compile check as above)
+    with open(os.path.join(d, "fftw3.h"), "w") as f:
+        f.write("#include <hipfft/hipfftw.h>\n")
+    with open(os.path.join(d, "tu.cpp"), "w") as f:
+        f.write('#include "hip_fft.h"\n#include "hip_fanout.h"\nfft_accelerator a = GPU_hipFFT;\n')
+    subprocess.check_call(["g++", "-std=c++20", "-fsyntax-only", "-Wall", "-Werror", "-Wno-unknown-pragmas", "-I" + d,
+                           "-I" + os.path.join(d, "src"), "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "phantomsdr_amd", "host"), os.path.join(d, "tu.cpp")])
+
+
+def test_level2_host_class_compiles_standalone():
+    """phantomsdr_amd/host/hip_fanout.h needs nothing but include/psdr.h"""
+    import subprocess
+    import tempfile
+    d = tempfile.mkdtemp()
+    with open(os.path.join(d, "tu.cpp"), "w") as f:
+        f.write('#include "hip_fanout.h"\nint use(HipFanout &f) { return f.add_audio_client(); }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "phantomsdr_amd", "host"), os.path.join(d, "tu.cpp")])
