@@ -358,8 +358,9 @@ __device__ __forceinline__ constexpr float image_scale() {
 // PAIR: real input feeding the fused pass 2 (k_fft_pass2_real).  The packed N/2-point transform Z is
 // untangled into the real signal's spectrum from the pairs (Z[k], conj Z[M-k]); bin k = c1 + M1*c2
 // pairs with row M1-c1, column M2-1-c2.  Two changes make that pairing thread-local in pass 2:
-//   * rows are stored interleaved, row c1 < M1/2 at slot 2*c1, its mirror M1-c1 at slot 2*c1+1
-//     (row M1/2 at slot 1, beside row 0): a pass-2 couple is a (row, mirror row) pair;
+//   * rows are regrouped: pass-2 tile g holds rows 8g..8g+7 (slots 0..7) and their mirrors M1-8g-p
+//     (slots 8+p; row M1/2 at slot 8 of tile 0, beside row 0): a pass-2 couple is a (row, mirror row)
+//     pair, and eight consecutive rows stay 1 KiB contiguous for pass 1's stores;
 //   * mirror rows (c1 > M1/2) are stored as conj(Y[c1][n2]) * W_M2^{n2}: the plain forward row
 //     transform of that sequence is G[c2] = conj(Z[c1][M2-1-c2]), exactly the partner of the
 //     couple's other half at the same output index c2.
@@ -458,9 +459,13 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
         const unsigned slot = xcd_slot(s, total);
         const unsigned f = slot / a.tiles_per_frame;
         const unsigned tl = slot - f * a.tiles_per_frame;
-        const int T2 = 1 << a.l2t2;
-        // this tile's block (plain) / its chunk of pass-2 tile 0 (PAIR)
-        cf *Yb = a.Y + (size_t)f * a.yframe + (PAIR ? (size_t)tl * (T2 * T) : (size_t)tl * a.yblk);
+        // this tile's block (plain) / its chunk of pass-2 tile 0 (PAIR: pass-2 tiles have 16 rows)
+        cf *Yb = a.Y + (size_t)f * a.yframe + (PAIR ? (size_t)tl * (16 * T) : (size_t)tl * a.yblk);
+        // PAIR: where the lane's part of a row index puts it (see the store below)
+        cf *Ylo = Yb + (size_t)(i0_ >> 3) * a.ytile + (i0_ & 7) * T + 2 * p_;
+        cf *Yhi = Yb - (size_t)((i0_ + 7) >> 3) * a.ytile + (8 + ((-i0_) & 7)) * T + 2 * p_;
+        (void)Ylo;
+        (void)Yhi;
         const bool more = snext < total;
         if (more) point_at(snext);
         // the index after `snext`: drawn one tile ago, published now, read after the barrier
@@ -561,11 +566,8 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
             },
             [&](int b, int sidx, int k1, c2 x) {
                 cf wA, wB, yA, yB;
-                int c1 = a.rot ? ((k1 - 1) & (L - 1)) : k1;
-                if constexpr (PAIR) c1 = k1 < L / 2 ? 2 * k1 : ((2 * (L - k1) + 1) & (L - 1));
-#ifdef PSDR_ABL_P1SLOT
-                c1 = k1;
-#endif
+                const int c1 = a.rot ? ((k1 - 1) & (L - 1)) : k1;
+                (void)c1;
                 if (sidx == 0) {
                     wA = b == 0 ? w00A : tbA[b];
                     wB = b == 0 ? w00B : tbB[b];
@@ -582,7 +584,20 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
                         yB = natural ? yB : mB;
                     }
                 }
-                cf *dst = PAIR ? Yb + (size_t)(c1 >> a.l2t2) * a.ytile + (c1 & (T2 - 1)) * T + 2 * p : Yb + (size_t)c1 * T + 2 * p;
+                cf *dst;
+                if constexpr (PAIR) {
+                    // row k1 < L/2 is row k1 & 7 of pass-2 tile k1 >> 3, its mirror L-k1 row 8 + (k1 & 7) of the
+                    // same tile.  k1 = i0 + (a multiple of L/16 known at compile time): the lane part lives
+                    // in Ylo / Yhi, the rest is a compile-time multiple of the (uniform) tile stride
+                    if (sidx < RL / 2) {
+                        dst = Ylo + (size_t)((b * L16 + sidx * PL) >> 3) * a.ytile;
+                    } else {
+                        dst = Yhi + (size_t)((L - sidx * PL - b * L16) >> 3) * a.ytile;
+                        if (sidx == RL / 2 && b == 0) dst = i0 == 0 ? Yb + 8 * T + 2 * p : dst;  // row L/2: beside row 0
+                    }
+                } else {
+                    dst = Yb + (size_t)c1 * T + 2 * p;
+                }
                 *reinterpret_cast<float4 *>(dst) = make_float4(yA.x, yA.y, yB.x, yB.y);
             },
             // ---- trickle the rest of the next tile's loads through the stages
@@ -1007,9 +1022,9 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             const int w = ((2 * i * NT) & (chunk - 1)) + ((2 * tidx) & (chunk - 1));
             const int rr = w >> log2TW, cc = w & (TW - 1);
             const int n2 = (((2 * i * NT) >> lc) + ((2 * tidx) >> lc)) * TW + cc;  // even
-            const int slot0 = lds_slot<H, true>(n2, rr >> 1);
-            tile_cf[2 * slot0 + (rr & 1)] = make_float2(r[i].x, r[i].y);
-            tile_cf[2 * (slot0 + H) + (rr & 1)] = make_float2(r[i].z, r[i].w);
+            const int slot0 = lds_slot<H, true>(n2, rr & 7);  // couple p = (row p, row 8 + p of the tile)
+            tile_cf[2 * slot0 + (rr >> 3)] = make_float2(r[i].x, r[i].y);
+            tile_cf[2 * (slot0 + H) + (rr >> 3)] = make_float2(r[i].z, r[i].w);
         }
         PSDR_SCHED_FENCE();
         if (more) static_for<0, EARLY>(issue);

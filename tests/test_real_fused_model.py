@@ -2,7 +2,7 @@
 the index algebra the kernel relies on, restated in numpy at small sizes and checked against
 numpy.fft.rfft.  This is host-side logic (no GPU): it pins
 
-  * the row pairing of pass 1's PAIR mode: row c1 at slot 2*c1, mirror row M1-c1 at slot 2*c1+1 stored
+  * the row pairing of pass 1's PAIR mode: pass-2 tile g = rows 8g..8g+7 + their mirrors M1-8g-p stored
     as conj(Y)*W_M2^{n2}, row M1/2 beside row 0;
   * the thread-local untangle X[k] = (a+b)/2 + W_N^k(-i)(a-b)/2, X[M-k] = conj((a+b)/2 - ...), with
     a = Z[k], b = conj(Z[M-k]) = the mirror row's plain forward transform at the same output index;
@@ -48,11 +48,12 @@ def pass1_pair(z, M1, M2):
     cW = np.exp(-2j * np.pi * n2 / M2)
     for c1 in range(M1):
         if c1 < M1 // 2:
-            slots[2 * c1] = Y[c1]
+            slots[16 * (c1 // 8) + c1 % 8] = Y[c1]
         elif c1 == M1 // 2:
-            slots[1] = Y[c1]                     # natural form, beside row 0
+            slots[8] = Y[c1]                     # natural form, beside row 0 (couple 0 of tile 0)
         else:
-            slots[2 * (M1 - c1) + 1] = np.conj(Y[c1]) * cW
+            m = M1 - c1
+            slots[16 * (m // 8) + 8 + m % 8] = np.conj(Y[c1]) * cW
     return slots
 
 
@@ -79,8 +80,8 @@ def fused_pass2(slots, M1, M2, seg_len):
             high = np.zeros((M2, 8))
             carry_w = np.zeros(M2)
             for p in range(8):
-                a = np.fft.fft(slots[16 * g + 2 * p])
-                b = np.fft.fft(slots[16 * g + 2 * p + 1])
+                a = np.fft.fft(slots[16 * g + p])
+                b = np.fft.fft(slots[16 * g + 8 + p])
                 c1 = 8 * g + p
                 if g == 0 and p == 0:
                     # row 0 <-> itself at column (M2-c2) % M2; row M1/2 <-> itself at column M2-1-c2
