@@ -575,6 +575,7 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
                     cmul_pair(wA, tbA[b], tsA[sidx], wB, tbB[b], tsB[sidx]);
                 }
                 cmul_pair(yA, x.a, wA, yB, x.b, wB);
+#ifndef PSDR_ABL_P1NOMIR
                 if constexpr (PAIR) {
                     if (sidx >= RL / 2) {  // k1 >= L/2 (compile time): mirror form, except row L/2 itself
                         cf mA, mB;
@@ -584,8 +585,13 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
                         yB = natural ? yB : mB;
                     }
                 }
+#endif
                 cf *dst;
+#ifdef PSDR_ABL_P1LINEAR
+                if constexpr (false) {
+#else
                 if constexpr (PAIR) {
+#endif
                     // row k1 < L/2 is row k1 & 7 of pass-2 tile k1 >> 3, its mirror L-k1 row 8 + (k1 & 7) of the
                     // same tile.  k1 = i0 + (a multiple of L/16 known at compile time): the lane part lives
                     // in Ylo / Yhi, the rest is a compile-time multiple of the (uniform) tile stride
