@@ -412,13 +412,23 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
         return res
 
     main_mode = args.shard
-    results = {main_mode: measure(main_mode, args.steps, args.warmup)}
-    for m in ("clients", "raw", "time"):
-        if m not in results:
+    results = {}
+    for m in (main_mode,) + tuple(x for x in ("clients", "raw", "time") if x != main_mode):
+        try:
+            results[m] = measure(m, args.steps if m == main_mode else min(args.steps, 30),
+                                 args.warmup if m == main_mode else min(args.warmup, 5))
+        except Exception as e:  # a mode that fails must not take the line with it
+            results[m] = {"error": repr(e)}
             try:
-                results[m] = measure(m, min(args.steps, 30), min(args.warmup, 5))
-            except Exception as e:
-                results[m] = {"error": repr(e)}
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+    if "value" not in results[main_mode]:  # report the first sharding that ran, and say so
+        ok = [m for m in results if "value" in results[m]]
+        if not ok:
+            raise SystemExit("every sharding failed: " + json.dumps(results))
+        results["_requested"] = {"shard": main_mode, "error": results[main_mode]["error"]}
+        main_mode = ok[0]
     if rank == 0:
         r = results[main_mode]
         out = {
@@ -430,8 +440,9 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
             "config": {k: r[k] for k in ("workload", "frames_per_step", "fft_size", "audio_clients", "waterfall_clients",
                                          "parallelism", "realtime_factor")},
             "roofline": r["roofline"], "path": r["path"], "xgmi": r["xgmi"],
+            "shard": main_mode,
             "sharding": {m: {k: v for k, v in results[m].items() if k in ("value", "ms_per_step", "steps", "audio_clients",
-                                                                           "parallelism", "xgmi", "error", "workload")}
+                                                                           "parallelism", "xgmi", "error", "workload", "shard")}
                          for m in results},
             "cpu_baseline": None,
         }

@@ -575,7 +575,6 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
                     cmul_pair(wA, tbA[b], tsA[sidx], wB, tbB[b], tsB[sidx]);
                 }
                 cmul_pair(yA, x.a, wA, yB, x.b, wB);
-#ifndef PSDR_ABL_P1NOMIR
                 if constexpr (PAIR) {
                     if (sidx >= RL / 2) {  // k1 >= L/2 (compile time): mirror form, except row L/2 itself
                         cf mA, mB;
@@ -585,13 +584,8 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
                         yB = natural ? yB : mB;
                     }
                 }
-#endif
                 cf *dst;
-#ifdef PSDR_ABL_P1LINEAR
-                if constexpr (false) {
-#else
                 if constexpr (PAIR) {
-#endif
                     // row k1 < L/2 is row k1 & 7 of pass-2 tile k1 >> 3, its mirror L-k1 row 8 + (k1 & 7) of the
                     // same tile.  k1 = i0 + (a multiple of L/16 known at compile time): the lane part lives
                     // in Ylo / Yhi, the rest is a compile-time multiple of the (uniform) tile stride
@@ -1067,10 +1061,8 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             const cf w0p = (p & 1) ? make_float2(-w0.x, -w0.y) : w0;  // (w0 carries the lane's sigma)
             untangle_pair(x.a, x.b, cmul(w0p, w32(t)), hscale, xk, xm);
             const int cm = L - 1 - c2i;
-#ifndef PSDR_ABL_NOX
             Xt[16 * c2i + p] = xk;
             Xt[16 * c2i + 15 - p] = xm;  // mirror row M1-p: element 7-p of the mirror octet
-#endif
             Pst[c2i * 16 + p] = bin_power(xk);
             Pst[cm * 16 + 15 - p] = bin_power(xm);  // (p >= 1 here: element 8-p at [7+8-p])
         };
@@ -1095,7 +1087,6 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         };
         auto emit_two = [&](int tA, int tB, cf mineB, cf sendB) {
             const cf recvA = make_float2(swap1(sendA.x), swap1(sendA.y)), recvB = make_float2(swap1(sendB.x), swap1(sendB.y));
-#ifndef PSDR_ABL_NOX
             // scalar base + 32-bit lane offset: the store's own address mode, no vector address math
             typedef __attribute__((address_space(1))) char gchar;
             typedef float gf4 __attribute__((ext_vector_type(4)));
@@ -1103,16 +1094,11 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             asm volatile("" : "+s"(bA), "+s"(bB));
             *(__attribute__((address_space(1))) gf4 *)(bA + gofs) = gf4{mineA.x, mineA.y, recvA.x, recvA.y};
             *(__attribute__((address_space(1))) gf4 *)(bB + gofs) = gf4{mineB.x, mineB.y, recvB.x, recvB.y};
-#endif
             *reinterpret_cast<float2 *>(Pstb + lbase + tA * lstride) = make_float2(bin_power(mineA), bin_power(recvA));
             *reinterpret_cast<float2 *>(Pstb + lbase + tB * lstride) = make_float2(bin_power(mineB), bin_power(recvB));
         };
         int tA = 0;
-#ifdef PSDR_ABL_NOG0
-        if (true) {
-#else
         if (g != 0) {
-#endif
             run_last_stage<L>(Wl, i0, u, [&](int b, int sidx, int c2i, c2 x) {
                 const cf sm = cadd(x.a, x.b), d = csub(x.a, x.b);
                 const cf wo = cmul(cmul(w0, w32(b + NBL * sidx)), make_float2(d.y, -d.x));  // sigma * W_N^k * (-i)(a-b)
@@ -1166,9 +1152,6 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             float *Pf = a.Pscr + (size_t)f * a.p_stride;
             float *seamP = a.seamP + ((size_t)f * S + si) * L * 8;
             constexpr int NG = 2 * L / NT;  // octets per thread: chunk q = 2*c2 + side
-#ifdef PSDR_ABL_NOREC
-            if (tidx >= 0) goto skip_rec;
-#endif
 #pragma unroll
             for (int k = 0; k < NG; k++) {
                 const int q = k * NT + tidx;
@@ -1194,9 +1177,6 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                 }
                 PSDR_SCHED_FENCE();
             }
-#ifdef PSDR_ABL_NOREC
-        skip_rec:;
-#endif
         }
         __syncthreads();  // the tile is free again
         if (seg_last) {
