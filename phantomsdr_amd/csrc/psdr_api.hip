@@ -135,7 +135,8 @@ struct psdr_ctx {
     bool real_fused = false;
     SpecLayout lay{};                // device layout of the spectrum (natural unless real_fused)
     int seg_len_env = 0;             // PSDR_SEG_LEN (tuning): tiles per chain segment
-    float *d_seamP = nullptr, *d_seamC = nullptr;
+    float *d_seamP = nullptr, *d_seamC = nullptr;  // of the current result set
+    float *seam_pool[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     size_t seam_cap = 0;             // segments the seam buffers hold
     int size_log2 = 0;
     int levels = 0;
@@ -496,6 +497,8 @@ void select_set(psdr_ctx *c, int set) {
     c->d_qt = c->qt_pool[set];
     c->d_pscr[0] = c->pscr_pool[set][0];
     c->d_pscr[1] = c->pscr_pool[set][1];
+    c->d_seamP = c->seam_pool[set][0];
+    c->d_seamC = c->seam_pool[set][1];
 }
 
 int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipEvent_t ev_raw_consumed = nullptr) {
@@ -574,6 +577,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     if (c->set_pending[c->cur_set] && c->side != c->stream)
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_set_done[c->cur_set], 0));
     auto run_pass2 = [&](bool fused) -> int { return launch_pass2(c, c->M2, c->T2, fused, a2, a2.total_slots); };
+    int seam_S = 0, seam_SL = 0;  // fused real path: the seam kernel runs with the consumers
     if (!c->is_real) {
         a2.X = c->d_spec;
         a2.spec_stride = c->spec_stride;
@@ -595,20 +599,8 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
         a2.total_slots = S * (unsigned)nframes;
         rc = c->M1 == 1024 ? launch_pass2_real_t<16>(c, a2) : launch_pass2_real_t<8>(c, a2);
         if (rc) return rc;
-        SeamArgs sa{};
-        sa.seamP = c->d_seamP;
-        sa.seamC = c->d_seamC;
-        sa.S = (int)S;
-        sa.SL = a2.seg_len;
-        sa.L = c->M2;
-        sa.size_log2 = c->size_log2;
-        sa.Qt = c->d_qt;
-        sa.qt_stride = c->qt_stride;
-        sa.Pscr = c->d_pscr[0];
-        sa.p_stride = c->p_stride;
-        ProfScope ps(c, K_SEAM);
-        hipLaunchKernelGGL(k_real_seam, dim3(S, nframes), dim3(256), 0, c->stream, sa);
-        HIPCHK(hipGetLastError());
+        seam_S = (int)S;
+        seam_SL = a2.seg_len;
     } else {
         a2.X = c->d_Z;
         a2.spec_stride = c->M;
@@ -642,6 +634,22 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     if (c->side != c->stream) {
         HIPCHK(hipEventRecord(c->ev_fft_done, c->stream));
         HIPCHK(hipStreamWaitEvent(c->side, c->ev_fft_done, 0));
+    }
+    if (seam_S) {  // fused real input: the mirror octets of every chain segment's first tile (epilogue.h)
+        SeamArgs sa{};
+        sa.seamP = c->d_seamP;
+        sa.seamC = c->d_seamC;
+        sa.S = seam_S;
+        sa.SL = seam_SL;
+        sa.L = c->M2;
+        sa.size_log2 = c->size_log2;
+        sa.Qt = c->d_qt;
+        sa.qt_stride = c->qt_stride;
+        sa.Pscr = c->d_pscr[0];
+        sa.p_stride = c->p_stride;
+        ProfScope ps(c, K_SEAM, c->side);
+        hipLaunchKernelGGL(k_real_seam, dim3(seam_S, nframes), dim3(256), 0, c->side, sa);
+        HIPCHK(hipGetLastError());
     }
     // remaining pyramid levels from the partial level in scratch
     int lvl = c->LT;
@@ -734,8 +742,10 @@ void free_all(psdr_ctx *c) {
     for (auto e : c->ring.ev_read)
         if (e) hipEventDestroy(e);
     if (c->ring.copy) hipStreamDestroy(c->ring.copy);
-    F(c->d_seamP);
-    F(c->d_seamC);
+    for (int st = 0; st < 2; st++) {
+        F(c->seam_pool[st][0]);
+        F(c->seam_pool[st][1]);
+    }
     F(c->d_tickets[0]);
     F(c->d_tickets[1]);
     F(c->y_pool[0]);
@@ -886,8 +896,10 @@ int build(psdr_ctx *c) {
         for (int nf = 1; nf <= c->max_batch; nf++)
             cap = std::max(cap, (size_t)nf * (size_t)((c->M1 / 16) / real_seg_len(c, nf)));
         c->seam_cap = cap;
-        HIPCHK(hipMalloc((void **)&c->d_seamP, cap * (size_t)c->M2 * 8 * sizeof(float)));
-        HIPCHK(hipMalloc((void **)&c->d_seamC, cap * (size_t)c->M2 * sizeof(float)));
+        for (int st = 0; st < 2; st++) {  // part of the double-buffered result sets: k_real_seam is a consumer
+            HIPCHK(hipMalloc((void **)&c->seam_pool[st][0], cap * (size_t)c->M2 * 8 * sizeof(float)));
+            HIPCHK(hipMalloc((void **)&c->seam_pool[st][1], cap * (size_t)c->M2 * sizeof(float)));
+        }
     }
     for (int s = 0; s < 2; s++) {
         HIPCHK(hipMalloc((void **)&c->spec_pool[s], F * c->spec_stride * sizeof(cf)));
