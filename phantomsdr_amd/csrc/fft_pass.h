@@ -308,7 +308,9 @@ struct Pass1Args {
     int rot;      // IQ: produce client order
     size_t yblk;    // !PAIR: elements of one pass-1 tile's block (M1 * T)
     int l2t2;       // PAIR: log2 of the rows per pass-2 tile
-    size_t ytile;   // PAIR: elements of one pass-2 tile's block (M2 * rows per tile)
+    size_t ytile;   // PAIR: elements between the chunks this pass-1 tile contributes to consecutive pass-2 tiles
+                    //       (tile-major: M2 * 16, the pass-2 tile's block; blocked: 16 * T, inside its own block)
+    size_t ytl;     // PAIR: elements between the first chunks of consecutive pass-1 tiles (tile-major: 16 * T; blocked: M1 * T)
     size_t yframe;  // elements between frames of Y
     unsigned tiles_per_frame;
     unsigned total_slots;
@@ -460,7 +462,7 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
         const unsigned f = slot / a.tiles_per_frame;
         const unsigned tl = slot - f * a.tiles_per_frame;
         // this tile's block (plain) / its chunk of pass-2 tile 0 (PAIR: pass-2 tiles have 16 rows)
-        cf *Yb = a.Y + (size_t)f * a.yframe + (PAIR ? (size_t)tl * (16 * T) : (size_t)tl * a.yblk);
+        cf *Yb = a.Y + (size_t)f * a.yframe + (PAIR ? (size_t)tl * a.ytl : (size_t)tl * a.yblk);
         // PAIR: where the lane's part of a row index puts it (see the store below)
         cf *Ylo = Yb + (size_t)(i0_ >> 3) * a.ytile + (i0_ & 7) * T + 2 * p_;
         cf *Yhi = Yb - (size_t)((i0_ + 7) >> 3) * a.ytile + (8 + ((-i0_) & 7)) * T + 2 * p_;
@@ -635,6 +637,8 @@ struct Pass2Args {
     int TW;       // pass-1 tile width (columns per block of Y)
     int log2TW;
     size_t yblk, ytile, yframe;  // pass-1 block (k_fft_pass2) / pass-2 tile block (k_fft_pass2_real) / frame strides, elements
+    size_t yjs;                  // k_fft_pass2_real: elements between the chunks of consecutive pass-1 tiles
+                                 // (tile-major: the chunk itself, 16 * TW: one linear block; blocked: M1 * TW)
     // fused IQ epilogue
     float inv_n;
     int size_log2;
@@ -942,7 +946,10 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
     const int SL = a.seg_len;
     const unsigned S = a.tiles_per_frame / (unsigned)SL;  // segments per frame
     float4 r[NLD];
-    const float4 *nxt = nullptr;
+    const cf *nxt = nullptr;
+    // element idx of the tile = (pass-1 tile j, row rr, column cc), idx = j*chunk + rr*TW + cc: chunk j of
+    // pass-2 tile g starts at g*ytile + j*yjs (tile-major Y: yjs = chunk, the tile is one linear block)
+    const unsigned lane_off = (unsigned)((size_t)((2 * tid) >> lc) * a.yjs + ((2 * tid) & (chunk - 1)));
     // tile j of segment sg: frame sg / S, g = (sg % S + 1) * SL - 1 - j (S, SL powers of two; the
     // segment index is wave-uniform: keep the tile's coordinates and addresses in scalar registers)
     const int l2S = 31 - __builtin_clz(S);
@@ -955,11 +962,12 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         unsigned f;
         int g;
         tile_of(sg, j, f, g);
-        nxt = reinterpret_cast<const float4 *>(a.Y + (size_t)f * a.yframe + (size_t)g * a.ytile) + tid;  // one linear block
+        nxt = a.Y + (size_t)f * a.yframe + (size_t)g * a.ytile + lane_off;
     };
     auto issue = [&](auto qc) {
         constexpr int i = decltype(qc)::value;
-        r[i] = nxt[i * NT];
+        const cf *q = nxt + (size_t)((2 * i * NT) >> lc) * a.yjs + ((2 * i * NT) & (chunk - 1));
+        r[i] = *reinterpret_cast<const float4 *>(q);
     };
     __shared__ unsigned s_next[2];
     TileQueue tq;

@@ -134,6 +134,7 @@ struct psdr_ctx {
     // three-pass form (pass 1, pass 2, k_untangle_real)
     bool real_fused = false;
     SpecLayout lay{};                // device layout of the spectrum (natural unless real_fused)
+    bool y_blocked = false;          // PSDR_REAL_YBLOCKED (tuning)
     int seg_len_env = 0;             // PSDR_SEG_LEN (tuning): tiles per chain segment
     float *d_seamP = nullptr, *d_seamC = nullptr;  // of the current result set
     float *seam_pool[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
@@ -526,7 +527,10 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     a1.TB = c->d_TB;
     a1.yblk = (size_t)c->M1 * (c->T1 * cols);  // plain: one linear block per pass-1 tile
     a1.l2t2 = ilog2((size_t)c->T2);
-    a1.ytile = (size_t)c->M2 * c->T2;  // fused real: pass-2-tile-major (fft_pass.h, "Y layout")
+    // fused real: pass-2-tile-major by default (fft_pass.h, "Y layout"); PSDR_REAL_YBLOCKED=1: rows regrouped
+    // inside the pass-1 tile's own linear block
+    a1.ytile = c->y_blocked ? (size_t)16 * (c->T1 * cols) : (size_t)c->M2 * c->T2;
+    a1.ytl = c->y_blocked ? a1.yblk : (size_t)16 * (c->T1 * cols);
     a1.yframe = c->M;
     a1.wdelta = c->wdelta;
     a1.M2 = c->M2;
@@ -556,7 +560,8 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     a2.log2M1 = c->log2M1;
     a2.TW = c->T1 * cols;
     a2.yblk = a1.yblk;
-    a2.ytile = a1.ytile;
+    a2.ytile = c->y_blocked ? (size_t)16 * (c->T1 * cols) : a1.ytile;
+    a2.yjs = c->y_blocked ? a1.yblk : (size_t)16 * (c->T1 * cols);
     a2.yframe = a1.yframe;
     a2.log2TW = ilog2((size_t)(c->T1 * cols));
     a2.inv_n = 1.0f / (float)c->N;
@@ -892,6 +897,7 @@ int build(psdr_ctx *c) {
         // one frame of k-order staging for psdr_read_spectrum / psdr_get_output_buffer
         HIPCHK(hipMalloc((void **)&c->d_Z, (c->M + 2) * sizeof(cf)));
         if (const char *e = getenv("PSDR_SEG_LEN")) c->seg_len_env = atoi(e);
+        c->y_blocked = getenv("PSDR_REAL_YBLOCKED") != nullptr;
         size_t cap = 0;
         for (int nf = 1; nf <= c->max_batch; nf++)
             cap = std::max(cap, (size_t)nf * (size_t)((c->M1 / 16) / real_seg_len(c, nf)));
