@@ -270,7 +270,28 @@ struct TileQueue {
     }
     // thread 0: start drawing (no wait)
     __device__ __forceinline__ void draw_begin() {
-        if (threadIdx.x == 0 && dynamic) pending = atomicAdd(tickets + (global ? 0u : (blockIdx.x & 7u)), 1u);
+        if (threadIdx.x == 0 && dynamic) {
+            // The address goes through a vector register the compiler cannot see through: with a
+            // uniform address the atomic optimiser rewrites this into "one lane adds, v_readfirstlane
+            // broadcasts", and the broadcast needs the result AT ONCE - an s_waitcnt vmcnt(0) at the top of
+            // every tile, which (vmcnt counts stores too, in order) also waits for the acknowledgement of
+            // every store of the previous tile.  Written this way the result is first touched one tile
+            // later, behind a counted wait (vmcnt(22) in the IQ pass 2).  Measured: nothing for the IQ
+            // passes (pass 2 moves 4.9 GB per 256 frames at 5.6 TB/s - it waits for memory either way),
+            // -3 % on the fused real-input pass 2 together with the scalar twiddle load there.
+            typedef __attribute__((address_space(1))) unsigned gu32;  // global, not flat: flat returns out of order
+            gu32 *p = (gu32 *)(tickets + (global ? 0u : (blockIdx.x & 7u)));
+            asm volatile("" : "+v"(p));
+            pending = __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // the first draw, before the tile loop: waits for it (and the first tile's loads, needed at once
+    // anyway), so that the loop is entered with nothing pending and the wait the compiler places in
+    // draw_end() counts only what one iteration issues after the atomic (loads of the next tile, stores
+    // of this one) instead of falling back to vmcnt(0)
+    __device__ __forceinline__ void draw_first() {
+        draw_begin();
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
     }
     // thread 0, synchronous (phase start, all_dynamic + global only): one index
     __device__ __forceinline__ unsigned draw_now() {
@@ -448,10 +469,10 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
         point_at(s);
         static_for<0, NCHK>(issue);
     }
-    tq.draw_begin();
     // table staging after the first tile's loads are in flight (one latency, not two)
     for (int i = tid; i < L; i += NT) Wl[i] = a.Wl[i];
     for (int i = tid; i < M2; i += NT) ldsTB[i] = a.TB[i];
+    tq.draw_first();
     __syncthreads();  // Wl and the twiddle table are visible
     PSDR_WGTRACE(a.trace, 1);
 
@@ -717,7 +738,7 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
         static_for<0, NLD>(issue);
     }
     for (int i = tid; i < L; i += NT) Wl[i] = a.Wl[i];  // visible after the loop's first barrier
-    tq.draw_begin();
+    tq.draw_first();
     PSDR_WGTRACE(a.trace, 1);
 
     int it = 0;
@@ -978,7 +999,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         static_for<0, NLD>(issue);
     }
     for (int i = tid; i < L; i += NT) Wl[i] = a.Wl[i];  // visible after the loop's first barrier
-    tq.draw_begin();
+    tq.draw_first();
 
     const float hscale = 0.5f * a.inv_n;
     const unsigned ubm = (1u << a.log2UB) - 1u;
@@ -1023,7 +1044,12 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         }
         int i0 = i0_, p = p_, tidx = tid;  // opaque copies (see pass 1)
         asm volatile("" : "+v"(i0), "+v"(p), "+v"(tidx));
-        const cf wg = a.UG[__builtin_amdgcn_readfirstlane(g)];
+        // (constant address space: the only way to get s_load here - as a plain global pointer the
+        // compiler picks a vector load, and since nothing is issued behind it when there is no next
+        // tile to prefetch, its wait degenerates to vmcnt(0) = "all of the next tile's loads are in")
+        typedef const __attribute__((address_space(4))) v2f ccf;
+        const v2f wgv = ((ccf *)a.UG)[__builtin_amdgcn_readfirstlane(g)];
+        const cf wg = make_float2(wgv.x, wgv.y);
         // transposing fill (as pass2_body)
 #pragma unroll
         for (int i = 0; i < NLD; i++) {
