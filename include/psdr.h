@@ -237,6 +237,38 @@ void psdr_wire_zstd_destroy(psdr_zstd *zs);
 size_t psdr_wire_zstd_bound(size_t nbytes);
 int psdr_wire_zstd_flush(psdr_zstd *zs, const void *in, size_t nbytes, uint8_t *out, size_t cap, size_t *len);
 
+/* The text frame a client receives first (broadcast_server::send_basic_info, src/websocket.cpp:42-66):
+ * a glaze (v2.4.4, subprojects/glaze.wrap) json_t object, i.e. a std::map - keys in lexicographic
+ * order at both levels - whose numbers are all doubles, written in their shortest round-trip form
+ * (integers without a fraction).  Strings are written as they are (the reference's are plain ASCII
+ * mode and codec names; '"' and '\\' are escaped).  *len excludes the terminating NUL that is also
+ * written. */
+typedef struct psdr_hello {
+    double sps, audio_max_sps, audio_max_fft, fft_size, fft_result_size, waterfall_size, basefreq;
+    double total_bandwidth;           /* is_real ? sps / 2 : sps */
+    double default_frequency, default_l, default_m, default_r;
+    const char *default_modulation;   /* "USB" | "LSB" | "AM" | "FM" */
+    const char *waterfall_compression, *audio_compression;
+} psdr_hello;
+int psdr_wire_hello_json(const psdr_hello *h, char *out, size_t cap, size_t *len);
+/* A client's command frame (Client::on_message, src/client.cpp:19-117): a JSON object tagged by
+ * "cmd" = "window" {l, r, m?, level?} | "demodulation" {demodulation} | "userid" {userid} | "mute"
+ * {mute}.  Like glz::read_json with default options: an unknown key, a value of the wrong type or
+ * malformed JSON rejects the message (PSDR_ERR_INVALID; the reference then ignores it, `if (ec)
+ * return`), a missing key leaves its field at 0 / absent, null is "absent" for the optional m and
+ * level.  text = the demodulation name or the user id cut to 32 characters (src/client.cpp:121). */
+enum { PSDR_CMD_WINDOW = 0, PSDR_CMD_DEMODULATION = 1, PSDR_CMD_USERID = 2, PSDR_CMD_MUTE = 3 };
+typedef struct psdr_command {
+    int32_t cmd;
+    int32_t l, r;
+    int32_t has_m, has_level;
+    double m;
+    int32_t level;
+    int32_t mute;
+    char text[36];
+} psdr_command;
+int psdr_wire_parse_command(const char *msg, size_t len, psdr_command *out);
+
 /* ---- instrumentation --------------------------------------------------------------- */
 /* when enabled, every kernel launch is bracketed by hipEvents on the context's stream */
 int psdr_set_profiling(psdr_ctx *ctx, int enable);

@@ -53,6 +53,8 @@ SYMBOLS = [
     ("psdr_wire_zstd_destroy", None, [_vp]),
     ("psdr_wire_zstd_bound", _sz, [_sz]),
     ("psdr_wire_zstd_flush", _i, [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]),
+    ("psdr_wire_hello_json", _i, [_vp, C.c_char_p, _sz, C.POINTER(_sz)]),
+    ("psdr_wire_parse_command", _i, [C.c_char_p, _sz, _vp]),
     ("psdr_ring_create", _i, [_vp, _i]),
     ("psdr_ring_write_async", _i, [_vp, _u64, _vp]),
     ("psdr_ring_wait", _i, [_vp, _u64]),
@@ -116,3 +118,17 @@ def check(rc):
     if rc != 0:
         raise PsdrError(rc, load().psdr_last_error().decode())
     return rc
+
+
+class Hello(C.Structure):
+    """struct psdr_hello (include/psdr.h)"""
+    _fields_ = [(n, C.c_double) for n in ("sps", "audio_max_sps", "audio_max_fft", "fft_size", "fft_result_size",
+                                          "waterfall_size", "basefreq", "total_bandwidth", "default_frequency",
+                                          "default_l", "default_m", "default_r")] + [
+        ("default_modulation", C.c_char_p), ("waterfall_compression", C.c_char_p), ("audio_compression", C.c_char_p)]
+
+
+class Command(C.Structure):
+    """struct psdr_command (include/psdr.h)"""
+    _fields_ = [("cmd", C.c_int32), ("l", C.c_int32), ("r", C.c_int32), ("has_m", C.c_int32), ("has_level", C.c_int32),
+                ("m", C.c_double), ("level", C.c_int32), ("mute", C.c_int32), ("text", C.c_char * 36)]

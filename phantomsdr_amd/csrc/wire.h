@@ -8,6 +8,8 @@
 // with to_cbor's encodings: the shortest integer head (RFC 8949 3.1), floats as binary32 when the
 // double survives the round trip through float, else binary64 (NaN/inf as binary16), byte strings
 // without a tag.  The payload ("data") is opaque here: FLAC/Opus frames or int8 waterfall rows.
+// The two text formats of the same section: the hello frame (send_basic_info, src/websocket.cpp:42-66)
+// and the command frame (Client::on_message, src/client.cpp:19-117), both glaze v2.4.4 JSON.
 // zstd: one ZSTD_CStream per client, ZSTD_compressStream2(..., ZSTD_e_flush) per packet
 // (src/waterfallcompression.cpp:33); libzstd is dlopen()ed (it is a system library, not part of this
 // repository), absent -> PSDR_ERR_UNSUPPORTED.
@@ -17,8 +19,11 @@
 #include <string.h>
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <mutex>
+#include <string>
 
 #include "../../include/psdr.h"
 
@@ -204,5 +209,242 @@ extern "C" int psdr_wire_zstd_flush(psdr_zstd *zs, const void *in, size_t n, uin
     const size_t rc = z.compressStream2(zs->stream, &ob, &ib, 1 /* ZSTD_e_flush */);
     if (z.isError(rc) || rc != 0 || ib.pos != n) return PSDR_ERR_INVALID;  // rc > 0: the output buffer was too small
     *len = ob.pos;
+    return PSDR_OK;
+}
+
+// ---- hello / command text frames --------------------------------------------------------------
+namespace psdr_wire {
+
+// shortest decimal form that reads back to the same double; integers without a fraction
+inline std::string json_number(double v) {
+    if (!std::isfinite(v)) return "null";  // glaze writes non-finite numbers as null
+    char buf[40];
+    if (v == std::floor(v) && std::fabs(v) < 9007199254740992.0) {
+        snprintf(buf, sizeof buf, "%.0f", v);
+        return buf[0] == '-' && buf[1] == '0' && !buf[2] ? "0" : buf;
+    }
+    for (int prec = 1; prec <= 17; prec++) {
+        snprintf(buf, sizeof buf, "%.*g", prec, v);
+        if (strtod(buf, nullptr) == v) break;
+    }
+    return buf;
+}
+inline std::string json_string(const char *s) {
+    std::string o = "\"";
+    for (; s && *s; s++) {
+        if (*s == '"' || *s == '\\') o += '\\';
+        o += *s;
+    }
+    return o + "\"";
+}
+
+// the few productions of JSON the command frames use: one flat object of strings, numbers, booleans, null
+struct Cursor {
+    const char *p, *e;
+    void ws() {
+        while (p < e && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++;
+    }
+    bool eat(char c) {
+        ws();
+        if (p < e && *p == c) {
+            p++;
+            return true;
+        }
+        return false;
+    }
+    bool lit(const char *w) {
+        const size_t n = strlen(w);
+        if ((size_t)(e - p) >= n && !memcmp(p, w, n)) {
+            p += n;
+            return true;
+        }
+        return false;
+    }
+    bool str(std::string &o) {
+        ws();
+        if (p >= e || *p != '"') return false;
+        p++;
+        o.clear();
+        while (p < e && *p != '"') {
+            if (*p == '\\') {
+                if (++p >= e) return false;
+                switch (*p) {
+                case '"': o += '"'; break;
+                case '\\': o += '\\'; break;
+                case '/': o += '/'; break;
+                case 'b': o += '\b'; break;
+                case 'f': o += '\f'; break;
+                case 'n': o += '\n'; break;
+                case 'r': o += '\r'; break;
+                case 't': o += '\t'; break;
+                case 'u': {  // BMP code point -> UTF-8 (surrogate pairs are not combined)
+                    if (e - p < 5) return false;
+                    unsigned cp = 0;
+                    for (int i = 1; i <= 4; i++) {
+                        const char c = p[i];
+                        const int d = c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1;
+                        if (d < 0) return false;
+                        cp = cp * 16 + (unsigned)d;
+                    }
+                    p += 4;
+                    if (cp < 0x80) {
+                        o += (char)cp;
+                    } else if (cp < 0x800) {
+                        o += (char)(0xC0 | (cp >> 6));
+                        o += (char)(0x80 | (cp & 0x3F));
+                    } else {
+                        o += (char)(0xE0 | (cp >> 12));
+                        o += (char)(0x80 | ((cp >> 6) & 0x3F));
+                        o += (char)(0x80 | (cp & 0x3F));
+                    }
+                    break;
+                }
+                default: return false;
+                }
+                p++;
+            } else {
+                o += *p++;
+            }
+        }
+        if (p >= e) return false;
+        p++;
+        return true;
+    }
+    bool num(double &v) {
+        ws();
+        const char *q = p;
+        if (q < e && *q == '-') q++;
+        if (q >= e || *q < '0' || *q > '9') return false;
+        while (q < e && ((*q >= '0' && *q <= '9') || *q == '.' || *q == 'e' || *q == 'E' || *q == '+' || *q == '-')) q++;
+        const std::string t(p, q);
+        char *end = nullptr;
+        v = strtod(t.c_str(), &end);
+        if (end != t.c_str() + t.size()) return false;
+        p = q;
+        return true;
+    }
+};
+
+}  // namespace psdr_wire
+
+extern "C" int psdr_wire_hello_json(const psdr_hello *h, char *out, size_t cap, size_t *len) {
+    if (!h || !out || !len) return PSDR_ERR_INVALID;
+    using psdr_wire::json_number;
+    using psdr_wire::json_string;
+    std::string s = "{";
+    s += "\"audio_compression\":" + json_string(h->audio_compression);
+    s += ",\"audio_max_fft\":" + json_number(h->audio_max_fft);
+    s += ",\"audio_max_sps\":" + json_number(h->audio_max_sps);
+    s += ",\"basefreq\":" + json_number(h->basefreq);
+    s += ",\"defaults\":{\"frequency\":" + json_number(h->default_frequency);
+    s += ",\"l\":" + json_number(h->default_l);
+    s += ",\"m\":" + json_number(h->default_m);
+    s += ",\"modulation\":" + json_string(h->default_modulation);
+    s += ",\"r\":" + json_number(h->default_r) + "}";
+    s += ",\"fft_result_size\":" + json_number(h->fft_result_size);
+    s += ",\"fft_size\":" + json_number(h->fft_size);
+    s += ",\"sps\":" + json_number(h->sps);
+    s += ",\"total_bandwidth\":" + json_number(h->total_bandwidth);
+    s += ",\"waterfall_compression\":" + json_string(h->waterfall_compression);
+    s += ",\"waterfall_size\":" + json_number(h->waterfall_size) + "}";
+    *len = s.size();
+    if (s.size() + 1 > cap) return PSDR_ERR_INVALID;
+    memcpy(out, s.c_str(), s.size() + 1);
+    return PSDR_OK;
+}
+
+extern "C" int psdr_wire_parse_command(const char *msg, size_t len, psdr_command *out) {
+    if (!msg || !out) return PSDR_ERR_INVALID;
+    psdr_wire::Cursor c{msg, msg + len};
+    psdr_command r;
+    memset(&r, 0, sizeof r);
+    r.cmd = -1;
+    // every key seen, typed by what the JSON holds; checked against the tagged alternative at the end
+    // (glaze reads the tag first wherever it stands, then the alternative's own keys)
+    bool have_l = false, have_r = false, have_dem = false, have_uid = false, have_mute = false, m_null = false, lv_null = false;
+    bool has_m = false, has_lv = false;
+    double l = 0, rr = 0, m = 0, lv = 0;
+    std::string cmd, dem, uid;
+    if (!c.eat('{')) return PSDR_ERR_INVALID;
+    if (!c.eat('}')) {
+        for (;;) {
+            std::string key;
+            if (!c.str(key) || !c.eat(':')) return PSDR_ERR_INVALID;
+            c.ws();
+            if (key == "cmd") {
+                if (!c.str(cmd)) return PSDR_ERR_INVALID;
+            } else if (key == "l") {
+                if (!c.num(l)) return PSDR_ERR_INVALID;
+                have_l = true;
+            } else if (key == "r") {
+                if (!c.num(rr)) return PSDR_ERR_INVALID;
+                have_r = true;
+            } else if (key == "m") {
+                if (c.lit("null"))
+                    m_null = true;
+                else if (c.num(m))
+                    has_m = true;
+                else
+                    return PSDR_ERR_INVALID;
+            } else if (key == "level") {
+                if (c.lit("null"))
+                    lv_null = true;
+                else if (c.num(lv))
+                    has_lv = true;
+                else
+                    return PSDR_ERR_INVALID;
+            } else if (key == "demodulation") {
+                if (!c.str(dem)) return PSDR_ERR_INVALID;
+                have_dem = true;
+            } else if (key == "userid") {
+                if (!c.str(uid)) return PSDR_ERR_INVALID;
+                have_uid = true;
+            } else if (key == "mute") {
+                if (c.lit("true"))
+                    r.mute = 1;
+                else if (c.lit("false"))
+                    r.mute = 0;
+                else
+                    return PSDR_ERR_INVALID;
+                have_mute = true;
+            } else {
+                return PSDR_ERR_INVALID;  // unknown key
+            }
+            if (c.eat(',')) continue;
+            if (c.eat('}')) break;
+            return PSDR_ERR_INVALID;
+        }
+    }
+    c.ws();
+    if (c.p != c.e) return PSDR_ERR_INVALID;
+    const bool window_keys = have_l || have_r || has_m || has_lv || m_null || lv_null;
+    auto as_int = [](double v, int32_t &o) {  // an int field: a fraction or an out-of-range value is a parse error
+        if (v != std::floor(v) || v < -2147483648.0 || v > 2147483647.0) return false;
+        o = (int32_t)v;
+        return true;
+    };
+    if (cmd == "window") {
+        if (have_dem || have_uid || have_mute) return PSDR_ERR_INVALID;
+        r.cmd = PSDR_CMD_WINDOW;
+        if (!as_int(l, r.l) || !as_int(rr, r.r)) return PSDR_ERR_INVALID;
+        r.has_m = has_m;
+        r.m = m;
+        r.has_level = has_lv;
+        if (has_lv && !as_int(lv, r.level)) return PSDR_ERR_INVALID;
+    } else if (cmd == "demodulation") {
+        if (window_keys || have_uid || have_mute) return PSDR_ERR_INVALID;
+        r.cmd = PSDR_CMD_DEMODULATION;
+        snprintf(r.text, sizeof r.text, "%.32s", dem.c_str());
+    } else if (cmd == "userid") {
+        if (window_keys || have_dem || have_mute) return PSDR_ERR_INVALID;
+        r.cmd = PSDR_CMD_USERID;
+        snprintf(r.text, sizeof r.text, "%.32s", uid.c_str());
+    } else if (cmd == "mute") {
+        if (window_keys || have_dem || have_uid) return PSDR_ERR_INVALID;
+        r.cmd = PSDR_CMD_MUTE;
+    } else {
+        return PSDR_ERR_INVALID;
+    }
+    *out = r;
     return PSDR_OK;
 }

@@ -151,3 +151,76 @@ def test_waterfall_packet_and_zstd_stream():
         z.ZSTD_freeDStream(ds)
     finally:
         L.psdr_wire_zstd_destroy(zs)
+
+
+# ---- text frames: hello (src/websocket.cpp:42-66) and commands (src/client.cpp:19-117) -------------
+def _hello(**kw):
+    import json
+    L = _lib.load()
+    h = _lib.Hello()
+    for k, v in kw.items():
+        setattr(h, k, v.encode() if isinstance(v, str) else float(v))
+    out = C.create_string_buffer(1024)
+    n = C.c_size_t(0)
+    assert L.psdr_wire_hello_json(C.byref(h), out, 1024, C.byref(n)) == 0
+    assert len(out.value) == n.value
+    return out.value.decode(), json.loads(out.value)
+
+
+def test_hello_json_is_the_sorted_map_of_doubles():
+    txt, js = _hello(sps=2000000, audio_max_sps=12000, audio_max_fft=360, fft_size=1 << 20, fft_result_size=1 << 20,
+                     waterfall_size=1024, basefreq=14000000, total_bandwidth=2000000, default_frequency=14074000,
+                     default_l=38797, default_m=38797.5, default_r=40370, default_modulation="USB",
+                     waterfall_compression="zstd", audio_compression="flac")
+    # std::map order at both levels, integers without a fraction, the one fractional number in its shortest form
+    assert txt == ('{"audio_compression":"flac","audio_max_fft":360,"audio_max_sps":12000,"basefreq":14000000,'
+                   '"defaults":{"frequency":14074000,"l":38797,"m":38797.5,"modulation":"USB","r":40370},'
+                   '"fft_result_size":1048576,"fft_size":1048576,"sps":2000000,"total_bandwidth":2000000,'
+                   '"waterfall_compression":"zstd","waterfall_size":1024}')
+    assert list(js) == sorted(js) and list(js["defaults"]) == sorted(js["defaults"])
+    # shortest round-trip form of a value that is not exact in binary
+    _, js = _hello(default_m=0.1, default_modulation="AM", waterfall_compression="zstd", audio_compression="opus")
+    assert js["defaults"]["m"] == 0.1 and '"m":0.1,' in _hello(default_m=0.1, default_modulation="AM",
+                                                            waterfall_compression="z", audio_compression="o")[0]
+    # too small a buffer is an error, the needed length is still reported
+    L = _lib.load()
+    h = _lib.Hello()
+    h.default_modulation = h.waterfall_compression = h.audio_compression = b"x"
+    small = C.create_string_buffer(8)
+    n = C.c_size_t(0)
+    assert L.psdr_wire_hello_json(C.byref(h), small, 8, C.byref(n)) != 0 and n.value > 8
+
+
+def _cmd(msg):
+    L = _lib.load()
+    c = _lib.Command()
+    b = msg.encode()
+    rc = L.psdr_wire_parse_command(b, len(b), C.byref(c))
+    return rc, c
+
+
+def test_command_frames():
+    rc, c = _cmd('{"cmd":"window","l":100,"r":460,"m":280.5,"level":3}')
+    assert rc == 0 and (c.cmd, c.l, c.r, c.has_m, c.m, c.has_level, c.level) == (0, 100, 460, 1, 280.5, 1, 3)
+    rc, c = _cmd(' { "l" : -5 , "cmd" : "window" , "r" : 7 } ')        # tag anywhere, optionals absent
+    assert rc == 0 and (c.cmd, c.l, c.r, c.has_m, c.has_level) == (0, -5, 7, 0, 0)
+    rc, c = _cmd('{"cmd":"window","l":1,"r":2,"m":null,"level":null}')  # null = std::nullopt
+    assert rc == 0 and (c.has_m, c.has_level) == (0, 0)
+    rc, c = _cmd('{"cmd":"window","r":2}')                              # a missing key keeps its default
+    assert rc == 0 and (c.l, c.r) == (0, 2)
+    rc, c = _cmd('{"cmd":"demodulation","demodulation":"LSB"}')
+    assert rc == 0 and c.cmd == 1 and c.text == b"LSB"
+    rc, c = _cmd('{"cmd":"userid","userid":"%s"}' % ("u" * 40))
+    assert rc == 0 and c.cmd == 2 and c.text == b"u" * 32              # substr(0, 32), src/client.cpp:121
+    rc, c = _cmd('{"cmd":"userid","userid":"a\\"b\\u00e9"}')
+    assert rc == 0 and c.text == 'a"b\u00e9'.encode("utf-8")
+    rc, c = _cmd('{"cmd":"mute","mute":true}')
+    assert rc == 0 and c.cmd == 3 and c.mute == 1
+    rc, c = _cmd('{"cmd":"mute","mute":false}')
+    assert rc == 0 and c.mute == 0
+    # rejected like `if (ec) return` (src/client.cpp:96-99)
+    for bad in ['', 'window', '{"cmd":"window","l":1,"r":2', '{"cmd":"zoom","l":1,"r":2}', '{"l":1,"r":2}',
+                '{"cmd":"window","l":1.5,"r":2}', '{"cmd":"window","l":"1","r":2}', '{"cmd":"window","l":1,"r":2,"x":0}',
+                '{"cmd":"mute","mute":1}', '{"cmd":"mute","mute":true,"l":1}', '{"cmd":"demodulation","demodulation":7}',
+                '{"cmd":"window","l":1,"r":2} trailing', '{"cmd":"window","l":3000000000,"r":2}']:
+        assert _cmd(bad)[0] != 0, bad
