@@ -293,13 +293,17 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
                broadcasts each spectrum batch (8N bytes per frame) over RCCL/xGMI
       raw      the same sharding, but rank 0 broadcasts the RAW new half-frames (cs16: 2N bytes per
                frame, 4x fewer) and every rank runs the forward FFT itself (SURVEY 8e variant i)
+      band     clients sharded by frequency band (rank g owns the windows starting in its 1/G of the spectrum);
+               rank 0 FFTs, packs and SCATTERS one band + halo per rank: 8N/G bytes per frame and link
+               (SURVEY 8e variant ii)
       time     the STREAM is sharded - batch g goes to rank g mod G with a two-frame warm-up instead of
                any exchange; every rank serves all the clients of its frames; no data-path collective
     """
     import torch.distributed as dist
     from phantomsdr_amd import SpectrumEngine
-    from phantomsdr_amd.distributed import (HipBackend, HipRawBackend, HipTimeBackend, RawShardedRunner, ShardedRunner,
-                                            TimeShardedRunner, assign_clients)
+    from phantomsdr_amd.distributed import (BandShardedRunner, HipBackend, HipBandBackend, HipRawBackend, HipTimeBackend,
+                                            RawShardedRunner, ShardedRunner, TimeShardedRunner, assign_clients,
+                                            assign_clients_by_band, band_bounds)
 
     device = torch.device("cuda", local_rank)
     if not dist.is_initialized():
@@ -317,9 +321,11 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
         # count stays a multiple of the work-group count; F = the NEW frames per step
         F = args.batch - warm
         per_gpu = wl["audio"]
+        # band mode: the uniformly drawn windows do not split evenly over the bands (the outer 5 % of the
+        # spectrum hold none): room for twice the mean
         eng = SpectrumEngine(wl["sps"], N, wl["is_real"], input_format=wl["fmt"], max_batch=F + warm,
-                             max_clients=max(per_gpu, 1), max_waterfall_clients=max(wl["waterfall"], 1),
-                             device=local_rank)
+                             max_clients=max(per_gpu * (2 if mode == "band" else 1), 1),
+                             max_waterfall_clients=max(wl["waterfall"], 1), device=local_rank)
         params = eng.params
         hb = eng.ctx.half_frame_bytes()
         nbatches = max(2, (args.ring_mib * (1 << 20)) // (hb * F))
@@ -347,7 +353,12 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
             bytes_per_frame = 0
         else:
             all_clients = make_clients(wl, params, seed=0x5D5D0004, count=per_gpu * world)
-            mine = assign_clients(len(all_clients), world)[rank]
+            if mode == "band":
+                halo = params["audio_fft_size"]
+                mine = assign_clients_by_band([(l, r) for _, l, _, r in all_clients], params["fft_result_size"], world,
+                                              halo)[rank]
+            else:
+                mine = assign_clients(len(all_clients), world)[rank]
             clients = [all_clients[c] for c in mine]
             for mode_, l, m, r in clients:
                 eng.add_audio_client(l, m, r, mode_)
@@ -359,6 +370,13 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
                 par = (f"clients sharded over {world} GPUs (client i -> rank i mod G); rank 0 broadcasts the RAW new "
                        "half-frames over RCCL, every rank runs the forward FFT")
                 bytes_per_frame = hb
+            elif mode == "band":
+                backend = HipBandBackend(torch, eng.ctx, device, ring.data_ptr() if ring is not None else 0, nbatches, F,
+                                         rank, world, halo)
+                runner = BandShardedRunner(backend, dist, rank, world, F)
+                par = (f"clients sharded by frequency band over {world} GPUs; rank 0 FFT + pack + RCCL scatter of one "
+                       "band (+ one window of halo) per rank")
+                bytes_per_frame = 8 * band_bounds(0, params["fft_result_size"], world, halo)[1]
             else:
                 backend = HipBackend(torch, eng.ctx, device, ring.data_ptr() if ring is not None else 0, nbatches, F)
                 runner = ShardedRunner(backend, dist, rank, world, F)
@@ -413,7 +431,7 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
 
     main_mode = args.shard
     results = {}
-    for m in (main_mode,) + tuple(x for x in ("clients", "raw", "time") if x != main_mode):
+    for m in (main_mode,) + tuple(x for x in ("clients", "raw", "band", "time") if x != main_mode):
         try:
             results[m] = measure(m, args.steps if m == main_mode else min(args.steps, 30),
                                  args.warmup if m == main_mode else min(args.warmup, 5))
@@ -546,9 +564,10 @@ def main():
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the clients256 / cfg3 sub-objects (profiling runs of one workload)")
     ap.add_argument("--ring-mib", type=int, default=512)
-    ap.add_argument("--shard", default="clients", choices=["clients", "time", "raw"],
+    ap.add_argument("--shard", default="clients", choices=["clients", "time", "raw", "band"],
                     help="N > 1: shard the clients with a spectrum broadcast (BASELINE.json configs[3], default), "
-                         "the clients with a RAW half-frame broadcast + replicated FFT, or the stream (no collective)")
+                         "the clients with a RAW half-frame broadcast + replicated FFT, the clients by frequency band "
+                         "with a scatter of one band per rank, or the stream (no collective)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path even with one rank (testing)")
     ap.add_argument("--cpu-baseline-only", default=None, metavar="WORKLOAD",

@@ -156,6 +156,17 @@ int psdr_demod_batch(psdr_ctx *ctx, uint64_t first_frame_num);
  * (SURVEY 8e). */
 int psdr_demod_batch_from(psdr_ctx *ctx, const float *d_spec, size_t frame_stride_bins,
                           int nframes, uint64_t first_frame_num);
+/* Band sharding (SURVEY 8e variant ii): a GPU that serves only the clients of one frequency band needs
+ * only that band of the spectrum.  psdr_pack_band copies bins [first_bin, first_bin + nbins) - indexed
+ * like the clients' l and r (IQ: client order, real: k), wrapping at the spectrum's end - of the first
+ * nframes frames of the last batch out of the device layout into a linear device buffer (stream
+ * ordered, no synchronisation): that is what is sent.  psdr_demod_batch_from_band is psdr_demod_batch_from
+ * on such a buffer; every active client's [l, r) must lie inside the band (PSDR_ERR_INVALID names the
+ * first that does not, and nothing is demodulated). */
+int psdr_pack_band(psdr_ctx *ctx, int nframes, uint32_t first_bin, uint32_t nbins, float *d_out,
+                   size_t out_stride_bins);
+int psdr_demod_batch_from_band(psdr_ctx *ctx, const float *d_band, size_t frame_stride_bins, uint32_t first_bin,
+                               uint32_t nbins, int nframes, uint64_t first_frame_num);
 /* results of the last demod batch for one client: audio [nframes][n/2] floats (the
  * demodulated, overlap-added samples handed to the DC blocker at src/signal.cpp:278),
  * pwr [nframes] (average_power, src/signal.cpp:117-119), nan_flags [nframes] (1 = the

@@ -360,6 +360,18 @@ __global__ __launch_bounds__(256) void k_spec_k_order(const cf *X, cf *out, size
     }
 }
 
+// band sharding (SURVEY 8e variant ii): bins [first, first + count) of every frame, in the order the
+// clients index them (IQ: client order, real: k order), out of the device layout into a linear
+// buffer - what one rank's clients need of the spectrum.  Indices wrap at R (the last band's halo).
+__global__ __launch_bounds__(256) void k_band_pack(const cf *X, size_t spec_stride, SpecLayout lay, int R, int first,
+                                                   int count, cf *out, size_t out_stride) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    int k = first + j;
+    if (k >= R) k -= R;
+    out[(size_t)blockIdx.y * out_stride + j] = X[(size_t)blockIdx.y * spec_stride + lay.pos(k)];
+}
+
 struct WfClient {
     int level, l, r;
     int active;

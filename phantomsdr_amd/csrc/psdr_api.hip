@@ -46,10 +46,10 @@ extern "C" const char *psdr_version(void) { return "phantomsdr_amd 0.1 (gfx950)"
 
 namespace {
 
-enum KernelId { K_PASS1, K_PASS2, K_UNTANGLE, K_TAIL, K_IDFT, K_OLA, K_WFALL, K_POST, K_SEAM, K_COUNT };
+enum KernelId { K_PASS1, K_PASS2, K_UNTANGLE, K_TAIL, K_IDFT, K_OLA, K_WFALL, K_POST, K_SEAM, K_BAND, K_COUNT };
 const char *kKernelNames[K_COUNT] = {"fft_pass1",  "fft_pass2", "untangle_real", "pyramid_tail",
                                      "demod_idft", "demod_ola", "waterfall_gather", "post_chain",
-                                     "real_seam"};
+                                     "real_seam",  "band_pack"};
 
 struct PendingEvent {
     hipEvent_t a, b;
@@ -1466,7 +1466,9 @@ extern "C" int psdr_client_set_audio_demodulation(psdr_ctx *c, int id, int mode)
     return PSDR_OK;
 }
 
-static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nframes, uint64_t first_frame_num) {
+// band != nullptr: `spec` is a linear window of bins [band[0], band[0] + band[1]) per frame
+static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nframes, uint64_t first_frame_num,
+                      const uint32_t *band = nullptr) {
     if (c->n <= 0) return fail(PSDR_ERR_STATE, "context created with audio_fft_size 0");
     HIPCHK(hipSetDevice(c->device));
     int nact = 0;
@@ -1476,6 +1478,14 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     ClientParams *d_clients = (ClientParams *)c->client_ring.dev(ring);
     {
         std::lock_guard<std::mutex> lk(c->mtx);
+        if (band) {  // checked under the same lock that fixes the windows this batch is demodulated with
+            for (size_t i = 0; i < c->aslots.size(); i++) {
+                const AudioSlot &s = c->aslots[i];
+                if (s.active && ((uint32_t)s.l < band[0] || (uint64_t)s.r > (uint64_t)band[0] + band[1]))
+                    return fail(PSDR_ERR_INVALID, "client %zu: window [%d, %d) outside the band [%u, %u)", i, s.l, s.r,
+                                band[0], band[0] + band[1]);
+            }
+        }
         for (size_t i = 0; i < c->aslots.size(); i++) {
             AudioSlot &s = c->aslots[i];
             if (!s.active) continue;
@@ -1500,6 +1510,10 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     a.spec_stride = spec_stride;
     a.is_real = c->is_real ? 1 : 0;
     a.lay = c->lay;
+    if (band) {
+        a.lay = SpecLayout{};
+        a.lay.k0 = (int)band[0];
+    }
     a.n = c->n;
     a.nframes = nframes;
     a.max_batch = c->max_batch;
@@ -1723,6 +1737,32 @@ extern "C" int psdr_demod_batch_from(psdr_ctx *c, const float *d_spec, size_t fr
     if (frame_stride_bins < (c->is_real ? c->N / 2 + 1 : c->N))
         return fail(PSDR_ERR_INVALID, "frame stride smaller than one spectrum");
     return demod_impl(c, (const cf *)d_spec, frame_stride_bins, nframes, first_frame_num);
+}
+
+extern "C" int psdr_pack_band(psdr_ctx *c, int nframes, uint32_t first_bin, uint32_t nbins, float *d_out,
+                              size_t out_stride_bins) {
+    if (!c || !d_out) return fail(PSDR_ERR_INVALID, "null argument");
+    if (c->last_nframes < 1) return fail(PSDR_ERR_STATE, "pack_band before process_batch/execute");
+    if (nframes < 1 || nframes > c->last_nframes)
+        return fail(PSDR_ERR_INVALID, "nframes %d outside [1, %d] (the last batch)", nframes, c->last_nframes);
+    const uint32_t R = (uint32_t)(c->is_real ? c->N / 2 : c->N);
+    if (first_bin >= R || nbins < 1 || nbins > R) return fail(PSDR_ERR_INVALID, "band [%u, +%u) outside [0, %u)", first_bin, nbins, R);
+    if (out_stride_bins < nbins) return fail(PSDR_ERR_INVALID, "output stride smaller than the band");
+    HIPCHK(hipSetDevice(c->device));
+    ProfScope ps(c, K_BAND, c->stream);
+    hipLaunchKernelGGL(k_band_pack, dim3((nbins + 255) / 256, nframes), dim3(256), 0, c->stream, c->d_spec, c->spec_stride,
+                       c->lay, (int)R, (int)first_bin, (int)nbins, (cf *)d_out, out_stride_bins);
+    HIPCHK(hipGetLastError());
+    return PSDR_OK;
+}
+extern "C" int psdr_demod_batch_from_band(psdr_ctx *c, const float *d_band, size_t frame_stride_bins, uint32_t first_bin,
+                                          uint32_t nbins, int nframes, uint64_t first_frame_num) {
+    if (!c || !d_band) return fail(PSDR_ERR_INVALID, "null argument");
+    if (nframes < 1 || nframes > c->max_batch)
+        return fail(PSDR_ERR_INVALID, "nframes %d outside [1, max_batch=%d]", nframes, c->max_batch);
+    if (nbins < 1 || frame_stride_bins < nbins) return fail(PSDR_ERR_INVALID, "frame stride smaller than the band");
+    const uint32_t band[2] = {first_bin, nbins};
+    return demod_impl(c, (const cf *)d_band, frame_stride_bins, nframes, first_frame_num, band);
 }
 
 extern "C" int psdr_read_audio(psdr_ctx *c, int id, int nframes, float *audio, float *pwr, int32_t *nan_flags,

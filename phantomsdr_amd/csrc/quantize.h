@@ -205,8 +205,9 @@ struct RecMap {
 // Consumers index through pos() (demodulation slices) or ask for k order (psdr_read_spectrum).
 struct SpecLayout {
     int mode, m1, l2m1, L, l2L;
+    int k0;  // mode 0 only: the buffer starts at bin k0 (a band of the spectrum, psdr_demod_batch_from_band)
     __host__ __device__ __forceinline__ size_t pos(int k) const {
-        if (!mode) return (size_t)k;
+        if (!mode) return (size_t)(k - k0);
         const int c1 = k & (m1 - 1), c2 = k >> l2m1;
         if (mode == 1) return ((((size_t)(c1 >> 4) << l2L) + c2) << 4) + (c1 & 15);
         if (c1 < (m1 >> 1)) return ((((size_t)(c1 >> 3) << l2L) + c2) << 4) + (c1 & 7);

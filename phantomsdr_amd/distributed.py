@@ -28,6 +28,13 @@ xGMI is point to point (7 links x ~153 GB/s per GPU), so a 1 -> G-1 broadcast is
 per link: 8.39 MB per 2^20-point frame / 153 GB/s = 55 us/frame; frames are batched F per
 collective to amortise the launch.  With G = 1 there is no collective at all.
 
+BAND sharding (`BandShardedRunner`, SURVEY 8e variant ii): a client only reads the bins of its own
+window, so a GPU that serves the clients of ONE frequency band needs only that band: rank g owns the
+clients whose window starts in bins [g*R/G, (g+1)*R/G) and receives those bins plus a halo of one
+maximal window (a client is assigned by its left edge), R/G + halo bins instead of R: one scatter
+per batch, 8.39 MB / G per frame and link.  The per-link ceiling of the ingest rate grows with G
+(9.5 GS/s x G for 2^20-point IQ frames) - the client sharding that scales.
+
 The orchestration below is backend-agnostic (the compute back-end is injected), so the
 sharding and the exchange are covered by world_size-2 gloo tests on CPU
 (tests/test_distributed_cpu.py) with the oracle as compute stand-in, and by the HIP
@@ -111,6 +118,62 @@ class RawShardedRunner:
             self.backend.forward_local()
             self.backend.demod(self.frame_num)
         self.first = False
+        self.frame_num += self.F
+
+
+def band_of(l, R, world):
+    """rank of the band a window starting at bin l belongs to"""
+    return min(int(l) * world // R, world - 1)
+
+
+def band_bounds(g, R, world, halo):
+    """(first bin, bins) of rank g's band: [g*R/G, (g+1)*R/G) plus `halo` bins, the same count on every
+    rank (the scatter wants equal pieces; the last band's halo wraps and is never read)"""
+    first = (g * R + world - 1) // world       # smallest l with band_of(l) == g
+    return first, min((R + world - 1) // world + 1 + halo, R)
+
+
+def assign_clients_by_band(windows, R, world, halo):
+    """windows: [(l, r)] in client bins -> list of client indices per rank; raises if a window does not
+    fit its band (it is wider than the halo)"""
+    out = [[] for _ in range(world)]
+    for i, (l, r) in enumerate(windows):
+        g = band_of(l, R, world)
+        first, cnt = band_bounds(g, R, world, halo)
+        if not (first <= l and r <= first + cnt):
+            raise ValueError(f"client {i}: window [{l}, {r}) does not fit band {g} = [{first}, {first + cnt})")
+        out[g].append(i)
+    return out
+
+
+class BandShardedRunner:
+    """SURVEY 8e variant (ii).  backend must provide
+      forward(step_index)        root only: F fresh spectra
+      pack_bands()               root only: list of G tensors [F, bins] (band g for rank g), contiguous
+      band_tensor()              this rank's receive tensor [F, bins]
+      demod_band(first_frame_num)  demodulate this rank's clients from band_tensor()
+    """
+
+    def __init__(self, backend, dist, rank, world, frames_per_step, root=0):
+        self.backend, self.dist = backend, dist
+        self.rank, self.world, self.F, self.root = rank, world, frames_per_step, root
+        self.frame_num = 0
+        self.bytes_broadcast = 0   # bytes that left the root per link (one band per peer)
+
+    def step(self, i):
+        ctx = getattr(self.backend, "stream_context", None)
+        with (ctx() if ctx else contextlib.nullcontext()):
+            bands = None
+            if self.rank == self.root:
+                self.backend.forward(i)
+                bands = self.backend.pack_bands()
+            t = self.backend.band_tensor()
+            if self.world > 1:
+                self.dist.scatter(t, scatter_list=bands if self.rank == self.root else None, src=self.root)
+                self.bytes_broadcast += t.numel() * t.element_size()
+            else:
+                t.copy_(bands[0])
+            self.backend.demod_band(self.frame_num)
         self.frame_num += self.F
 
 
@@ -223,6 +286,56 @@ class HipBackend:
         from ._lib import check
         check(self.ctx.lib.psdr_demod_batch_from(self.ctx.h, C.c_void_p(self.spec_ptr),
                                                  self.stride_bins, self.F, first_frame_num))
+        self.ctx.last_nframes = self.ctx.last_demod_frames = self.F
+
+
+class HipBandBackend:
+    """BandShardedRunner back-end on the HIP library.  The root packs the G bands out of the device
+    layout (psdr_pack_band, one small kernel per band) into one send buffer; every rank demodulates
+    from its linear band buffer (psdr_demod_batch_from_band)."""
+
+    def __init__(self, torch, ctx, device, ring_ptr, nbatches, frames_per_step, rank, world, halo, root=0):
+        import ctypes as C
+        from ._lib import check
+        self.torch, self.ctx, self.F = torch, ctx, frames_per_step
+        self.ring_ptr, self.nbatches, self.rank, self.world = ring_ptr, nbatches, rank, world
+        self.hb = ctx.half_frame_bytes()
+        self.R = ctx.N // 2 if ctx.is_real else ctx.N
+        self.first, self.bins = band_bounds(rank, self.R, world, halo)
+        self.halo = halo
+        self.stream = torch.cuda.Stream(device=device)
+        assert self.stream.cuda_stream != 0
+        check(ctx.lib.psdr_set_stream(ctx.h, C.c_void_p(self.stream.cuda_stream)))
+        self.band = torch.empty((frames_per_step, self.bins), dtype=torch.complex64, device=device)
+        self.send = (torch.empty((world, frames_per_step, self.bins), dtype=torch.complex64, device=device)
+                     if rank == root else None)
+
+    def stream_context(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    def forward(self, i):
+        b = i % self.nbatches
+        self.ctx.process_batch(self.ring_ptr, self.F, offset_bytes=b * self.F * self.hb)
+
+    def pack_bands(self):
+        import ctypes as C
+        from ._lib import check
+        for g in range(self.world):
+            first, bins = band_bounds(g, self.R, self.world, self.halo)
+            check(self.ctx.lib.psdr_pack_band(self.ctx.h, self.F, first, bins, C.c_void_p(self.send[g].data_ptr()), bins))
+        return [self.send[g] for g in range(self.world)]
+
+    def band_tensor(self):
+        return self.band
+
+    def demod_band(self, first_frame_num):
+        import ctypes as C
+        from ._lib import check
+        check(self.ctx.lib.psdr_demod_batch_from_band(self.ctx.h, C.c_void_p(self.band.data_ptr()), self.bins,
+                                                      self.first, self.bins, self.F, first_frame_num))
         self.ctx.last_nframes = self.ctx.last_demod_frames = self.F
 
 

@@ -234,6 +234,137 @@ def test_two_rank_raw_broadcast_matches_single_process():
         assert np.array_equal(a, b)
 
 
+# ---------------------------------------------------------------------------------------
+# band sharding (SURVEY 8e variant ii): rank g receives only the bins its clients can read
+# ---------------------------------------------------------------------------------------
+HALO = NAUD
+
+
+def _band_clients():
+    """windows (client bins) in both halves of the spectrum, one straddling the band edge (it belongs to
+    the band of its left edge and reads the halo), one touching each end of the spectrum"""
+    out = [("USB", 0, 0.0, 14), ("AM", 400, 425.0, 450), ("FM", N // 2 - 30, float(N // 2 - 5), N // 2 + 20),
+           ("LSB", N // 2 - 14, float(N // 2), N // 2), ("USB", N // 2, N // 2 + 0.5, N // 2 + 14),
+           ("AM", 3000, 3025.0, 3050), ("LSB", N - 15, float(N - 1), N - 1)]
+    return out
+
+
+class OracleBandBackend:
+    BASE = N // 2 + 1   # client bin c is FFT bin (c + BASE) mod N (src/websocket.cpp:157-160)
+
+    def __init__(self, torch, halves, my_clients, rank, world):
+        from oracle import oracle as O
+        from phantomsdr_amd.distributed import band_bounds
+        self.O, self.torch, self.halves, self.world = O, torch, halves, world
+        self.bb = band_bounds
+        self.fo = O.FFT(N, False, 3, 0, NAUD)
+        self.first, self.bins = band_bounds(rank, N, world, HALO)
+        self.band = torch.zeros((F, self.bins), dtype=torch.complex64)
+        self.specs = None
+        self.clients = []
+        for mode, l, m, r in my_clients:
+            c = O.AudioClient(False, NAUD, 12000, N)
+            c.set_audio_demodulation(mode)
+            c.set_audio_range(l, m, r)
+            self.clients.append(c)
+        self.audio = [[] for _ in my_clients]
+
+    def forward(self, i):
+        self.specs = []
+        for f in range(F):
+            g = i * F + f
+            self.fo.load(self.halves[g], self.halves[g + 1])
+            self.fo.execute()
+            self.specs.append(self.fo.output()[:N].copy())
+
+    def pack_bands(self):
+        out = []
+        for g in range(self.world):
+            first, bins = self.bb(g, N, self.world, HALO)
+            k = ((first + np.arange(bins)) % N + self.BASE) % N
+            out.append(self.torch.from_numpy(np.stack([s[k] for s in self.specs])))
+        return out
+
+    def band_tensor(self):
+        return self.band
+
+    def demod_band(self, first_frame_num):
+        k = ((self.first + np.arange(self.bins)) % N + self.BASE) % N
+        for f in range(F):
+            full = np.zeros(N + NAUD, np.complex64)       # only the band is known on this rank
+            full[k] = self.band[f].numpy()
+            full[N:] = full[:NAUD]                         # the wrap copy of src/fft.cpp:96-97
+            for ci, c in enumerate(self.clients):
+                a, _, _, _ = c.send_audio(full, first_frame_num + f, fft=self.fo)
+                self.audio[ci].append(a)
+
+
+def _band_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from phantomsdr_amd.distributed import BandShardedRunner, assign_clients_by_band, gather_audio_to_root
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        allc = _band_clients()
+        mine = assign_clients_by_band([(l, r) for _, l, _, r in allc], N, world, HALO)[rank]
+        be = OracleBandBackend(torch, _halves() if rank == 0 else None, [allc[i] for i in mine], rank, world)
+        runner = BandShardedRunner(be, dist, rank, world, F)
+        for i in range(NBATCH):
+            runner.step(i)
+        merged = gather_audio_to_root(dist, rank, world, mine, [np.stack(a) for a in be.audio], len(allc))
+        if rank == 0:
+            q.put((merged, runner.bytes_broadcast, [len(x) for x in
+                                                    assign_clients_by_band([(l, r) for _, l, _, r in allc], N, world, HALO)]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_band_sharding_matches_single_process():
+    """each rank sees HALF the spectrum (+ one window of halo) and its clients hear the same audio"""
+    import torch
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    from phantomsdr_amd.distributed import ShardedRunner, band_bounds
+    allc = _band_clients()
+    be = OracleBackend(torch, _halves(), allc)
+    r1 = ShardedRunner(be, None, 0, 1, F)
+    for i in range(NBATCH):
+        r1.step(i)
+    ref = [np.stack(a) for a in be.audio]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_band_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    merged, nbytes, split = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert split == [4, 3]                                  # both ranks serve clients
+    bins = band_bounds(0, N, 2, HALO)[1]
+    assert bins == N // 2 + 1 + HALO and nbytes == NBATCH * F * bins * 8   # half a spectrum per link and frame
+    for a, b in zip(merged, ref):
+        assert np.array_equal(a, b)
+
+
+def test_band_assignment_rejects_a_window_wider_than_the_halo():
+    from phantomsdr_amd.distributed import assign_clients_by_band, band_bounds, band_of
+    with pytest.raises(ValueError):
+        assign_clients_by_band([(N // 2 - 10, N // 2 + 200)], N, 2, HALO)
+    # every left edge has exactly one band, bands tile the spectrum for any G (also non powers of two)
+    for G in (1, 2, 3, 7, 8):
+        firsts = [band_bounds(g, N, G, HALO)[0] for g in range(G)]
+        assert firsts[0] == 0 and firsts == sorted(firsts)
+        for l in list(range(0, N, 97)) + [N - 1] + firsts + [f - 1 for f in firsts[1:]]:
+            g = band_of(l, N, G)
+            first, cnt = band_bounds(g, N, G, HALO)
+            assert first <= l < first + cnt - HALO
+
+
 def test_time_sharding_refuses_the_post_chain():
     from phantomsdr_amd.distributed import TimeShardedRunner
 

@@ -234,3 +234,78 @@ def test_cfg4_share_demod_from_matches_unsharded_and_oracle():
             check(e.ctx.lib.psdr_set_stream(e.ctx.h, None))
         for e in (engA, engB, engC, engD):
             e.close()
+
+
+@pytest.mark.parametrize("wl_name,world,g", [("cfg4", 8, 5), ("cfg4", 8, 7), ("cfg3", 4, 3), ("cfg3", 4, 0)])
+def test_band_sharding_matches_unsharded(wl_name, world, g):
+    """SURVEY 8e variant (ii) on ONE GPU: the root packs band g out of the device layout (psdr_pack_band:
+    tile-major IQ lines for cfg4, the fused real layout for cfg3), a second context that never runs an FFT
+    receives it (a device copy stands in for the RCCL scatter) and demodulates rank g's clients with
+    psdr_demod_batch_from_band.  Bit-identical to the unsharded path (which test_cfg*_fullsize check against
+    the oracle); the last band's halo wraps around the end of the spectrum."""
+    import torch
+    from phantomsdr_amd import SpectrumEngine
+    from phantomsdr_amd._lib import check
+    from phantomsdr_amd.distributed import HipBandBackend, assign_clients_by_band, band_bounds
+    B = _bench()
+    wl = B.WORKLOADS[wl_name]
+    N, F, nb_, is_real = wl["fft_size"], 3, 2, wl["is_real"]
+    dev = torch.device("cuda", 0)
+    x = synth_stream((nb_ * F + 1) * (N // 2), is_real, seed=17, fft_size=N)
+    raw = quantize_raw(x, wl["fmt"], is_real)
+    del x
+    ring = torch.from_numpy(raw.view(np.int16)).to(dev)
+    torch.cuda.synchronize()
+    ncl = 64
+    mk = lambda: SpectrumEngine(wl["sps"], N, is_real, input_format=wl["fmt"], max_batch=F, max_clients=ncl + 1,
+                                max_waterfall_clients=1)
+    engA, engR, engG = mk(), mk(), mk()
+    try:
+        p = engA.params
+        n, R = p["audio_fft_size"], p["fft_result_size"]
+        allc = B.make_clients(dict(wl, modes=("USB", "LSB", "AM", "FM")), p, seed=0x5D5D0004, count=ncl * world)
+        # plus windows on the band's own edges: the first bin of the band, and one that ends in the halo
+        first, bins = band_bounds(g, R, world, n)
+        nxt = band_bounds(g + 1, R, world, n)[0] if g + 1 < world else R
+        allc += [("USB", first, float(first), first + 40), ("AM", nxt - 20, float(nxt - 1), min(nxt + 20, R - 1)),
+                 ("LSB", nxt - 41, float(nxt - 1), nxt - 1)]
+        shard = assign_clients_by_band([(l, r) for _, l, _, r in allc], R, world, n)
+        assert all(len(sh) > 0 for sh in shard)
+        mine = [allc[i] for i in shard[g]][-ncl:]
+        assert len(mine) >= 8 and mine[-3:] == allc[-3:]
+        gA, gG = ([e.add_audio_client(l, m, r, mode) for mode, l, m, r in mine] for e in (engA, engG))
+        hb = engA.ctx.half_frame_bytes()
+        root = HipBandBackend(torch, engR.ctx, dev, ring.data_ptr(), nb_, F, 0, world, n)
+        recv = HipBandBackend(torch, engG.ctx, dev, 0, nb_, F, g, world, n, root=-1)
+        assert (recv.first, recv.bins) == (first, bins)
+        for b in range(nb_):
+            engA.ctx.process_batch(ring.data_ptr(), F, offset_bytes=b * F * hb)
+            engA.ctx.demod_batch(b * F)
+            engA.ctx.synchronize()
+            with root.stream_context():
+                root.forward(b)
+                bands = root.pack_bands()
+            root.synchronize()
+            with recv.stream_context():
+                recv.band_tensor().copy_(bands[g])
+                recv.demod_band(b * F)
+            recv.synchronize()
+            for ci in range(len(mine)):
+                a1, p1, n1 = gA[ci].read_audio(F)
+                a2, p2, n2 = gG[ci].read_audio(F)
+                assert np.array_equal(a1.view(np.uint32), a2.view(np.uint32)), f"batch {b} client {ci} {mine[ci]} audio"
+                assert np.array_equal(p1.view(np.uint32), p2.view(np.uint32)), f"batch {b} client {ci} pwr"
+                assert np.array_equal(n1, n2)
+        # a window outside the band is refused and nothing runs
+        other = (g + world // 2) % world
+        o_first = band_bounds(other, R, world, n)[0]
+        bad = engG.add_audio_client(o_first + 5, float(o_first + 5), o_first + 30, "USB")
+        rc = engG.ctx.lib.psdr_demod_batch_from_band(engG.ctx.h, C.c_void_p(recv.band.data_ptr()), recv.bins, recv.first,
+                                                     recv.bins, F, 0)
+        assert rc != 0 and b"outside the band" in engG.ctx.lib.psdr_last_error()
+        del bad
+    finally:
+        for e in (engR, engG):
+            check(e.ctx.lib.psdr_set_stream(e.ctx.h, None))
+        for e in (engA, engR, engG):
+            e.close()
