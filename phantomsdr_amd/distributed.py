@@ -147,34 +147,69 @@ def assign_clients_by_band(windows, R, world, halo):
 
 
 class BandShardedRunner:
-    """SURVEY 8e variant (ii).  backend must provide
-      forward(step_index)        root only: F fresh spectra
-      pack_bands()               root only: list of G tensors [F, bins] (band g for rank g), contiguous
-      band_tensor()              this rank's receive tensor [F, bins]
-      demod_band(first_frame_num)  demodulate this rank's clients from band_tensor()
+    """SURVEY 8e variant (ii).  backend must provide (par = 0/1: which of two buffer sets)
+      forward(step_index)             root only: F fresh spectra
+      pack_bands(par)                 root only: list of G tensors [F, bins] (band g for rank g), contiguous
+      band_tensor(par)                this rank's receive tensor [F, bins]
+      demod_band(first_frame_num, par)  demodulate this rank's clients from band_tensor(par)
+
+    pipelined (default): the scatter of batch i is asynchronous and is only waited for one step later,
+    right before batch i is demodulated - so it runs beside the root's forward transform + pack of
+    batch i+1 and beside everybody's demodulation of batch i-1 (send and receive buffers alternate).
+    The step rate is max(compute, link time) instead of their sum; results arrive one step late and
+    flush() delivers the last batch.  The order of operations per client is unchanged, so the audio is
+    bit-identical to the unpipelined and to the unsharded run.
     """
 
-    def __init__(self, backend, dist, rank, world, frames_per_step, root=0):
+    def __init__(self, backend, dist, rank, world, frames_per_step, root=0, pipelined=True):
         self.backend, self.dist = backend, dist
         self.rank, self.world, self.F, self.root = rank, world, frames_per_step, root
+        self.pipelined = pipelined
         self.frame_num = 0
         self.bytes_broadcast = 0   # bytes that left the root per link (one band per peer)
+        self._n = 0
+        self._pending = None
+
+    def _ctx(self):
+        ctx = getattr(self.backend, "stream_context", None)
+        return ctx() if ctx else contextlib.nullcontext()
+
+    def _drain(self):
+        work, par, first = self._pending
+        self._pending = None
+        if work is not None:
+            work.wait()          # NCCL: the back-end's stream waits; gloo: the host does
+        self.backend.demod_band(first, par)
 
     def step(self, i):
-        ctx = getattr(self.backend, "stream_context", None)
-        with (ctx() if ctx else contextlib.nullcontext()):
+        par = self._n & 1
+        with self._ctx():
             bands = None
             if self.rank == self.root:
                 self.backend.forward(i)
-                bands = self.backend.pack_bands()
-            t = self.backend.band_tensor()
+                bands = self.backend.pack_bands(par)
+            t = self.backend.band_tensor(par)
+            work = None
             if self.world > 1:
-                self.dist.scatter(t, scatter_list=bands if self.rank == self.root else None, src=self.root)
+                work = self.dist.scatter(t, scatter_list=bands if self.rank == self.root else None, src=self.root,
+                                         async_op=self.pipelined)
                 self.bytes_broadcast += t.numel() * t.element_size()
             else:
                 t.copy_(bands[0])
-            self.backend.demod_band(self.frame_num)
+            if self.pipelined:
+                if self._pending is not None:
+                    self._drain()
+                self._pending = (work, par, self.frame_num)
+            else:
+                self.backend.demod_band(self.frame_num, par)
         self.frame_num += self.F
+        self._n += 1
+
+    def flush(self):
+        """demodulate the batch still in flight (call after the last step)"""
+        if self._pending is not None:
+            with self._ctx():
+                self._drain()
 
 
 class TimeShardedRunner:
@@ -306,8 +341,8 @@ class HipBandBackend:
         self.stream = torch.cuda.Stream(device=device)
         assert self.stream.cuda_stream != 0
         check(ctx.lib.psdr_set_stream(ctx.h, C.c_void_p(self.stream.cuda_stream)))
-        self.band = torch.empty((frames_per_step, self.bins), dtype=torch.complex64, device=device)
-        self.send = (torch.empty((world, frames_per_step, self.bins), dtype=torch.complex64, device=device)
+        self.band = torch.empty((2, frames_per_step, self.bins), dtype=torch.complex64, device=device)
+        self.send = (torch.empty((2, world, frames_per_step, self.bins), dtype=torch.complex64, device=device)
                      if rank == root else None)
 
     def stream_context(self):
@@ -320,21 +355,21 @@ class HipBandBackend:
         b = i % self.nbatches
         self.ctx.process_batch(self.ring_ptr, self.F, offset_bytes=b * self.F * self.hb)
 
-    def pack_bands(self):
+    def pack_bands(self, par=0):
         import ctypes as C
         from ._lib import check
         for g in range(self.world):
             first, bins = band_bounds(g, self.R, self.world, self.halo)
-            check(self.ctx.lib.psdr_pack_band(self.ctx.h, self.F, first, bins, C.c_void_p(self.send[g].data_ptr()), bins))
-        return [self.send[g] for g in range(self.world)]
+            check(self.ctx.lib.psdr_pack_band(self.ctx.h, self.F, first, bins, C.c_void_p(self.send[par, g].data_ptr()), bins))
+        return [self.send[par, g] for g in range(self.world)]
 
-    def band_tensor(self):
-        return self.band
+    def band_tensor(self, par=0):
+        return self.band[par]
 
-    def demod_band(self, first_frame_num):
+    def demod_band(self, first_frame_num, par=0):
         import ctypes as C
         from ._lib import check
-        check(self.ctx.lib.psdr_demod_batch_from_band(self.ctx.h, C.c_void_p(self.band.data_ptr()), self.bins,
+        check(self.ctx.lib.psdr_demod_batch_from_band(self.ctx.h, C.c_void_p(self.band[par].data_ptr()), self.bins,
                                                       self.first, self.bins, self.F, first_frame_num))
         self.ctx.last_nframes = self.ctx.last_demod_frames = self.F
 

@@ -259,7 +259,7 @@ class OracleBandBackend:
         self.bb = band_bounds
         self.fo = O.FFT(N, False, 3, 0, NAUD)
         self.first, self.bins = band_bounds(rank, N, world, HALO)
-        self.band = torch.zeros((F, self.bins), dtype=torch.complex64)
+        self.band = torch.zeros((2, F, self.bins), dtype=torch.complex64)
         self.specs = None
         self.clients = []
         for mode, l, m, r in my_clients:
@@ -277,7 +277,7 @@ class OracleBandBackend:
             self.fo.execute()
             self.specs.append(self.fo.output()[:N].copy())
 
-    def pack_bands(self):
+    def pack_bands(self, par):
         out = []
         for g in range(self.world):
             first, bins = self.bb(g, N, self.world, HALO)
@@ -285,21 +285,21 @@ class OracleBandBackend:
             out.append(self.torch.from_numpy(np.stack([s[k] for s in self.specs])))
         return out
 
-    def band_tensor(self):
-        return self.band
+    def band_tensor(self, par):
+        return self.band[par]
 
-    def demod_band(self, first_frame_num):
+    def demod_band(self, first_frame_num, par):
         k = ((self.first + np.arange(self.bins)) % N + self.BASE) % N
         for f in range(F):
             full = np.zeros(N + NAUD, np.complex64)       # only the band is known on this rank
-            full[k] = self.band[f].numpy()
+            full[k] = self.band[par, f].numpy()
             full[N:] = full[:NAUD]                         # the wrap copy of src/fft.cpp:96-97
             for ci, c in enumerate(self.clients):
                 a, _, _, _ = c.send_audio(full, first_frame_num + f, fft=self.fo)
                 self.audio[ci].append(a)
 
 
-def _band_worker(rank, world, port, q):
+def _band_worker(rank, world, port, q, pipelined=True):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -311,9 +311,12 @@ def _band_worker(rank, world, port, q):
         allc = _band_clients()
         mine = assign_clients_by_band([(l, r) for _, l, _, r in allc], N, world, HALO)[rank]
         be = OracleBandBackend(torch, _halves() if rank == 0 else None, [allc[i] for i in mine], rank, world)
-        runner = BandShardedRunner(be, dist, rank, world, F)
+        runner = BandShardedRunner(be, dist, rank, world, F, pipelined=pipelined)
         for i in range(NBATCH):
             runner.step(i)
+            if pipelined:   # results arrive one step late
+                assert all(len(a) == i * F for a in be.audio)
+        runner.flush()
         merged = gather_audio_to_root(dist, rank, world, mine, [np.stack(a) for a in be.audio], len(allc))
         if rank == 0:
             q.put((merged, runner.bytes_broadcast, [len(x) for x in
@@ -322,8 +325,10 @@ def _band_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_band_sharding_matches_single_process():
-    """each rank sees HALF the spectrum (+ one window of halo) and its clients hear the same audio"""
+@pytest.mark.parametrize("pipelined", [True, False])
+def test_two_rank_band_sharding_matches_single_process(pipelined):
+    """each rank sees HALF the spectrum (+ one window of halo) and its clients hear the same audio; with the
+    scatter of batch i in flight beside the transform of batch i+1 (pipelined) or in lock step"""
     import torch
     import torch.multiprocessing as mp
     sys.path.insert(0, ROOT)
@@ -337,7 +342,7 @@ def test_two_rank_band_sharding_matches_single_process():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_band_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_band_worker, args=(r, 2, port, q, pipelined)) for r in range(2)]
     for p in procs:
         p.start()
     merged, nbytes, split = q.get(timeout=180)
