@@ -255,18 +255,15 @@ struct TileQueue {
     unsigned *tickets;
     unsigned total, base;  // indices below 2*gridDim.x are the static first tiles
     unsigned pending;      // thread 0: ticket drawn from the own counter, not yet examined
-    bool dynamic, global, nostatic;
+    bool dynamic, global;
     // global_: ONE counter for the whole chip (perfect balance, no XCD affinity)
-    // all_dynamic: no static first tiles (the second phase of a single launch: work-groups
-    // arrive one by one); the first two indices come from draw_now()
-    __device__ __forceinline__ void init(unsigned *t, unsigned total_, bool global_ = false, bool all_dynamic = false) {
+    __device__ __forceinline__ void init(unsigned *t, unsigned total_, bool global_ = false) {
         global = global_;
-        nostatic = all_dynamic;
         tickets = t;
         total = total_;
-        base = all_dynamic ? 0u : gridDim.x >> 2;  // 2*gridDim.x / 8
+        base = gridDim.x >> 2;  // 2*gridDim.x / 8
         pending = 0;
-        dynamic = t != nullptr && (all_dynamic || 2u * gridDim.x < total_);
+        dynamic = t != nullptr && 2u * gridDim.x < total_;
     }
     // thread 0: start drawing (no wait)
     __device__ __forceinline__ void draw_begin() {
@@ -293,11 +290,6 @@ struct TileQueue {
         draw_begin();
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
     }
-    // thread 0, synchronous (phase start, all_dynamic + global only): one index
-    __device__ __forceinline__ unsigned draw_now() {
-        const unsigned s = atomicAdd(tickets, 1u);
-        return s < total ? s : 0xFFFFFFFFu;
-    }
     // thread 0: finish the draw begun one tile ago and publish the index (or 0xFFFFFFFF) to
     // *slot; `prev` is the index two positions earlier in this work-group's sequence
     __device__ __forceinline__ void draw_end(unsigned *slot, unsigned prev2) {
@@ -307,7 +299,7 @@ struct TileQueue {
                 if (prev2 < total) s = prev2 + 2u * gridDim.x;
             } else if (dynamic) {
                 const unsigned x = blockIdx.x & 7u;
-                s = global ? pending + (nostatic ? 0u : 2u * gridDim.x) : (pending + base) * 8u + x;
+                s = global ? pending + 2u * gridDim.x : (pending + base) * 8u + x;
                 if (s >= total) s = 0xFFFFFFFFu;  // no stealing across XCDs: probing seven more
                                                   // counters costs a memory round trip each
             }
@@ -731,7 +723,7 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
     // pass 2 has no use for XCD affinity (full-line stores, tile-major records) and the XCDs
     // differ by ~10 % in speed: one chip-wide counter (pass 1 keeps the per-XCD queues: adjacent
     // tiles share the 128-byte lines of the raw rows)
-    tq.init(a.tickets, total, true, false);
+    tq.init(a.tickets, total, true);
     unsigned s = blockIdx.x, snext = blockIdx.x + gridDim.x;
     if (s < total) {
         point_at(s);
@@ -953,6 +945,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
     constexpr int NLD = 16;
     constexpr int NTICK = 2 * (Plan<L>::NS - 1);
     constexpr int EARLY = 4;
+    PSDR_WGTRACE(a.trace, 0);
     constexpr int LPT = (NLD - EARLY + NTICK - 1) / NTICK;
     constexpr int NBL = 16 / LastStage<L>::R;
     const int tid = threadIdx.x;
@@ -992,7 +985,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
     };
     __shared__ unsigned s_next[2];
     TileQueue tq;
-    tq.init(a.tickets, total, true, false);
+    tq.init(a.tickets, total, true);
     unsigned s = blockIdx.x, snext = blockIdx.x + gridDim.x;
     if (s < total) {
         point_at(s, 0);
@@ -1218,11 +1211,13 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             s = snext;
             snext = s2;
             j = 0;
+            PSDR_WGTRACE(a.trace, 1 + segit);  // (tuning builds) end of the work-group's segit-th segment
             segit++;
         } else {
             j++;
         }
     }
+    PSDR_WGTRACE(a.trace, 7);
 }
 
 }  // namespace psdr
