@@ -2,7 +2,9 @@
 """Determinism soak: the same 64-frame batch of 2^20-point IQ frames processed over and over
 (with demodulation and waterfall running on the side stream) must give bit-identical spectra,
 pyramids and audio every time - tile tickets, double-buffered result sets and the persistent
-work-groups' LDS hazards all show up here if they are wrong.   tools/soak.py [iterations]"""
+work-groups' LDS hazards all show up here if they are wrong.   tools/soak.py [iterations] [real]
+With `real`: 2^21-point real frames (the fused second pass: chained tiles, carried rows in LDS, seam buffers
+double-buffered against the side stream's seam kernel)."""
 import os
 import sys
 import zlib
@@ -14,8 +16,10 @@ sys.path.insert(0, ROOT)
 from phantomsdr_amd import SpectrumEngine  # noqa: E402
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-N, F = 1 << 20, 64
-eng = SpectrumEngine(35_000_000, N, False, input_format="s16", max_batch=F, max_clients=16, max_waterfall_clients=4)
+is_real = len(sys.argv) > 2 and sys.argv[2] == "real"
+N, F = (1 << 21, 64) if is_real else (1 << 20, 64)
+eng = SpectrumEngine(70_000_000 if is_real else 35_000_000, N, is_real, input_format="s16", max_batch=F, max_clients=16,
+                     max_waterfall_clients=4)
 hb = eng.ctx.half_frame_bytes()
 rng = np.random.default_rng(7)
 raw = rng.integers(-2000, 2000, size=(2 * F + 1) * hb // 2, dtype=np.int16)
