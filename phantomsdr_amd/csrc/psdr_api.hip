@@ -461,7 +461,10 @@ int launch_pass2_real_t(psdr_ctx *c, const Pass2Args &a) {
 }
 // Tiles of one frame a work-group walks in a chain: long chains carry the mirror-side octets in LDS
 // (nothing extra in HBM), short chains give the persistent grid enough independent segments.  Aim
-// for about four segments per work-group.
+// for about two segments per work-group: the pass is bound by memory, not by balance (256 frames of
+// 2^21 points, same box: 1012-1023 us with 16 segments per work-group, 990-1030 with 8, 4 or 2), and
+// every segment costs one seam (k_real_seam: 177 / 89 / 52 / 31 us at 4 / 8 / 16 / 32 tiles per segment,
+// run beside the next batch's pass 1, which it slows).
 int real_seg_len(const psdr_ctx *c, int nframes) {
     const int G = c->M1 / 16;
     if (c->seg_len_env > 0) {
@@ -469,7 +472,7 @@ int real_seg_len(const psdr_ctx *c, int nframes) {
         while (sl * 2 <= c->seg_len_env && sl * 2 <= G) sl *= 2;
         return sl;
     }
-    const long long want = (long long)G * nframes / (4LL * std::max(c->num_cus, 1));
+    const long long want = (long long)G * nframes / (2LL * std::max(c->num_cus, 1));
     int sl = 1;
     while (sl * 2 <= want && sl * 2 <= G) sl *= 2;
     return sl;
