@@ -637,14 +637,15 @@ def main():
     del run
 
     # more of BASELINE.json's single-GPU shapes, each with its own value and whole-path fraction:
-    # the target's own wording (256 concurrent audio clients on one MI355X) and configs[2]
+    # the target's own wording (256 concurrent audio clients on one MI355X), configs[2] and one GPU's
+    # share of configs[4] (2^22-point real frames, 128 of the 1024 clients + 8 of the 64 waterfalls)
     extra = {}
     if not args.no_extra and wl_name == "cfg2":
-        for key, name, nc in (("clients256", "cfg2", 256), ("cfg3", "cfg3", None)):
+        for key, name, nc in (("clients256", "cfg2", 256), ("cfg3", "cfg3", None), ("cfg5_share", "cfg5", None)):
             try:
                 w2 = WORKLOADS[name] if nc is None else dict(WORKLOADS[name], modes=("USB", "LSB", "AM", "FM"))
                 r2 = SingleGpuRun(torch, device, local_rank, name, w2, F, args.ring_mib, nclients=nc)
-                st = min(args.steps, 50)
+                st = min(args.steps, 25 if name == "cfg5" else 50)
                 sm = r2.summary(r2.timed(st, min(args.warmup, 5), min_reps=3, min_total_s=0.3), st)
                 sm.update({"workload": (name + ": " + w2["desc"]) if nc is None else
                            f"cfg2 shape with {nc} mixed USB/LSB/AM/FM audio clients + {w2['waterfall']} waterfall clients on one GPU",
@@ -677,6 +678,7 @@ def main():
                  "kernels": kernels},
         "clients256": extra.get("clients256"),
         "cfg3": extra.get("cfg3"),
+        "cfg5_share": extra.get("cfg5_share"),
         "post_chain": post,
         "cpu_baseline": cpu,
     }
