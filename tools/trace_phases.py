@@ -57,4 +57,13 @@ for p in range(2):
         print(f"   {names2[k]:9s} {np.nanmin(col):7.2f} {np.nanmedian(col):7.2f} {np.nanmax(col):7.2f}")
     # per XCD (wg % 8) exit medians
     print("   exit by XCD:", " ".join(f"{np.nanmedian(rel[x::8, 7]):.1f}" for x in range(8)))
+# device-side boundary between the two passes of the same step (100 MHz wall clock, absolute):
+# last work-group of pass 1 out -> first work-group of pass 2 in -> its first tile's loads have landed
+e1, x1 = wg[0][:, 0].astype(np.float64), wg[0][:, 7].astype(np.float64)
+e2, pr2 = wg[1][:, 0].astype(np.float64), wg[1][:, 1].astype(np.float64)
+ok = (e1 > 0) & (x1 > 0) & (e2 > 0)
+if ok.any():
+    print("== boundary pass 1 -> pass 2 (us): median exit -> last exit %.1f | last exit -> first entry %.1f | first -> last entry %.1f | "
+          "entry -> prologue done (median) %.1f" % ((x1[ok].max() - np.median(x1[ok])) / 100, (e2[ok].min() - x1[ok].max()) / 100,
+                                                   (e2[ok].max() - e2[ok].min()) / 100, np.median(pr2[ok] - e2[ok]) / 100))
 eng.close()
