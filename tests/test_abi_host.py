@@ -101,13 +101,13 @@ def test_client_sharding_plan():
     assert assign_clients(5, 2) == [[0, 2, 4], [1, 3]]
 
 
-def _build_c_example():
+def _build_c_example(name="level1_demo"):
     import subprocess
     import tempfile
     d = tempfile.mkdtemp()
-    out = os.path.join(d, "level1_demo")
-    subprocess.check_call(["gcc", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "examples", "level1_demo.c"),
+    out = os.path.join(d, name)
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", name + ".c"),
                            "-L" + os.path.join(ROOT, "phantomsdr_amd"), "-lpsdr_hip", "-lm",
                            "-Wl,-rpath," + os.path.join(ROOT, "phantomsdr_amd"), "-o", out])
     return d, out
@@ -230,3 +230,158 @@ def test_level2_host_class_compiles_standalone():
         f.write('#include "hip_fanout.h"\nint use(HipFanout &f) { return f.add_audio_client(); }\n')
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
                            "-I" + os.path.join(ROOT, "phantomsdr_amd", "host"), os.path.join(d, "tu.cpp")])
+
+
+# ---- examples/stream_demo.c: stdin -> ingest ring -> FFT -> demodulation / waterfall -> the reference's packets ----
+STREAM_ARGS = dict(log2n=16, fmt="s16", sps=2_048_000, audio_sps=12000, batch=5)
+
+
+def _stream_demo_cmd(exe):
+    N = 1 << STREAM_ARGS["log2n"]
+    a = [exe, str(STREAM_ARGS["log2n"]), "0", STREAM_ARGS["fmt"], str(STREAM_ARGS["sps"]), str(STREAM_ARGS["audio_sps"]),
+         str(STREAM_ARGS["batch"])]
+    clients = [("USB", 20000, 20000.5, 20090), ("AM", 41000, 41080.0, 41160), ("FM", 9000, 9100.25, 9200), ("LSB", 50000, 50096.0, 50096)]
+    for mode, l, m, r in clients:
+        a += ["--audio", '{"cmd":"window","l":%d,"r":%d,"m":%r}' % (l, r, m), '{"cmd":"demodulation","demodulation":"%s"}' % mode]
+    wins = [(0, N), (30000, 32048)]
+    for l, r in wins:
+        a += ["--waterfall", '{"cmd":"window","l":%d,"r":%d}' % (l, r)]
+    return a, clients, wins
+
+
+def test_stream_demo_compiles_and_fails_loudly_without_a_gpu():
+    import subprocess
+    _, exe = _build_c_example("stream_demo")
+    cmd, _, _ = _stream_demo_cmd(exe)
+    r = subprocess.run(cmd, input=b"", capture_output=True)
+    if not HAVE_GPU:
+        assert r.returncode == 2 and b"No HIP devices found" in r.stderr
+
+
+@pytest.mark.gpu
+def test_stream_demo_end_to_end_against_the_oracle():
+    """raw cs16 on stdin through the ingest ring (13 half-frames: batches of 5, 5 and 2 frames, copies running
+    ahead of the transforms), four audio clients and two waterfall clients configured with the reference's JSON
+    command frames; stdout carries the hello frame, one audio CBOR packet per client and frame and one zstd-
+    streamed waterfall CBOR packet per client and sent frame.  Every packet is decoded here (own CBOR decoder,
+    libzstd's streaming API) and its payload compared with the oracle run on the same samples."""
+    import ctypes as C
+    import json
+    import subprocess
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import quantize_raw, synth_stream
+    from oracle import oracle as O
+    from test_wire_formats import cbor_decode
+    from phantomsdr_amd.core import derived_params
+    _, exe = _build_c_example("stream_demo")
+    cmd, clients, wins = _stream_demo_cmd(exe)
+    N, nfr = 1 << STREAM_ARGS["log2n"], 12
+    x = synth_stream((nfr + 1) * (N // 2), False, seed=33, fft_size=N)
+    raw = quantize_raw(x, "s16", False)
+    r = subprocess.run(cmd, input=raw.tobytes(), capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    p = derived_params(STREAM_ARGS["sps"], N, False, STREAM_ARGS["audio_sps"], 1024)
+    n, levels, skip = p["audio_fft_size"], p["downsample_levels"], p["skip_num"]
+    assert ("%d frames of %d points" % (nfr, N)).encode() in r.stderr and ("n = %d, levels = %d, skip = %d" % (n, levels, skip)).encode() in r.stderr
+    # split the record stream
+    recs, b, i = [], r.stdout, 0
+    while i < len(b):
+        kind, cl, ln = chr(b[i]), int.from_bytes(b[i + 1:i + 5], "little"), int.from_bytes(b[i + 5:i + 9], "little")
+        recs.append((kind, cl, b[i + 9:i + 9 + ln]))
+        i += 9 + ln
+    assert i == len(b)
+    hello = json.loads(recs[0][2])
+    assert recs[0][0] == "H" and hello["fft_size"] == N and hello["audio_max_fft"] == n and hello["defaults"]["l"] == clients[0][1]
+    # oracle on the same samples
+    conv = O.convert(raw, "s16").view(np.complex64).reshape(nfr + 1, N // 2)
+    fo = O.FFT(N, False, levels, 0, n)
+    ocl = []
+    for mode, l, m, rr in clients:
+        c = O.AudioClient(False, n, STREAM_ARGS["audio_sps"], N)
+        c.set_audio_demodulation(mode)
+        assert c.on_window_message(l, m, rr)
+        ocl.append(c)
+    want_audio, want_q = {}, []
+    for f in range(nfr):
+        fo.load(conv[f], conv[f + 1])
+        fo.execute()
+        spec = fo.output().copy()
+        want_q.append(fo.quantized().copy())
+        for ci, c in enumerate(ocl):
+            a_o, p_o, _, dropped = c.send_audio(spec, f, fft=fo)
+            assert not dropped
+            want_audio[(ci, f)] = (a_o, p_o, c.mode)
+    # audio packets: one per client and frame, in frame order per client, labelled with the client's window
+    seen = {}
+    for kind, cl, body in recs:
+        if kind != "A":
+            continue
+        d = cbor_decode(body)
+        assert list(d) == ["data", "frame_num", "l", "m", "pwr", "r"]
+        mode, l, m, rr = clients[cl]
+        assert (d["l"], d["m"], d["r"]) == (l, m, rr)
+        f = d["frame_num"]
+        assert f == seen.get(cl, -1) + 1
+        seen[cl] = f
+        a_g = np.frombuffer(d["data"], np.float32)
+        a_o, p_o, omode = want_audio[(cl, f)]
+        assert a_g.size == n // 2
+        assert abs(d["pwr"] - p_o) <= 1e-4 * max(abs(p_o), 1e-30) + 1e-30
+        if omode == O.FM:
+            dd = np.abs(np.angle(np.exp(1j * (a_g.astype(np.float64) - a_o))))
+            assert np.median(dd) < 2e-3
+        else:
+            assert np.abs(a_g - a_o).max() <= 3e-4 * max(np.abs(a_o).max(), 1e-30) + 1e-9, (cl, f)
+    assert seen == {ci: nfr - 1 for ci in range(len(clients))}
+    # waterfall packets: every skip-th frame, through ONE zstd stream per client
+    z = None
+    try:
+        z = C.CDLL("libzstd.so.1")
+    except OSError:
+        pass
+    kinds = {k for k, _, _ in recs}
+    assert ("Z" in kinds) == (z is not None) and ("Z" in kinds) != ("W" in kinds)
+
+    class Buf(C.Structure):
+        _fields_ = [("p", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+    if z is not None:
+        z.ZSTD_createDStream.restype = C.c_void_p
+        z.ZSTD_decompressStream.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        z.ZSTD_decompressStream.restype = C.c_size_t
+        z.ZSTD_freeDStream.argtypes = [C.c_void_p]
+    streams, nsent = {}, {}
+    for kind, cl, body in recs:
+        if kind not in "WZ":
+            continue
+        if kind == "Z":
+            ds = streams.setdefault(cl, z.ZSTD_createDStream())
+            src = (C.c_uint8 * len(body)).from_buffer_copy(body)
+            dst = (C.c_uint8 * (N + 256))()
+            ib, ob = Buf(C.cast(src, C.c_void_p), len(body), 0), Buf(C.cast(dst, C.c_void_p), len(dst), 0)
+            z.ZSTD_decompressStream(ds, C.byref(ob), C.byref(ib))
+            assert ib.pos == len(body)          # a flushed packet decodes completely on arrival
+            body = bytes(dst[: ob.pos])
+        d = cbor_decode(body)
+        assert list(d) == ["data", "frame_num", "l", "r"]
+        f = d["frame_num"]
+        assert f % skip == 0 and f == nsent.get(cl, -skip) + skip
+        nsent[cl] = f
+        # the level WaterfallClient::on_window_message picks for this window (src/waterfall.cpp:62-79)
+        l0, r0 = wins[cl]
+        best, lv, lf, rf, ll, rr = 2048.0, levels - 1, float(l0), float(r0), l0, r0
+        for i2 in range(levels):
+            if abs((rf - lf) - 1024.0) < best:
+                best, lv, ll, rr = abs((rf - lf) - 1024.0), i2, int(round(lf)), int(round(rf))
+            lf, rf = lf / 2, rf / 2
+        assert (d["l"], d["r"]) == (ll << lv, rr << lv)
+        row = np.frombuffer(d["data"], np.int8)
+        off = sum(N >> t for t in range(lv))
+        want = want_q[f][off + ll: off + rr]
+        dq = np.abs(row.astype(np.int16) - want.astype(np.int16))
+        assert row.size == rr - ll and dq.max() <= 1 and (dq != 0).mean() <= 5e-3, (cl, f, dq.max())
+    last = ((nfr - 1) // skip) * skip
+    assert nsent == {0: last, 1: last}
+    for ds in streams.values():
+        z.ZSTD_freeDStream(ds)
