@@ -139,9 +139,11 @@ int main(int argc, char **argv) {
         put_record('H', 0, js, (uint32_t)len);
     }
 
-    /* ingest ring in HBM + pinned staging of the same shape: half k sits in slot k % nh of both */
+    /* ingest ring in HBM + pinned staging of the same shape: half k sits in slot k % nh of both.  Three
+     * batches long: batches start at multiples of `batch`, so none crosses the end of the ring, and the copies
+     * of the next batch never have to wait for the transform of the current one */
     const size_t hb = psdr_half_frame_bytes(ctx);
-    const int nh = 2 * batch + 2;
+    const int nh = 3 * batch;
     CHECK(psdr_ring_create(ctx, nh));
     float *staging = NULL;
     CHECK(psdr_host_alloc(ctx, (size_t)nh * hb / sizeof(float) + 1, &staging));

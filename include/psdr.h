@@ -119,7 +119,9 @@ size_t psdr_half_frame_bytes(const psdr_ctx *ctx);
  * The context owns a ring of `nhalves` raw half-frames in HBM.  psdr_ring_write_async() copies one
  * half-frame from (pinned) host memory into slot `half_index % nhalves` on a dedicated COPY stream and
  * returns at once; psdr_process_ring() transforms frames first_half .. first_half+nframes-1 (frame f
- * = halves f, f+1; the window may wrap around the ring) after waiting, on the device, for the copies
+ * = halves f, f+1; the frames of one call must not cross the end of the ring - first_half % nhalves +
+ * nframes <= nhalves, the last frame's second half may be slot 0 again: size the ring as a multiple of the
+ * batch) after waiting, on the device, for the copies
  * of exactly the halves it reads - so the PCIe transfer of later halves overlaps the transform of
  * earlier ones.  A slot may be rewritten as soon as the psdr_process_ring() call that read it has
  * been issued (the copy waits for that batch on the device).  The source buffer must stay valid
