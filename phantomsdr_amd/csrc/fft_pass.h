@@ -687,7 +687,14 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
     constexpr int NLD = 16;                          // 16-byte loads per thread and tile
     constexpr int NTICK = 2 * (Plan<L>::NS - 1);     // ticks that carry loads (not the last stage)
     constexpr int EARLY = 4;                         // loads issued right after the registers die
-    constexpr int LPT = (NLD - EARLY + NTICK - 1) / NTICK;
+    // ... and LATE of them only in the epilogue (half before the last stage, half before the record loop):
+    // with all sixteen issued during the front stages the read side of the memory system idles while the
+    // tile's 150 KB of stores drain.  Same box, interleaved, 256 frames: 857 -> 833 us (LATE 8 or 10, EARLY
+    // 4 or 2 alike); the fused real-input pass 1014 -> 970 us.  (Pass 1 gains nothing from it - its stores
+    // are the whole last stage - and loses 35 us with eight loads that late.)
+    constexpr int LATE = FUSED ? 8 : 0;
+    constexpr int NFRONT = NLD - LATE;
+    constexpr int LPT = (NFRONT - EARLY + NTICK - 1) / NTICK;
     const int tid = threadIdx.x;
     PSDR_WGTRACE(a.trace, 0);
     const int p_ = tid % H, i0_ = tid / H;
@@ -776,7 +783,10 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
         (void)Xt;
         float *Pst = reinterpret_cast<float *>(smem);  // reuses the (dead) tile after the last read
         run_stages<L, T, true>(
-            tile, Wl, i0, p, u, [&]() {},
+            tile, Wl, i0, p, u,
+            [&]() {
+                if (LATE > 0 && more) static_for<NFRONT, NFRONT + LATE / 2>(issue);
+            },
             [&](int, int, int c2i, c2 x) {
                 if (FUSED) {
                     x.a.x *= a.inv_n;
@@ -797,8 +807,8 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
                 if (more)
                     static_switch<0, NTICK>(k, [&](auto kc) {
                         constexpr int K = decltype(kc)::value;
-                        constexpr int lo = EARLY + K * LPT < NLD ? EARLY + K * LPT : NLD;
-                        constexpr int hi = lo + LPT < NLD ? lo + LPT : NLD;
+                        constexpr int lo = EARLY + K * LPT < NFRONT ? EARLY + K * LPT : NFRONT;
+                        constexpr int hi = lo + LPT < NFRONT ? lo + LPT : NFRONT;
                         static_for<lo, hi>(issue);
                     });
             },
@@ -807,6 +817,7 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
 
         if (FUSED) {
             __syncthreads();
+            if (LATE > 0 && more) static_for<NFRONT + LATE / 2, NLD>(issue);
             PSDR_TRACE(a.trace, it, 11);
             constexpr int CH = T < 16 ? T : 16;  // values per chunk (one aligned group)
             constexpr int NG = (L * T / CH) / NT;  // chunks per thread; chunks tile Pst linearly
@@ -946,7 +957,9 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
     constexpr int NTICK = 2 * (Plan<L>::NS - 1);
     constexpr int EARLY = 4;
     PSDR_WGTRACE(a.trace, 0);
-    constexpr int LPT = (NLD - EARLY + NTICK - 1) / NTICK;
+    constexpr int LATE = 8;  // loads of the next tile issued in the epilogue (half before the last stage, half before the octet loop; see pass2_body)
+    constexpr int NFRONT = NLD - LATE;
+    constexpr int LPT = (NFRONT - EARLY + NTICK - 1) / NTICK;
     constexpr int NBL = 16 / LastStage<L>::R;
     const int tid = threadIdx.x;
     const int p_ = tid % H, i0_ = tid / H;
@@ -1072,12 +1085,13 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                 if (more)
                     static_switch<0, NTICK>(k, [&](auto kc) {
                         constexpr int K = decltype(kc)::value;
-                        constexpr int lo = EARLY + K * LPT < NLD ? EARLY + K * LPT : NLD;
-                        constexpr int hi = lo + LPT < NLD ? lo + LPT : NLD;
+                        constexpr int lo = EARLY + K * LPT < NFRONT ? EARLY + K * LPT : NFRONT;
+                        constexpr int hi = lo + LPT < NFRONT ? lo + LPT : NFRONT;
                         static_for<lo, hi>(issue);
                     });
             },
             [&](int) {});
+        if (LATE > 0 && more) static_for<NFRONT, NFRONT + LATE / 2>(issue);
         const cf w0 = cmul(wc, wg);
         cf *Xt = Xf + (size_t)g * (16 * L);  // line (g, c) of the frame starts at Xt + 16 * c
         // Octet staging Pst[c2][16]: [0..8) the low octet of column c2; [8..15) elements 1..7 of the
@@ -1174,6 +1188,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             }
         }
         __syncthreads();  // octet staging (and the carry) complete
+        if (LATE > 0 && more) static_for<NFRONT + LATE / 2, NLD>(issue);
         {
             int8_t *Qf = a.Qt + (size_t)f * a.qt_stride;
             float *Pf = a.Pscr + (size_t)f * a.p_stride;
