@@ -291,6 +291,8 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
 
       clients  audio clients sharded over the ranks (client i -> rank i mod G); rank 0 FFTs and
                broadcasts each spectrum batch (8N bytes per frame) over RCCL/xGMI
+      clients_pipelined  the same exchange, software-pipelined: the broadcast of batch i (from a staged copy) runs
+               beside the transform of batch i+1 and the demodulation of batch i-1
       raw      the same sharding, but rank 0 broadcasts the RAW new half-frames (cs16: 2N bytes per
                frame, 4x fewer) and every rank runs the forward FFT itself (SURVEY 8e variant i)
       band     clients sharded by frequency band (rank g owns the windows starting in its 1/G of the spectrum);
@@ -301,9 +303,9 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
     """
     import torch.distributed as dist
     from phantomsdr_amd import SpectrumEngine
-    from phantomsdr_amd.distributed import (BandShardedRunner, HipBackend, HipBandBackend, HipRawBackend, HipTimeBackend,
-                                            RawShardedRunner, ShardedRunner, TimeShardedRunner, assign_clients,
-                                            assign_clients_by_band, band_bounds)
+    from phantomsdr_amd.distributed import (BandShardedRunner, HipBackend, HipBandBackend, HipPipelinedBackend, HipRawBackend,
+                                            HipTimeBackend, PipelinedShardedRunner, RawShardedRunner, ShardedRunner,
+                                            TimeShardedRunner, assign_clients, assign_clients_by_band, band_bounds)
 
     device = torch.device("cuda", local_rank)
     if not dist.is_initialized():
@@ -370,6 +372,13 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
                 par = (f"clients sharded over {world} GPUs (client i -> rank i mod G); rank 0 broadcasts the RAW new "
                        "half-frames over RCCL, every rank runs the forward FFT")
                 bytes_per_frame = hb
+            elif mode == "clients_pipelined":
+                backend = HipPipelinedBackend(torch, eng.ctx, device, ring.data_ptr() if ring is not None else 0, nbatches, F,
+                                              rank == 0)
+                runner = PipelinedShardedRunner(backend, dist, rank, world, F)
+                par = (f"clients sharded over {world} GPUs (client i -> rank i mod G); rank 0 FFT + staged copy + RCCL "
+                       "broadcast of the spectrum batch, the broadcast of batch i overlapping the transform of batch i+1")
+                bytes_per_frame = 8 * params["fft_result_size"]
             elif mode == "band":
                 backend = HipBandBackend(torch, eng.ctx, device, ring.data_ptr() if ring is not None else 0, nbatches, F,
                                          rank, world, halo)
@@ -434,7 +443,7 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
 
     main_mode = args.shard
     results = {}
-    for m in (main_mode,) + tuple(x for x in ("clients", "raw", "band", "time") if x != main_mode):
+    for m in (main_mode,) + tuple(x for x in ("clients", "clients_pipelined", "raw", "band", "time") if x != main_mode):
         try:
             results[m] = measure(m, args.steps if m == main_mode else min(args.steps, 30),
                                  args.warmup if m == main_mode else min(args.warmup, 5))
@@ -567,7 +576,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the clients256 / cfg3 sub-objects (profiling runs of one workload)")
     ap.add_argument("--ring-mib", type=int, default=512)
-    ap.add_argument("--shard", default="clients", choices=["clients", "time", "raw", "band"],
+    ap.add_argument("--shard", default="clients", choices=["clients", "clients_pipelined", "time", "raw", "band"],
                     help="N > 1: shard the clients with a spectrum broadcast (BASELINE.json configs[3], default), "
                          "the clients with a RAW half-frame broadcast + replicated FFT, the clients by frequency band "
                          "with a scatter of one band per rank, or the stream (no collective)")

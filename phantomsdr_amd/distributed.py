@@ -80,6 +80,57 @@ class ShardedRunner:
         self.frame_num += self.F
 
 
+class PipelinedShardedRunner:
+    """ShardedRunner with the broadcast of batch i running beside the root's transform of batch i+1 and
+    everybody's demodulation of batch i-1 (the same one-step software pipeline as BandShardedRunner, with
+    the whole spectrum as the one "band"): the step rate becomes max(compute, link time) instead of their
+    sum.  The root copies each finished spectrum batch out of the transform's own buffer into one of two
+    send buffers (that copy is what lets the next transform start); results arrive one step late, flush()
+    delivers the last batch.  backend: forward(i) (root), stage(par) (root: fill spectrum_tensor(par)),
+    spectrum_tensor(par), demod(first_frame_num, par)."""
+
+    def __init__(self, backend, dist, rank, world, frames_per_step, root=0):
+        self.backend, self.dist = backend, dist
+        self.rank, self.world, self.F, self.root = rank, world, frames_per_step, root
+        self.frame_num = 0
+        self.bytes_broadcast = 0
+        self._n = 0
+        self._pending = None
+
+    def _ctx(self):
+        ctx = getattr(self.backend, "stream_context", None)
+        return ctx() if ctx else contextlib.nullcontext()
+
+    def _drain(self):
+        work, par, first = self._pending
+        self._pending = None
+        if work is not None:
+            work.wait()
+        self.backend.demod(first, par)
+
+    def step(self, i):
+        par = self._n & 1
+        with self._ctx():
+            if self.rank == self.root:
+                self.backend.forward(i)
+                self.backend.stage(par)
+            work = None
+            if self.world > 1:
+                t = self.backend.spectrum_tensor(par)
+                work = self.dist.broadcast(t, src=self.root, async_op=True)
+                self.bytes_broadcast += t.numel() * t.element_size()
+            if self._pending is not None:
+                self._drain()
+            self._pending = (work, par, self.frame_num)
+        self.frame_num += self.F
+        self._n += 1
+
+    def flush(self):
+        if self._pending is not None:
+            with self._ctx():
+                self._drain()
+
+
 class RawShardedRunner:
     """SURVEY 8e variant (i): clients sharded as in ShardedRunner, but what crosses xGMI is the RAW
     new half-frames (cs16: 2.1 MB per 2^20-point frame, 4x fewer bytes than the 8.39 MB spectrum)
@@ -371,6 +422,48 @@ class HipBandBackend:
         from ._lib import check
         check(self.ctx.lib.psdr_demod_batch_from_band(self.ctx.h, C.c_void_p(self.band[par].data_ptr()), self.bins,
                                                       self.first, self.bins, self.F, first_frame_num))
+        self.ctx.last_nframes = self.ctx.last_demod_frames = self.F
+
+
+class HipPipelinedBackend:
+    """PipelinedShardedRunner back-end on the HIP library: the staged copy is psdr_pack_band over the whole
+    spectrum (linear, client order), the receivers demodulate with psdr_demod_batch_from_band."""
+
+    def __init__(self, torch, ctx, device, ring_ptr, nbatches, frames_per_step, is_root):
+        import ctypes as C
+        from ._lib import check
+        self.torch, self.ctx, self.F = torch, ctx, frames_per_step
+        self.ring_ptr, self.nbatches = ring_ptr, nbatches
+        self.hb = ctx.half_frame_bytes()
+        self.R = ctx.N // 2 if ctx.is_real else ctx.N
+        self.stream = torch.cuda.Stream(device=device)
+        assert self.stream.cuda_stream != 0
+        check(ctx.lib.psdr_set_stream(ctx.h, C.c_void_p(self.stream.cuda_stream)))
+        self.buf = torch.empty((2, frames_per_step, self.R), dtype=torch.complex64, device=device)
+
+    def stream_context(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    def forward(self, i):
+        b = i % self.nbatches
+        self.ctx.process_batch(self.ring_ptr, self.F, offset_bytes=b * self.F * self.hb)
+
+    def stage(self, par):
+        import ctypes as C
+        from ._lib import check
+        check(self.ctx.lib.psdr_pack_band(self.ctx.h, self.F, 0, self.R, C.c_void_p(self.buf[par].data_ptr()), self.R))
+
+    def spectrum_tensor(self, par):
+        return self.buf[par]
+
+    def demod(self, first_frame_num, par):
+        import ctypes as C
+        from ._lib import check
+        check(self.ctx.lib.psdr_demod_batch_from_band(self.ctx.h, C.c_void_p(self.buf[par].data_ptr()), self.R, 0, self.R,
+                                                      self.F, first_frame_num))
         self.ctx.last_nframes = self.ctx.last_demod_frames = self.F
 
 

@@ -139,6 +139,78 @@ def test_two_rank_sharding_matches_single_process():
 
 
 # ---------------------------------------------------------------------------------------
+# the same sharding with the broadcast of batch i overlapping the transform of batch i+1
+# ---------------------------------------------------------------------------------------
+class OraclePipelinedBackend(OracleBackend):
+    def __init__(self, torch, halves, my_clients):
+        super().__init__(torch, halves, my_clients)
+        self.bufs = torch.zeros((2, F, N + NAUD), dtype=torch.complex64)
+
+    def stage(self, par):
+        self.bufs[par].copy_(self.spec)
+
+    def spectrum_tensor(self, par):
+        return self.bufs[par]
+
+    def demod(self, first_frame_num, par):
+        for f in range(F):
+            s = self.bufs[par, f].numpy()
+            for ci, c in enumerate(self.clients):
+                a, _, _, _ = c.send_audio(s, first_frame_num + f, fft=self.fo)
+                self.audio[ci].append(a)
+
+
+def _pipe_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from phantomsdr_amd.distributed import PipelinedShardedRunner, assign_clients, gather_audio_to_root
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        allc = _clients()
+        mine = assign_clients(len(allc), world)[rank]
+        be = OraclePipelinedBackend(torch, _halves(), [allc[i] for i in mine])
+        runner = PipelinedShardedRunner(be, dist, rank, world, F)
+        for i in range(NBATCH):
+            runner.step(i)
+            assert all(len(a) == i * F for a in be.audio)      # one step late
+        runner.flush()
+        merged = gather_audio_to_root(dist, rank, world, mine, [np.stack(a) for a in be.audio], len(allc))
+        if rank == 0:
+            q.put((merged, runner.bytes_broadcast))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_pipelined_broadcast_matches_single_process():
+    import torch
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    from phantomsdr_amd.distributed import ShardedRunner
+    allc = _clients()
+    be = OracleBackend(torch, _halves(), allc)
+    r1 = ShardedRunner(be, None, 0, 1, F)
+    for i in range(NBATCH):
+        r1.step(i)
+    ref = [np.stack(a) for a in be.audio]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    merged, nbytes = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert nbytes == NBATCH * F * (N + NAUD) * 8
+    for a, b in zip(merged, ref):
+        assert np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------
 # raw-half broadcast (SURVEY 8e variant i): the new half-frames cross the wire, every rank transforms
 # ---------------------------------------------------------------------------------------
 class OracleRawBackend:

@@ -309,3 +309,52 @@ def test_band_sharding_matches_unsharded(wl_name, world, g):
             check(e.ctx.lib.psdr_set_stream(e.ctx.h, None))
         for e in (engA, engR, engG):
             e.close()
+
+
+def test_pipelined_broadcast_backend_matches_unsharded():
+    """PipelinedShardedRunner + HipPipelinedBackend on ONE GPU (world = 1): transform, staged linear copy of
+    the whole spectrum (psdr_pack_band over [0, R)), demodulation one step late from the staged copy
+    (psdr_demod_batch_from_band) - bit-identical to psdr_process_batch + psdr_demod_batch."""
+    import torch
+    from phantomsdr_amd import SpectrumEngine
+    from phantomsdr_amd._lib import check
+    from phantomsdr_amd.distributed import HipPipelinedBackend, PipelinedShardedRunner
+    B = _bench()
+    wl = B.WORKLOADS["cfg4"]
+    N, F, nb_ = wl["fft_size"], 3, 3
+    dev = torch.device("cuda", 0)
+    x = synth_stream((nb_ * F + 1) * (N // 2), False, seed=23, fft_size=N)
+    raw = quantize_raw(x, "s16", False)
+    del x
+    ring = torch.from_numpy(raw.view(np.int16)).to(dev)
+    torch.cuda.synchronize()
+    mk = lambda: SpectrumEngine(wl["sps"], N, False, input_format="s16", max_batch=F, max_clients=32, max_waterfall_clients=1)
+    engA, engB = mk(), mk()
+    try:
+        clients = B.make_clients(dict(wl, modes=("USB", "LSB", "AM", "FM")), engA.params, seed=5, count=32)
+        gA, gB = ([e.add_audio_client(l, m, r, mode) for mode, l, m, r in clients] for e in (engA, engB))
+        hb = engA.ctx.half_frame_bytes()
+        runner = PipelinedShardedRunner(HipPipelinedBackend(torch, engB.ctx, dev, ring.data_ptr(), nb_, F, True), None, 0, 1, F)
+        want = []
+        for b in range(nb_):
+            engA.ctx.process_batch(ring.data_ptr(), F, offset_bytes=b * F * hb)
+            engA.ctx.demod_batch(b * F)
+            engA.ctx.synchronize()
+            want.append([g.read_audio(F) for g in gA])
+        for b in range(nb_ + 1):
+            if b < nb_:
+                runner.step(b)
+            else:
+                runner.flush()
+            runner.backend.synchronize()
+            if b == 0:
+                continue                      # results arrive one step late
+            for ci in range(len(clients)):
+                a2, p2, n2 = gB[ci].read_audio(F)
+                a1, p1, n1 = want[b - 1][ci]
+                assert np.array_equal(a1.view(np.uint32), a2.view(np.uint32)), f"batch {b - 1} client {ci}"
+                assert np.array_equal(p1.view(np.uint32), p2.view(np.uint32)) and np.array_equal(n1, n2)
+    finally:
+        check(engB.ctx.lib.psdr_set_stream(engB.ctx.h, None))
+        for e in (engA, engB):
+            e.close()
