@@ -168,3 +168,41 @@ def test_ring_ingest_matches_flat_upload(N, is_real):
     finally:
         a.close()
         b.close()
+
+
+def test_band_calls_refuse_bad_arguments():
+    """psdr_pack_band / psdr_demod_batch_from_band: state and range errors come back as codes with a message,
+    nothing is launched"""
+    from phantomsdr_amd import AudioClient, Context
+    N, n, F = 1 << 14, 60, 2
+    ctx = Context(N, False, _levels(N), additional_size=n, audio_fft_size=n, audio_rate=12000, input_format="s16",
+                  max_batch=F, max_clients=2, max_waterfall_clients=1, skip_num=1)
+    try:
+        L = ctx.lib
+        buf = ctx.dev_alloc(F * N * 8)
+        assert L.psdr_pack_band(ctx.h, 1, 0, 64, buf, 64) == -4          # before any batch
+        x = synth_stream((F + 1) * (N // 2), False, seed=3, fft_size=N)
+        raw = quantize_raw(x, "s16", False)
+        d = ctx.dev_alloc(raw.nbytes)
+        ctx.h2d(d, raw)
+        ctx.process_batch(d, F)
+        assert L.psdr_pack_band(ctx.h, F + 1, 0, 64, buf, 64) == -1      # more frames than the batch
+        assert L.psdr_pack_band(ctx.h, F, N, 64, buf, 64) == -1          # first bin outside
+        assert L.psdr_pack_band(ctx.h, F, 0, N + 1, buf, N + 1) == -1    # wider than the spectrum
+        assert L.psdr_pack_band(ctx.h, F, 0, 64, buf, 32) == -1          # stride < bins
+        assert L.psdr_pack_band(ctx.h, F, 0, 64, None, 64) == -1
+        assert L.psdr_pack_band(ctx.h, F, N - 10, 64, buf, 64) == 0       # wraps at the end: fine
+        c = AudioClient(ctx)
+        c.set_audio_demodulation("USB")
+        assert c.on_window_message(1000, 1000.0, 1030)
+        assert L.psdr_demod_batch_from_band(ctx.h, buf, 64, 990, 64, F, 0) == 0        # [990, 1054) holds it
+        assert L.psdr_demod_batch_from_band(ctx.h, buf, 64, 1001, 64, F, 0) == -1      # l below the band
+        assert b"outside the band" in L.psdr_last_error()
+        assert L.psdr_demod_batch_from_band(ctx.h, buf, 64, 980, 40, F, 0) == -1       # r beyond the band
+        assert L.psdr_demod_batch_from_band(ctx.h, buf, 16, 990, 64, F, 0) == -1       # stride < bins
+        assert L.psdr_demod_batch_from_band(ctx.h, buf, 64, 990, 64, F + 1, 0) == -1   # > max_batch
+        ctx.synchronize()
+        ctx.dev_free(buf)
+        ctx.dev_free(d)
+    finally:
+        ctx.close()
