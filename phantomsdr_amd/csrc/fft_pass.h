@@ -1034,6 +1034,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         unsigned f;
         int g;
         tile_of(s, j, f, g);
+        PSDR_TRACE(a.trace, it, 0);
         const bool seg_first = j == 0, seg_last = j == SL - 1;
         const unsigned si = s - f * S;
         bool more;
@@ -1069,10 +1070,13 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         PSDR_SCHED_FENCE();
         if (more) static_for<0, EARLY>(issue);
         PSDR_SCHED_FENCE();
+        PSDR_TRACE(a.trace, it, 1);
         __syncthreads();
+        PSDR_TRACE(a.trace, it, 2);
         c2 u[16];
         tile_read<L, H, true>(u, tile, i0, p);
         __syncthreads();
+        PSDR_TRACE(a.trace, it, 3);
 
         cf *Xf = a.X + (size_t)f * a.spec_stride;
         float *Pst = reinterpret_cast<float *>(smem);             // [L][16]: low octet, high octet
@@ -1090,7 +1094,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                         static_for<lo, hi>(issue);
                     });
             },
-            [&](int) {});
+            [&](int k) { PSDR_TRACE(a.trace, it, k); });
         if (LATE > 0 && more) static_for<NFRONT, NFRONT + LATE / 2>(issue);
         const cf w0 = cmul(wc, wg);
         cf *Xt = Xf + (size_t)g * (16 * L);  // line (g, c) of the frame starts at Xt + 16 * c
@@ -1187,7 +1191,9 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                 }
             }
         }
+        PSDR_TRACE(a.trace, it, 10);
         __syncthreads();  // octet staging (and the carry) complete
+        PSDR_TRACE(a.trace, it, 11);
         if (LATE > 0 && more) static_for<NFRONT + LATE / 2, NLD>(issue);
         {
             int8_t *Qf = a.Qt + (size_t)f * a.qt_stride;
@@ -1220,7 +1226,9 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                 PSDR_SCHED_FENCE();
             }
         }
+        PSDR_TRACE(a.trace, it, 12);
         __syncthreads();  // the tile is free again
+        PSDR_TRACE(a.trace, it, 13);
         if (seg_last) {
             const unsigned s2 = s_next[segit & 1];
             s = snext;

@@ -24,6 +24,15 @@ fn = C.CDLL(os.environ.get("PSDR_LIB")).psdr_debug_trace
 fn.argtypes = [C.c_void_p, C.c_void_p]
 assert fn(eng.ctx.h, buf) == 0
 allv = np.array(buf, dtype=np.int64)
+t = allv[2432:2560].reshape(8, 16)
+names = {0: "top", 1: "xpose-wr(+ld wait)", 2: "bar", 3: "rd+bar", 4: "stage0", 5: "bar", 6: "rd+bar",
+         7: "stage1", 8: "bar", 9: "rd+bar", 10: "last stage+untangle+stores", 11: "bar", 12: "octet loop", 13: "bar(end)"}
+print("pass 2 (real), work-group 0, cycles between marks:")
+for it in range(1, 5):
+    row = t[it]
+    marks = sorted([(k, row[k]) for k in range(14) if row[k] != 0], key=lambda x: x[1])
+    out = [f"{names.get(k1, k1)}={c1 - c0}" for (k0, c0), (k1, c1) in zip(marks[:-1], marks[1:])]
+    print(f" it{it}: total={marks[-1][1] - marks[0][1] if marks else 0}  " + "  ".join(out))
 w = allv[2688:4736].reshape(256, 8).astype(np.float64)
 t0 = w[:, 0][w[:, 0] > 0].min()
 rel = (w - t0) / 100.0
