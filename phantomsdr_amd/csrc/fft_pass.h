@@ -254,8 +254,9 @@ __device__ __forceinline__ unsigned xcd_slot(unsigned bid, unsigned total) {
 struct TileQueue {
     unsigned *tickets;
     unsigned total, base;  // indices below 2*gridDim.x are the static first tiles
-    unsigned pending;      // thread 0: ticket drawn from the own counter, not yet examined
-    bool dynamic, global;
+    unsigned pending;      // thread 0: ticket drawn, not yet examined
+    unsigned ptx;          // ... and the XCD whose counter it came from
+    bool dynamic, global, own_done;
     // global_: ONE counter for the whole chip (perfect balance, no XCD affinity)
     __device__ __forceinline__ void init(unsigned *t, unsigned total_, bool global_ = false) {
         global = global_;
@@ -263,6 +264,8 @@ struct TileQueue {
         total = total_;
         base = gridDim.x >> 2;  // 2*gridDim.x / 8
         pending = 0;
+        ptx = blockIdx.x & 7u;
+        own_done = false;
         dynamic = t != nullptr && 2u * gridDim.x < total_;
     }
     // thread 0: start drawing (no wait)
@@ -277,7 +280,8 @@ struct TileQueue {
             // passes (pass 2 moves 4.9 GB per 256 frames at 5.6 TB/s - it waits for memory either way),
             // -3 % on the fused real-input pass 2 together with the scalar twiddle load there.
             typedef __attribute__((address_space(1))) unsigned gu32;  // global, not flat: flat returns out of order
-            gu32 *p = (gu32 *)(tickets + (global ? 0u : (blockIdx.x & 7u)));
+            ptx = own_done ? (blockIdx.x & 7u) ^ 1u : blockIdx.x & 7u;
+            gu32 *p = (gu32 *)(tickets + (global ? 0u : ptx));
             asm volatile("" : "+v"(p));
             pending = __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -298,10 +302,24 @@ struct TileQueue {
             if (!tickets) {  // static round-robin
                 if (prev2 < total) s = prev2 + 2u * gridDim.x;
             } else if (dynamic) {
-                const unsigned x = blockIdx.x & 7u;
-                s = global ? pending + 2u * gridDim.x : (pending + base) * 8u + x;
-                if (s >= total) s = 0xFFFFFFFFu;  // no stealing across XCDs: probing seven more
-                                                  // counters costs a memory round trip each
+                s = global ? pending + 2u * gridDim.x : (pending + base) * 8u + ptx;
+#ifndef PSDR_NO_PARTNER_STEAL
+                if (!global && s >= total && !own_done) {
+                    // The own queue is empty: go on with the queue of the neighbouring XCD (x ^ 1).  Pass 1's
+                    // even XCDs are consistently ~2 % slower than the odd ones (tools/trace_phases.py, every
+                    // box seen), which left the chip half idle for the last 12-17 us of every launch.  One
+                    // synchronous draw per work-group (its result is needed now), asynchronous ones after.
+                    // (Probing all seven other counters was tried in round 1: +27 us per launch.)
+                    own_done = true;
+                    ptx = (blockIdx.x & 7u) ^ 1u;
+                    typedef __attribute__((address_space(1))) unsigned gu32;
+                    gu32 *p = (gu32 *)(tickets + ptx);
+                    asm volatile("" : "+v"(p));
+                    const unsigned t2 = __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s = (t2 + base) * 8u + ptx;
+                }
+#endif
+                if (s >= total) s = 0xFFFFFFFFu;
             }
             *slot = s;
         }
