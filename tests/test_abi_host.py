@@ -11,6 +11,16 @@ import pytest
 from conftest import HAVE_GPU, ROOT
 
 
+def _mkdtemp():
+    """a scratch directory that does not outlive the test session"""
+    import atexit
+    import shutil
+    import tempfile
+    d = tempfile.mkdtemp(prefix="psdr_test_")
+    atexit.register(shutil.rmtree, d, ignore_errors=True)
+    return d
+
+
 def header_functions():
     txt = open(os.path.join(ROOT, "include", "psdr.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
@@ -104,7 +114,7 @@ def test_client_sharding_plan():
 def _build_c_example(name="level1_demo"):
     import subprocess
     import tempfile
-    d = tempfile.mkdtemp()
+    d = _mkdtemp()
     out = os.path.join(d, name)
     subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "examples", name + ".c"),
@@ -169,7 +179,7 @@ def test_cpp_adapter_compiles_against_the_reference_header():
     (<hipfft/hipfftw.h>) is generated in a temporary directory - nothing is built or linked from it."""
     import subprocess
     import tempfile
-    d = tempfile.mkdtemp()
+    d = _mkdtemp()
     with open(os.path.join(d, "fftw3.h"), "w") as f:
         f.write("#include <hipfft/hipfftw.h>\n")
     with open(os.path.join(d, "tu.cpp"), "w") as f:
@@ -199,7 +209,7 @@ def test_integration_patches_apply_to_the_reference_tree():
     import shutil
     import subprocess
     import tempfile
-    d = tempfile.mkdtemp()
+    d = _mkdtemp()
     shutil.copytree("/root/reference/src", os.path.join(d, "src"))
     shutil.copy("/root/reference/meson.build", d)
     for name in ("level1.patch", "level2.patch"):
@@ -225,7 +235,7 @@ def test_level2_host_class_compiles_standalone():
     """phantomsdr_amd/host/hip_fanout.h needs nothing but include/psdr.h"""
     import subprocess
     import tempfile
-    d = tempfile.mkdtemp()
+    d = _mkdtemp()
     with open(os.path.join(d, "tu.cpp"), "w") as f:
         f.write('#include "hip_fanout.h"\nint use(HipFanout &f) { return f.add_audio_client(); }\n')
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
