@@ -156,12 +156,14 @@ __global__ __launch_bounds__(64) void k_pc_ma2(PostArgs a) {
     float s1 = fresh ? 0.f : a.dc_s1[slot], s2 = fresh ? 0.f : a.dc_s2[slot];
     const float rD = 1.0f / 32.0f;
     float xs[2][KB], ms[2][KB];  // x / m1 of the blocks two and one back (alternating roles)
+    // (ms holds the first running SUM of the steps whose average the second sum evicts: s1 = 32 * m1
+    // exactly, so the eviction and the insertion are one fma each - see block())
 #pragma unroll
     for (int i = 0; i < KB; i++) {
         xs[0][i] = X[i];
         xs[1][i] = X[KB + i];
-        ms[0][i] = M1[i];
-        ms[1][i] = M1[KB + i];
+        ms[0][i] = __fmul_rn(M1[i], 32.0f);
+        ms[1][i] = __fmul_rn(M1[KB + i], 32.0f);
     }
     pc_f4 nw[AHEAD + 1][4];  // the new x of blocks b .. b+AHEAD (a ring of register sets)
     auto fetch = [&](auto kc, int blk) {
@@ -180,10 +182,14 @@ __global__ __launch_bounds__(64) void k_pc_ma2(PostArgs a) {
         for (int i = 0; i < KB; i++) {
             const float xn = nv[i >> 2][i & 3];
             s1 = __fadd_rn(__fadd_rn(s1, -xold[i]), xn);
-            const float m1 = __fmul_rn(s1, rD);
-            s2 = __fadd_rn(__fadd_rn(s2, -mold[i]), m1);
-            mold[i] = m1;
-            o[i] = __fsub_rn(i + 1 < KB ? xold[i + 1] : xnext[0], __fmul_rn(s2, rD));
+            // m1 = s1 / 32 is exact (a power of two), so rounding (s2 - m1_old) + m1 and x - s2 / 32 after the
+            // exact products is the reference's arithmetic with three fused operations instead of five:
+            //   t  = s2 - s1_old / 32        s2 = t + s1 / 32        out = x_{t-D+1} - s2 / 32
+            // (the loop is bound by its own instruction stream: 7 -> 5 operations per sample)
+            const float t2 = __fmaf_rn(-mold[i], rD, s2);
+            s2 = __fmaf_rn(s1, rD, t2);
+            mold[i] = s1;
+            o[i] = __fmaf_rn(-s2, rD, i + 1 < KB ? xold[i + 1] : xnext[0]);
         }
 #pragma unroll
         for (int i = 0; i < KB; i++) xold[i] = nv[i >> 2][i & 3];
@@ -229,8 +235,8 @@ __global__ __launch_bounds__(64) void k_pc_ma2(PostArgs a) {
     const int t1 = nfull * KB;
 #pragma unroll
     for (int i = 0; i < KB; i++) {
-        M1[t1 + i] = (b & 1) ? ms[1][i] : ms[0][i];
-        M1[t1 + KB + i] = (b & 1) ? ms[0][i] : ms[1][i];
+        M1[t1 + i] = __fmul_rn((b & 1) ? ms[1][i] : ms[0][i], rD);
+        M1[t1 + KB + i] = __fmul_rn((b & 1) ? ms[0][i] : ms[1][i], rD);
     }
     for (int t = t1; t < T; t++) {
         s1 = __fadd_rn(__fadd_rn(s1, -X[t]), X[D + t]);
@@ -320,9 +326,15 @@ __global__ __launch_bounds__(64) void k_pc_gain(PostArgs a) {
     const float att = a.attack, rel = a.release;
     // gain <- gain + (w < gain ? attack : release) * (w - gain): three operations per sample
     // (fma(-a, g - w, g) and fma(a, w - g, g) are the same value: negating both factors is exact)
+    // The coefficient is picked by the sign BIT of d (arithmetic shift + bit-field insert): a compare would
+    // go through VCC, and VCC -> v_cndmask costs two wait states on this part in a loop that is nothing but
+    // its own instruction stream.  (d = -0 picks the attack coefficient where the reference picks release:
+    // the product is a zero either way and the sum is the same.)
     auto step = [&](float w) -> float {
         const float d = __fsub_rn(w, gain);
-        gain = __fmaf_rn(d < 0.f ? att : rel, d, gain);
+        int mk = __float_as_int(d) >> 31, cbits;
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(cbits) : "v"(mk), "v"(__float_as_int(att)), "v"(__float_as_int(rel)));
+        gain = __fmaf_rn(__int_as_float(cbits), d, gain);
         return gain;
     };
     // while the look-ahead buffer is filling (only right after a reset / for a new client) the
