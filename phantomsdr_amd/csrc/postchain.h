@@ -155,80 +155,99 @@ __global__ __launch_bounds__(64) void k_pc_ma2(PostArgs a) {
     float *__restrict__ V1 = a.V1 + (size_t)slot * a.pv + a.vo + (a.L - 1);  // 16-byte aligned (vo)
     float s1 = fresh ? 0.f : a.dc_s1[slot], s2 = fresh ? 0.f : a.dc_s2[slot];
     const float rD = 1.0f / 32.0f;
-    float xs[2][KB], ms[2][KB];  // x / m1 of the blocks two and one back (alternating roles)
-    // (ms holds the first running SUM of the steps whose average the second sum evicts: s1 = 32 * m1
-    // exactly, so the eviction and the insertion are one fma each - see block())
+    // x lives in a ring of SIX register sets of one 16-step block each: at block b the sets hold the blocks
+    // b-2 and b-1 (the values the first sum evicts; the first of b-1 is x_{t-D+1} of the block's last step,
+    // getLatest(delay - 1), src/utils.h:160-166), b (inserted now) and b+1..b+3 (loads in flight).  Nothing is
+    // ever copied from set to set - the ring is indexed at compile time, six blocks per trip.  ms: the first
+    // running SUM of the steps whose average the second sum evicts, two alternating sets (s1 = 32 * m1 exactly,
+    // so the eviction and the insertion are one fma each).
+    pc_f4 xr[6][4];
+    float ms[2][KB];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        xr[4][q] = reinterpret_cast<const pc_f4 *>(X)[q];          // block -2
+        xr[5][q] = reinterpret_cast<const pc_f4 *>(X + KB)[q];     // block -1
+    }
 #pragma unroll
     for (int i = 0; i < KB; i++) {
-        xs[0][i] = X[i];
-        xs[1][i] = X[KB + i];
         ms[0][i] = __fmul_rn(M1[i], 32.0f);
         ms[1][i] = __fmul_rn(M1[KB + i], 32.0f);
     }
-    pc_f4 nw[AHEAD + 1][4];  // the new x of blocks b .. b+AHEAD (a ring of register sets)
     auto fetch = [&](auto kc, int blk) {
         constexpr int k = decltype(kc)::value;
         if (blk < nfull) {
             const pc_f4 *src = reinterpret_cast<const pc_f4 *>(X + D + blk * KB);  // D, KB, px: multiples of 4
 #pragma unroll
-            for (int q = 0; q < 4; q++) nw[k][q] = src[q];
+            for (int q = 0; q < 4; q++) xr[k][q] = src[q];
         }
     };
-    // xold / mold: x and m1 of block b-2 (evicted, then overwritten with block b's); xnext[0] is
-    // x_{t-D+1} of the block's last step (getLatest(delay - 1), src/utils.h:160-166)
-    auto block = [&](const pc_f4 (&nv)[4], float (&xold)[KB], const float (&xnext)[KB], float (&mold)[KB], int t0) {
-        float o[KB];
+    // m1 = s1 / 32 is exact (a power of two), so rounding (s2 - m1_old) + m1 and x - s2 / 32 after the exact
+    // products is the reference's arithmetic with three fused operations instead of five:
+    //   t = s2 - s1_old / 32      s2 = t + s1 / 32      out = x_{t-D+1} - s2 / 32
+    // (the loop is bound by its own instruction stream: 7 -> 5 operations per sample, and no moves)
+    const float nrD = -rD;
+    auto block = [&](auto jc, int t0) {
+        constexpr int J = decltype(jc)::value, E = (J + 4) % 6, N1 = (J + 5) % 6, P = J & 1;
+        pc_f4 o[4];
 #pragma unroll
         for (int i = 0; i < KB; i++) {
-            const float xn = nv[i >> 2][i & 3];
-            s1 = __fadd_rn(__fadd_rn(s1, -xold[i]), xn);
-            // m1 = s1 / 32 is exact (a power of two), so rounding (s2 - m1_old) + m1 and x - s2 / 32 after the
-            // exact products is the reference's arithmetic with three fused operations instead of five:
-            //   t  = s2 - s1_old / 32        s2 = t + s1 / 32        out = x_{t-D+1} - s2 / 32
-            // (the loop is bound by its own instruction stream: 7 -> 5 operations per sample)
-            const float t2 = __fmaf_rn(-mold[i], rD, s2);
+            s1 = __fadd_rn(__fsub_rn(s1, xr[E][i >> 2][i & 3]), xr[J][i >> 2][i & 3]);
+            const float t2 = __fmaf_rn(ms[P][i], nrD, s2);
             s2 = __fmaf_rn(s1, rD, t2);
-            mold[i] = s1;
-            o[i] = __fmaf_rn(-s2, rD, i + 1 < KB ? xold[i + 1] : xnext[0]);
+            ms[P][i] = s1;
+            const float xd = i + 1 < KB ? xr[E][(i + 1) >> 2][(i + 1) & 3] : xr[N1][0][0];
+            o[i >> 2][i & 3] = __fmaf_rn(s2, nrD, xd);
         }
 #pragma unroll
-        for (int i = 0; i < KB; i++) xold[i] = nv[i >> 2][i & 3];
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            reinterpret_cast<pc_f4 *>(V1 + t0)[q] = pc_f4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+        for (int q = 0; q < 4; q++) reinterpret_cast<pc_f4 *>(V1 + t0)[q] = o[q];
     };
-    // software pipeline: blocks b+1 .. b+AHEAD are in flight while block b runs; the ring of register
-    // sets is indexed at compile time (4 blocks per trip)
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>;
+    using I5 = std::integral_constant<int, 5>;
     fetch(I0{}, 0);
     fetch(I1{}, 1);
     fetch(I2{}, 2);
     int b = 0;
-    for (; b + 4 <= nfull; b += 4) {
+    for (; b + 6 <= nfull; b += 6) {
         fetch(I3{}, b + 3);
-        block(nw[0], xs[0], xs[1], ms[0], b * KB);
-        fetch(I0{}, b + 4);
-        block(nw[1], xs[1], xs[0], ms[1], (b + 1) * KB);
-        fetch(I1{}, b + 5);
-        block(nw[2], xs[0], xs[1], ms[0], (b + 2) * KB);
-        fetch(I2{}, b + 6);
-        block(nw[3], xs[1], xs[0], ms[1], (b + 3) * KB);
+        block(I0{}, b * KB);
+        fetch(I4{}, b + 4);
+        block(I1{}, (b + 1) * KB);
+        fetch(I5{}, b + 5);
+        block(I2{}, (b + 2) * KB);
+        fetch(I0{}, b + 6);
+        block(I3{}, (b + 3) * KB);
+        fetch(I1{}, b + 7);
+        block(I4{}, (b + 4) * KB);
+        fetch(I2{}, b + 8);
+        block(I5{}, (b + 5) * KB);
     }
-    // up to three more whole blocks (already fetched into sets 0..2; b is a multiple of 4: set 0 pairs with xs[0])
+    // up to five more whole blocks (b is a multiple of 6: block b + j lives in set j)
     if (b < nfull) {
-        block(nw[0], xs[0], xs[1], ms[0], b * KB);
+        fetch(I3{}, b + 3);
+        block(I0{}, b * KB);
         b++;
-    }
-    if (b < nfull) {
-        block(nw[1], xs[1], xs[0], ms[1], b * KB);
-        b++;
-    }
-    if (b < nfull) {
-        block(nw[2], xs[0], xs[1], ms[0], b * KB);
-        b++;
+        if (b < nfull) {
+            fetch(I4{}, b + 3);
+            block(I1{}, b * KB);
+            b++;
+            if (b < nfull) {
+                fetch(I5{}, b + 3);
+                block(I2{}, b * KB);
+                b++;
+                if (b < nfull) {
+                    block(I3{}, b * KB);
+                    b++;
+                    if (b < nfull) {
+                        block(I4{}, b * KB);
+                        b++;
+                    }
+                }
+            }
+        }
     }
     // now (b even) ms[0] is the older set of m1 values, else ms[1]: the window of m1 values in time
     // order goes to rows t1.. of M1 for the remaining T - nfull*KB (< KB) steps, one by one
