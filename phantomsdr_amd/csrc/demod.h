@@ -527,76 +527,88 @@ __global__ __launch_bounds__(256, 5) void k_demod_idft_fixed(DemodArgs a, int na
     }
 }
 
-// one WAVE per (client, frame): no shared memory, no barrier (NaN flag by wave vote);
-// grid = ceil(nact * nframes / 4) work-groups of 256 threads
+// one WAVE per (client, group of PSDR_OLA_FG consecutive frames): no shared memory, no barrier (NaN flag by
+// wave vote).  A wave's life is three dependent round trips to memory (client parameters, then the two
+// halves it adds, then the stores) whatever it does in between - with one frame per wave 65 536 waves of
+// ~10 us each passed through the few wave slots the FFT passes leave free (256 clients x 256 frames:
+// 700-800 us); a group of frames shares the parameter load and has all its loads in flight together.
+// grid = ceil(nact * ceil(nframes / FG) / 4) work-groups of 256 threads
+#ifndef PSDR_OLA_FG
+#define PSDR_OLA_FG 8
+#endif
 __global__ __launch_bounds__(256) void k_demod_ola(DemodArgs a, int nact) {
+    constexpr int FG = PSDR_OLA_FG;
     const int n = a.n, h = n / 2, tid = threadIdx.x & 63, NT = 64;
+    const int F = a.nframes, ngrp = (F + FG - 1) / FG;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= nact * a.nframes) return;
-    const int ci = item / a.nframes;
+    if (item >= nact * ngrp) return;
+    const int ci = item / ngrp;
     const ClientParams cp = a.clients[ci];
-    const int f = item - ci * a.nframes;
-    const int F = a.nframes;
+    const int f0 = (item - ci * ngrp) * FG;
     const size_t srow = (size_t)cp.slot;
     const cf *yp = a.ypost + (srow * a.max_batch) * n;  // this client's frames
-    const cf *y = yp + (size_t)f * n;
     const int cur = cp.state_cur, nxt = cur ^ 1;
     const float *rp_old = a.real_prev + ((size_t)cur * a.slots + srow) * h;
     float *rp_new = a.real_prev + ((size_t)nxt * a.slots + srow) * h;
     const cf *bt_old = a.bb_tail + ((size_t)cur * a.slots + srow) * h;
     cf *bt_new = a.bb_tail + ((size_t)nxt * a.slots + srow) * h;
-    float *out = a.audio + (srow * a.max_batch + f) * h;
-    int s_nan = 0;  // per lane; combined by a wave vote at the end
-    const bool last = (f == F - 1);
-
-    if (cp.mode < 2) {
-        for (int j = tid; j < h; j += NT) {
-            const float prev = (f == 0) ? rp_old[j] : yp[(size_t)(f - 1) * n + h + j].x;
-            const float v = y[j].x + prev;  // dsp_add_float :171
-            out[j] = v;
-            if (isnan(v)) s_nan = 1;
-            if (last) {
-                rp_new[j] = y[h + j].x;  // :273-275
-                bt_new[j] = bt_old[j];
-            }
-        }
-        if (last && tid == 0) a.bb_last[(size_t)nxt * a.slots + srow] = a.bb_last[(size_t)cur * a.slots + srow];
-    } else {
-        for (int j = tid; j < h; j += NT) {
-            const cf pv = (f == 0) ? bt_old[j] : yp[(size_t)(f - 1) * n + h + j];
-            const cf b = make_float2(y[j].x + pv.x, y[j].y + pv.y);  // dsp_add_complex :235
-            float v;
-            if (cp.mode == 2) {
-                v = sqrtf(fmaf(b.x, b.x, b.y * b.y));  // dsp_am_demod
-            } else {
-                cf pr;
-                if (j > 0) {
-                    const cf pv1 = (f == 0) ? bt_old[j - 1] : yp[(size_t)(f - 1) * n + h + j - 1];
-                    pr = make_float2(y[j - 1].x + pv1.x, y[j - 1].y + pv1.y);
-                } else if (f == 0) {
-                    pr = a.bb_last[(size_t)cur * a.slots + srow];
-                } else {
-                    // B'_{f-1}[h-1] = y_{f-1}[h-1] + (tail of frame f-2, or the carried tail)
-                    const cf y1 = yp[(size_t)(f - 1) * n + h - 1];
-                    const cf t1 = (f == 1) ? bt_old[h - 1] : yp[(size_t)(f - 2) * n + n - 1];
-                    pr = make_float2(y1.x + t1.x, y1.y + t1.y);
+#pragma unroll
+    for (int g = 0; g < FG; g++) {
+        const int f = f0 + g;
+        if (f >= F) break;
+        const cf *y = yp + (size_t)f * n;
+        float *out = a.audio + (srow * a.max_batch + f) * h;
+        int s_nan = 0;  // per lane; combined by a wave vote at the end
+        const bool last = (f == F - 1);
+        if (cp.mode < 2) {
+            for (int j = tid; j < h; j += NT) {
+                const float prev = (f == 0) ? rp_old[j] : yp[(size_t)(f - 1) * n + h + j].x;
+                const float v = y[j].x + prev;  // dsp_add_float :171
+                out[j] = v;
+                if (isnan(v)) s_nan = 1;
+                if (last) {
+                    rp_new[j] = y[h + j].x;  // :273-275
+                    bt_new[j] = bt_old[j];
                 }
-                // arg(b * conj(pr)), src/utils/dsp.cpp:32
-                const float re = fmaf(b.x, pr.x, b.y * pr.y);
-                const float im = fmaf(b.x, -pr.y, b.y * pr.x);
-                v = atan2f(im, re);
             }
-            out[j] = v;
-            if (isnan(v)) s_nan = 1;
-            if (last) {
-                bt_new[j] = y[h + j];  // :200-203 (second half kept for the next frame)
-                rp_new[j] = rp_old[j];
-                if (j == h - 1) a.bb_last[(size_t)nxt * a.slots + srow] = b;  // `prev` of :200
+            if (last && tid == 0) a.bb_last[(size_t)nxt * a.slots + srow] = a.bb_last[(size_t)cur * a.slots + srow];
+        } else {
+            for (int j = tid; j < h; j += NT) {
+                const cf pv = (f == 0) ? bt_old[j] : yp[(size_t)(f - 1) * n + h + j];
+                const cf b = make_float2(y[j].x + pv.x, y[j].y + pv.y);  // dsp_add_complex :235
+                float v;
+                if (cp.mode == 2) {
+                    v = sqrtf(fmaf(b.x, b.x, b.y * b.y));  // dsp_am_demod
+                } else {
+                    cf pr;
+                    if (j > 0) {
+                        const cf pv1 = (f == 0) ? bt_old[j - 1] : yp[(size_t)(f - 1) * n + h + j - 1];
+                        pr = make_float2(y[j - 1].x + pv1.x, y[j - 1].y + pv1.y);
+                    } else if (f == 0) {
+                        pr = a.bb_last[(size_t)cur * a.slots + srow];
+                    } else {
+                        // B'_{f-1}[h-1] = y_{f-1}[h-1] + (tail of frame f-2, or the carried tail)
+                        const cf y1 = yp[(size_t)(f - 1) * n + h - 1];
+                        const cf t1 = (f == 1) ? bt_old[h - 1] : yp[(size_t)(f - 2) * n + n - 1];
+                        pr = make_float2(y1.x + t1.x, y1.y + t1.y);
+                    }
+                    // arg(b * conj(pr)), src/utils/dsp.cpp:32
+                    const float re = fmaf(b.x, pr.x, b.y * pr.y);
+                    const float im = fmaf(b.x, -pr.y, b.y * pr.x);
+                    v = atan2f(im, re);
+                }
+                out[j] = v;
+                if (isnan(v)) s_nan = 1;
+                if (last) {
+                    bt_new[j] = y[h + j];  // :200-203 (second half kept for the next frame)
+                    rp_new[j] = rp_old[j];
+                    if (j == h - 1) a.bb_last[(size_t)nxt * a.slots + srow] = b;  // `prev` of :200
+                }
             }
         }
+        const int any_nan = __any(s_nan);
+        if (tid == 0) a.nan_flags[srow * a.max_batch + f] = any_nan ? 1 : 0;
     }
-    const int any_nan = __any(s_nan);
-    if (tid == 0) a.nan_flags[srow * a.max_batch + f] = any_nan ? 1 : 0;
 }
 
 }  // namespace psdr

@@ -1565,7 +1565,7 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     }
     {
         ProfScope ps(c, K_OLA, c->side);
-        const unsigned items = (unsigned)nact * (unsigned)nframes;
+        const unsigned items = (unsigned)nact * (unsigned)((nframes + PSDR_OLA_FG - 1) / PSDR_OLA_FG);
         hipLaunchKernelGGL(k_demod_ola, dim3((items + 3) / 4), dim3(256), 0, c->side, a, nact);
         HIPCHK(hipGetLastError());
     }
