@@ -228,6 +228,37 @@ def cpu_baseline_subprocess(wl_name, timeout_s=240):
     return {"error": err}
 
 
+def visible_hip_devices():
+    """hipGetDeviceCount without creating a context in this (launcher) process"""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        n = ctypes.c_int(0)
+        return n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+    except OSError:
+        return 0
+
+
+def self_launch(ngpus):
+    """N > 1 without a launcher: re-execute as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py <same arguments>`.  Refuses (exit code 3, nothing on stdout)
+    when fewer than N devices are visible: an N-GPU line is never printed by fewer than N ranks."""
+    import socket
+    import subprocess
+    have = visible_hip_devices()
+    if have < ngpus:
+        sys.stderr.write(f"bench.py: --gpus {ngpus} but {have} HIP device(s) visible; not running\n")
+        raise SystemExit(3)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def emit(out):
     """the ONE JSON line, as the last thing on stdout: RCCL prints a banner through C stdio whose
     buffer would otherwise be flushed after Python's at exit"""
@@ -241,32 +272,57 @@ def emit(out):
         print(json.dumps(out), flush=True)
 
 
-def kernel_roofline(ctx, step, first_step, nsteps, wl, wl_name, params, clients, waterfalls, frames_per_launch):
-    """per-kernel durations from a profiled replay (hipEvents on the library's own streams) and the
-    roofline block of the dominant kernel (DESIGN.md "Roofline accounting")"""
-    ctx.set_profiling(True)
-    ctx.reset_kernel_stats()
-    for i in range(nsteps):
-        step(first_step + i)
-    ctx.synchronize()
-    stats = ctx.kernel_stats()
-    ctx.set_profiling(False)
+def kernel_roofline(ctx, step, first_step, nsteps, wl, wl_name, params, clients, waterfalls, frames_per_launch,
+                    clock_us=None, ms_per_step=None):
+    """Per-kernel durations and the roofline block of the dominant kernel (DESIGN.md "Roofline accounting").
+
+    clock_us: {"fft_pass1": [...], "fft_pass2": [...]} - per-launch durations of the two FFT passes stamped on
+      the device clock INSIDE the timed loop (psdr_set_profiling mode 2: first work-group in -> last work-group
+      out, no marker packets between the kernels).  `roofline.achieved` uses their median.
+    hipEvents: a replay of at least 50 steps after the timed loop with every launch bracketed by events on
+      the stream it runs on (mode 1), in chunks of 5 steps; reported per kernel as the median chunk.  The
+      marker packets lengthen the two passes (their sum can exceed the step): `perturbed` says so."""
+    nsteps = max(nsteps, 50)
+    chunk = 5
+    ctx.set_profiling(1)
+    per_chunk = {}
+    launches = {}
+    for c0 in range(0, nsteps, chunk):
+        ctx.reset_kernel_stats()
+        for i in range(chunk):
+            step(first_step + c0 + i)
+        ctx.synchronize()
+        for name, (ms, cnt) in ctx.kernel_stats().items():
+            per_chunk.setdefault(name, []).append(ms / cnt * 1e3)
+            launches[name] = launches.get(name, 0) + int(cnt)
+    ctx.set_profiling(0)
     ab = algorithmic_bytes_per_frame(wl, params, clients, waterfalls)
     Fl = frames_per_launch
-    # algorithmic bytes by kernel: pass 1 reads the raw input once; pass 2 (+fused epilogue)
-    # writes the spectrum and the pyramid; the demod kernels read slices and write audio;
-    # intermediates count zero.
+    # algorithmic bytes by kernel: pass 1 reads the raw input once; the kernel that finishes the spectrum
+    # writes it and the pyramid (IQ: pass 2; real input of 2^21 points and more: the fused pass 2; smaller real
+    # transforms: the untangle pass); the demodulation kernels read slices and write audio; intermediates count zero.
+    three_pass_real = wl["is_real"] and "untangle_real" in per_chunk
     per_kernel_bytes = {
         "fft_pass1": ab["input"] * Fl,
-        "fft_pass2": (ab["spectrum"] + (ab["pyramid"] if not wl["is_real"] else 0)) * Fl,
-        "untangle_real": (ab["spectrum"] + ab["pyramid"]) * Fl if wl["is_real"] else 0,
+        "fft_pass2": 0 if three_pass_real else (ab["spectrum"] + ab["pyramid"]) * Fl,
+        "untangle_real": (ab["spectrum"] + ab["pyramid"]) * Fl if three_pass_real else 0,
         "demod_idft": ab["clients"] * Fl,
     }
-    kernels = {name: {"avg_us": round(ms / cnt * 1e3, 3), "launches": int(cnt)} for name, (ms, cnt) in stats.items()}
-    dom = max(stats, key=lambda k: stats[k][0]) if stats else None
+    kernels = {name: {"hip_event_us_median": round(float(np.median(v)), 3), "launches": launches[name]}
+               for name, v in per_chunk.items()}
+    clock_med = {}
+    for name, v in (clock_us or {}).items():
+        if len(v):
+            clock_med[name] = float(np.median(v))
+            kernels.setdefault(name, {})
+            kernels[name].update({"device_clock_us_median": round(clock_med[name], 3),
+                                  "device_clock_us_min_max": [round(float(np.min(v)), 2), round(float(np.max(v)), 2)],
+                                  "device_clock_launches": int(len(v))})
+    dur = {name: clock_med.get(name, float(np.median(v))) for name, v in per_chunk.items()}
+    dom = max(dur, key=lambda k: dur[k]) if dur else None
     roofline = None
     if dom:
-        avg_s = stats[dom][0] / stats[dom][1] / 1e3
+        avg_s = dur[dom] / 1e6
         achieved = per_kernel_bytes.get(dom, 0) / avg_s
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
@@ -278,10 +334,25 @@ def kernel_roofline(ctx, step, first_step, nsteps, wl, wl_name, params, clients,
                     traffic = int(traffic * Fl / tj.get("_frames_per_launch", Fl))
             except Exception:
                 traffic = None
+        ev = {k: float(np.median(per_chunk[k])) for k in ("fft_pass1", "fft_pass2", "untangle_real") if k in per_chunk}
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
+                    "traffic_source": "rocprofv3 --pmc passes of this workload (profiles/traffic.json), scaled to this batch size",
                     "algorithmic_bytes_per_launch": int(per_kernel_bytes.get(dom, 0)),
-                    "avg_launch_us": round(avg_s * 1e6, 2)}
+                    "avg_launch_us": round(avg_s * 1e6, 2),
+                    "method": ("median launch duration on the device clock, stamped by the kernel itself inside the timed loop"
+                               if dom in clock_med else "median of hipEvent brackets in a replay after the timed loop"),
+                    "hip_event_us": round(ev.get(dom, 0.0), 2) if dom in ev else None}
+        if ms_per_step:
+            # the passes of one step run back to back on one stream: their durations cannot add up to more
+            # than the step unless the measurement itself lengthened them
+            roofline["passes_sum_over_step"] = {
+                "device_clock": round(sum(clock_med.get(k, 0.0) for k in ("fft_pass1", "fft_pass2")) / (ms_per_step * 1e3), 4)
+                if clock_med else None,
+                "hip_events": round(sum(ev.values()) / (ms_per_step * 1e3), 4)}
+            roofline["perturbed"] = bool(sum(ev.values()) > 1.03 * ms_per_step * 1e3)
+            roofline["perturbed_note"] = ("hipEvent figures only: the marker packets between the kernels lengthen the "
+                                          "passes; `achieved` does not use them when device-clock stamps exist")
     return roofline, kernels, ab
 
 
@@ -421,7 +492,7 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
         frames = steps * F * (world if time_mode else 1)
         msps = frames * (N // 2) / dt / 1e6
         roofline, kernels, _ = kernel_roofline(eng.ctx, step, warmup + steps, min(steps, 20), wl, wl_name, params,
-                                               clients, waterfalls, F + warm)
+                                               clients, waterfalls, F + warm, ms_per_step=dt / steps * 1e3)
         fence()
         ab = algorithmic_bytes_per_frame(wl, params, clients, waterfalls)
         res = {"value": round(msps, 2), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
@@ -463,7 +534,8 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
         r = results[main_mode]
         out = {
             "metric": "ingest MSamples/s + concurrent audio clients at 2^20-pt FFT",
-            "value": r["value"], "unit": "MSamples/s", "n_gpus": world, "steps": args.steps,
+            "value": r["value"], "unit": "MSamples/s", "n_gpus": int(dist.get_world_size()) if dist.is_initialized() else world,
+            "rccl_ranks": int(dist.get_world_size()) if dist.is_initialized() else 0, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
@@ -530,9 +602,15 @@ class SingleGpuRun:
         """`warmup` untimed steps, then repetitions of EXACTLY `steps` steps, each bracketed by a full
         synchronisation; at least `min_reps` and until `min_total_s` of timed work.  Returns the
         per-repetition wall times (seconds)."""
+        ctx = self.eng.ctx
         for i in range(warmup):
             self.step(i)
         self.sync()
+        # the two FFT passes stamp the device clock at their first work-group's entry and their last
+        # work-group's exit (two atomics per work-group and launch; no events, no marker packets): the
+        # per-kernel durations of the roofline block come from THIS loop, not from a replay
+        ctx.set_profiling(2)
+        ctx.reset_kernel_stats()
         times, k = [], warmup
         while len(times) < min_reps or (sum(times) < min_total_s and len(times) < max_reps):
             self.sync()
@@ -542,6 +620,8 @@ class SingleGpuRun:
             self.sync()
             times.append(time.perf_counter() - t0)
             k += steps
+        self.clock_us = {name: ctx.kernel_samples(name) for name in ("fft_pass1", "fft_pass2")}
+        ctx.set_profiling(0)
         self.next_step = k
         return times
 
@@ -549,11 +629,21 @@ class SingleGpuRun:
         med = float(np.median(times))
         frames = steps * self.F
         ab = algorithmic_bytes_per_frame(self.wl, self.params, self.clients, self.waterfalls)
-        return {"value": round(frames * (self.N // 2) / med / 1e6, 2), "ms_per_step": round(med / steps * 1e3, 4),
-                "frames_per_s": round(frames / med, 1), "frac_of_hbm_peak": round(ab["total"] * frames / med / HBM_PEAK, 4),
-                "algorithmic_bytes_per_frame": int(ab["total"]), "repetitions": len(times),
-                "ms_per_step_min_max": [round(min(times) / steps * 1e3, 4), round(max(times) / steps * 1e3, 4)],
-                "timed_s": round(sum(times), 3)}
+        out = {"value": round(frames * (self.N // 2) / med / 1e6, 2), "ms_per_step": round(med / steps * 1e3, 4),
+               "frames_per_s": round(frames / med, 1), "frac_of_hbm_peak": round(ab["total"] * frames / med / HBM_PEAK, 4),
+               "algorithmic_bytes_per_frame": int(ab["total"]), "repetitions": len(times),
+               "ms_per_step_min_max": [round(min(times) / steps * 1e3, 4), round(max(times) / steps * 1e3, 4)],
+               "timed_s": round(sum(times), 3)}
+        clk = getattr(self, "clock_us", None) or {}
+        if all(len(clk.get(k, ())) for k in ("fft_pass1", "fft_pass2")):
+            # the two passes on the device clock, from the timed loop itself; pass 2 (IQ and fused real alike)
+            # finishes the spectrum and the pyramid: those are its algorithmic bytes
+            p1, p2 = float(np.median(clk["fft_pass1"])), float(np.median(clk["fft_pass2"]))
+            fused = not self.wl["is_real"] or self.wl["fft_size"] >= (1 << 21)
+            out["passes_device_clock_us"] = {"fft_pass1": round(p1, 2), "fft_pass2": round(p2, 2)}
+            if fused:
+                out["pass2_frac_of_hbm_peak"] = round((ab["spectrum"] + ab["pyramid"]) * self.F / (p2 * 1e-6) / HBM_PEAK, 4)
+        return out
 
     def close(self):
         self.eng.close()
@@ -596,11 +686,21 @@ def main():
         print(json.dumps(cpu_baseline(wl, p, cl, wf, fft_library="" if args.cpu_builtin_fft else None)), flush=True)
         return
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become N ranks (one process per GPU over RCCL) by re-executing
+        # under torch.distributed.run, exactly the command line the driver would have written
+        return self_launch(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        if world > 1 and args.gpus == 1:
+            args.gpus = world  # launched by torchrun without --gpus: the launcher's world size is the run
+        else:
+            raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s): refusing to report a "
+                             f"{world}-GPU run as a {args.gpus}-GPU one")
     if args.batch <= 0:
         args.batch = 256
 
@@ -622,8 +722,8 @@ def main():
     head = run.summary(times, args.steps)
 
     # per-kernel durations: profiled replay of the same steps (the events do not perturb `value`)
-    roofline, kernels, ab = kernel_roofline(eng.ctx, run.step, run.next_step, min(args.steps, 50), wl, wl_name, params,
-                                            clients, waterfalls, F)
+    roofline, kernels, ab = kernel_roofline(eng.ctx, run.step, run.next_step, 50, wl, wl_name, params,
+                                            clients, waterfalls, F, clock_us=run.clock_us, ms_per_step=head["ms_per_step"])
 
     # SURVEY 8f-2 (widened row): the optional post-demodulation chain (DC blocker + AGC + int16),
     # measured separately - it is NOT part of `value` (the metric's clients end at float audio)
@@ -680,7 +780,10 @@ def main():
                    "audio_fft_size": params["audio_fft_size"], "ring_MiB": round(nhalves * hb / 2 ** 20, 1),
                    "realtime_factor": round(head["value"] * 1e6 / wl["sps"], 1),
                    "timing": f"median of {head['repetitions']} repetitions of exactly {args.steps} steps "
-                             f"({head['timed_s']} s timed), each bracketed by a full synchronisation"},
+                             f"({head['timed_s']} s timed), each bracketed by a full synchronisation; inputs resident in "
+                             "HBM before, results (spectrum, pyramid, audio, waterfall rows) resident in HBM after: "
+                             "the device-to-host copy of the results is NOT in the timed region (audio + waterfall rows: "
+                             "a few MB per step against GBs of device traffic)"},
         "roofline": roofline,
         "path": {"algorithmic_bytes_per_frame": head["algorithmic_bytes_per_frame"], "frames_per_s": head["frames_per_s"],
                  "frac_of_hbm_peak": head["frac_of_hbm_peak"], "ms_per_step_min_max": head["ms_per_step_min_max"],

@@ -283,8 +283,15 @@ typedef struct psdr_command {
 int psdr_wire_parse_command(const char *msg, size_t len, psdr_command *out);
 
 /* ---- instrumentation --------------------------------------------------------------- */
-/* when enabled, every kernel launch is bracketed by hipEvents on the context's stream */
-int psdr_set_profiling(psdr_ctx *ctx, int enable);
+/* mode 0: off.  1: every kernel launch is bracketed by hipEvents on the stream it is launched on (the
+ * marker packets between the kernels lengthen the two FFT passes by several per cent: use it for a replay,
+ * not for a timed region).  2: no events; the two FFT passes stamp the device's constant 100 MHz clock at
+ * their first work-group's entry and their last work-group's exit (two fire-and-forget atomics per
+ * work-group) - cheap enough to stay on inside a timed region; up to 8192 launches per pass between resets. */
+int psdr_set_profiling(psdr_ctx *ctx, int mode);
+/* per-launch durations (microseconds) of kernel `name` ("fft_pass1", "fft_pass2", ...) since the last
+ * reset, oldest first; *n_out = how many exist (may exceed cap) */
+int psdr_get_kernel_samples(psdr_ctx *ctx, const char *name, double *us_out, int cap, int *n_out);
 /* accumulated since the last reset: name[i] (static strings), total ms, launch count */
 int psdr_get_kernel_stats(psdr_ctx *ctx, int max_entries, const char **names, double *total_ms,
                           int64_t *launches, int *n_out);

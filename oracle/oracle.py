@@ -329,6 +329,9 @@ class AudioClient:
         audio = np.zeros(self.n // 2, np.float32)
         pwr = C.c_float(0)
         pcm = np.zeros(self.n // 2, np.int32) if post else None
+        # FM's first sample pairs with the previous frame's last baseband sample (src/signal.cpp:258-262):
+        # kept for the tests' conditioned FM bound (tests/helpers.py fm_tolerance)
+        self.bb_prev = complex(self.baseband()[self.n // 2 - 1])
         rc = lib().orc_client_send_audio(self.h, _p(buf), int(frame_num), _p(audio),
                                          C.byref(pwr), _p(pcm) if post else None)
         return audio, pwr.value, pcm, bool(rc)

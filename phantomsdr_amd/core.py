@@ -179,8 +179,19 @@ class Context:
         return q[off:off + (self.R >> i)]
 
     # --- instrumentation ---------------------------------------------------------------
-    def set_profiling(self, on):
-        check(self.lib.psdr_set_profiling(self.h, int(on)))
+    def set_profiling(self, mode):
+        """0 / False: off; 1 / True: hipEvent brackets around every launch; 2: device-clock stamps inside the
+        two FFT passes (cheap enough for a timed region)"""
+        check(self.lib.psdr_set_profiling(self.h, int(mode)))
+
+    def kernel_samples(self, name):
+        """per-launch durations (microseconds) of kernel `name` since the last reset"""
+        n = C.c_int(0)
+        check(self.lib.psdr_get_kernel_samples(self.h, name.encode(), None, 0, C.byref(n)))
+        out = np.empty(max(n.value, 1), np.float64)
+        check(self.lib.psdr_get_kernel_samples(self.h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_double)), n.value,
+                                               C.byref(n)))
+        return out[: n.value]
 
     def reset_kernel_stats(self):
         check(self.lib.psdr_reset_kernel_stats(self.h))

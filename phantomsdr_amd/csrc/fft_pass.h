@@ -77,6 +77,21 @@
 
 namespace psdr {
 
+// Device-clock stamps of a launch (psdr_set_profiling mode 2): k[0] = earliest work-group entry, k[1] = latest
+// work-group exit (after its stores were acknowledged) on the constant 100 MHz clock.  Two fire-and-forget
+// atomics per work-group and launch: the duration of a pass is measured inside the very loop that is being
+// timed, with no marker packets between the kernels (hipEvent brackets lengthen the passes by ~9 %).
+__device__ __forceinline__ void kclk_begin(unsigned long long *k) {
+    if (k && threadIdx.x == 0) __hip_atomic_fetch_min(k, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void kclk_end(unsigned long long *k) {
+    if (k) {  // uniform
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's stores have been acknowledged
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_max(k + 1, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // compile-time loops/dispatch: register arrays must only ever be indexed by constants
 // (a runtime-looking index puts the whole array in scratch memory)
 template <int I, int N, typename F>
@@ -188,36 +203,83 @@ __device__ __forceinline__ void run_front_stages(float4 *tile, const cf *Wl, int
                                                  Mark mark) {
     using P = Plan<L>;
     constexpr int H = T / 2;
-    stage_compute<L, P::R0, 1>(u, i0, Wl,
-                               [&](int, int, int pos, c2 x) { tile[lds_slot<H, SWZ>(pos, p)] = pack_c2(x); });
+    // timing-only ablations of pass 1 (SWZ == false), tools/ab_p1.sh: results are WRONG with any of them
+#if defined(PSDR_ABL_P1_NOX1)
+    constexpr bool kX1 = SWZ;
+#else
+    constexpr bool kX1 = true;
+#endif
+#if defined(PSDR_ABL_P1_NOX2) || defined(PSDR_ABL_P1_NOX1)
+    constexpr bool kX2 = SWZ;
+#else
+    constexpr bool kX2 = true;
+#endif
+    // PSDR_ABL_P1_KEEPBAR=n with PSDR_ABL_P1_NOBAR: the first n of the four barriers stay
+#ifndef PSDR_ABL_P1_KEEPBAR
+#define PSDR_ABL_P1_KEEPBAR 0
+#endif
+    int nbar_ = 0;
+    (void)nbar_;
+#if defined(PSDR_ABL_P1_NOBAR)
+#define PSDR_P1_BARRIER()                                    \
+    do {                                                     \
+        if (SWZ || nbar_++ < PSDR_ABL_P1_KEEPBAR)            \
+            __syncthreads();                                 \
+        else                                                 \
+            __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */ \
+    } while (0)
+#else
+#define PSDR_P1_BARRIER() __syncthreads()
+#endif
+    if constexpr (kX1) {
+        stage_compute<L, P::R0, 1>(u, i0, Wl,
+                                   [&](int, int, int pos, c2 x) { tile[lds_slot<H, SWZ>(pos, p)] = pack_c2(x); });
+    } else {
+        c2 v[16];
+        stage_compute<L, P::R0, 1>(u, i0, Wl, [&](int b, int s, int, c2 x) { v[b + s * (16 / P::R0)] = x; });
+#pragma unroll
+        for (int e = 0; e < 16; e++) u[e] = v[e];
+    }
     PSDR_SCHED_FENCE();
     tick(0);
     PSDR_SCHED_FENCE();
     mark(4);
-    __syncthreads();
-    mark(5);
-    tile_read<L, H, SWZ>(u, tile, i0, p);
-    __syncthreads();
+    if constexpr (kX1) {
+        PSDR_P1_BARRIER();
+        mark(5);
+        tile_read<L, H, SWZ>(u, tile, i0, p);
+        PSDR_P1_BARRIER();
+    }
     mark(6);
     PSDR_SCHED_FENCE();
     tick(1);
     PSDR_SCHED_FENCE();
     if constexpr (P::NS == 3) {
-        stage_compute<L, P::R1, P::R0>(
-            u, i0, Wl, [&](int, int, int pos, c2 x) { tile[lds_slot<H, SWZ>(pos, p)] = pack_c2(x); });
+        if constexpr (kX2) {
+            stage_compute<L, P::R1, P::R0>(
+                u, i0, Wl, [&](int, int, int pos, c2 x) { tile[lds_slot<H, SWZ>(pos, p)] = pack_c2(x); });
+        } else {
+            c2 v[16];
+            stage_compute<L, P::R1, P::R0>(u, i0, Wl, [&](int b, int s, int, c2 x) { v[b + s * (16 / P::R1)] = x; });
+#pragma unroll
+            for (int e = 0; e < 16; e++) u[e] = v[e];
+        }
         PSDR_SCHED_FENCE();
         tick(2);
         PSDR_SCHED_FENCE();
         mark(7);
-        __syncthreads();
-        mark(8);
-        tile_read<L, H, SWZ>(u, tile, i0, p);
-        __syncthreads();
+        if constexpr (kX2) {
+            PSDR_P1_BARRIER();
+            mark(8);
+            tile_read<L, H, SWZ>(u, tile, i0, p);
+            PSDR_P1_BARRIER();
+        }
         mark(9);
         PSDR_SCHED_FENCE();
         tick(3);
         PSDR_SCHED_FENCE();
     }
+#undef PSDR_P1_BARRIER
 }
 template <int L, typename EmitLast>
 __device__ __forceinline__ void run_last_stage(const cf *Wl, int i0, c2 (&u)[16], EmitLast emit_last) {
@@ -254,12 +316,14 @@ __device__ __forceinline__ unsigned xcd_slot(unsigned bid, unsigned total) {
 struct TileQueue {
     unsigned *tickets;
     unsigned total, base;  // indices below 2*gridDim.x are the static first tiles
-    unsigned pending;      // thread 0: ticket drawn, not yet examined
+    unsigned pending;      // owner thread: ticket drawn, not yet examined
     unsigned ptx;          // ... and the XCD whose counter it came from
+    unsigned owner;        // the thread that draws (0 unless the kernel has a loader wave)
     bool dynamic, global, own_done;
     // global_: ONE counter for the whole chip (perfect balance, no XCD affinity)
-    __device__ __forceinline__ void init(unsigned *t, unsigned total_, bool global_ = false) {
+    __device__ __forceinline__ void init(unsigned *t, unsigned total_, bool global_ = false, unsigned owner_ = 0) {
         global = global_;
+        owner = owner_;
         tickets = t;
         total = total_;
         base = gridDim.x >> 2;  // 2*gridDim.x / 8
@@ -270,7 +334,7 @@ struct TileQueue {
     }
     // thread 0: start drawing (no wait)
     __device__ __forceinline__ void draw_begin() {
-        if (threadIdx.x == 0 && dynamic) {
+        if (threadIdx.x == owner && dynamic) {
             // The address goes through a vector register the compiler cannot see through: with a
             // uniform address the atomic optimiser rewrites this into "one lane adds, v_readfirstlane
             // broadcasts", and the broadcast needs the result AT ONCE - an s_waitcnt vmcnt(0) at the top of
@@ -297,7 +361,7 @@ struct TileQueue {
     // thread 0: finish the draw begun one tile ago and publish the index (or 0xFFFFFFFF) to
     // *slot; `prev` is the index two positions earlier in this work-group's sequence
     __device__ __forceinline__ void draw_end(unsigned *slot, unsigned prev2) {
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == owner) {
             unsigned s = 0xFFFFFFFFu;
             if (!tickets) {  // static round-robin
                 if (prev2 < total) s = prev2 + 2u * gridDim.x;
@@ -347,6 +411,7 @@ struct Pass1Args {
     unsigned total_slots;
     unsigned *tickets;  // TileQueue counters of this launch (8, zeroed)
     unsigned long long *trace;
+    unsigned long long *kclk;  // device-clock stamps of this launch (kclk_begin / kclk_end) or nullptr
 };
 
 // the raw words of two adjacent complex samples (columns 2p, 2p+1 of one row) -> c2
@@ -418,6 +483,7 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
     constexpr int LPT = (NCHK - EARLY + NTICK - 1) / NTICK;
     const int tid = threadIdx.x;
     PSDR_WGTRACE(a.trace, 0);
+    kclk_begin(a.kclk);
     const int p_ = tid % H, i0_ = tid / H;
     const int M2 = a.M2;
     const size_t M = (size_t)L << a.log2M2;
@@ -631,6 +697,9 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
                 } else {
                     dst = Yb + (size_t)c1 * T + 2 * p;
                 }
+#ifdef PSDR_ABL_P1_NOSTORE
+                if (yA.x == 1.2345678e-33f)  // timing-only: (almost) never true, keeps the arithmetic alive
+#endif
                 *reinterpret_cast<float4 *>(dst) = make_float4(yA.x, yA.y, yB.x, yB.y);
             },
             // ---- trickle the rest of the next tile's loads through the stages
@@ -652,6 +721,7 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
         snext = s2;
     }
     PSDR_WGTRACE(a.trace, 7);
+    kclk_end(a.kclk);
 }
 template <int L, int T, int SB, bool PAIR = false>
 __global__ __launch_bounds__(L *T / 32) void k_fft_pass1(Pass1Args a) {
@@ -682,6 +752,7 @@ struct Pass2Args {
     unsigned total_slots;
     unsigned *tickets;  // TileQueue counters of this launch (8, zeroed)
     unsigned long long *trace;
+    unsigned long long *kclk;  // device-clock stamps of this launch (kclk_begin / kclk_end) or nullptr
     // fused real-input epilogue (k_fft_pass2_real)
     const cf *UA, *UB;  // W_N^{h << log2UB}, W_N^{l}: untangle twiddles
     const cf *UG;       // W_N^{8g}, g < M1/16: the tile's factor of the untangle twiddle
@@ -694,8 +765,11 @@ struct Pass2Args {
 // pass 2: row FFT (length L = M2) of T adjacent rows c1 (T/2 couples); FUSED adds /N,
 // |X|^2, int8 level 0..LT of the pyramid.  L*T/32 threads.
 // TWC: pass-1 tile width when known at compile time (all fill addresses fold), 0: a.TW
-template <int L, int T, bool FUSED, int TWC>
+// YCM: Y is couple-major, [frame][pass-1 tile][couple][c1][2] (written by k_fft_pass1_w, fft_pass1w.h): the 16
+// rows of this tile are one 256-byte piece of every (pass-1 tile, couple) block
+template <int L, int T, bool FUSED, int TWC, bool YCM = false>
 __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
+    static_assert(!YCM || (T == 16 && TWC == 16), "couple-major Y: 16-row tiles of 16-column pass-1 tiles");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *tile = reinterpret_cast<float4 *>(smem);
     cf *tile_cf = reinterpret_cast<cf *>(smem);
@@ -715,6 +789,7 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
     constexpr int LPT = (NFRONT - EARLY + NTICK - 1) / NTICK;
     const int tid = threadIdx.x;
     PSDR_WGTRACE(a.trace, 0);
+    kclk_begin(a.kclk);
     const int p_ = tid % H, i0_ = tid / H;
     const int M1 = a.M1;
     const unsigned total = a.total_slots;
@@ -735,12 +810,17 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
         const unsigned slot = xcd_slot(sidx, total);
         const unsigned f = slot / a.tiles_per_frame;
         const unsigned tl = slot - f * a.tiles_per_frame;
-        nxt = a.Y + (size_t)f * a.yframe + (size_t)(tl * T) * TW;
+        nxt = a.Y + (size_t)f * a.yframe + (size_t)(tl * T) * (YCM ? 2 : TW);
     };
+    // couple-major Y: load q = i*NT + tid is (row rr = q & 15, couple pc = (q >> 4) & 7, pass-1 tile j = q >> 7)
+    const unsigned ycm_lane = (unsigned)((size_t)(tid >> 7) * blk + ((size_t)((tid >> 4) & 7) * a.M1 + (tid & 15)) * 2);
     auto issue = [&](auto qc) {
         constexpr int i = decltype(qc)::value;
-        // uniform part of idx = 2*i*NT: block (2*i*NT)>>lc, offset (2*i*NT)&(chunk-1)
-        const cf *q = nxt + (size_t)((2 * i * NT) >> lc) * blk + ((2 * i * NT) & (chunk - 1)) + lane_off;
+        const cf *q;
+        if constexpr (YCM)
+            q = nxt + (size_t)((i * NT) >> 7) * blk + ycm_lane;
+        else  // uniform part of idx = 2*i*NT: block (2*i*NT)>>lc, offset (2*i*NT)&(chunk-1)
+            q = nxt + (size_t)((2 * i * NT) >> lc) * blk + ((2 * i * NT) & (chunk - 1)) + lane_off;
         r[i] = *reinterpret_cast<const float4 *>(q);
     };
     __shared__ unsigned s_next[2];
@@ -776,8 +856,9 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
 #pragma unroll
         for (int i = 0; i < NLD; i++) {
             const int w = ((2 * i * NT) & (chunk - 1)) + ((2 * tidx) & (chunk - 1));
-            const int rr = w >> log2TW, cc = w & (TW - 1);
-            const int n2 = (((2 * i * NT) >> lc) + ((2 * tidx) >> lc)) * TW + cc;  // even
+            const int rr = YCM ? (tidx & 15) : w >> log2TW, cc = w & (TW - 1);
+            const int n2 = YCM ? (((i * NT) >> 7) + (tidx >> 7)) * 16 + 2 * ((tidx >> 4) & 7)
+                               : (((2 * i * NT) >> lc) + ((2 * tidx) >> lc)) * TW + cc;  // even
             const int slot0 = lds_slot<H, true>(n2, rr >> 1);  // rows n2, n2+1 share the swizzle
             tile_cf[2 * slot0 + (rr & 1)] = make_float2(r[i].x, r[i].y);
             tile_cf[2 * (slot0 + H) + (rr & 1)] = make_float2(r[i].z, r[i].w);
@@ -880,11 +961,12 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
         snext = s2;
     }
     PSDR_WGTRACE(a.trace, 7);
+    kclk_end(a.kclk);
 }
 
-template <int L, int T, bool FUSED, int TWC>
+template <int L, int T, bool FUSED, int TWC, bool YCM = false>
 __global__ __launch_bounds__(L *T / 32) void k_fft_pass2(Pass2Args a) {
-    pass2_body<L, T, FUSED, TWC>(a);
+    pass2_body<L, T, FUSED, TWC, YCM>(a);
 }
 
 // ---- pass 2 for REAL input, fused with the Hermitian untangle, /N, |X|^2 and pyramid levels 0..3 ----
@@ -975,6 +1057,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
     constexpr int NTICK = 2 * (Plan<L>::NS - 1);
     constexpr int EARLY = 4;
     PSDR_WGTRACE(a.trace, 0);
+    kclk_begin(a.kclk);
     constexpr int LATE = 8;  // loads of the next tile issued in the epilogue (half before the last stage, half before the octet loop; see pass2_body)
     constexpr int NFRONT = NLD - LATE;
     constexpr int LPT = (NFRONT - EARLY + NTICK - 1) / NTICK;
@@ -1259,6 +1342,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         }
     }
     PSDR_WGTRACE(a.trace, 7);
+    kclk_end(a.kclk);
 }
 
 }  // namespace psdr

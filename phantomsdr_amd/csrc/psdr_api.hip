@@ -17,6 +17,7 @@
 #include "demod.h"
 #include "epilogue.h"
 #include "fft_pass.h"
+#include "fft_pass1w.h"
 #include "postchain.h"
 #include "wire.h"
 
@@ -133,6 +134,9 @@ struct psdr_ctx {
     // and builds pyramid levels 0..3 itself (k_fft_pass2_real); smaller real transforms keep the
     // three-pass form (pass 1, pass 2, k_untangle_real)
     bool real_fused = false;
+    // 2^20-point IQ transforms of 8/16-bit samples: pass 1 with wave-owned column couples (fft_pass1w.h), Y
+    // couple-major; PSDR_P1_CLASSIC=1 keeps the barrier-synchronised kernel (tuning / A-B)
+    bool p1_wave = false;
     SpecLayout lay{};                // device layout of the spectrum (natural unless real_fused)
     bool y_blocked = false;          // PSDR_REAL_YBLOCKED (tuning)
     int seg_len_env = 0;             // PSDR_SEG_LEN (tuning): tiles per chain segment
@@ -256,11 +260,17 @@ struct psdr_ctx {
     } ring;
 
     // instrumentation
-    bool profiling = false;
+    bool profiling = false;   // psdr_set_profiling mode 1: hipEvent brackets around every launch
+    bool kclock = false;      // mode 2: device-clock stamps inside the two FFT passes (fft_pass.h kclk_*)
+    static constexpr unsigned KCLK_SLOTS = 8192;  // launches per pass that can be stamped between two resets
+    unsigned long long *d_kclk = nullptr;         // [2 passes][KCLK_SLOTS][begin, end]
+    unsigned kclk_pos[2] = {0, 0}, kclk_done[2] = {0, 0};
+    double wall_clock_khz = 100000.0;
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> pool;
     double k_ms[K_COUNT] = {0};
     int64_t k_n[K_COUNT] = {0};
+    std::vector<float> k_samples[K_COUNT];  // per-launch durations in us since the last reset (bounded)
     hipEvent_t t0 = nullptr, t1 = nullptr;
 };
 
@@ -313,11 +323,51 @@ void resolve_pending(psdr_ctx *c) {
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             c->k_ms[p.kid] += ms;
             c->k_n[p.kid] += 1;
+            if (c->k_samples[p.kid].size() < 65536) c->k_samples[p.kid].push_back(ms * 1e3f);
         }
         c->pool.push_back(p.a);
         c->pool.push_back(p.b);
     }
     c->pending.clear();
+}
+
+// mode 2: the stamps of the launches since the last call -> k_ms / k_n / k_samples of the two passes
+void resolve_kclock(psdr_ctx *c) {
+    if (!c->d_kclk) return;
+    bool any = false;
+    for (int w = 0; w < 2; w++) any = any || c->kclk_done[w] < std::min(c->kclk_pos[w], psdr_ctx::KCLK_SLOTS);
+    if (!any) return;
+    hipStreamSynchronize(c->p1);
+    hipStreamSynchronize(c->stream);
+    std::vector<unsigned long long> h((size_t)2 * psdr_ctx::KCLK_SLOTS * 2);
+    if (hipMemcpy(h.data(), c->d_kclk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return;
+    for (int w = 0; w < 2; w++) {
+        const int kid = w == 0 ? K_PASS1 : K_PASS2;
+        const unsigned end = std::min(c->kclk_pos[w], psdr_ctx::KCLK_SLOTS);
+        for (unsigned i = c->kclk_done[w]; i < end; i++) {
+            const unsigned long long b = h[((size_t)w * psdr_ctx::KCLK_SLOTS + i) * 2], e = h[((size_t)w * psdr_ctx::KCLK_SLOTS + i) * 2 + 1];
+            if (e <= b) continue;  // (never launched / no work-group ran)
+            const double us = (double)(e - b) * 1e3 / c->wall_clock_khz;
+            c->k_ms[kid] += us * 1e-3;
+            c->k_n[kid] += 1;
+            if (c->k_samples[kid].size() < 65536) c->k_samples[kid].push_back((float)us);
+        }
+        c->kclk_done[w] = end;
+    }
+}
+// stamp slot of the next launch of pass `which` (nullptr: mode 2 off or the ring is full)
+unsigned long long *next_kclk(psdr_ctx *c, int which) {
+    if (!c->kclock || !c->d_kclk || c->kclk_pos[which] >= psdr_ctx::KCLK_SLOTS) return nullptr;
+    return c->d_kclk + ((size_t)which * psdr_ctx::KCLK_SLOTS + c->kclk_pos[which]++) * 2;
+}
+// re-arm the whole ring: begin = ~0, end = 0 (streams drained by the caller)
+int reset_kclock(psdr_ctx *c) {
+    if (!c->d_kclk) return PSDR_OK;
+    std::vector<unsigned long long> h((size_t)2 * psdr_ctx::KCLK_SLOTS * 2);
+    for (size_t i = 0; i < h.size(); i += 2) h[i] = ~0ull, h[i + 1] = 0ull;
+    HIPCHK(hipMemcpy(c->d_kclk, h.data(), h.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    c->kclk_pos[0] = c->kclk_pos[1] = c->kclk_done[0] = c->kclk_done[1] = 0;
+    return PSDR_OK;
 }
 
 std::vector<cf> make_twiddles(size_t count, size_t mult, size_t period, int sign) {
@@ -381,16 +431,29 @@ int launch_pass1_t(psdr_ctx *c, const Pass1Args &a, unsigned blocks) {
     HIPCHK(hipGetLastError());
     return PSDR_OK;
 }
-template <int L, int T, bool FUSED, int TWC>
+template <int L, int T, bool FUSED, int TWC, bool YCM = false>
 int launch_pass2_t(psdr_ctx *c, const Pass2Args &a, unsigned blocks) {
     constexpr size_t lds = (size_t)L * T * sizeof(cf) + (size_t)L * sizeof(cf);
     // (per context = per device: the attribute is a property of the function ON a device)
-    if (c->lds_attr_done.insert((const void *)k_fft_pass2<L, T, FUSED, TWC>).second)
-        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass2<L, T, FUSED, TWC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (c->lds_attr_done.insert((const void *)k_fft_pass2<L, T, FUSED, TWC, YCM>).second)
+        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass2<L, T, FUSED, TWC, YCM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope ps(c, K_PASS2);
     unsigned grid = persistent_grid(c, blocks, lds);
     if (c->p2_grid && c->p2_grid < grid) grid = c->p2_grid;
-    hipLaunchKernelGGL((k_fft_pass2<L, T, FUSED, TWC>), dim3(grid), dim3(L * T / 32), lds, c->stream, a);
+    hipLaunchKernelGGL((k_fft_pass2<L, T, FUSED, TWC, YCM>), dim3(grid), dim3(L * T / 32), lds, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return PSDR_OK;
+}
+// pass 1 with wave-owned column couples (fft_pass1w.h): 2^20-point IQ frames of 8/16-bit samples
+template <int SB>
+int launch_pass1_w(psdr_ctx *c, const Pass1Args &a, unsigned blocks) {
+    constexpr size_t lds = pass1w_lds_bytes<SB>();
+    if (c->lds_attr_done.insert((const void *)k_fft_pass1_w<SB>).second)
+        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass1_w<SB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope ps(c, K_PASS1, c->p1);
+    unsigned grid = persistent_grid(c, blocks, lds);
+    if (c->p1_grid && c->p1_grid < grid) grid = c->p1_grid;
+    hipLaunchKernelGGL((k_fft_pass1_w<SB>), dim3(grid), dim3(kPass1wThreads), lds, c->p1, a);
     HIPCHK(hipGetLastError());
     return PSDR_OK;
 }
@@ -420,6 +483,7 @@ int launch_pass1(psdr_ctx *c, int L, int T, int sb, const Pass1Args &a, unsigned
     P1CASE(256, 64)
     P1CASE(512, 32)
     P1CASE(1024, 16)
+    P1CASE(1024, 8)
     P1CASE(2048, 8)
     return fail(PSDR_ERR_UNSUPPORTED, "no pass-1 kernel for L=%d T=%d", L, T);
 }
@@ -542,13 +606,16 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     a1.is_real = c->is_real ? 1 : 0;
     a1.rot = c->is_real ? 0 : 1;
     a1.trace = c->d_trace;
+    a1.kclk = next_kclk(c, 0);
     {
         int rc = next_tickets(c, 0, c->p1, &a1.tickets);
         if (rc) return rc;
     }
     a1.tiles_per_frame = tiles1;
     a1.total_slots = tiles1 * (unsigned)nframes;
-    int rc = launch_pass1(c, c->M1, c->T1, sb, a1, a1.total_slots, c->real_fused);
+    const bool wave1 = c->p1_wave && sb <= 4;  // (f32 / f64 samples: the image does not fit, classic kernel)
+    int rc = wave1 ? (sb == 2 ? launch_pass1_w<2>(c, a1, a1.total_slots) : launch_pass1_w<4>(c, a1, a1.total_slots))
+                   : launch_pass1(c, c->M1, c->T1, sb, a1, a1.total_slots, c->real_fused);
     if (rc) return rc;
     if (ev_raw_consumed) HIPCHK(hipEventRecord(ev_raw_consumed, c->p1));  // pass 1 is the only reader of the raw halves
     if (piped) {
@@ -575,6 +642,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     a2.Pscr = c->d_pscr[0];
     a2.p_stride = c->p_stride;
     a2.trace = c->d_trace ? c->d_trace + 128 + 2304 : nullptr;
+    a2.kclk = next_kclk(c, 1);
     {
         int rc2 = next_tickets(c, 1, c->stream, &a2.tickets);
         if (rc2) return rc2;
@@ -584,7 +652,10 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     // pass 2 overwrites this result set: its previous consumers (two batches ago) must be done
     if (c->set_pending[c->cur_set] && c->side != c->stream)
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_set_done[c->cur_set], 0));
-    auto run_pass2 = [&](bool fused) -> int { return launch_pass2(c, c->M2, c->T2, fused, a2, a2.total_slots); };
+    auto run_pass2 = [&](bool fused) -> int {
+        if (wave1) return launch_pass2_t<1024, 16, true, 16, true>(c, a2, a2.total_slots);  // couple-major Y
+        return launch_pass2(c, c->M2, c->T2, fused, a2, a2.total_slots);
+    };
     int seam_S = 0, seam_SL = 0;  // fused real path: the seam kernel runs with the consumers
     if (!c->is_real) {
         a2.X = c->d_spec;
@@ -740,6 +811,7 @@ void free_all(psdr_ctx *c) {
     if (c->d_Wl2 != c->d_Wl1) F(c->d_Wl2);
     F(c->d_TA);
     F(c->d_trace);
+    F(c->d_kclk);
     F(c->d_TB);
     F(c->d_UA);
     F(c->d_UB);
@@ -1072,6 +1144,7 @@ extern "C" int psdr_create(const psdr_config *cfg, psdr_ctx **out) {
     c->M1 = 1 << c->log2M1;
     c->M2 = 1 << c->log2M2;
     c->T1 = pick_T(c->M1, c->M2);
+    if (const char *e = getenv("PSDR_T1")) c->T1 = std::min(c->T1, std::max(8, atoi(e)));  // tuning: narrower pass-1 tiles, several work-groups per CU
     c->T2 = pick_T(c->M2, c->M1);
     c->size_log2 = (int)std::lround(std::log2((double)N)) + cfg->brightness_offset;
     c->levels = cfg->downsample_levels;
@@ -1116,6 +1189,7 @@ extern "C" int psdr_create(const psdr_config *cfg, psdr_ctx **out) {
             c->lay.l2L = c->log2M2;
         }
     }
+    c->p1_wave = !is_real && c->M1 == 1024 && c->M2 == 1024 && c->T1 == 16 && c->T2 == 16 && getenv("PSDR_P1_CLASSIC") == nullptr;
     c->p_stride = std::max<size_t>(c->R >> c->LT, 64);
     if (cfg->skip_num < 1) c->cfg.skip_num = 1;
     if (cfg->waterfall_size < 0) {
@@ -2018,16 +2092,43 @@ extern "C" int psdr_read_quantized(psdr_ctx *c, int frame, int8_t *out) {
 }
 
 // ---- instrumentation -------------------------------------------------------------------------
-extern "C" int psdr_set_profiling(psdr_ctx *c, int enable) {
+extern "C" int psdr_set_profiling(psdr_ctx *c, int mode) {
     if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    if (mode < 0 || mode > 2) return fail(PSDR_ERR_INVALID, "profiling mode %d (0 off, 1 hipEvents, 2 device clocks)", mode);
+    HIPCHK(hipSetDevice(c->device));
     resolve_pending(c);
-    c->profiling = enable != 0;
+    resolve_kclock(c);
+    c->profiling = mode == 1;
+    if (mode == 2 && !c->d_kclk) {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) == hipSuccess && khz > 0) c->wall_clock_khz = khz;
+        HIPCHK(hipMalloc((void **)&c->d_kclk, (size_t)2 * psdr_ctx::KCLK_SLOTS * 2 * sizeof(unsigned long long)));
+        int rc = drain(c);
+        if (rc) return rc;
+        rc = reset_kclock(c);
+        if (rc) return rc;
+    }
+    c->kclock = mode == 2;
     return PSDR_OK;
+}
+extern "C" int psdr_get_kernel_samples(psdr_ctx *c, const char *name, double *us_out, int cap, int *n_out) {
+    if (!c || !name || !n_out) return fail(PSDR_ERR_INVALID, "null argument");
+    resolve_pending(c);
+    resolve_kclock(c);
+    for (int k = 0; k < K_COUNT; k++) {
+        if (strcmp(name, kKernelNames[k]) != 0) continue;
+        const int n = (int)c->k_samples[k].size();
+        for (int i = 0; i < n && i < cap && us_out; i++) us_out[i] = c->k_samples[k][i];
+        *n_out = n;
+        return PSDR_OK;
+    }
+    return fail(PSDR_ERR_INVALID, "no kernel named '%s'", name);
 }
 extern "C" int psdr_get_kernel_stats(psdr_ctx *c, int max_entries, const char **names, double *total_ms,
                                      int64_t *launches, int *n_out) {
     if (!c) return fail(PSDR_ERR_INVALID, "null argument");
     resolve_pending(c);
+    resolve_kclock(c);
     int n = 0;
     for (int k = 0; k < K_COUNT && n < max_entries; k++) {
         if (c->k_n[k] == 0) continue;
@@ -2045,6 +2146,13 @@ extern "C" int psdr_reset_kernel_stats(psdr_ctx *c) {
     for (int k = 0; k < K_COUNT; k++) {
         c->k_ms[k] = 0;
         c->k_n[k] = 0;
+        c->k_samples[k].clear();
+    }
+    if (c->d_kclk) {  // re-arm the stamp ring
+        HIPCHK(hipSetDevice(c->device));
+        int rc = drain(c);
+        if (rc) return rc;
+        return reset_kclock(c);
     }
     return PSDR_OK;
 }

@@ -1,9 +1,10 @@
 """Multi-GPU operation: one process per GPU, `torch.distributed` (backend
 "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 
-The reference has no multi-GPU path; this is new design.  Two ways to shard the path:
+The reference has no multi-GPU path; this is new design.  Ways to shard the path (bench.py --shard; its
+default is CLIENT sharding with a spectrum broadcast, the shape BASELINE.json names):
 
-TIME sharding (default, `TimeShardedRunner`): the stream itself is the partitioned object.
+TIME sharding (`--shard time`, `TimeShardedRunner`): the stream itself is the partitioned object.
 Frames are independent for the forward FFT and for every client's inverse transform; the
 only cross-frame state is the overlap-add tail (second half of the previous frame's
 transform) and FM's last sample, and both are functions of the two preceding frames alone.
@@ -14,7 +15,7 @@ ring (its own PCIe link in a deployment), and there is NO data-path collective a
 Cost: (F+2)/F work per batch.  (The reference's stale cross-mode state - buffers that
 survive a mode switch, src/signal.cpp:316-328 - is carried only within a rank.)
 
-CLIENT sharding (`ShardedRunner`, the shape BASELINE.json's north_star names): after ONE
+CLIENT sharding (bench.py's default, `ShardedRunner`, the shape BASELINE.json's north_star names): after ONE
 exchange step the audio clients are independent units, so they shard across ranks:
 
   rank 0 ("ingest")  owns the raw sample ring, runs the forward FFT + waterfall pyramid

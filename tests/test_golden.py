@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import rel_err, rel_l2
+from helpers import check_fm, rel_err, rel_l2
 from oracle import oracle as O
 
 FIXTURES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
@@ -90,8 +90,7 @@ def test_hip_matches_fixture(path):
                 assert nan[f] == 0
                 assert abs(p[f] - g["pwr"][ci, f]) <= 1e-4 * max(abs(g["pwr"][ci, f]), 1e-30)
                 if g["clients"][ci][0] == "FM":
-                    dd = np.abs(np.angle(np.exp(1j * (a[f].astype(np.float64) - g["audio"][ci, f]))))
-                    assert dd.max() < 2e-3
+                    check_fm(a[f], g["audio"][ci, f], g["baseband"][ci, f], g["baseband_prev"][ci, f], f"client {ci} frame {f}")
                 else:
                     assert rel_l2(a[f], g["audio"][ci, f]) < 1e-4
         ctx.dev_free(d)

@@ -1,0 +1,136 @@
+"""The launch shapes bench.py TIMES, against the oracle.
+
+test_gpu_fullsize.py runs every BASELINE shape for 3-5 frames: a fused real-input launch that small
+walks chains of 1 or 2 tiles, and no frame of a 256-frame launch ever meets the oracle.  Here:
+
+  * the fused real-input second pass (k_fft_pass2_real) with chain segments of 4, 16, 32 and 64 tiles
+    at 2^21 points and of 64 tiles at 2^22 points (PSDR_SEG_LEN pins what real_seg_len() would pick
+    for F = 256: 32 tiles at 2^21, 64 at 2^22) - a chain of >= 3 tiles has a MIDDLE tile, with carry-in
+    AND carry-out and the LDS double-buffer toggle - spectrum, int8 pyramid, every client's audio and
+    the gathered waterfall rows against the oracle                    (src/fft_impl.cpp:144-174)
+  * ONE F = 256 launch each of cfg2 and cfg3, exactly as bench.py's SingleGpuRun drives it (its ring
+    generator, its clients, psdr_process_batch + psdr_demod_batch + psdr_waterfall_batch), two
+    consecutive batches so that the cross-batch tails are in; frames 0, 2, 127 and 255 of the SECOND
+    launch - spectrum, pyramid, waterfall rows and all clients' audio - against the oracle run on the
+    same raw half-frames                                             (src/signal.cpp:102-275)
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import rel_err, rel_l2
+from oracle import oracle as O
+from test_gpu_fullsize import SPEC_L2, SPEC_TOL, _check_audio, _check_pyramid, _oracle_clients, run_workload
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench():
+    import bench
+    return bench
+
+
+@pytest.fixture
+def seg_len_env():
+    old = os.environ.get("PSDR_SEG_LEN")
+
+    def set_(v):
+        os.environ["PSDR_SEG_LEN"] = str(v)
+    yield set_
+    if old is None:
+        os.environ.pop("PSDR_SEG_LEN", None)
+    else:
+        os.environ["PSDR_SEG_LEN"] = old
+
+
+@pytest.mark.parametrize("wl_name,seg_len,splits", [("cfg3", 4, (2, 1)), ("cfg3", 16, (2, 1)), ("cfg3", 32, (1, 2)),
+                                                    ("cfg3", 64, (2, 1)), ("cfg5", 64, (1, 1)), ("cfg5", 128, (1, 1))])
+def test_fused_real_pass_long_chains_vs_oracle(wl_name, seg_len, splits, seg_len_env):
+    """chain segments as long as the bench's (and longer: one chain per frame), few frames, everything vs the oracle"""
+    seg_len_env(seg_len)  # read by psdr_create
+    B = _bench()
+    wl = dict(B.WORKLOADS[wl_name])
+    if wl_name == "cfg5":
+        wl["audio"] = 32  # the full client set is test_cfg5_share_fullsize_vs_oracle's; here the chain is the subject
+    run_workload(wl, splits=splits, seed=1234 + seg_len)
+
+
+def _default_seg_len(M1, nframes, num_cus=256):
+    """real_seg_len() of psdr_api.hip"""
+    G = M1 // 16
+    want = G * nframes // (2 * num_cus)
+    sl = 1
+    while sl * 2 <= want and sl * 2 <= G:
+        sl *= 2
+    return sl
+
+
+def test_bench_seg_len_is_what_the_chain_tests_cover():
+    assert _default_seg_len(1024, 256) == 32 and _default_seg_len(2048, 256) == 64
+
+
+@pytest.mark.parametrize("wl_name", ["cfg2", "cfg3"])
+def test_bench_launch_256_frames_vs_oracle(wl_name):
+    """bench.py's own launch: SingleGpuRun.step() twice with F = 256, then frames {0, 2, 127, 255} of the second
+    launch against the oracle (which runs frames g-2, g-1, g: the overlap-add tail and FM's last sample are
+    functions of the two preceding frames)."""
+    import torch
+    B = _bench()
+    wl = B.WORKLOADS[wl_name]
+    F = 256
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    N, is_real = wl["fft_size"], wl["is_real"]
+    hb_mib = (N // 2) * (1 if is_real else 2) * 2 / 2 ** 20
+    run = B.SingleGpuRun(torch, dev, 0, wl_name, wl, F, int(2 * F * hb_mib) + 8)
+    try:
+        assert run.nbatches == 2
+        eng, p = run.eng, run.params
+        R, n, levels, skip = p["fft_result_size"], p["audio_fft_size"], p["downsample_levels"], p["skip_num"]
+        run.step(0)
+        run.step(1)
+        run.sync()
+        first = F  # frame number of the second launch's first frame
+        got = [g.read_audio(F) for g in eng.audio_clients]
+        wrows = [w.read_waterfall()[0] for w in eng.waterfall_clients]
+        sent = [f for f in range(F) if (first + f) % skip == 0]
+        for wi, w in enumerate(wrows):
+            assert w.shape[0] == len(sent)
+        check = [0, 2, 127, 255]
+        assert any(f in sent for f in check) or not run.waterfalls
+        nb = N // 2 if is_real else N
+        fo = O.FFT(N, is_real, levels, 0, n)
+        ring = run.ring  # [halves][samples] int16 on the device
+        for f in check:
+            g = first + f
+            rows = ring[g - 2: g + 2].cpu().numpy()  # halves g-2 .. g+1
+            conv = O.convert(rows.reshape(-1), "s16")
+            halves = (conv if is_real else conv.view(np.complex64)).reshape(4, N // 2)
+            ocl = _oracle_clients(run.clients, is_real, n, R)
+            for k in range(3):
+                fo.load(halves[k], halves[k + 1])
+                fo.execute()
+                spec_o = fo.output().copy()
+                res = [o.send_audio(spec_o, g - 2 + k, fft=fo) for o in ocl]
+            tag = f"{wl_name} frame {f} of the second 256-frame launch"
+            Xg = eng.ctx.read_spectrum(f)
+            assert rel_err(Xg[:nb], spec_o[:nb]) < SPEC_TOL, tag
+            assert rel_l2(Xg[:nb], spec_o[:nb]) < SPEC_L2, tag
+            qg = eng.ctx.read_quantized(f)
+            _check_pyramid(qg, Xg, fo.quantized().copy(), N, is_real, levels, tag)
+            if f in sent:
+                si = sent.index(f)
+                for wi, (lv, l, r) in enumerate(run.waterfalls):
+                    assert np.array_equal(wrows[wi][si], eng.ctx.quantized_level(qg, lv)[l:r]), f"{tag} waterfall {wi}"
+            for ci, o in enumerate(ocl):
+                a_o, p_o, _, dropped = res[ci]
+                _check_audio(f"{tag} client {ci} {run.clients[ci]}", o.mode, got[ci][0][f], got[ci][1][f], got[ci][2][f],
+                             a_o, p_o, dropped, o)
+    finally:
+        run.close()

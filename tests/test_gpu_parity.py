@@ -5,7 +5,7 @@ the GPU's own spectrum, and >= 99.9 % identical (rest +-1) against the oracle's.
 import numpy as np
 import pytest
 
-from helpers import quantize_raw, rel_err, rel_l2, synth_stream
+from helpers import check_fm, quantize_raw, rel_err, rel_l2, synth_stream
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -166,10 +166,8 @@ def run_demod_case(N, is_real, n, clients, nbatches, F, seed, fmt="s16", mode_ch
                     assert abs(p_g - p_o) <= 1e-4 * max(abs(p_o), 1e-30), tag
                     scale = max(np.abs(a_o).max(), 1e-30)
                     if o.mode == O.FM:
-                        # phase of a noisy vector: compare where the discriminator input is
-                        # well conditioned (|angle| away from the +-pi cut)
-                        dd = np.abs(np.angle(np.exp(1j * (a_g.astype(np.float64) - a_o))))
-                        assert dd.max() < 2e-3, f"{tag}: FM max abs err {dd.max():.2e}"
+                        # 1e-4 rad, conditioned by |B|max / |B[i]| (helpers.fm_tolerance)
+                        check_fm(a_g, a_o, o.baseband()[: o.n // 2], o.bb_prev, tag)
                     else:
                         assert rel_l2(a_g, a_o) < AUDIO_TOL, f"{tag}: rel L2 {rel_l2(a_g, a_o):.2e}"
                         assert np.abs(a_g - a_o).max() <= 2e-4 * scale, tag

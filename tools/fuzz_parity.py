@@ -11,7 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from helpers import quantize_raw, rel_err, rel_l2, synth_stream  # noqa: E402
+from helpers import check_fm, quantize_raw, rel_err, rel_l2, synth_stream  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 from phantomsdr_amd import AudioClient, Context, WaterfallClient  # noqa: E402
 
@@ -135,9 +135,7 @@ def one_case(rng, case):
                     assert abs(p_g - p_o) <= 1e-4 * max(abs(p_o), 1e-30) + 1e-30, tag
                     scale = max(np.abs(a_o).max(), 1e-30)
                     if o.mode == O.FM:
-                        dd = np.abs(np.angle(np.exp(1j * (a_g.astype(np.float64) - a_o))))
-                        # ill-conditioned where the discriminator input is tiny: compare robustly
-                        assert np.median(dd) < 2e-3, tag + f" FM median {np.median(dd):.2e}"
+                        check_fm(a_g, a_o, o.baseband()[: o.n // 2], o.bb_prev, tag)
                     else:
                         # relative to the larger of the audio's own peak and the slice's amplitude sqrt(w*pwr):
                         # a one-bin slice whose phase sits near +-90 degrees demodulates (c2r: only Re of

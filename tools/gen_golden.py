@@ -69,6 +69,10 @@ def main():
         audio = np.zeros((len(cl), nframes, n // 2), np.float32)
         pwr = np.zeros((len(cl), nframes), np.float32)
         pcm = np.zeros((len(cl), nframes, n // 2), np.int32)
+        # the complex baseband the AM/FM outputs are taken from (and the sample FM's first output pairs with):
+        # the tests condition the FM bound on it (tests/helpers.py fm_tolerance)
+        bb = np.zeros((len(cl), nframes, n // 2), np.complex64)
+        bb_prev = np.zeros((len(cl), nframes), np.complex64)
         for f in range(nframes):
             fo.load(halves[f], halves[f + 1])
             fo.execute()
@@ -77,9 +81,11 @@ def main():
             for ci, c in enumerate(ocl):
                 a, p, pc, _ = c.send_audio(spec[f], f, fft=fo, post=True)
                 audio[ci, f], pwr[ci, f], pcm[ci, f] = a, p, pc
+                bb[ci, f], bb_prev[ci, f] = c.baseband()[: n // 2], c.bb_prev
         np.savez_compressed(
             os.path.join(OUT, name + ".npz"), raw=raw, fmt=fmt, N=N, is_real=is_real, n=n,
-            levels=levels, spectrum=spec, quantized=quant, audio=audio, pwr=pwr, pcm=pcm,
+            levels=levels, spectrum=spec, quantized=quant, audio=audio, pwr=pwr, pcm=pcm, baseband=bb,
+            baseband_prev=bb_prev,
             client_modes=np.array([c[0] for c in cl]), client_l=np.array([c[1] for c in cl]),
             client_m=np.array([c[2] for c in cl]), client_r=np.array([c[3] for c in cl]))
         print(name, os.path.getsize(os.path.join(OUT, name + ".npz")) // 1024, "KiB")

@@ -20,6 +20,7 @@ ap.add_argument("--clients", type=int, default=16)
 ap.add_argument("--ring-mib", type=int, default=512)
 ap.add_argument("--tag", default="")
 ap.add_argument("--post", action="store_true", help="enable the post-demodulation chain")
+ap.add_argument("--mode", type=int, default=2, help="1: hipEvent brackets around every kernel; 2: device-clock stamps of the two passes")
 args = ap.parse_args()
 
 from phantomsdr_amd import SpectrumEngine  # noqa: E402
@@ -43,7 +44,7 @@ eng.add_waterfall_client()
 for i in range(5):
     eng.step((i % nb) * F, F)
 eng.ctx.synchronize()
-eng.ctx.set_profiling(True)
+eng.ctx.set_profiling(args.mode)
 eng.ctx.reset_kernel_stats()
 eng.ctx.timer_start()
 for i in range(args.steps):
@@ -54,5 +55,9 @@ out = {"tag": args.tag or os.environ.get("PSDR_LIB", "default"), "N": N, "F": F,
        "us_per_frame_total": round(total_ms * 1e3 / (args.steps * F), 3)}
 for k, (ms, cnt) in st.items():
     out[k] = round(ms / cnt * 1e3, 2)
+if args.mode == 2:
+    for k in ("fft_pass1", "fft_pass2"):
+        out[k + "_median"] = round(float(np.median(eng.ctx.kernel_samples(k))), 2)
+out["mode"] = args.mode
 print(json.dumps(out))
 eng.close()
