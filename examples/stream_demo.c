@@ -148,8 +148,6 @@ int main(int argc, char **argv) {
     float *staging = NULL;
     CHECK(psdr_host_alloc(ctx, (size_t)nh * hb / sizeof(float) + 1, &staging));
     const int h2 = n / 2;
-    float *audio = malloc((size_t)batch * h2 * sizeof(float)), *pwr = malloc((size_t)batch * sizeof(float));
-    int32_t *nanf = malloc((size_t)batch * sizeof(int32_t));
     int8_t *rows = malloc((size_t)batch * R);
     const size_t pcap = psdr_wire_packet_bound((size_t)(R > (uint32_t)h2 * 4 ? R : (uint32_t)h2 * 4));
     uint8_t *pkt = malloc(pcap), *zbuf = malloc(psdr_wire_zstd_bound(pcap) + 64);
@@ -176,14 +174,20 @@ int main(int argc, char **argv) {
         CHECK(psdr_process_ring(ctx, frame, nf));
         if (na) CHECK(psdr_demod_batch(ctx, frame));
         if (nw) CHECK(psdr_waterfall_batch(ctx, frame));
+        /* ONE copy of every client's results of the batch to the host (psdr_fetch_batch), then pointers into it */
+        if (na) CHECK(psdr_fetch_batch(ctx));
         for (int c = 0; c < na; c++) {
-            int got = 0;
-            CHECK(psdr_read_audio(ctx, aid[c], batch, audio, pwr, nanf, &got));
-            for (int f = 0; f < got; f++) {
-                if (nanf[f]) continue; /* the reference drops the frame (src/signal.cpp:266-271) */
+            for (int f = 0; f < nf; f++) {
+                const float *a = NULL;
+                float p = 0;
+                int32_t nanflag = 0;
+                CHECK(psdr_fetched_audio(ctx, aid[c], f, &a, &p, &nanflag, NULL));
+                if (nanflag) continue; /* the reference drops the frame (src/signal.cpp:266-271) */
                 size_t len = 0;
-                CHECK(psdr_wire_audio_packet(frame + (uint64_t)f, al[c], am[c], ar[c], pwr[f], audio + (size_t)f * h2,
-                                             (size_t)h2 * sizeof(float), pkt, pcap, &len));
+                /* labels as AudioClient::send_audio sends them (src/signal.cpp:104-105, 287): l = audio_l = l - l = 0,
+                 * m = audio_mid, r = audio_r = r - l */
+                CHECK(psdr_wire_audio_packet(frame + (uint64_t)f, 0, am[c], ar[c] - al[c], p, a, (size_t)h2 * sizeof(float), pkt, pcap,
+                                             &len));
                 put_record('A', (uint32_t)c, pkt, (uint32_t)len);
             }
         }
@@ -214,6 +218,6 @@ int main(int argc, char **argv) {
     for (int c = 0; c < nw; c++) psdr_wire_zstd_destroy(wz[c]);
     psdr_host_free(ctx, staging);
     psdr_destroy(ctx);
-    free(audio), free(pwr), free(nanf), free(rows), free(pkt), free(zbuf);
+    free(rows), free(pkt), free(zbuf);
     return 0;
 }

@@ -40,7 +40,8 @@ typedef enum psdr_status {
     PSDR_ERR_HIP = -3,         /* a HIP runtime call failed */
     PSDR_ERR_STATE = -4,       /* call order violated (e.g. execute before load) */
     PSDR_ERR_NOMEM = -5,
-    PSDR_ERR_UNSUPPORTED = -6  /* size outside what the kernels are built for */
+    PSDR_ERR_UNSUPPORTED = -6, /* size outside what the kernels are built for */
+    PSDR_ERR_NO_DATA = -7      /* the client slot was not part of the batch whose results are asked for */
 } psdr_status;
 
 /* input.driver.format, src/spectrumserver.cpp:349-364 / src/samplereader.cpp:72-81 */
@@ -177,6 +178,18 @@ int psdr_demod_batch_from_band(psdr_ctx *ctx, const float *d_band, size_t frame_
  * (PSDR_ERR_INVALID otherwise, nothing is written); *nframes_out (may be NULL) = rows written. */
 int psdr_read_audio(psdr_ctx *ctx, int id, int nframes, float *audio, float *pwr, int32_t *nan_flags,
                     int *nframes_out);
+/* A client added after the last psdr_demod_batch has no results in it (the reference's frame loop would not
+ * have posted a task for it either, src/websocket.cpp:156-185): psdr_read_audio / psdr_read_pcm / psdr_fetched_audio
+ * return PSDR_ERR_NO_DATA for such a slot instead of the previous occupant's samples.
+ *
+ * Batched read-back - what a per-frame fan-out should use: psdr_fetch_batch copies the last demod batch's audio,
+ * pwr, NaN flags (and PCM with the post chain on) of ALL client slots into pinned host memory owned by the
+ * context with ONE synchronisation and at most four strided copies; psdr_fetched_audio then hands out pointers
+ * into that block (valid until the next psdr_fetch_batch) without touching the device.  frame: index inside the
+ * batch.  audio / pcm: audio_fft_size/2 values.  Any output pointer may be NULL. */
+int psdr_fetch_batch(psdr_ctx *ctx);
+int psdr_fetched_audio(psdr_ctx *ctx, int id, int frame, const float **audio, float *pwr, int32_t *nan_flag,
+                       const int32_t **pcm);
 /* device-resident results (no copy): audio of client slot `id` */
 int psdr_audio_device_ptr(psdr_ctx *ctx, int id, const float **d_audio, const float **d_pwr);
 

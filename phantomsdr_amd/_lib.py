@@ -87,6 +87,9 @@ SYMBOLS = [
     ("psdr_set_profiling", _i, [_vp, _i]),
     ("psdr_get_kernel_stats", _i,
      [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(_i)]),
+    ("psdr_fetch_batch", _i, [_vp]),
+    ("psdr_fetched_audio", _i, [_vp, _i, _i, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_float), C.POINTER(C.c_int32),
+                                C.POINTER(C.POINTER(C.c_int32))]),
     ("psdr_get_kernel_samples", _i, [_vp, C.c_char_p, C.POINTER(C.c_double), _i, C.POINTER(_i)]),
     ("psdr_reset_kernel_stats", _i, [_vp]),
     ("psdr_timer_start", _i, [_vp]),

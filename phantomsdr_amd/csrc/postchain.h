@@ -276,10 +276,13 @@ __global__ __launch_bounds__(64) void k_pc_ma2(PostArgs a) {
 
 // grid (client, block k of L rows of V1, 2): z = 0: prefix maxima of |v| inside the block, 1: suffix
 // maxima.  max is associative and exact, so this one IS parallel: the block's rows go through LDS
-// (coalesced both ways), each lane scans a contiguous chunk, the chunk totals are combined by a
-// wave scan.  dynamic LDS: L floats
+// (coalesced both ways), each lane scans a contiguous piece, the piece totals are combined by a wave
+// scan.  The block is walked in chunks of PC_SCAN_CHUNK rows with the running maximum carried from chunk
+// to chunk, so the LDS need does not grow with the look-ahead L (200 ms: 2400 rows at 12 kHz, 38400 at
+// the 192 kHz of the reference's shipped config.toml - 150 KB if the block had to fit at once).
+constexpr int PC_SCAN_CHUNK = 4096;
 __global__ __launch_bounds__(64) void k_pc_scan(PostArgs a) {
-    extern __shared__ float pc_blk[];
+    __shared__ float pc_blk[PC_SCAN_CHUNK];
     const int lane = threadIdx.x;
     const int slot = a.clients[blockIdx.x].slot;
     const int rows = a.L - 1 + a.len[slot];
@@ -288,27 +291,34 @@ __global__ __launch_bounds__(64) void k_pc_scan(PostArgs a) {
     const int n = r1 - r0;
     const float *__restrict__ v1 = a.V1 + (size_t)slot * a.pv + a.vo + r0;
     const bool suffix = blockIdx.z != 0;
-    // LDS position i = distance from the scan's start (suffix scans run backwards)
-    for (int i = lane; i < n; i += 64) pc_blk[suffix ? n - 1 - i : i] = fabsf(v1[i]);
-    __syncthreads();
-    const int C = (n + 63) / 64, i0 = lane * C, i1 = min(i0 + C, n);
-    float m = 0.f;
-    for (int i = i0; i < i1; i++) m = fmaxf(m, pc_blk[i]);
-    float incl = m;  // inclusive wave scan of the chunk maxima
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const float o = __shfl_up(incl, d, 64);
-        if (lane >= d) incl = fmaxf(incl, o);
-    }
-    float run = __shfl_up(incl, 1, 64);  // maximum of all earlier chunks
-    if (lane == 0) run = 0.f;
-    for (int i = i0; i < i1; i++) {
-        run = fmaxf(run, pc_blk[i]);
-        pc_blk[i] = run;
-    }
-    __syncthreads();
     float *__restrict__ out = (suffix ? a.S : a.P) + (size_t)slot * a.pv + r0;
-    for (int i = lane; i < n; i += 64) out[i] = pc_blk[suffix ? n - 1 - i : i];
+    float carry = 0.f;  // maximum of everything before this chunk (scan order)
+    // scan position q = distance from the scan's start (suffix scans run backwards): row q, or n - 1 - q
+    for (int q0 = 0; q0 < n; q0 += PC_SCAN_CHUNK) {
+        const int m = min(PC_SCAN_CHUNK, n - q0);
+        for (int i = lane; i < m; i += 64) pc_blk[i] = fabsf(v1[suffix ? n - 1 - (q0 + i) : q0 + i]);
+        __syncthreads();
+        const int C = (m + 63) / 64, i0 = min(lane * C, m), i1 = min(i0 + C, m);
+        float mx = 0.f;
+        for (int i = i0; i < i1; i++) mx = fmaxf(mx, pc_blk[i]);
+        float incl = mx;  // inclusive wave scan of the piece maxima
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl = fmaxf(incl, o);
+        }
+        float run = __shfl_up(incl, 1, 64);  // maximum of all earlier pieces of this chunk ...
+        if (lane == 0) run = 0.f;
+        run = fmaxf(run, carry);             // ... and of all earlier chunks
+        for (int i = i0; i < i1; i++) {
+            run = fmaxf(run, pc_blk[i]);
+            pc_blk[i] = run;
+        }
+        carry = fmaxf(carry, __shfl(incl, 63, 64));
+        __syncthreads();
+        for (int i = lane; i < m; i += 64) out[suffix ? n - 1 - (q0 + i) : q0 + i] = pc_blk[i];
+        __syncthreads();
+    }
 }
 
 // w_t = desired / (peak_t + 1e-10), peak_t = max |V1| over rows [t, t+L-1] = max(S[t], P[t+L-1]);
@@ -456,11 +466,11 @@ __global__ __launch_bounds__(256) void k_pc_history(PostArgs a) {
         }
         return;
     }
+    // V1 and V1n are the two buffers of the double-buffered stream: source and destination never overlap, a plain
+    // copy (no LDS: at 192 kHz the L - 1 rows would be 150 KB of it)
     const float *v = a.V1 + (size_t)slot * a.pv + a.vo;
     float *vn = a.V1n + (size_t)slot * a.pv + a.vo;
-    for (int r = threadIdx.x; r < a.L - 1; r += blockDim.x) pc_hist[r] = v[r + T];
-    __syncthreads();
-    for (int r = threadIdx.x; r < a.L - 1; r += blockDim.x) vn[r] = pc_hist[r];
+    for (int r = threadIdx.x; r < a.L - 1; r += blockDim.x) vn[r] = v[r + T];
 }
 
 }  // namespace psdr

@@ -64,6 +64,7 @@ struct AudioSlot {
     int mode = PSDR_USB;
     int state_cur = 0;
     int agc_reset = 2;  // post chain: 1 = AGC::reset pending (set_audio_demodulation), 2 = fresh client
+    uint64_t last_seq = 0;  // the demodulation batch (ctx->demod_seq) that last included this slot; 0: none yet
 };
 struct WfSlot {
     bool active = false;
@@ -135,7 +136,7 @@ struct psdr_ctx {
     // three-pass form (pass 1, pass 2, k_untangle_real)
     bool real_fused = false;
     // 2^20-point IQ transforms of 8/16-bit samples: pass 1 with wave-owned column couples (fft_pass1w.h), Y
-    // couple-major; PSDR_P1_CLASSIC=1 keeps the barrier-synchronised kernel (tuning / A-B)
+    // couple-major.  Experimental, off unless PSDR_P1_WAVE=1: correct (parity tests run it), not yet faster
     bool p1_wave = false;
     SpecLayout lay{};                // device layout of the spectrum (natural unless real_fused)
     bool y_blocked = false;          // PSDR_REAL_YBLOCKED (tuning)
@@ -237,6 +238,13 @@ struct psdr_ctx {
     int *d_nan = nullptr;
     ParamRing client_ring;
     int last_demod_frames = 0;
+    uint64_t demod_seq = 0;  // number of demodulation batches so far (AudioSlot::last_seq)
+    // psdr_fetch_batch: pinned host mirror of the last batch's results, [slot][frame][...]
+    float *h_audio = nullptr, *h_pwr = nullptr;
+    int32_t *h_nan = nullptr, *h_pcm = nullptr;
+    int fetched_frames = 0;
+    uint64_t fetched_seq = 0;
+    bool fetched_pcm = false;
 
     // waterfall clients
     std::vector<WfSlot> wslots;
@@ -859,6 +867,10 @@ void free_all(psdr_ctx *c) {
     };
     H(c->h_out);
     H(c->h_q);
+    H(c->h_audio);
+    H(c->h_pwr);
+    H(c->h_nan);
+    H(c->h_pcm);
     for (auto &p : c->pending) {
         hipEventDestroy(p.a);
         hipEventDestroy(p.b);
@@ -1189,7 +1201,8 @@ extern "C" int psdr_create(const psdr_config *cfg, psdr_ctx **out) {
             c->lay.l2L = c->log2M2;
         }
     }
-    c->p1_wave = !is_real && c->M1 == 1024 && c->M2 == 1024 && c->T1 == 16 && c->T2 == 16 && getenv("PSDR_P1_CLASSIC") == nullptr;
+    // opt-in (PSDR_P1_WAVE=1): measured 640-670 us against the barrier kernel's 600-615 us per 256 frames
+    c->p1_wave = !is_real && c->M1 == 1024 && c->M2 == 1024 && c->T1 == 16 && c->T2 == 16 && getenv("PSDR_P1_WAVE") != nullptr;
     c->p_stride = std::max<size_t>(c->R >> c->LT, 64);
     if (cfg->skip_num < 1) c->cfg.skip_num = 1;
     if (cfg->waterfall_size < 0) {
@@ -1558,14 +1571,19 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
         if (band) {  // checked under the same lock that fixes the windows this batch is demodulated with
             for (size_t i = 0; i < c->aslots.size(); i++) {
                 const AudioSlot &s = c->aslots[i];
-                if (s.active && ((uint32_t)s.l < band[0] || (uint64_t)s.r > (uint64_t)band[0] + band[1]))
+                // an empty window (a client between psdr_client_add and its first set_audio_range) reads no bin
+                if (s.active && s.r > s.l && ((uint32_t)s.l < band[0] || (uint64_t)s.r > (uint64_t)band[0] + band[1])) {
+                    c->client_ring.idx = (c->client_ring.idx + ParamRing::K - 1) % ParamRing::K;  // hand the slot back
                     return fail(PSDR_ERR_INVALID, "client %zu: window [%d, %d) outside the band [%u, %u)", i, s.l, s.r,
                                 band[0], band[0] + band[1]);
+                }
             }
         }
+        c->demod_seq++;
         for (size_t i = 0; i < c->aslots.size(); i++) {
             AudioSlot &s = c->aslots[i];
             if (!s.active) continue;
+            s.last_seq = c->demod_seq;
             ClientParams &p = h_clients[nact++];
             p.l = s.l;
             p.r = s.r;
@@ -1684,12 +1702,12 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
         }
         {  // ---- stage 2
             ProfScope ps(c, K_POST, s2);
-            hipLaunchKernelGGL(k_pc_scan, dim3(nact, nblk, 2), dim3(64), (size_t)pa.L * sizeof(float), s2, pa);
+            hipLaunchKernelGGL(k_pc_scan, dim3(nact, nblk, 2), dim3(64), 0, s2, pa);
             hipLaunchKernelGGL(k_pc_want, dim3(nact, (unsigned)((Tb + 255) / 256)), dim3(256), 0, s2, pa);
             hipLaunchKernelGGL(k_pc_gain, dim3(cb), dim3(64), 0, s2, pa);
             hipLaunchKernelGGL(k_pc_out, dim3(nact, nframes), dim3(256), 0, s2, pa);
             pa.hist_sel = 1;
-            hipLaunchKernelGGL(k_pc_history, dim3(nact), dim3(256), (size_t)(pa.L - 1) * sizeof(float), s2, pa);
+            hipLaunchKernelGGL(k_pc_history, dim3(nact), dim3(256), 0, s2, pa);  // (V1 -> V1n: a plain copy, no LDS)
             HIPCHK(hipGetLastError());
         }
         if (piped) {
@@ -1706,6 +1724,71 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
         HIPCHK(hipEventRecord(c->ev_set_done[c->cur_set], c->side));
         c->set_pending[c->cur_set] = true;
     }
+    return PSDR_OK;
+}
+
+// A slot whose client attached AFTER the last demodulation batch holds the previous occupant's results (or
+// nothing): the reference's per-client task would not exist for that frame either (src/websocket.cpp:156-185 walks
+// signal_slices at the time of the frame).  PSDR_ERR_NO_DATA, nothing is copied.
+static int slot_in_last_batch(psdr_ctx *c, int id) {
+    std::lock_guard<std::mutex> lk(c->mtx);
+    if (c->demod_seq == 0 || c->aslots[id].last_seq != c->demod_seq)
+        return fail(PSDR_ERR_NO_DATA, "client %d was not part of the last demodulation batch", id);
+    return PSDR_OK;
+}
+
+// ---- batched read-back: ONE synchronisation and at most four copies per batch for ALL clients ----------------
+// (src/websocket.cpp:156-185 makes one pass over signal_slices per frame; per-client psdr_read_audio would pay a
+// synchronisation and three copies per client and frame)
+extern "C" int psdr_fetch_batch(psdr_ctx *c) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    if (c->n <= 0) return fail(PSDR_ERR_STATE, "context created with audio_fft_size 0");
+    const size_t F = (size_t)c->last_demod_frames, h = (size_t)c->n / 2, mb = (size_t)c->max_batch, S = c->aslots.size();
+    if (F == 0 || c->demod_seq == 0) return fail(PSDR_ERR_STATE, "no demodulated batch to fetch");
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->h_audio) {
+        HIPCHK(hipHostMalloc((void **)&c->h_audio, S * mb * h * sizeof(float), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&c->h_pwr, S * mb * sizeof(float), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&c->h_nan, S * mb * sizeof(int32_t), hipHostMallocDefault));
+    }
+    if (c->post_on && !c->h_pcm) HIPCHK(hipHostMalloc((void **)&c->h_pcm, S * mb * h * sizeof(int32_t), hipHostMallocDefault));
+    {
+        int rc = drain(c);
+        if (rc) return rc;
+    }
+    // rows [slot][0..F) of the device arrays [slot][max_batch][...]: one strided copy each
+    HIPCHK(hipMemcpy2DAsync(c->h_audio, mb * h * sizeof(float), c->d_audio, mb * h * sizeof(float), F * h * sizeof(float), S,
+                            hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpy2DAsync(c->h_pwr, mb * sizeof(float), c->d_pwr, mb * sizeof(float), F * sizeof(float), S,
+                            hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpy2DAsync(c->h_nan, mb * sizeof(int32_t), c->d_nan, mb * sizeof(int), F * sizeof(int32_t), S,
+                            hipMemcpyDeviceToHost, c->stream));
+    if (c->post_on)
+        HIPCHK(hipMemcpy2DAsync(c->h_pcm, mb * h * sizeof(int32_t), c->post.pcm, mb * h * sizeof(int32_t), F * h * sizeof(int32_t), S,
+                                hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->fetched_frames = (int)F;
+    c->fetched_seq = c->demod_seq;
+    c->fetched_pcm = c->post_on;
+    return PSDR_OK;
+}
+extern "C" int psdr_fetched_audio(psdr_ctx *c, int id, int frame, const float **audio, float *pwr, int32_t *nan_flag,
+                                  const int32_t **pcm) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    {
+        std::lock_guard<std::mutex> lk(c->mtx);
+        int rc = check_slot(c, id);
+        if (rc) return rc;
+        if (c->fetched_seq == 0) return fail(PSDR_ERR_STATE, "psdr_fetch_batch() first");
+        if (c->aslots[id].last_seq != c->fetched_seq)
+            return fail(PSDR_ERR_NO_DATA, "client %d was not part of the fetched batch", id);
+    }
+    if (frame < 0 || frame >= c->fetched_frames) return fail(PSDR_ERR_INVALID, "frame %d not in the fetched batch of %d", frame, c->fetched_frames);
+    const size_t h = (size_t)c->n / 2, mb = (size_t)c->max_batch, row = (size_t)id * mb + (size_t)frame;
+    if (audio) *audio = c->h_audio + row * h;
+    if (pwr) *pwr = c->h_pwr[row];
+    if (nan_flag) *nan_flag = c->h_nan[row];
+    if (pcm) *pcm = c->fetched_pcm ? c->h_pcm + row * h : nullptr;
     return PSDR_OK;
 }
 
@@ -1738,7 +1821,9 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
         a.desired = 0.2f;
         a.attack = (float)(1 - std::exp((double)(-1.0f / (50.0f * 0.001f * sr))));
         a.release = (float)(1 - std::exp((double)(-1.0f / (300.0f * 0.001f * sr))));
-        if (a.D < 1 || a.L < 2)
+        // the DC blocker's history (D floats) is moved in place through LDS (k_pc_history): 12288 floats = 48 KiB, i.e.
+        // audio rates up to 4.6 MHz; the AGC look-ahead L has no such limit (k_pc_scan walks it in chunks)
+        if (a.D < 1 || a.L < 2 || a.D > 12288)
             return fail(PSDR_ERR_UNSUPPORTED, "audio_rate %d: DC delay %d / look-ahead %d unsupported", rate, a.D, a.L);
         auto alloc = [&](void **ptr, size_t bytes) -> int {
             HIPCHK(hipMalloc(ptr, std::max<size_t>(bytes, 16)));
@@ -1793,7 +1878,9 @@ extern "C" int psdr_read_pcm(psdr_ctx *c, int id, int nframes, int32_t *pcm, int
     if (F == 0) return fail(PSDR_ERR_STATE, "no demodulated batch to read");
     if (nframes < (int)F) return fail(PSDR_ERR_INVALID, "buffer holds %d frames, the last batch has %zu", nframes, F);
     {
-        int rc = drain(c);
+        int rc = slot_in_last_batch(c, id);
+        if (rc) return rc;
+        rc = drain(c);
         if (rc) return rc;
     }
     HIPCHK(hipMemcpy(pcm, c->post.pcm + (size_t)id * mb * h, F * h * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1856,7 +1943,9 @@ extern "C" int psdr_read_audio(psdr_ctx *c, int id, int nframes, float *audio, f
     if (nframes < (int)F) return fail(PSDR_ERR_INVALID, "buffers hold %d frames, the last batch has %zu", nframes, F);
     if (nframes_out) *nframes_out = (int)F;
     {
-        int rc = drain(c);
+        int rc = slot_in_last_batch(c, id);
+        if (rc) return rc;
+        rc = drain(c);
         if (rc) return rc;
     }
     if (audio)

@@ -310,12 +310,30 @@ struct Cursor {
         p++;
         return true;
     }
+    // a JSON number, strictly: -?(0|[1-9][0-9]*)(\.[0-9]+)?([eE][+-]?[0-9]+)?  (strtod alone would take "01", "1." or "1e")
     bool num(double &v) {
         ws();
         const char *q = p;
+        auto digit = [&](const char *x) { return x < e && *x >= '0' && *x <= '9'; };
         if (q < e && *q == '-') q++;
-        if (q >= e || *q < '0' || *q > '9') return false;
-        while (q < e && ((*q >= '0' && *q <= '9') || *q == '.' || *q == 'e' || *q == 'E' || *q == '+' || *q == '-')) q++;
+        if (!digit(q)) return false;
+        if (*q == '0') {
+            q++;
+            if (digit(q)) return false;  // leading zero
+        } else {
+            while (digit(q)) q++;
+        }
+        if (q < e && *q == '.') {
+            q++;
+            if (!digit(q)) return false;
+            while (digit(q)) q++;
+        }
+        if (q < e && (*q == 'e' || *q == 'E')) {
+            q++;
+            if (q < e && (*q == '+' || *q == '-')) q++;
+            if (!digit(q)) return false;
+            while (digit(q)) q++;
+        }
         const std::string t(p, q);
         char *end = nullptr;
         v = strtod(t.c_str(), &end);
@@ -359,12 +377,23 @@ extern "C" int psdr_wire_parse_command(const char *msg, size_t len, psdr_command
     psdr_command r;
     memset(&r, 0, sizeof r);
     r.cmd = -1;
-    // every key seen, typed by what the JSON holds; checked against the tagged alternative at the end
-    // (glaze reads the tag first wherever it stands, then the alternative's own keys)
-    bool have_l = false, have_r = false, have_dem = false, have_uid = false, have_mute = false, m_null = false, lv_null = false;
+    // Client::on_message reads a std::variant of four structs tagged by "cmd" (src/client.cpp:19-89).  glaze picks the
+    // alternative from the FIRST key that decides it: the tag, or a key that only one alternative has - and every key
+    // of these four structs belongs to exactly one of them.  The object is then read as that struct: its own keys in
+    // any order, missing ones keep their defaults, the tag key is skipped wherever it stands (whatever it says), any
+    // other key is an error; an object without a deciding key matches no alternative.  (glaze 2.4.4 is not in the
+    // image: restated from its documented variant handling, pinned only by tests/test_wire_formats.py.)
+    int sel = -1;  // PSDR_CMD_*
     bool has_m = false, has_lv = false;
     double l = 0, rr = 0, m = 0, lv = 0;
-    std::string cmd, dem, uid;
+    std::string dem, uid;
+    auto owner = [](const std::string &k) {
+        if (k == "l" || k == "r" || k == "m" || k == "level") return (int)PSDR_CMD_WINDOW;
+        if (k == "demodulation") return (int)PSDR_CMD_DEMODULATION;
+        if (k == "userid") return (int)PSDR_CMD_USERID;
+        if (k == "mute") return (int)PSDR_CMD_MUTE;
+        return -1;
+    };
     if (!c.eat('{')) return PSDR_ERR_INVALID;
     if (!c.eat('}')) {
         for (;;) {
@@ -372,43 +401,48 @@ extern "C" int psdr_wire_parse_command(const char *msg, size_t len, psdr_command
             if (!c.str(key) || !c.eat(':')) return PSDR_ERR_INVALID;
             c.ws();
             if (key == "cmd") {
+                std::string cmd;
                 if (!c.str(cmd)) return PSDR_ERR_INVALID;
-            } else if (key == "l") {
-                if (!c.num(l)) return PSDR_ERR_INVALID;
-                have_l = true;
-            } else if (key == "r") {
-                if (!c.num(rr)) return PSDR_ERR_INVALID;
-                have_r = true;
-            } else if (key == "m") {
-                if (c.lit("null"))
-                    m_null = true;
-                else if (c.num(m))
-                    has_m = true;
-                else
-                    return PSDR_ERR_INVALID;
-            } else if (key == "level") {
-                if (c.lit("null"))
-                    lv_null = true;
-                else if (c.num(lv))
-                    has_lv = true;
-                else
-                    return PSDR_ERR_INVALID;
-            } else if (key == "demodulation") {
-                if (!c.str(dem)) return PSDR_ERR_INVALID;
-                have_dem = true;
-            } else if (key == "userid") {
-                if (!c.str(uid)) return PSDR_ERR_INVALID;
-                have_uid = true;
-            } else if (key == "mute") {
-                if (c.lit("true"))
-                    r.mute = 1;
-                else if (c.lit("false"))
-                    r.mute = 0;
-                else
-                    return PSDR_ERR_INVALID;
-                have_mute = true;
+                if (sel < 0) {
+                    sel = cmd == "window" ? PSDR_CMD_WINDOW : cmd == "demodulation" ? PSDR_CMD_DEMODULATION
+                        : cmd == "userid" ? PSDR_CMD_USERID : cmd == "mute" ? PSDR_CMD_MUTE : -1;
+                    if (sel < 0) return PSDR_ERR_INVALID;
+                }
             } else {
-                return PSDR_ERR_INVALID;  // unknown key
+                const int own = owner(key);
+                if (own < 0) return PSDR_ERR_INVALID;  // unknown key
+                if (sel < 0) sel = own;
+                if (own != sel) return PSDR_ERR_INVALID;  // a key of another alternative
+                if (key == "l") {
+                    if (!c.num(l)) return PSDR_ERR_INVALID;
+                } else if (key == "r") {
+                    if (!c.num(rr)) return PSDR_ERR_INVALID;
+                } else if (key == "m") {
+                    if (c.lit("null"))
+                        has_m = false;
+                    else if (c.num(m))
+                        has_m = true;
+                    else
+                        return PSDR_ERR_INVALID;
+                } else if (key == "level") {
+                    if (c.lit("null"))
+                        has_lv = false;
+                    else if (c.num(lv))
+                        has_lv = true;
+                    else
+                        return PSDR_ERR_INVALID;
+                } else if (key == "demodulation") {
+                    if (!c.str(dem)) return PSDR_ERR_INVALID;
+                } else if (key == "userid") {
+                    if (!c.str(uid)) return PSDR_ERR_INVALID;
+                } else {  // mute
+                    if (c.lit("true"))
+                        r.mute = 1;
+                    else if (c.lit("false"))
+                        r.mute = 0;
+                    else
+                        return PSDR_ERR_INVALID;
+                }
             }
             if (c.eat(',')) continue;
             if (c.eat('}')) break;
@@ -417,33 +451,23 @@ extern "C" int psdr_wire_parse_command(const char *msg, size_t len, psdr_command
     }
     c.ws();
     if (c.p != c.e) return PSDR_ERR_INVALID;
-    const bool window_keys = have_l || have_r || has_m || has_lv || m_null || lv_null;
+    if (sel < 0) return PSDR_ERR_INVALID;  // {}: no alternative
     auto as_int = [](double v, int32_t &o) {  // an int field: a fraction or an out-of-range value is a parse error
         if (v != std::floor(v) || v < -2147483648.0 || v > 2147483647.0) return false;
         o = (int32_t)v;
         return true;
     };
-    if (cmd == "window") {
-        if (have_dem || have_uid || have_mute) return PSDR_ERR_INVALID;
-        r.cmd = PSDR_CMD_WINDOW;
+    r.cmd = sel;
+    if (sel == PSDR_CMD_WINDOW) {
         if (!as_int(l, r.l) || !as_int(rr, r.r)) return PSDR_ERR_INVALID;
         r.has_m = has_m;
         r.m = m;
         r.has_level = has_lv;
         if (has_lv && !as_int(lv, r.level)) return PSDR_ERR_INVALID;
-    } else if (cmd == "demodulation") {
-        if (window_keys || have_uid || have_mute) return PSDR_ERR_INVALID;
-        r.cmd = PSDR_CMD_DEMODULATION;
+    } else if (sel == PSDR_CMD_DEMODULATION) {
         snprintf(r.text, sizeof r.text, "%.32s", dem.c_str());
-    } else if (cmd == "userid") {
-        if (window_keys || have_dem || have_mute) return PSDR_ERR_INVALID;
-        r.cmd = PSDR_CMD_USERID;
+    } else if (sel == PSDR_CMD_USERID) {
         snprintf(r.text, sizeof r.text, "%.32s", uid.c_str());
-    } else if (cmd == "mute") {
-        if (window_keys || have_dem || have_uid) return PSDR_ERR_INVALID;
-        r.cmd = PSDR_CMD_MUTE;
-    } else {
-        return PSDR_ERR_INVALID;
     }
     *out = r;
     return PSDR_OK;

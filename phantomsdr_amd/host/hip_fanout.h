@@ -31,6 +31,8 @@ class HipFanout {
         bool post_chain;           // DC blocker + AGC + int16 on the GPU too
         int ring_halves;           // half-frames of raw samples kept in HBM (>= 3)
     };
+    // (the constructor and the frame loop's own calls throw std::runtime_error on failure: they run on the server's
+    // main / fft_task threads, where the reference's own set-up throws too)
     explicit HipFanout(const Params &p) : ctx{nullptr}, prm{p}, next_half{0} {
         psdr_config cfg{};
         cfg.struct_size = sizeof(cfg);
@@ -66,47 +68,55 @@ class HipFanout {
     // a new half-frame has been read: its copy to HBM starts at once and overlaps the GPU work on the
     // previous frame (the reference overlaps the read of half k+2 with the FFT of (k, k+1), src/fft.cpp:56-67)
     void push_half(const void *raw_half) { chk(psdr_ring_write_async(ctx, next_half++, raw_half)); }
-    // the frame made of the two newest half-frames: FFT + pyramid, then every client (src/fft.cpp:61-105).
-    // frame_num is the server's counter before its increment.
-    void process_frame(uint64_t frame_num) {
-        if (next_half < 2) return;
+    // the frame made of the two newest half-frames: FFT + pyramid, then every client (src/fft.cpp:61-105), and ONE
+    // copy of all clients' results into pinned host memory (psdr_fetch_batch) - the per-client tasks the server posts
+    // afterwards only read that block.  frame_num is the server's counter before its increment.  Returns false when
+    // there is nothing to send yet (fewer than two half-frames).
+    bool process_frame(uint64_t frame_num) {
+        if (next_half < 2) return false;
         const uint64_t first = next_half - 2;
         // a frame window must not cross the ring end more than by the guard half-frame
         chk(psdr_process_ring(ctx, first, 1));
         chk(psdr_demod_batch(ctx, frame_num));                                         // signal_loop()
         if (frame_num % (uint64_t)prm.skip_num == 0) chk(psdr_waterfall_batch(ctx, frame_num));  // waterfall_loop()
+        have_audio = psdr_fetch_batch(ctx) == PSDR_OK;  // (PSDR_ERR_STATE: no audio client yet)
+        return true;
     }
 
     // ---- AudioClient (src/signal.cpp:8-97, 300-336) --------------------------------------------------
+    // The hooks below run on websocket / asio handler threads inside AudioClient::set_audio_range and
+    // ::set_audio_demodulation, which never throw in the reference: they report failure through their return value
+    // (the previous window / mode stays in force on the GPU) instead of an exception.
     int add_audio_client() {
         int id = -1;
-        chk(psdr_client_add(ctx, &id));
-        return id;
+        return psdr_client_add(ctx, &id) == PSDR_OK ? id : -1;
     }
-    void remove_audio_client(int id) { psdr_client_remove(ctx, id); }
-    void set_audio_range(int id, int l, double m, int r) { chk(psdr_client_set_audio_range(ctx, id, l, m, r)); }
+    void remove_audio_client(int id) {
+        if (id >= 0) psdr_client_remove(ctx, id);
+    }
+    bool set_audio_range(int id, int l, double m, int r) { return id >= 0 && psdr_client_set_audio_range(ctx, id, l, m, r) == PSDR_OK; }
     bool on_audio_window_message(int id, int l, double m, int r) {
-        return psdr_client_on_window_message(ctx, id, l, m, r) == PSDR_OK;  // false: the reference returns silently
+        return id >= 0 && psdr_client_on_window_message(ctx, id, l, m, r) == PSDR_OK;  // false: the reference returns silently
     }
-    void set_audio_demodulation(int id, psdr_mode mode) { chk(psdr_client_set_audio_demodulation(ctx, id, mode)); }
-    // the tail of send_audio for one client (asio pool).  Returns false when the reference would have
-    // dropped the frame (NaN guard, src/signal.cpp:266-271).  audio: audio_max_fft_size/2 floats,
-    // pcm (post_chain only): as many int32.
-    bool fetch_audio(int id, float *audio, int32_t *pcm, float *average_power) {
+    bool set_audio_demodulation(int id, psdr_mode mode) { return id >= 0 && psdr_client_set_audio_demodulation(ctx, id, mode) == PSDR_OK; }
+    // the tail of send_audio for one client (asio pool): pointers into the block process_frame() fetched; no device
+    // call.  Returns false when there is nothing to send: the reference would have dropped the frame (NaN guard,
+    // src/signal.cpp:266-271), or the client attached after this frame was demodulated.  audio: audio_max_fft_size/2
+    // floats; pcm: as many int32, nullptr unless the post chain runs on the GPU.
+    bool fetch_audio(int id, const float **audio, const int32_t **pcm, float *average_power) {
         int32_t nan = 0;
-        chk(psdr_read_audio(ctx, id, 1, audio, average_power, &nan, nullptr));
-        if (nan) return false;
-        if (prm.post_chain && pcm) chk(psdr_read_pcm(ctx, id, 1, pcm, nullptr));
-        return true;
+        if (!have_audio || id < 0 || psdr_fetched_audio(ctx, id, 0, audio, average_power, &nan, pcm) != PSDR_OK) return false;
+        return nan == 0;
     }
 
     // ---- WaterfallClient (src/waterfall.cpp:6-99) -----------------------------------------------------
     int add_waterfall_client() {
         int id = -1;
-        chk(psdr_waterfall_add(ctx, &id));
-        return id;
+        return psdr_waterfall_add(ctx, &id) == PSDR_OK ? id : -1;
     }
-    void remove_waterfall_client(int id) { psdr_waterfall_remove(ctx, id); }
+    void remove_waterfall_client(int id) {
+        if (id >= 0) psdr_waterfall_remove(ctx, id);
+    }
     bool on_waterfall_window_message(int id, int l, int r, int *level, int *nl, int *nr) {
         return psdr_waterfall_on_window_message(ctx, id, l, r, level, nl, nr) == PSDR_OK;
     }
@@ -114,10 +124,9 @@ class HipFanout {
     // batch they were gathered in; empty when this frame was not a waterfall frame
     bool fetch_waterfall(int id, std::vector<int8_t> &row, int *l_label, int *r_label) {
         int ns = 0, lv = 0, l = 0, r = 0;
-        chk(psdr_read_waterfall(ctx, id, nullptr, 0, &ns, &lv, &l, &r));
-        if (ns == 0) return false;
+        if (id < 0 || psdr_read_waterfall(ctx, id, nullptr, 0, &ns, &lv, &l, &r) != PSDR_OK || ns == 0) return false;
         row.resize((size_t)ns * (size_t)(r - l));
-        chk(psdr_read_waterfall(ctx, id, row.data(), row.size(), &ns, &lv, &l, &r));
+        if (psdr_read_waterfall(ctx, id, row.data(), row.size(), &ns, &lv, &l, &r) != PSDR_OK) return false;
         *l_label = l << lv;
         *r_label = r << lv;
         return true;
@@ -129,6 +138,7 @@ class HipFanout {
     psdr_ctx *ctx;
     Params prm;
     uint64_t next_half;
+    bool have_audio = false;
     static void chk(int rc) {
         if (rc != PSDR_OK) throw std::runtime_error(psdr_last_error());
     }

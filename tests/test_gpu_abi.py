@@ -206,3 +206,115 @@ def test_band_calls_refuse_bad_arguments():
         ctx.dev_free(d)
     finally:
         ctx.close()
+
+
+def test_fetch_batch_matches_per_client_reads_and_guards_late_clients():
+    """psdr_fetch_batch + psdr_fetched_audio (one synchronisation, at most four copies per batch for ALL clients: the
+    granularity of src/websocket.cpp:156-185's one pass over signal_slices) hand out exactly what psdr_read_audio /
+    psdr_read_pcm copy per client; a client that attached AFTER the batch was demodulated gets PSDR_ERR_NO_DATA from
+    both paths instead of the previous occupant's samples (the reference would not have posted a task for it)."""
+    from phantomsdr_amd import AudioClient, Context
+    from phantomsdr_amd._lib import PsdrError
+    N, F, n = 1 << 14, 5, 248
+    ctx = Context(N, False, _levels(N), additional_size=n, audio_fft_size=n, input_format="s16", max_batch=F + 2, max_clients=4)
+    lib, h = ctx.lib, ctx.h
+    try:
+        raw = quantize_raw(synth_stream((2 * F + 1) * (N // 2), False, seed=8, fft_size=N), "s16", False)
+        d = ctx.dev_alloc(raw.nbytes)
+        ctx.h2d(d, raw)
+        ctx.set_post_chain(True)
+        cl = []
+        for i, mode in enumerate(["USB", "AM", "FM"]):
+            g = AudioClient(ctx)
+            g.set_audio_demodulation(mode)
+            g.set_audio_range(3000 + 400 * i, 3050.0 + 400 * i, 3100 + 400 * i)
+            cl.append(g)
+        old = cl.pop(1)
+        old_id = old.id
+        ctx.process_batch(d, F)
+        ctx.demod_batch(0)
+        old.on_close()                       # the slot is freed after the batch ...
+        late = AudioClient(ctx)              # ... and taken by a client that was not part of it
+        assert late.id == old_id
+        with pytest.raises(PsdrError) as e:
+            late.read_audio()
+        assert e.value.code == -7
+        with pytest.raises(PsdrError) as e:
+            late.read_pcm()
+        assert e.value.code == -7
+        assert lib.psdr_fetch_batch(h) == 0
+        pa, pp = C.POINTER(C.c_float)(), C.POINTER(C.c_int32)()
+        pw, nf = C.c_float(0), C.c_int32(0)
+        assert lib.psdr_fetched_audio(h, late.id, 0, C.byref(pa), C.byref(pw), C.byref(nf), C.byref(pp)) == -7
+        for g in cl:
+            a, p, nan = g.read_audio()
+            pcm = g.read_pcm()
+            for f in range(F):
+                assert lib.psdr_fetched_audio(h, g.id, f, C.byref(pa), C.byref(pw), C.byref(nf), C.byref(pp)) == 0
+                assert np.array_equal(np.ctypeslib.as_array(pa, (n // 2,)).view(np.uint32), a[f].view(np.uint32))
+                assert np.array_equal(np.ctypeslib.as_array(pp, (n // 2,)), pcm[f])
+                assert np.float32(pw.value) == p[f] and nf.value == nan[f]
+            assert lib.psdr_fetched_audio(h, g.id, F, C.byref(pa), None, None, None) == -1   # frame outside the batch
+        # the next batch includes the late client: both paths serve it
+        late.set_audio_range(5000, 5040.0, 5080)
+        ctx.process_batch(d, F, offset_bytes=F * ctx.half_frame_bytes())
+        ctx.demod_batch(F)
+        a, _, _ = late.read_audio()
+        assert lib.psdr_fetch_batch(h) == 0
+        assert lib.psdr_fetched_audio(h, late.id, F - 1, C.byref(pa), None, None, None) == 0
+        assert np.array_equal(np.ctypeslib.as_array(pa, (n // 2,)).view(np.uint32), a[F - 1].view(np.uint32))
+        ctx.dev_free(d)
+    finally:
+        ctx.close()
+
+
+def test_band_demodulation_ignores_clients_without_a_window():
+    """psdr_demod_batch_from_band: a client between psdr_client_add and its first set_audio_range has the empty
+    window [0, 0) - outside every band but the first - and reads no bin: it must not fail the batch for everyone
+    (ADVICE r2); a real window outside the band still does."""
+    import ctypes
+    from phantomsdr_amd import AudioClient, Context
+    N, F, n = 1 << 14, 3, 248
+    ctx = Context(N, False, _levels(N), additional_size=n, audio_fft_size=n, input_format="s16", max_batch=F, max_clients=4)
+    lib, h = ctx.lib, ctx.h
+    try:
+        raw = quantize_raw(synth_stream((F + 1) * (N // 2), False, seed=9, fft_size=N), "s16", False)
+        d = ctx.dev_alloc(raw.nbytes)
+        ctx.h2d(d, raw)
+        g = AudioClient(ctx)
+        g.set_audio_range(9000, 9030.0, 9060)
+        ctx.process_batch(d, F)
+        ctx.demod_batch(0)
+        want = g.read_audio()[0].copy()
+        first, bins = 8192, 4096 + n
+        band = ctx.dev_alloc(F * bins * 8)
+        assert lib.psdr_pack_band(h, F, first, bins, band, bins) == 0
+        fresh = AudioClient(ctx)  # no window yet
+        # a second context plays the receiving rank
+        rx = Context(N, False, _levels(N), additional_size=n, audio_fft_size=n, input_format="s16", max_batch=F, max_clients=4)
+        try:
+            g2 = AudioClient(rx)
+            g2.set_audio_range(9000, 9030.0, 9060)
+            empty = AudioClient(rx)
+            host = np.empty(F * bins * 2, np.float32)
+            ctx.d2h(host, band)
+            band2 = rx.dev_alloc(host.nbytes)
+            rx.h2d(band2, host)
+            assert rx.lib.psdr_demod_batch_from_band(rx.h, band2, bins, first, bins, F, 0) == 0, rx.lib.psdr_last_error()
+            rx.last_demod_frames = F
+            assert np.array_equal(g2.read_audio(F)[0].view(np.uint32), want.view(np.uint32))
+            assert np.abs(empty.read_audio(F)[0]).max() == 0          # an empty slice demodulates to silence
+            empty.set_audio_range(100, 130.0, 160)                    # a real window outside the band: refused
+            assert rx.lib.psdr_demod_batch_from_band(rx.h, band2, bins, first, bins, F, F) != 0
+            assert b"outside the band" in rx.lib.psdr_last_error()
+            # ... and the refusal left the parameter ring usable
+            empty.on_close()
+            assert rx.lib.psdr_demod_batch_from_band(rx.h, band2, bins, first, bins, F, F) == 0
+            rx.dev_free(band2)
+        finally:
+            rx.close()
+        del fresh
+        ctx.dev_free(band)
+        ctx.dev_free(d)
+    finally:
+        ctx.close()

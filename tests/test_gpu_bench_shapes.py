@@ -134,3 +134,43 @@ def test_bench_launch_256_frames_vs_oracle(wl_name):
                              a_o, p_o, dropped, o)
     finally:
         run.close()
+
+
+def test_wave_owned_pass1_bench_launch_vs_oracle(monkeypatch):
+    """the experimental barrier-free first pass (PSDR_P1_WAVE=1, fft_pass1w.h: wave-owned column couples, image hand-over
+    through LDS flags, couple-major Y) on the bench's own 256-frame launch: every work-group walks 64 tiles, so the
+    hand-over counters, the ticket sequence and the rotated loop all run in steady state"""
+    monkeypatch.setenv("PSDR_P1_WAVE", "1")
+    test_bench_launch_256_frames_vs_oracle("cfg2")
+
+
+@pytest.mark.parametrize("fmt", ["u8", "s16", "u16"])
+def test_wave_owned_pass1_formats_vs_classic(monkeypatch, fmt):
+    """the same samples through both first passes: spectra within float rounding of each other (the two kernels order
+    their arithmetic identically except for the twiddle recurrences), pyramids equal up to the quantiser's boundaries"""
+    from phantomsdr_amd import Context
+    from helpers import quantize_raw, synth_stream
+    N, F = 1 << 20, 24  # 1536 tiles: six per work-group
+    x = synth_stream((F + 1) * (N // 2), False, seed=3, sigma=2.0 ** -5 if fmt == "u8" else 2.0 ** -9, fft_size=N)
+    raw = quantize_raw(x, fmt, False)
+
+    def run(wave):
+        if wave:
+            monkeypatch.setenv("PSDR_P1_WAVE", "1")
+        else:
+            monkeypatch.delenv("PSDR_P1_WAVE", raising=False)
+        ctx = Context(N, False, 11, input_format=fmt, max_batch=F)
+        try:
+            d = ctx.dev_alloc(raw.nbytes)
+            ctx.h2d(d, raw)
+            ctx.process_batch(d, F)
+            out = [(ctx.read_spectrum(f).copy(), ctx.read_quantized(f).copy()) for f in range(F)]
+            ctx.dev_free(d)
+            return out
+        finally:
+            ctx.close()
+    a, b = run(True), run(False)
+    for f in range(F):
+        assert rel_err(a[f][0], b[f][0]) < 2e-6, f"frame {f}"
+        dq = np.abs(a[f][1].astype(np.int16) - b[f][1].astype(np.int16))
+        assert dq.max() <= 1 and (dq != 0).mean() < 1e-3

@@ -393,19 +393,22 @@ def test_error_paths():
         ctx.close()
 
 
-def test_post_chain_bit_exact():
+@pytest.mark.parametrize("audio_rate,F,nb", [(12000, 8, 5), (192000, 128, 5)])
+def test_post_chain_bit_exact(audio_rate, F, nb):
     """DC blocker + AGC + int16 conversion on the GPU (psdr_set_post_chain) against the oracle's
     chain fed with the SAME float audio (the GPU's own demodulator output): the recurrences are
     sequential f32, so the PCM must be identical.  Covers the AGC look-ahead start-up (2400
-    samples), several batches, a mode change (AGC reset, src/signal.cpp:316-328) and a client
-    added late."""
+    samples at 12 kHz), several batches, a mode change (AGC reset, src/signal.cpp:316-328) and a
+    client added late.  192000 is the audio_sps of the reference's shipped config.toml (WBFM): DC delay
+    512 (the generic moving-average kernels), look-ahead 38400 samples (k_pc_scan in chunks; the batch
+    is sized so that the look-ahead fills: 640 frames of 124 samples)."""
     from phantomsdr_amd import AudioClient, Context
-    N, n, F, nb = 1 << 14, 248, 8, 5
+    N, n = 1 << 14, 248
     R, levels = N, levels_for(N)
     nframes = nb * F
     x = synth_stream((nframes + 1) * (N // 2), False, seed=77, fft_size=N)
     raw = quantize_raw(x, "s16", False)
-    ctx = Context(N, False, levels, additional_size=n, audio_fft_size=n, audio_rate=12000,
+    ctx = Context(N, False, levels, additional_size=n, audio_fft_size=n, audio_rate=audio_rate,
                   input_format="s16", max_batch=F, max_clients=4)
     try:
         ctx.set_post_chain(True)
@@ -418,7 +421,7 @@ def test_post_chain_bit_exact():
             g.set_audio_demodulation(mode)
             g.set_audio_range(l, mid, r)
             gcl.append(g)
-            chains.append(O.PostChain(12000))
+            chains.append(O.PostChain(audio_rate))
         hb = ctx.half_frame_bytes()
         total = 0
         for b in range(nb):
@@ -430,7 +433,7 @@ def test_post_chain_bit_exact():
                 g.set_audio_demodulation("USB")
                 g.set_audio_range(12000, 12010.0, 12200)
                 gcl.append(g)
-                chains.append(O.PostChain(12000))
+                chains.append(O.PostChain(audio_rate))
             ctx.process_batch(d, F, offset_bytes=b * F * hb)
             ctx.demod_batch(b * F)
             for g, ch in zip(gcl, chains):

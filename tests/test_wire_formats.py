@@ -218,9 +218,21 @@ def test_command_frames():
     assert rc == 0 and c.cmd == 3 and c.mute == 1
     rc, c = _cmd('{"cmd":"mute","mute":false}')
     assert rc == 0 and c.mute == 0
+    # the alternative is decided by the FIRST deciding key: the tag, or a key only one alternative has (every key of
+    # these four structs is such a key); a tag that comes later is skipped
+    rc, c = _cmd('{"l":1,"r":2}')
+    assert rc == 0 and (c.cmd, c.l, c.r) == (0, 1, 2)
+    rc, c = _cmd('{"mute":true}')
+    assert rc == 0 and (c.cmd, c.mute) == (3, 1)
+    rc, c = _cmd('{"demodulation":"AM","cmd":"window"}')
+    assert rc == 0 and c.cmd == 1 and c.text == b"AM"
+    rc, c = _cmd('{"cmd":"window","l":1e2,"r":-0,"m":1.25e1}')          # JSON numbers: exponents, -0
+    assert rc == 0 and (c.l, c.r, c.m) == (100, 0, 12.5)
     # rejected like `if (ec) return` (src/client.cpp:96-99)
-    for bad in ['', 'window', '{"cmd":"window","l":1,"r":2', '{"cmd":"zoom","l":1,"r":2}', '{"l":1,"r":2}',
+    for bad in ['', 'window', '{}', '{"cmd":"window","l":1,"r":2', '{"cmd":"zoom","l":1,"r":2}', '{"l":1,"mute":true}',
                 '{"cmd":"window","l":1.5,"r":2}', '{"cmd":"window","l":"1","r":2}', '{"cmd":"window","l":1,"r":2,"x":0}',
                 '{"cmd":"mute","mute":1}', '{"cmd":"mute","mute":true,"l":1}', '{"cmd":"demodulation","demodulation":7}',
-                '{"cmd":"window","l":1,"r":2} trailing', '{"cmd":"window","l":3000000000,"r":2}']:
+                '{"cmd":"window","l":1,"r":2} trailing', '{"cmd":"window","l":3000000000,"r":2}', '{"l":1,"cmd":7}',
+                '{"cmd":"window","l":01,"r":2}', '{"cmd":"window","l":1.,"r":2}', '{"cmd":"window","l":+1,"r":2}',
+                '{"cmd":"window","l":1e,"r":2}', '{"cmd":"window","l":.5,"r":2}', '{"cmd":"window","l":-,"r":2}']:
         assert _cmd(bad)[0] != 0, bad

@@ -80,10 +80,12 @@ n1 = {"meson_options.txt": "option('psdr_dir', type : 'string', value : '', desc
 
 # ------------------------------------------------------------------------------------ level 2
 def spectrumserver_h(L):
-    L = after(L, '#include "fft.h"', H(["class HipFanout;  // hip_fanout.h: Level 2 of the MI355X back-end"]))
+    L = after(L, '#include "fft.h"', H(["class HipFanout;  // hip_fanout.h: Level 2 of the MI355X back-end",
+                                         "namespace psdr_level2 { struct Access; }  // hip_level2.h"]))
     return after(L, "std::unique_ptr<FFT> fft;", H([
         '    std::unique_ptr<HipFanout> fanout;  // all per-client DSP on the GPU (accelerator = "hip", hip_fanout = true)',
-        "    void fft_task_hip();                // src/fft_hip.cpp"]))
+        "    void fft_task_hip();                // src/fft_hip.cpp",
+        "    friend struct psdr_level2::Access;  // the body of fft_task_hip (hip_level2.h)"]))
 
 
 def spectrumserver_cpp(L):
@@ -129,25 +131,26 @@ def signal_h(L):
         "    void psdr_attach(HipFanout *fo);                       // src/signal.cpp",
         "    void send_audio_hip(HipFanout *fo, size_t frame_num);  // src/fft_hip.cpp",
         "    HipFanout *psdr_fo = nullptr;",
-        "    int psdr_id = -1;"]))
-    return after(L, '#include "client.h"', H(['#include "hip_fanout.h"']))
+        "    int psdr_id = -1;",
+        "    friend struct psdr_level2::Access;                     // the body of send_audio_hip (hip_level2.h)"]))
+    return after(L, '#include "client.h"', H(['#include "hip_fanout.h"', "namespace psdr_level2 { struct Access; }"]))
 
 
 def signal_cpp(L):
     # every state change is forwarded to the GPU-side client
     L = after(L, "void AudioClient::set_audio_range(int l, double m, int r) {", H([
-        "    if (psdr_fo) psdr_fo->set_audio_range(psdr_id, l, m, r);"]))
+        "    if (psdr_fo) (void)psdr_fo->set_audio_range(psdr_id, l, m, r);  // never throws; a rejected window keeps the old one on the GPU"]))
     L = after(L, "void AudioClient::set_audio_demodulation(demodulation_mode demodulation) {", H([
-        "    if (psdr_fo) psdr_fo->set_audio_demodulation(psdr_id, (psdr_mode)demodulation);"]))
+        "    if (psdr_fo) (void)psdr_fo->set_audio_demodulation(psdr_id, (psdr_mode)demodulation);"]))
     L = after(L, "    this->agc.reset();", H([
-        "    if (psdr_fo) psdr_fo->set_audio_demodulation(psdr_id, (psdr_mode)this->demodulation);  // also resets the GPU AGC"]))
+        "    if (psdr_fo) (void)psdr_fo->set_audio_demodulation(psdr_id, (psdr_mode)this->demodulation);  // also resets the GPU AGC"]))
     L = after(L, "void AudioClient::on_close() {", H(["    if (psdr_fo) psdr_fo->remove_audio_client(psdr_id);"]))
     # (the file has no trailing newline: appending would rewrite its last line - insert above the destructor)
     return after(L, "AudioClient::~AudioClient() {", H([
         "void AudioClient::psdr_attach(HipFanout *fo) {",
         "    psdr_fo = fo;",
-        "    psdr_id = fo->add_audio_client();",
-        "    fo->set_audio_demodulation(psdr_id, (psdr_mode)demodulation);",
+        "    psdr_id = fo->add_audio_client();  // -1: every GPU slot is taken - this client gets no audio",
+        "    (void)fo->set_audio_demodulation(psdr_id, (psdr_mode)demodulation);",
         "}"]), offset=0)
 
 
@@ -156,19 +159,20 @@ def waterfall_h(L):
         "    void psdr_attach(HipFanout *fo);",
         "    void send_waterfall_hip(HipFanout *fo, size_t frame_num);  // src/fft_hip.cpp",
         "    HipFanout *psdr_fo = nullptr;",
-        "    int psdr_id = -1;"]))
-    return after(L, '#include "client.h"', H(['#include "hip_fanout.h"']))
+        "    int psdr_id = -1;",
+        "    friend struct psdr_level2::Access;                         // the body of send_waterfall_hip (hip_level2.h)"]))
+    return after(L, '#include "client.h"', H(['#include "hip_fanout.h"', "namespace psdr_level2 { struct Access; }"]))
 
 
 def waterfall_cpp(L):
     L = after(L, "    this->level = level;", H([
-        "    if (psdr_fo) psdr_waterfall_set_range(psdr_fo->context(), psdr_id, level, l, r);"]))
+        "    if (psdr_fo && psdr_id >= 0) psdr_waterfall_set_range(psdr_fo->context(), psdr_id, level, l, r);"]))
     L = after(L, "void WaterfallClient::on_close() {", H(["    if (psdr_fo) psdr_fo->remove_waterfall_client(psdr_id);"]))
     return after(L, "void WaterfallClient::on_close() {", H([
         "void WaterfallClient::psdr_attach(HipFanout *fo) {",
         "    psdr_fo = fo;",
         "    psdr_id = fo->add_waterfall_client();",
-        "    psdr_waterfall_set_range(fo->context(), psdr_id, level, l, r);",
+        "    if (psdr_id >= 0) psdr_waterfall_set_range(fo->context(), psdr_id, level, l, r);",
         "}"]), offset=0)
 
 

@@ -25,16 +25,15 @@ fn.argtypes = [C.c_void_p, C.c_void_p]
 assert fn(eng.ctx.h, buf) == 0
 allv = np.array(buf, dtype=np.int64)
 t = allv[0:128].reshape(8, 16)
-names = ["top", "convert", "stage0", "exch1", "stage1", "exch2", "ready-spin", "read-image", "", "", "twiddle+stores"]
-marks = [0, 1, 2, 3, 4, 5, 6, 7, 10]
+names = {1: "convert", 2: "stage0", 8: "alpha-wait", 9: "alpha-write+fetch", 3: "exch1", 4: "stage1", 5: "exch2", 6: "beta-wait", 7: "beta-read",
+         10: "twiddle+stores"}
+order = [0, 1, 2, 8, 9, 3, 4, 5, 6, 7, 10]
 for it in range(8):
     row = t[it]
     if row[0] == 0:
         continue
-    d = [f"{names[k1]}={row[k1] - row[k0]}" for k0, k1 in zip(marks[:-1], marks[1:]) if row[k1] and row[k0]]
+    pts = [(k, row[k]) for k in order if row[k]]
+    d = [f"{names[k1]}={c1 - c0}" for (k0, c0), (k1, c1) in zip(pts[:-1], pts[1:])]
     nxt = t[it + 1][0] - row[0] if it < 7 and t[it + 1][0] else 0
     print(f"it{it}: total={row[10] - row[0]} period={nxt}  " + "  ".join(d))
-    if row[8] and row[13]:
-        print(f"      loader k={it}: wait-freed={row[11] - row[8]} issue={row[12] - row[11]} land={row[13] - row[12]}  "
-              f"(published {row[13] - row[0]} after the compute wave's top of tile {it})")
 eng.close()
