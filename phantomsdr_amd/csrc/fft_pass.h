@@ -412,6 +412,7 @@ struct Pass1Args {
     unsigned *tickets;  // TileQueue counters of this launch (8, zeroed)
     unsigned long long *trace;
     unsigned long long *kclk;  // device-clock stamps of this launch (kclk_begin / kclk_end) or nullptr
+    unsigned ymask;            // frame index mask of Y (~0u; a timing-only experiment aliases frames: PSDR_Y_ALIAS)
 };
 
 // the raw words of two adjacent complex samples (columns 2p, 2p+1 of one row) -> c2
@@ -559,7 +560,7 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
         const unsigned f = slot / a.tiles_per_frame;
         const unsigned tl = slot - f * a.tiles_per_frame;
         // this tile's block (plain) / its chunk of pass-2 tile 0 (PAIR: pass-2 tiles have 16 rows)
-        cf *Yb = a.Y + (size_t)f * a.yframe + (PAIR ? (size_t)tl * a.ytl : (size_t)tl * a.yblk);
+        cf *Yb = a.Y + (size_t)(f & a.ymask) * a.yframe + (PAIR ? (size_t)tl * a.ytl : (size_t)tl * a.yblk);
         // PAIR: where the lane's part of a row index puts it (see the store below)
         cf *Ylo = Yb + (size_t)(i0_ >> 3) * a.ytile + (i0_ & 7) * T + 2 * p_;
         cf *Yhi = Yb - (size_t)((i0_ + 7) >> 3) * a.ytile + (8 + ((-i0_) & 7)) * T + 2 * p_;
@@ -753,6 +754,7 @@ struct Pass2Args {
     unsigned *tickets;  // TileQueue counters of this launch (8, zeroed)
     unsigned long long *trace;
     unsigned long long *kclk;  // device-clock stamps of this launch (kclk_begin / kclk_end) or nullptr
+    unsigned ymask;            // as Pass1Args::ymask
     // fused real-input epilogue (k_fft_pass2_real)
     const cf *UA, *UB;  // W_N^{h << log2UB}, W_N^{l}: untangle twiddles
     const cf *UG;       // W_N^{8g}, g < M1/16: the tile's factor of the untangle twiddle
@@ -810,17 +812,27 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
         const unsigned slot = xcd_slot(sidx, total);
         const unsigned f = slot / a.tiles_per_frame;
         const unsigned tl = slot - f * a.tiles_per_frame;
-        nxt = a.Y + (size_t)f * a.yframe + (size_t)(tl * T) * (YCM ? 2 : TW);
+        nxt = a.Y + (size_t)(f & a.ymask) * a.yframe + (size_t)(tl * T) * (YCM ? 2 : TW);
     };
     // couple-major Y: load q = i*NT + tid is (row rr = q & 15, couple pc = (q >> 4) & 7, pass-1 tile j = q >> 7)
     const unsigned ycm_lane = (unsigned)((size_t)(tid >> 7) * blk + ((size_t)((tid >> 4) & 7) * a.M1 + (tid & 15)) * 2);
+    // SPLIT (fused kernels): register i holds the tile's load number i ^ 8, so that the loads issued FIRST (i < 8) are
+    // the upper half of the LDS tile (n2 >= L/2).  The powers the record loop reads (Pst) live in the lower half only,
+    // so a wave that has finished its records fills the upper half of the NEXT tile at once; the "tile is free again"
+    // barrier moves between the two half-fills, where the late loads (i >= 8: the lower half) have had longer to land.
+#ifdef PSDR_P2_NO_SPLITFILL
+    constexpr bool SPLIT = false;
+#else
+    constexpr bool SPLIT = FUSED;
+#endif
     auto issue = [&](auto qc) {
         constexpr int i = decltype(qc)::value;
+        constexpr int ip = SPLIT ? (i ^ (NLD / 2)) : i;  // which sixteenth of the tile
         const cf *q;
         if constexpr (YCM)
-            q = nxt + (size_t)((i * NT) >> 7) * blk + ycm_lane;
-        else  // uniform part of idx = 2*i*NT: block (2*i*NT)>>lc, offset (2*i*NT)&(chunk-1)
-            q = nxt + (size_t)((2 * i * NT) >> lc) * blk + ((2 * i * NT) & (chunk - 1)) + lane_off;
+            q = nxt + (size_t)((ip * NT) >> 7) * blk + ycm_lane;
+        else  // uniform part of idx = 2*ip*NT: block (2*ip*NT)>>lc, offset (2*ip*NT)&(chunk-1)
+            q = nxt + (size_t)((2 * ip * NT) >> lc) * blk + ((2 * ip * NT) & (chunk - 1)) + lane_off;
         r[i] = *reinterpret_cast<const float4 *>(q);
     };
     __shared__ unsigned s_next[2];
@@ -855,13 +867,19 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
         // transposing fill: point (n2, row rr) goes to half rr&1 of couple rr>>1
 #pragma unroll
         for (int i = 0; i < NLD; i++) {
-            const int w = ((2 * i * NT) & (chunk - 1)) + ((2 * tidx) & (chunk - 1));
+            const int ip = SPLIT ? (i ^ (NLD / 2)) : i;
+            const int w = ((2 * ip * NT) & (chunk - 1)) + ((2 * tidx) & (chunk - 1));
             const int rr = YCM ? (tidx & 15) : w >> log2TW, cc = w & (TW - 1);
-            const int n2 = YCM ? (((i * NT) >> 7) + (tidx >> 7)) * 16 + 2 * ((tidx >> 4) & 7)
-                               : (((2 * i * NT) >> lc) + ((2 * tidx) >> lc)) * TW + cc;  // even
+            const int n2 = YCM ? (((ip * NT) >> 7) + (tidx >> 7)) * 16 + 2 * ((tidx >> 4) & 7)
+                               : (((2 * ip * NT) >> lc) + ((2 * tidx) >> lc)) * TW + cc;  // even
             const int slot0 = lds_slot<H, true>(n2, rr >> 1);  // rows n2, n2+1 share the swizzle
             tile_cf[2 * slot0 + (rr & 1)] = make_float2(r[i].x, r[i].y);
             tile_cf[2 * (slot0 + H) + (rr & 1)] = make_float2(r[i].z, r[i].w);
+            if (SPLIT && i == NLD / 2 - 1) {
+                PSDR_SCHED_FENCE();
+                __syncthreads();  // every wave has finished the previous tile's record loop: the lower half is free
+                PSDR_SCHED_FENCE();
+            }
         }
         PSDR_SCHED_FENCE();
         if (more) static_for<0, EARLY>(issue);
@@ -954,7 +972,7 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
             }
         }
         PSDR_TRACE(a.trace, it, 12);
-        __syncthreads();  // the tile is free again
+        if (!SPLIT) __syncthreads();  // the tile is free again (SPLIT: between the next tile's two half-fills)
         PSDR_TRACE(a.trace, it, 13);
         PSDR_WGTRACE(a.trace, 2 + it);
         s = snext;
@@ -1090,7 +1108,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         unsigned f;
         int g;
         tile_of(sg, j, f, g);
-        nxt = a.Y + (size_t)f * a.yframe + (size_t)g * a.ytile + lane_off;
+        nxt = a.Y + (size_t)(f & a.ymask) * a.yframe + (size_t)g * a.ytile + lane_off;
     };
     auto issue = [&](auto qc) {
         constexpr int i = decltype(qc)::value;

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(kPass1wThreads) void k_fft_pass1_w(Pass1Args a) {
             }
         }
         // couple-major block of this tile: [couple][c1][2]
-        cf *Yb = a.Y + (size_t)f * a.yframe + (size_t)tl * a.yblk + (size_t)w * (2 * L);
+        cf *Yb = a.Y + (size_t)(f & a.ymask) * a.yframe + (size_t)tl * a.yblk + (size_t)w * (2 * L);
         cf *Yl = Yb + 2 * (i0 - (a.rot ? 1 : 0));                   // row k1 - rot of this lane's first output
         cf *Y00 = (a.rot && i0 == 0) ? Yb + 2 * (L - 1) : Yl;      // ... which wraps for bin 0
         stage_compute<L, RL, PL>(u, i0, Wl, [&](int b, int sidx, int, c2 x) {

@@ -615,6 +615,8 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     a1.rot = c->is_real ? 0 : 1;
     a1.trace = c->d_trace;
     a1.kclk = next_kclk(c, 0);
+    a1.ymask = ~0u;
+    if (const char *e = getenv("PSDR_Y_ALIAS")) a1.ymask = (unsigned)atoi(e) - 1u;  // timing-only: WRONG results (frames share Y)
     {
         int rc = next_tickets(c, 0, c->p1, &a1.tickets);
         if (rc) return rc;
@@ -651,6 +653,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     a2.p_stride = c->p_stride;
     a2.trace = c->d_trace ? c->d_trace + 128 + 2304 : nullptr;
     a2.kclk = next_kclk(c, 1);
+    a2.ymask = a1.ymask;
     {
         int rc2 = next_tickets(c, 1, c->stream, &a2.tickets);
         if (rc2) return rc2;

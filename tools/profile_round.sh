@@ -14,6 +14,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- $B > $O
 # collection crashes on torch's own ring-generation kernels), same N / F / clients as the bench
 case $WL in
   cfg3) K="python $R/tools/kernel_times.py --fft 21 --real --clients 64 --batch 256 --steps 4";;
+  cfg5) K="python $R/tools/kernel_times.py --fft 22 --real --clients 128 --batch 256 --steps 3 --ring-mib 2100";;
   *)    K="python $R/tools/kernel_times.py --fft 20 --clients 16 --batch 256 --steps 4";;
 esac
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- $K > $O/pmc_fetch.log 2>&1
