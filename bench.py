@@ -246,6 +246,8 @@ def self_launch(ngpus):
     import socket
     import subprocess
     have = visible_hip_devices()
+    if os.environ.get("PSDR_BENCH_ONE_DEVICE") == "1" and have >= 1:
+        have = ngpus  # testing mode: all ranks share cuda:0 (see run_sharded_bench)
     if have < ngpus:
         sys.stderr.write(f"bench.py: --gpus {ngpus} but {have} HIP device(s) visible; not running\n")
         raise SystemExit(3)
@@ -379,10 +381,17 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
                                             TimeShardedRunner, assign_clients, assign_clients_by_band, band_bounds)
 
     device = torch.device("cuda", local_rank)
+    # PSDR_BENCH_ONE_DEVICE=1 (testing only): every rank on cuda:0 over gloo - RCCL refuses two ranks on one device -
+    # so that the N-process orchestration (self-launch, runners, HIP back-ends, stream ordering around the
+    # collectives) can be exercised on a one-GPU box.  The line says so in `testing_mode`; its numbers mean nothing.
+    one_device = os.environ.get("PSDR_BENCH_ONE_DEVICE") == "1"
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     def measure(mode, steps, warmup):
         time_mode = mode == "time"
@@ -543,6 +552,7 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
                                          "parallelism", "realtime_factor")},
             "roofline": r["roofline"], "path": r["path"], "xgmi": r["xgmi"],
             "shard": main_mode,
+            "testing_mode": "PSDR_BENCH_ONE_DEVICE: all ranks on cuda:0 over gloo - orchestration smoke test, not a measurement" if one_device else None,
             "sharding": {m: {k: v for k, v in results[m].items() if k in ("value", "ms_per_step", "steps", "audio_clients",
                                                                            "parallelism", "xgmi", "error", "workload", "shard")}
                          for m in results},
@@ -707,6 +717,8 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if os.environ.get("PSDR_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 

@@ -165,6 +165,10 @@ class RawShardedRunner:
             if self.world > 1:
                 t = self.backend.raw_tensor()
                 t = t if self.first else t[1:]   # row 0 is already everywhere after the first step
+                # the collective moves BYTES: RCCL/NCCL carry no 16-bit integer type (torch refuses int16 on the
+                # nccl backend, gloo answers "Invalid scalar type") - found by the two-process run of bench.py on
+                # one GPU (PSDR_BENCH_ONE_DEVICE), round 3
+                t = getattr(self.backend, "wire_view", lambda x: x)(t)
                 self.dist.broadcast(t, src=self.root)
                 self.bytes_broadcast += t.numel() * t.element_size()
             self.backend.forward_local()
@@ -487,6 +491,10 @@ class HipRawBackend:
 
     def raw_tensor(self):
         return self.raw
+
+    def wire_view(self, t):
+        """what a collective is given: the same memory as unsigned bytes"""
+        return t.view(self.torch.uint8)
 
     def load_raw(self, i):
         b = i % self.nbatches

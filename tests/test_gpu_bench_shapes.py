@@ -174,3 +174,24 @@ def test_wave_owned_pass1_formats_vs_classic(monkeypatch, fmt):
         assert rel_err(a[f][0], b[f][0]) < 2e-6, f"frame {f}"
         dq = np.abs(a[f][1].astype(np.int16) - b[f][1].astype(np.int16))
         assert dq.max() <= 1 and (dq != 0).mean() < 1e-3
+
+
+def test_bench_gpus_2_runs_every_sharding_as_two_processes():
+    """`python bench.py --gpus 2` with no launcher around it: the self-launch, two ranks, all five shardings with the
+    HIP back-ends.  A one-GPU box cannot run RCCL with two ranks, so PSDR_BENCH_ONE_DEVICE=1 puts both ranks on cuda:0
+    over gloo: an orchestration test (it found int16 tensors handed to a collective), not a measurement."""
+    import json
+    import subprocess
+    env = dict(os.environ, PSDR_BENCH_ONE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch", "8", "--ring-mib", "64"], capture_output=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["testing_mode"]
+    assert set(d["sharding"]) == {"clients", "clients_pipelined", "raw", "band", "time"}
+    for mode, v in d["sharding"].items():
+        assert v.get("error") is None and v["value"] > 0, (mode, v)
