@@ -148,8 +148,38 @@ struct LastStage {
 // earlier radices.  butterfly i = i0 + b*L/16, k = i mod P, j = (i-k)*R + k
 //   x_q = u[b + q*16/R] * W_L^{q*k*L/(P*R)};  out[j + s*P] = DFT_R(x)[s]
 // emit(b, s, pos, value)
+// The stage twiddles of a thread do not depend on the tile (k is a function of i0 and b only): StageTw keeps
+// them in registers for the whole persistent loop instead of reading the LDS table once per tile (27 of the 43
+// table reads per thread and tile of a 1024-point pass; under the package power cap of DESIGN.md 5.2 an LDS byte
+// is time).  PSDR_TW_P1_MASK / PSDR_TW_P2_MASK (bit 0: second stage, bit 1: last stage) select it per pass.
+template <int L>
+struct StageTw {
+    using P = Plan<L>;
+    static constexpr int NB1 = 16 / P::R1, NB2 = P::NS == 3 ? 16 / P::R2 : 1;
+    cf s1[NB1][P::R1 - 1];                          // stage 1: W_L^{q k L/(R0 R1)}, k = i & (R0 - 1)
+    cf s2[NB2][(P::NS == 3 ? P::R2 : 2) - 1];       // stage 2: W_L^{q k L/(R0 R1 R2)}, k = i & (R0 R1 - 1)
+    __device__ __forceinline__ void load(const cf *W, int i0) {  // W: the L-entry table (global or LDS)
+        constexpr int L16 = L / 16;
+#pragma unroll
+        for (int b = 0; b < NB1; b++) {
+            const int k = (i0 + b * L16) & (P::R0 - 1);
+#pragma unroll
+            for (int q = 1; q < P::R1; q++) s1[b][q - 1] = W[q * k * (L / (P::R0 * P::R1))];
+        }
+        if constexpr (P::NS == 3) {
+#pragma unroll
+            for (int b = 0; b < NB2; b++) {
+                const int k = (i0 + b * L16) & (P::R0 * P::R1 - 1);
+#pragma unroll
+                for (int q = 1; q < P::R2; q++) s2[b][q - 1] = W[q * k * (L / (P::R0 * P::R1 * P::R2))];
+            }
+        }
+    }
+};
+
+// twr: nullptr (twiddles from the table Wl) or this stage's rows of a StageTw, [NB][R - 1]
 template <int L, int R, int P, typename Emit>
-__device__ __forceinline__ void stage_compute(c2 (&u)[16], int i0, const cf *Wl, Emit emit) {
+__device__ __forceinline__ void stage_compute(c2 (&u)[16], int i0, const cf *Wl, Emit emit, const cf (*twr)[R - 1] = nullptr) {
     constexpr int NB = 16 / R;
     constexpr int L16 = L / 16;
 #pragma unroll
@@ -162,8 +192,13 @@ __device__ __forceinline__ void stage_compute(c2 (&u)[16], int i0, const cf *Wl,
         for (int q = 0; q < R; q++) x[q] = u[b + q * NB];
         if (P > 1) {
             const int step = k * (L / (P * R));
+            if (twr) {
 #pragma unroll
-            for (int q = 1; q < R; q++) x[q] = cmul(x[q], Wl[q * step]);
+                for (int q = 1; q < R; q++) x[q] = cmul(x[q], twr[b][q - 1]);
+            } else {
+#pragma unroll
+                for (int q = 1; q < R; q++) x[q] = cmul(x[q], Wl[q * step]);
+            }
         }
         dftR<R>(x);
 #pragma unroll
@@ -200,7 +235,7 @@ __device__ __forceinline__ void tile_read(c2 (&u)[16], const float4 *tile, int i
 // every stage but the last (the last stage's outputs go to the caller's emit)
 template <int L, int T, bool SWZ, typename Tick, typename Mark>
 __device__ __forceinline__ void run_front_stages(float4 *tile, const cf *Wl, int i0, int p, c2 (&u)[16], Tick tick,
-                                                 Mark mark) {
+                                                 Mark mark, const StageTw<L> *stw = nullptr) {
     using P = Plan<L>;
     constexpr int H = T / 2;
     // timing-only ablations of pass 1 (SWZ == false), tools/ab_p1.sh: results are WRONG with any of them
@@ -257,7 +292,8 @@ __device__ __forceinline__ void run_front_stages(float4 *tile, const cf *Wl, int
     if constexpr (P::NS == 3) {
         if constexpr (kX2) {
             stage_compute<L, P::R1, P::R0>(
-                u, i0, Wl, [&](int, int, int pos, c2 x) { tile[lds_slot<H, SWZ>(pos, p)] = pack_c2(x); });
+                u, i0, Wl, [&](int, int, int pos, c2 x) { tile[lds_slot<H, SWZ>(pos, p)] = pack_c2(x); },
+                stw ? stw->s1 : nullptr);
         } else {
             c2 v[16];
             stage_compute<L, P::R1, P::R0>(u, i0, Wl, [&](int b, int s, int, c2 x) { v[b + s * (16 / P::R1)] = x; });
@@ -282,16 +318,23 @@ __device__ __forceinline__ void run_front_stages(float4 *tile, const cf *Wl, int
 #undef PSDR_P1_BARRIER
 }
 template <int L, typename EmitLast>
-__device__ __forceinline__ void run_last_stage(const cf *Wl, int i0, c2 (&u)[16], EmitLast emit_last) {
-    stage_compute<L, LastStage<L>::R, LastStage<L>::Pp>(
-        u, i0, Wl, [&](int b, int s, int pos, c2 x) { emit_last(b, s, pos, x); });
+__device__ __forceinline__ void run_last_stage(const cf *Wl, int i0, c2 (&u)[16], EmitLast emit_last,
+                                               const StageTw<L> *stw = nullptr) {
+    if constexpr (Plan<L>::NS == 3) {
+        stage_compute<L, LastStage<L>::R, LastStage<L>::Pp>(
+            u, i0, Wl, [&](int b, int s, int pos, c2 x) { emit_last(b, s, pos, x); }, stw ? stw->s2 : nullptr);
+    } else {
+        stage_compute<L, LastStage<L>::R, LastStage<L>::Pp>(
+            u, i0, Wl, [&](int b, int s, int pos, c2 x) { emit_last(b, s, pos, x); }, stw ? stw->s1 : nullptr);
+    }
 }
 template <int L, int T, bool SWZ, typename PreLast, typename EmitLast, typename Tick, typename Mark>
 __device__ __forceinline__ void run_stages(float4 *tile, const cf *Wl, int i0, int p, c2 (&u)[16],
-                                           PreLast pre_last, EmitLast emit_last, Tick tick, Mark mark) {
-    run_front_stages<L, T, SWZ>(tile, Wl, i0, p, u, tick, mark);
+                                           PreLast pre_last, EmitLast emit_last, Tick tick, Mark mark,
+                                           const StageTw<L> *stw_front = nullptr, const StageTw<L> *stw_last = nullptr) {
+    run_front_stages<L, T, SWZ>(tile, Wl, i0, p, u, tick, mark, stw_front);
     pre_last();
-    run_last_stage<L>(Wl, i0, u, emit_last);
+    run_last_stage<L>(Wl, i0, u, emit_last, stw_last);
 }
 
 // XCD-aware slot mapping: work-group b runs on XCD b%8 (observed; used for speed only).
@@ -552,6 +595,16 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
     tq.draw_first();
     __syncthreads();  // Wl and the twiddle table are visible
     PSDR_WGTRACE(a.trace, 1);
+    // This thread's twiddles of the SECOND stage stay in registers for every tile of the persistent loop (StageTw):
+    // same box, interleaved, cfg2, per 256 frames - pass 1 577 -> 552 us and the whole step -1.5 ... -2 %.  Keeping the
+    // last stage's twelve as well (PSDR_TW_P1_MASK=3) makes pass 1 itself faster still (525 us) but the step no faster:
+    // at 238 VGPRs the previous batch's consumer kernels no longer fit beside a pass-1 work-group and run later instead.
+#ifndef PSDR_TW_P1_MASK
+#define PSDR_TW_P1_MASK 1
+#endif
+    StageTw<L> stw;
+    if (PSDR_TW_P1_MASK) stw.load(Wl, i0_);
+    const StageTw<L> *stw_front = (Plan<L>::NS == 3 && (PSDR_TW_P1_MASK & 1)) ? &stw : nullptr, *stw_last = (PSDR_TW_P1_MASK & 2) ? &stw : nullptr;
 
     int it = 0;
     for (; s < total; it++) {
@@ -713,7 +766,7 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
                         static_for<lo, hi>(issue);
                     });
             },
-            [&](int k) { PSDR_TRACE(a.trace, it, k); });
+            [&](int k) { PSDR_TRACE(a.trace, it, k); }, stw_front, stw_last);
         PSDR_TRACE(a.trace, it, 10);
         PSDR_WGTRACE(a.trace, 2 + it);
         // (published by thread 0 before the stages' barriers)
@@ -847,6 +900,14 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
         static_for<0, NLD>(issue);
     }
     for (int i = tid; i < L; i += NT) Wl[i] = a.Wl[i];  // visible after the loop's first barrier
+    // (register-resident stage twiddles, as in pass 1: measured without effect here - 866 vs 865 us with the second
+    // stage's fifteen at 240 VGPRs, spills with the last stage's twelve on top - so off unless PSDR_TW_P2_MASK says so)
+#ifndef PSDR_TW_P2_MASK
+#define PSDR_TW_P2_MASK 0
+#endif
+    StageTw<L> stw;
+    if (PSDR_TW_P2_MASK) stw.load(a.Wl, i0_);  // (from the global table: the LDS copy is not visible yet)
+    const StageTw<L> *stw_front = (Plan<L>::NS == 3 && (PSDR_TW_P2_MASK & 1)) ? &stw : nullptr, *stw_last = (PSDR_TW_P2_MASK & 2) ? &stw : nullptr;
     tq.draw_first();
     PSDR_WGTRACE(a.trace, 1);
 
@@ -929,7 +990,7 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
                         static_for<lo, hi>(issue);
                     });
             },
-            [&](int k) { PSDR_TRACE(a.trace, it, k); });
+            [&](int k) { PSDR_TRACE(a.trace, it, k); }, stw_front, stw_last);
         PSDR_TRACE(a.trace, it, 10);
 
         if (FUSED) {
