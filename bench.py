@@ -461,11 +461,13 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
                 bytes_per_frame = 8 * params["fft_result_size"]
             elif mode == "band":
                 backend = HipBandBackend(torch, eng.ctx, device, ring.data_ptr() if ring is not None else 0, nbatches, F,
-                                         rank, world, halo)
+                                         rank, world, halo, banded=False if os.environ.get("PSDR_BAND_PACK") == "1" else None)
                 runner = BandShardedRunner(backend, dist, rank, world, F)
-                par = (f"clients sharded by frequency band over {world} GPUs; rank 0 FFT + pack + RCCL scatter of one "
+                how = ("rank 0's second FFT pass writes one contiguous region per band, the regions are the send buffers (no pack)"
+                       if backend.banded else "rank 0 FFT + pack")
+                par = (f"clients sharded by frequency band over {world} GPUs; {how} + RCCL scatter of one "
                        "band (+ one window of halo) per rank, the scatter of batch i overlapping the transform of batch i+1")
-                bytes_per_frame = 8 * band_bounds(0, params["fft_result_size"], world, halo)[1]
+                bytes_per_frame = 8 * backend.bins
             else:
                 backend = HipBackend(torch, eng.ctx, device, ring.data_ptr() if ring is not None else 0, nbatches, F)
                 runner = ShardedRunner(backend, dist, rank, world, F)

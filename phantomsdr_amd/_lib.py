@@ -69,6 +69,9 @@ SYMBOLS = [
     ("psdr_demod_batch_from", _i, [_vp, _vp, _sz, _i, _u64]),
     ("psdr_pack_band", _i, [_vp, _i, C.c_uint32, C.c_uint32, _vp, _sz]),
     ("psdr_demod_batch_from_band", _i, [_vp, _vp, _sz, C.c_uint32, C.c_uint32, _i, _u64]),
+    ("psdr_set_band_layout", _i, [_vp, _i, C.c_uint32]),
+    ("psdr_band_region", _i, [_vp, _i, _pp, C.POINTER(_sz), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("psdr_demod_batch_from_band_region", _i, [_vp, _vp, _sz, C.c_uint32, C.c_uint32, _i, _u64]),
     ("psdr_read_audio", _i, [_vp, _i, _i, _vp, _vp, _vp, C.POINTER(_i)]),
     ("psdr_audio_device_ptr", _i, [_vp, _i, _pp, _pp]),
     ("psdr_set_post_chain", _i, [_vp, _i]),

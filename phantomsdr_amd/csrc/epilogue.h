@@ -372,6 +372,27 @@ __global__ __launch_bounds__(256) void k_band_pack(const cf *X, size_t spec_stri
     out[(size_t)blockIdx.y * out_stride + j] = X[(size_t)blockIdx.y * spec_stride + lay.pos(k)];
 }
 
+// banded spectrum (SpecLayout mode 3): lines Lb .. Lb+H-1 of every tile of band b = lines 0 .. H-1 of the same tile of
+// band b+1 (the last band gets the spectrum's first columns: never read, windows do not wrap).  One thread per 16 bytes.
+__global__ __launch_bounds__(256) void k_band_halo(cf *X, size_t spec_stride, SpecLayout lay, int nbands, int nframes,
+                                                   int tiles, int H) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int piece = (int)(q & 7);
+    size_t r = q >> 3;
+    const int h = (int)(r % (size_t)H);
+    r /= (size_t)H;
+    const int tl = (int)(r % (size_t)tiles);
+    r /= (size_t)tiles;
+    const int f = (int)(r % (size_t)nframes);
+    const size_t b = r / (size_t)nframes;
+    if (b >= (size_t)nbands) return;
+    const int Lb = 1 << lay.l2Lb;
+    const size_t bn = b + 1 == (size_t)nbands ? 0 : b + 1;
+    const float4 *src = reinterpret_cast<const float4 *>(X + bn * lay.band_stride + (size_t)f * spec_stride + ((size_t)tl * lay.Lw + h) * 16);
+    float4 *dst = reinterpret_cast<float4 *>(X + b * lay.band_stride + (size_t)f * spec_stride + ((size_t)tl * lay.Lw + Lb + h) * 16);
+    dst[piece] = src[piece];
+}
+
 struct WfClient {
     int level, l, r;
     int active;

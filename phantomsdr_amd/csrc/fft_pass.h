@@ -808,6 +808,10 @@ struct Pass2Args {
     unsigned long long *trace;
     unsigned long long *kclk;  // device-clock stamps of this launch (kclk_begin / kclk_end) or nullptr
     unsigned ymask;            // as Pass1Args::ymask
+    // BAND kernels: the spectrum goes out in band regions (SpecLayout mode 3, quantize.h): column c2 of tile tl is the
+    // line ((c2 >> l2Lb) * band_stride) + (tl * Lw + (c2 & lbmask)) * 16 of the frame's slot in its band's region
+    int l2Lb, lbmask, Lw;
+    size_t band_stride;
     // fused real-input epilogue (k_fft_pass2_real)
     const cf *UA, *UB;  // W_N^{h << log2UB}, W_N^{l}: untangle twiddles
     const cf *UG;       // W_N^{8g}, g < M1/16: the tile's factor of the untangle twiddle
@@ -822,8 +826,11 @@ struct Pass2Args {
 // TWC: pass-1 tile width when known at compile time (all fill addresses fold), 0: a.TW
 // YCM: Y is couple-major, [frame][pass-1 tile][couple][c1][2] (written by k_fft_pass1_w, fft_pass1w.h): the 16
 // rows of this tile are one 256-byte piece of every (pass-1 tile, couple) block
-template <int L, int T, bool FUSED, int TWC, bool YCM = false>
+// BAND: banded spectrum layout (band sharding without a pack pass: every band's lines of a whole batch form one
+// contiguous region, which is what is sent over the link)
+template <int L, int T, bool FUSED, int TWC, bool YCM = false, bool BAND = false>
 __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
+    static_assert(!BAND || (FUSED && L == 1024 && T == 16), "banded layout: the tile-major IQ spectrum only");
     static_assert(!YCM || (T == 16 && TWC == 16), "couple-major Y: 16-row tiles of 16-column pass-1 tiles");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *tile = reinterpret_cast<float4 *>(smem);
@@ -965,7 +972,8 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
             [&]() {
                 if (LATE > 0 && more) static_for<NFRONT, NFRONT + LATE / 2>(issue);
             },
-            [&](int, int, int c2i, c2 x) {
+            [&](int bb, int ss, int c2i, c2 x) {
+                (void)bb, (void)ss;
                 if (FUSED) {
                     x.a.x *= a.inv_n;
                     x.a.y *= a.inv_n;
@@ -976,7 +984,13 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
                         make_float2(fmaf(x.a.x, x.a.x, x.a.y * x.a.y), fmaf(x.b.x, x.b.x, x.b.y * x.b.y));
                 }
                 // FUSED (IQ) tiles of 1024-point rows: tile-major lines (SpecLayout mode 1, quantize.h)
-                if constexpr (FUSED && L == 1024 && T == 16)
+                if constexpr (BAND) {
+                    // c2i = i0 + tcol with i0 < 64 <= band width: band and column inside the band follow from tcol
+                    // alone (uniform, known after unrolling)
+                    const int tcol = (L / 16) * (bb + (16 / LastStage<L>::R) * ss);
+                    cf *Xb = Xf + (size_t)(tcol >> a.l2Lb) * a.band_stride + ((size_t)tl * a.Lw + (tcol & a.lbmask)) * T;
+                    *reinterpret_cast<float4 *>(Xb + i0 * T + 2 * p) = pack_c2(x);
+                } else if constexpr (FUSED && L == 1024 && T == 16)
                     *reinterpret_cast<float4 *>(Xt + c2i * T + 2 * p) = pack_c2(x);
                 else
                     *reinterpret_cast<float4 *>(Xf + ((size_t)c2i << a.log2M1) + c1base + 2 * p) = pack_c2(x);
@@ -1043,9 +1057,9 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
     kclk_end(a.kclk);
 }
 
-template <int L, int T, bool FUSED, int TWC, bool YCM = false>
+template <int L, int T, bool FUSED, int TWC, bool YCM = false, bool BAND = false>
 __global__ __launch_bounds__(L *T / 32) void k_fft_pass2(Pass2Args a) {
-    pass2_body<L, T, FUSED, TWC, YCM>(a);
+    pass2_body<L, T, FUSED, TWC, YCM, BAND>(a);
 }
 
 // ---- pass 2 for REAL input, fused with the Hermitian untangle, /N, |X|^2 and pyramid levels 0..3 ----

@@ -139,6 +139,7 @@ struct psdr_ctx {
     // couple-major.  Experimental, off unless PSDR_P1_WAVE=1: correct (parity tests run it), not yet faster
     bool p1_wave = false;
     SpecLayout lay{};                // device layout of the spectrum (natural unless real_fused)
+    int nbands = 0, band_H = 0;      // psdr_set_band_layout: band regions (SpecLayout mode 3), halo columns per band
     bool y_blocked = false;          // PSDR_REAL_YBLOCKED (tuning)
     int seg_len_env = 0;             // PSDR_SEG_LEN (tuning): tiles per chain segment
     float *d_seamP = nullptr, *d_seamC = nullptr;  // of the current result set
@@ -439,16 +440,16 @@ int launch_pass1_t(psdr_ctx *c, const Pass1Args &a, unsigned blocks) {
     HIPCHK(hipGetLastError());
     return PSDR_OK;
 }
-template <int L, int T, bool FUSED, int TWC, bool YCM = false>
+template <int L, int T, bool FUSED, int TWC, bool YCM = false, bool BAND = false>
 int launch_pass2_t(psdr_ctx *c, const Pass2Args &a, unsigned blocks) {
     constexpr size_t lds = (size_t)L * T * sizeof(cf) + (size_t)L * sizeof(cf);
     // (per context = per device: the attribute is a property of the function ON a device)
-    if (c->lds_attr_done.insert((const void *)k_fft_pass2<L, T, FUSED, TWC, YCM>).second)
-        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass2<L, T, FUSED, TWC, YCM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (c->lds_attr_done.insert((const void *)k_fft_pass2<L, T, FUSED, TWC, YCM, BAND>).second)
+        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass2<L, T, FUSED, TWC, YCM, BAND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope ps(c, K_PASS2);
     unsigned grid = persistent_grid(c, blocks, lds);
     if (c->p2_grid && c->p2_grid < grid) grid = c->p2_grid;
-    hipLaunchKernelGGL((k_fft_pass2<L, T, FUSED, TWC, YCM>), dim3(grid), dim3(L * T / 32), lds, c->stream, a);
+    hipLaunchKernelGGL((k_fft_pass2<L, T, FUSED, TWC, YCM, BAND>), dim3(grid), dim3(L * T / 32), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return PSDR_OK;
 }
@@ -579,7 +580,9 @@ void select_set(psdr_ctx *c, int set) {
 
 int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipEvent_t ev_raw_consumed = nullptr) {
     // alternate the result set when the consumers run on their own stream
-    if (c->side != c->stream) select_set(c, c->cur_set ^ 1);
+    // (banded spectrum: also on a caller's stream - the regions of batch b are read by the peers, asynchronously,
+    // while batch b+1 is transformed)
+    if (c->side != c->stream || c->nbands) select_set(c, c->cur_set ^ 1);
     const int cols = 1;
     const int sb = fmt <= PSDR_FMT_S8 ? 2 : (fmt <= PSDR_FMT_S16 ? 4 : 8);  // image bytes per sample
     const unsigned tiles1 = (unsigned)(c->M2 / (c->T1 * cols)), tiles2 = (unsigned)(c->M1 / c->T2);
@@ -671,8 +674,23 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     if (!c->is_real) {
         a2.X = c->d_spec;
         a2.spec_stride = c->spec_stride;
-        rc = run_pass2(true);
-        if (rc) return rc;
+        if (c->nbands) {
+            a2.l2Lb = c->lay.l2Lb;
+            a2.lbmask = (1 << c->lay.l2Lb) - 1;
+            a2.Lw = c->lay.Lw;
+            a2.band_stride = c->lay.band_stride;
+            rc = launch_pass2_t<1024, 16, true, 16, false, true>(c, a2, a2.total_slots);
+            if (rc) return rc;
+            if (c->band_H > 0) {  // the first columns of band b+1 once more, behind band b's own
+                const size_t n16 = (size_t)c->nbands * nframes * (c->M1 / 16) * c->band_H * 8;  // 16-byte pieces
+                hipLaunchKernelGGL(k_band_halo, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream, c->d_spec,
+                                   c->spec_stride, c->lay, c->nbands, nframes, c->M1 / 16, c->band_H);
+                HIPCHK(hipGetLastError());
+            }
+        } else {
+            rc = run_pass2(true);
+            if (rc) return rc;
+        }
     } else if (c->real_fused) {
         a2.X = c->d_spec;
         a2.spec_stride = c->spec_stride;
@@ -1559,9 +1577,10 @@ extern "C" int psdr_client_set_audio_demodulation(psdr_ctx *c, int id, int mode)
     return PSDR_OK;
 }
 
-// band != nullptr: `spec` is a linear window of bins [band[0], band[0] + band[1]) per frame
+// band != nullptr: `spec` is a window of bins [band[0], band[0] + band[1]) per frame - linear, or (band_tiled) one
+// band region of a banded spectrum (SpecLayout mode 4)
 static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nframes, uint64_t first_frame_num,
-                      const uint32_t *band = nullptr) {
+                      const uint32_t *band = nullptr, bool band_tiled = false) {
     if (c->n <= 0) return fail(PSDR_ERR_STATE, "context created with audio_fft_size 0");
     HIPCHK(hipSetDevice(c->device));
     int nact = 0;
@@ -1611,6 +1630,15 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     if (band) {
         a.lay = SpecLayout{};
         a.lay.k0 = (int)band[0];
+        if (band_tiled) {
+            a.lay.mode = 4;
+            a.lay.m1 = c->M1;
+            a.lay.l2m1 = c->log2M1;
+            a.lay.L = c->M2;
+            a.lay.l2L = c->log2M2;
+            a.lay.Lw = (int)(band[1] >> c->log2M1);
+            a.lay.c2_0 = (int)(band[0] >> c->log2M1);
+        }
     }
     a.n = c->n;
     a.nframes = nframes;
@@ -1932,6 +1960,66 @@ extern "C" int psdr_demod_batch_from_band(psdr_ctx *c, const float *d_band, size
     return demod_impl(c, (const cf *)d_band, frame_stride_bins, nframes, first_frame_num, band);
 }
 
+// ---- band sharding without the pack: pass 2 writes band regions ------------------------------------------------
+extern "C" int psdr_set_band_layout(psdr_ctx *c, int nbands, uint32_t halo_bins) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    if (c->is_real || c->lay.mode == 0 || c->lay.mode == 2 || c->M1 != 1024 || c->M2 != 1024 || c->p1_wave)
+        return fail(PSDR_ERR_UNSUPPORTED, "banded spectrum: 2^20-point IQ frames only (use psdr_pack_band)");
+    if (nbands < 1 || nbands > 16 || (nbands & (nbands - 1))) return fail(PSDR_ERR_INVALID, "nbands %d: a power of two <= 16", nbands);
+    if (halo_bins > (uint32_t)c->M) return fail(PSDR_ERR_INVALID, "halo of %u bins", halo_bins);
+    HIPCHK(hipSetDevice(c->device));
+    {
+        int rc = drain(c);
+        if (rc) return rc;
+    }
+    HIPCHK(hipDeviceSynchronize());
+    const int H = (int)((halo_bins + (uint32_t)c->M1 - 1) >> c->log2M1), Lb = c->M2 / nbands, Lw = Lb + H;
+    const size_t F = (size_t)c->max_batch, fs = (size_t)c->M1 * Lw;
+    for (int s = 0; s < 2; s++) {
+        if (c->spec_pool[s]) HIPCHK(hipFree(c->spec_pool[s]));
+        c->spec_pool[s] = nullptr;
+        HIPCHK(hipMalloc((void **)&c->spec_pool[s], (size_t)nbands * F * fs * sizeof(cf)));
+        HIPCHK(hipMemset(c->spec_pool[s], 0, (size_t)nbands * F * fs * sizeof(cf)));
+    }
+    c->nbands = nbands;
+    c->band_H = H;
+    c->spec_stride = fs;  // frame to frame INSIDE a region
+    c->lay.mode = 3;
+    c->lay.l2Lb = ilog2((size_t)Lb);
+    c->lay.Lw = Lw;
+    c->lay.band_stride = F * fs;
+    c->lay.c2_0 = 0;
+    c->set_pending[0] = c->set_pending[1] = false;
+    select_set(c, c->cur_set);
+    c->last_nframes = 0;
+    c->out_valid = false;
+    return PSDR_OK;
+}
+extern "C" int psdr_band_region(psdr_ctx *c, int band, const float **d_region, size_t *frame_stride_bins, uint32_t *first_bin,
+                                uint32_t *nbins) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    if (!c->nbands) return fail(PSDR_ERR_STATE, "psdr_set_band_layout() first");
+    if (band < 0 || band >= c->nbands) return fail(PSDR_ERR_INVALID, "band %d outside [0, %d)", band, c->nbands);
+    if (d_region) *d_region = (const float *)(c->d_spec + (size_t)band * c->lay.band_stride);
+    if (frame_stride_bins) *frame_stride_bins = c->spec_stride;
+    if (first_bin) *first_bin = (uint32_t)((size_t)band << (c->lay.l2Lb + c->log2M1));
+    if (nbins) *nbins = (uint32_t)c->spec_stride;
+    return PSDR_OK;
+}
+extern "C" int psdr_demod_batch_from_band_region(psdr_ctx *c, const float *d_region, size_t frame_stride_bins, uint32_t first_bin,
+                                                 uint32_t nbins, int nframes, uint64_t first_frame_num) {
+    if (!c || !d_region) return fail(PSDR_ERR_INVALID, "null argument");
+    if (c->is_real || c->M2 != 1024) return fail(PSDR_ERR_UNSUPPORTED, "band regions: IQ frames with 1024-point rows only");
+    if (nframes < 1 || nframes > c->max_batch)
+        return fail(PSDR_ERR_INVALID, "nframes %d outside [1, max_batch=%d]", nframes, c->max_batch);
+    const uint32_t m1 = (uint32_t)c->M1;
+    if (nbins < m1 || (nbins & (m1 - 1)) || (first_bin & (m1 - 1)) || first_bin >= (uint32_t)c->M)
+        return fail(PSDR_ERR_INVALID, "band region [%u, +%u): whole columns of %u bins", first_bin, nbins, m1);
+    if (frame_stride_bins < nbins) return fail(PSDR_ERR_INVALID, "frame stride smaller than the band");
+    const uint32_t band[2] = {first_bin, nbins};
+    return demod_impl(c, (const cf *)d_region, frame_stride_bins, nframes, first_frame_num, band, true);
+}
+
 extern "C" int psdr_read_audio(psdr_ctx *c, int id, int nframes, float *audio, float *pwr, int32_t *nan_flags,
                                int *nframes_out) {
     if (!c) return fail(PSDR_ERR_INVALID, "null argument");
@@ -2140,6 +2228,7 @@ extern "C" int psdr_read_waterfall(psdr_ctx *c, int id, int8_t *out, size_t out_
 extern "C" int psdr_spectrum_device_ptr(psdr_ctx *c, int frame, const float **d_spec, size_t *nbins) {
     if (!c) return fail(PSDR_ERR_INVALID, "null argument");
     if (frame < 0 || frame >= c->max_batch) return fail(PSDR_ERR_INVALID, "frame %d out of range", frame);
+    if (c->nbands) return fail(PSDR_ERR_UNSUPPORTED, "banded spectrum: a frame is not one piece (psdr_band_region)");
     if (d_spec) *d_spec = (const float *)(c->d_spec + (size_t)frame * c->spec_stride);
     if (nbins) *nbins = c->is_real ? c->N / 2 + 1 : c->N;
     return PSDR_OK;

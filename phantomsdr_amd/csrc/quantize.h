@@ -202,14 +202,30 @@ struct RecMap {
 //           octet of tile g is rows M1-8g-7..M1-8g ascending (g = 0: its last element is row M1/2
 //           instead of "row M1").  The halves of a line are the two real-signal bins a
 //           (row, mirror row) couple produces together.
+//   mode 3  IQ, BANDED (band sharding, psdr_set_band_layout): the columns are split into 2^(l2L - l2Lb) bands of
+//           Lb = 2^l2Lb columns; band b owns one region of the buffer (band_stride bins apart) that holds ALL frames of
+//           the batch, each frame as tiles of Lw = Lb + halo lines: line (tl, c2) of mode 1 is line tl * Lw + (c2 & (Lb-1))
+//           of the frame's slot in region c2 >> l2Lb; lines Lb .. Lw-1 of a tile repeat the first columns of the NEXT
+//           band (k_band_halo), so that a window that starts in a band can be read from that band's region alone.
+//           One region is what one peer receives: no pack pass.
+//   mode 4  one band region as received (psdr_demod_batch_from_band_region): columns c2_0 .. c2_0 + Lw - 1
 // Consumers index through pos() (demodulation slices) or ask for k order (psdr_read_spectrum).
 struct SpecLayout {
     int mode, m1, l2m1, L, l2L;
     int k0;  // mode 0 only: the buffer starts at bin k0 (a band of the spectrum, psdr_demod_batch_from_band)
+    int l2Lb, Lw, c2_0;  // modes 3, 4
+    size_t band_stride;  // mode 3
     __host__ __device__ __forceinline__ size_t pos(int k) const {
         if (!mode) return (size_t)(k - k0);
         const int c1 = k & (m1 - 1), c2 = k >> l2m1;
         if (mode == 1) return ((((size_t)(c1 >> 4) << l2L) + c2) << 4) + (c1 & 15);
+        if (mode == 3)
+            return (size_t)(c2 >> l2Lb) * band_stride + ((((size_t)(c1 >> 4) * Lw) + (c2 & ((1 << l2Lb) - 1))) << 4) + (c1 & 15);
+        if (mode == 4) {
+            int cl = c2 - c2_0;
+            if (cl < 0) cl += L;  // the last band's halo is the spectrum's first column
+            return ((((size_t)(c1 >> 4) * Lw) + cl) << 4) + (c1 & 15);
+        }
         if (c1 < (m1 >> 1)) return ((((size_t)(c1 >> 3) << l2L) + c2) << 4) + (c1 & 7);
         const int hp = c1 == (m1 >> 1) ? m1 - 1 : c1 - 1;  // rows above M1/2 shift down, M1/2 goes last
         const int g = (m1 - 1 - hp) >> 3;

@@ -250,6 +250,8 @@ class BandShardedRunner:
                 work = self.dist.scatter(t, scatter_list=bands if self.rank == self.root else None, src=self.root,
                                          async_op=self.pipelined)
                 self.bytes_broadcast += t.numel() * t.element_size()
+            elif getattr(self.backend, "adopt", None) and self.backend.adopt(bands[0], par):
+                pass             # one rank, nothing to ship: the region is demodulated where pass 2 wrote it
             else:
                 t.copy_(bands[0])
             if self.pipelined:
@@ -380,26 +382,54 @@ class HipBackend:
         self.ctx.last_nframes = self.ctx.last_demod_frames = self.F
 
 
-class HipBandBackend:
-    """BandShardedRunner back-end on the HIP library.  The root packs the G bands out of the device
-    layout (psdr_pack_band, one small kernel per band) into one send buffer; every rank demodulates
-    from its linear band buffer (psdr_demod_batch_from_band)."""
+def banded_bounds(g, R, world, halo, column=1024):
+    """(first bin, bins) of rank g's band REGION in a banded spectrum (psdr_set_band_layout): whole columns of
+    `column` bins, the halo rounded up to columns.  Contains band_bounds(g, ...) for every g."""
+    per = R // world
+    return g * per, per + -(-halo // column) * column
 
-    def __init__(self, torch, ctx, device, ring_ptr, nbatches, frames_per_step, rank, world, halo, root=0):
+
+class HipBandBackend:
+    """BandShardedRunner back-end on the HIP library.
+
+    banded (default where the library supports it: 2^20-point IQ frames, world a power of two <= 16): the root's
+    second FFT pass writes the spectrum as one contiguous region per band (psdr_set_band_layout) and the regions ARE
+    the send buffers - no pack pass, no second copy of the spectrum on the root; every rank demodulates from its region
+    (psdr_demod_batch_from_band_region).  Two result sets alternate inside the library, so the region of batch b is
+    stable while batch b+1 is transformed and the (asynchronous) scatter of b is in flight.
+
+    Otherwise the root packs the G bands out of the device layout (psdr_pack_band, one small kernel per band) into
+    one send buffer and every rank demodulates from its linear band buffer (psdr_demod_batch_from_band)."""
+
+    def __init__(self, torch, ctx, device, ring_ptr, nbatches, frames_per_step, rank, world, halo, root=0, banded=None):
         import ctypes as C
         from ._lib import check
         self.torch, self.ctx, self.F = torch, ctx, frames_per_step
         self.ring_ptr, self.nbatches, self.rank, self.world = ring_ptr, nbatches, rank, world
         self.hb = ctx.half_frame_bytes()
         self.R = ctx.N // 2 if ctx.is_real else ctx.N
-        self.first, self.bins = band_bounds(rank, self.R, world, halo)
         self.halo = halo
+        self.device, self.root = device, root
         self.stream = torch.cuda.Stream(device=device)
         assert self.stream.cuda_stream != 0
         check(ctx.lib.psdr_set_stream(ctx.h, C.c_void_p(self.stream.cuda_stream)))
+        can = (not ctx.is_real) and ctx.N == 1 << 20 and world <= 16 and world & (world - 1) == 0
+        if banded is None:
+            banded = can
+        if banded and not can:
+            raise ValueError("banded band sharding: 2^20-point IQ frames and a power-of-two world <= 16")
+        self.banded = banded
+        if banded:
+            self.first, self.bins = banded_bounds(rank, self.R, world, halo)
+            if rank == root:  # (a receiver's context keeps its own layout: it never transforms)
+                check(ctx.lib.psdr_set_band_layout(ctx.h, world, halo))
+            self.send = None
+        else:
+            self.first, self.bins = band_bounds(rank, self.R, world, halo)
+            self.send = (torch.empty((2, world, frames_per_step, self.bins), dtype=torch.complex64, device=device)
+                         if rank == root else None)
         self.band = torch.empty((2, frames_per_step, self.bins), dtype=torch.complex64, device=device)
-        self.send = (torch.empty((2, world, frames_per_step, self.bins), dtype=torch.complex64, device=device)
-                     if rank == root else None)
+        self._adopted = {}
 
     def stream_context(self):
         return self.torch.cuda.stream(self.stream)
@@ -411,9 +441,24 @@ class HipBandBackend:
         b = i % self.nbatches
         self.ctx.process_batch(self.ring_ptr, self.F, offset_bytes=b * self.F * self.hb)
 
+    def _regions(self):
+        """the G band regions of the batch just transformed, as tensors aliasing the library's buffer"""
+        import ctypes as C
+        from ._lib import check
+        out = []
+        for g in range(self.world):
+            p, fs, fb, nb = C.c_void_p(), C.c_size_t(), C.c_uint32(), C.c_uint32()
+            check(self.ctx.lib.psdr_band_region(self.ctx.h, g, C.byref(p), C.byref(fs), C.byref(fb), C.byref(nb)))
+            assert (fb.value, nb.value) == banded_bounds(g, self.R, self.world, self.halo) and fs.value == nb.value
+            t = alias_device_f32(self.torch, p.value, self.F * nb.value * 2, self.device)
+            out.append(self.torch.view_as_complex(t.view(self.F, nb.value, 2)))
+        return out
+
     def pack_bands(self, par=0):
         import ctypes as C
         from ._lib import check
+        if self.banded:
+            return self._regions()
         for g in range(self.world):
             first, bins = band_bounds(g, self.R, self.world, self.halo)
             check(self.ctx.lib.psdr_pack_band(self.ctx.h, self.F, first, bins, C.c_void_p(self.send[par, g].data_ptr()), bins))
@@ -422,11 +467,24 @@ class HipBandBackend:
     def band_tensor(self, par=0):
         return self.band[par]
 
+    def adopt(self, region, par=0):
+        """world = 1 (bench.py --force-sharded on one GPU): demodulate band 0 in place instead of copying it into the
+        receive buffer.  PSDR_BAND_STANDIN=1 keeps the copy as a stand-in for the link transfer (it over-states what a
+        scatter costs the root: the peers only READ the regions)."""
+        import os
+        if not self.banded or os.environ.get("PSDR_BAND_STANDIN") == "1":
+            return False
+        self._adopted[par] = region
+        return True
+
     def demod_band(self, first_frame_num, par=0):
         import ctypes as C
         from ._lib import check
-        check(self.ctx.lib.psdr_demod_batch_from_band(self.ctx.h, C.c_void_p(self.band[par].data_ptr()), self.bins,
-                                                      self.first, self.bins, self.F, first_frame_num))
+        fn = self.ctx.lib.psdr_demod_batch_from_band_region if self.banded else self.ctx.lib.psdr_demod_batch_from_band
+        src = self._adopted.pop(par, None)
+        if src is None:
+            src = self.band[par]
+        check(fn(self.ctx.h, C.c_void_p(src.data_ptr()), self.bins, self.first, self.bins, self.F, first_frame_num))
         self.ctx.last_nframes = self.ctx.last_demod_frames = self.F
 
 

@@ -442,6 +442,24 @@ def test_band_assignment_rejects_a_window_wider_than_the_halo():
             assert first <= l < first + cnt - (HALO if G > 1 else 0)   # (G = 1: the band is the spectrum)
 
 
+def test_banded_regions_contain_the_packed_bands():
+    """psdr_set_band_layout's regions (whole columns of 1024 bins, halo rounded up) hold everything psdr_pack_band's
+    linear bands hold, for every rank count the banded layout supports: the client assignment does not change"""
+    from phantomsdr_amd.distributed import band_bounds, banded_bounds
+    R = 1 << 20
+    for G in (1, 2, 4, 8, 16):
+        for halo in (0, 248, 360, 720, 1024, 1500):
+            sizes = set()
+            for g in range(G):
+                f0, n0 = band_bounds(g, R, G, halo)
+                f1, n1 = banded_bounds(g, R, G, halo)
+                assert f1 % 1024 == 0 and n1 % 1024 == 0 and f1 == g * (R // G)
+                if G > 1:
+                    assert f1 <= f0 and f0 + n0 <= f1 + n1 + (1 if halo % 1024 == 0 else 0)
+                sizes.add(n1)
+            assert len(sizes) == 1  # the scatter wants equal pieces
+
+
 def test_time_sharding_refuses_the_post_chain():
     from phantomsdr_amd.distributed import TimeShardedRunner
 

@@ -238,20 +238,24 @@ def test_cfg4_share_demod_from_matches_unsharded_and_oracle():
             e.close()
 
 
-@pytest.mark.parametrize("wl_name,world,g", [("cfg4", 8, 5), ("cfg4", 8, 7), ("cfg3", 4, 3), ("cfg3", 4, 0)])
-def test_band_sharding_matches_unsharded(wl_name, world, g):
-    """SURVEY 8e variant (ii) on ONE GPU: the root packs band g out of the device layout (psdr_pack_band:
-    tile-major IQ lines for cfg4, the fused real layout for cfg3), a second context that never runs an FFT
-    receives it (a device copy stands in for the RCCL scatter) and demodulates rank g's clients with
-    psdr_demod_batch_from_band.  Bit-identical to the unsharded path (which test_cfg*_fullsize check against
-    the oracle); the last band's halo wraps around the end of the spectrum."""
+@pytest.mark.parametrize("wl_name,world,g,banded", [("cfg4", 8, 5, True), ("cfg4", 8, 7, True), ("cfg4", 8, 0, True),
+                                                    ("cfg4", 16, 9, True), ("cfg4", 2, 1, True), ("cfg4", 8, 5, False),
+                                                    ("cfg4", 8, 7, False), ("cfg3", 4, 3, False), ("cfg3", 4, 0, False)])
+def test_band_sharding_matches_unsharded(wl_name, world, g, banded):
+    """SURVEY 8e variant (ii) on ONE GPU.  banded: the root's second FFT pass writes the spectrum as one region per
+    band (psdr_set_band_layout; the halo columns by k_band_halo) and region g is handed over as it is.  Otherwise the
+    root packs band g out of the device layout (psdr_pack_band: tile-major IQ lines for cfg4, the fused real layout
+    for cfg3).  A second context that never runs an FFT receives it (a device copy stands in for the RCCL scatter) and
+    demodulates rank g's clients (psdr_demod_batch_from_band_region / _from_band).  Bit-identical to the unsharded
+    path (which test_cfg*_fullsize check against the oracle); the last band's halo wraps around the end of the
+    spectrum.  The banded root also still answers psdr_read_spectrum, its own demodulation and the pyramid."""
     import torch
     from phantomsdr_amd import SpectrumEngine
     from phantomsdr_amd._lib import check
-    from phantomsdr_amd.distributed import HipBandBackend, assign_clients_by_band, band_bounds
+    from phantomsdr_amd.distributed import HipBandBackend, assign_clients_by_band, band_bounds, banded_bounds
     B = _bench()
     wl = B.WORKLOADS[wl_name]
-    N, F, nb_, is_real = wl["fft_size"], 3, 2, wl["is_real"]
+    N, F, nb_, is_real = wl["fft_size"], 3, 3, wl["is_real"]
     dev = torch.device("cuda", 0)
     x = synth_stream((nb_ * F + 1) * (N // 2), is_real, seed=17, fft_size=N)
     raw = quantize_raw(x, wl["fmt"], is_real)
@@ -277,9 +281,13 @@ def test_band_sharding_matches_unsharded(wl_name, world, g):
         assert len(mine) >= 8 and mine[-3:] == allc[-3:]
         gA, gG = ([e.add_audio_client(l, m, r, mode) for mode, l, m, r in mine] for e in (engA, engG))
         hb = engA.ctx.half_frame_bytes()
-        root = HipBandBackend(torch, engR.ctx, dev, ring.data_ptr(), nb_, F, 0, world, n)
-        recv = HipBandBackend(torch, engG.ctx, dev, 0, nb_, F, g, world, n, root=-1)
-        assert (recv.first, recv.bins) == (first, bins)
+        root = HipBandBackend(torch, engR.ctx, dev, ring.data_ptr(), nb_, F, 0, world, n, banded=banded)
+        recv = HipBandBackend(torch, engG.ctx, dev, 0, nb_, F, g, world, n, root=-1, banded=banded)
+        assert root.banded == banded and recv.banded == banded
+        assert (recv.first, recv.bins) == (banded_bounds(g, R, world, n) if banded else (first, bins))
+        assert recv.first <= first and first + bins <= recv.first + recv.bins
+        if banded:  # the root serves clients of its own too, from the banded buffer
+            gR = [engR.add_audio_client(l, m, r, mode) for mode, l, m, r in mine]
         for b in range(nb_):
             engA.ctx.process_batch(ring.data_ptr(), F, offset_bytes=b * F * hb)
             engA.ctx.demod_batch(b * F)
@@ -287,7 +295,16 @@ def test_band_sharding_matches_unsharded(wl_name, world, g):
             with root.stream_context():
                 root.forward(b)
                 bands = root.pack_bands()
+                if banded:
+                    engR.ctx.demod_batch(b * F)
             root.synchronize()
+            if banded:
+                for f in range(F):
+                    assert np.array_equal(engR.ctx.read_spectrum(f).view(np.uint32), engA.ctx.read_spectrum(f).view(np.uint32))
+                    assert np.array_equal(engR.ctx.read_quantized(f), engA.ctx.read_quantized(f))
+                for ci in range(len(mine)):
+                    a1, a3 = gA[ci].read_audio(F), gR[ci].read_audio(F)
+                    assert all(np.array_equal(np.asarray(u).view(np.uint32), np.asarray(v).view(np.uint32)) for u, v in zip(a1, a3))
             with recv.stream_context():
                 recv.band_tensor().copy_(bands[g])
                 recv.demod_band(b * F)
@@ -302,8 +319,8 @@ def test_band_sharding_matches_unsharded(wl_name, world, g):
         other = (g + world // 2) % world
         o_first = band_bounds(other, R, world, n)[0]
         bad = engG.add_audio_client(o_first + 5, float(o_first + 5), o_first + 30, "USB")
-        rc = engG.ctx.lib.psdr_demod_batch_from_band(engG.ctx.h, C.c_void_p(recv.band.data_ptr()), recv.bins, recv.first,
-                                                     recv.bins, F, 0)
+        fn = engG.ctx.lib.psdr_demod_batch_from_band_region if banded else engG.ctx.lib.psdr_demod_batch_from_band
+        rc = fn(engG.ctx.h, C.c_void_p(recv.band.data_ptr()), recv.bins, recv.first, recv.bins, F, 0)
         assert rc != 0 and b"outside the band" in engG.ctx.lib.psdr_last_error()
         del bad
     finally:
