@@ -98,10 +98,10 @@ struct ColTailArgs {
     float *Pout;
     size_t out_stride;
 };
-// levels +1..+4 of 16 consecutive groups (chunk `ch` of row c); returns their sum
+// levels +1..+4 of 16 consecutive groups (chunk `ch` of row c); returns their sum.  The quantised bytes go to the
+// wave's LDS image sq: level lvl_in + d of the wave's 64 rows is the contiguous piece [64][NG >> d] at soff[d].
 template <int NG>
-__device__ __forceinline__ float col_chunk16(float (&v)[16], int ch, int c, const ColTailArgs &a, int8_t *Qf,
-                                             const size_t (&qoff)[12]) {
+__device__ __forceinline__ float col_chunk16(float (&v)[16], int ch, int cl, const ColTailArgs &a, int8_t *sq, const int (&soff)[12]) {
 #pragma unroll
     for (int d = 1; d <= 4; d++) {
         const int cnt = 16 >> d;
@@ -109,7 +109,7 @@ __device__ __forceinline__ float col_chunk16(float (&v)[16], int ch, int c, cons
         for (int i = 0; i < cnt; i++) v[i] = __fadd_rn(v[2 * i], v[2 * i + 1]);
         const int lv = a.lvl_in + d;
         if (lv < a.nlevels) {
-            int8_t *dst = Qf + qoff[d] + (size_t)c * (NG >> d) + ch * cnt;
+            int8_t *dst = sq + soff[d] + cl * (NG >> d) + ch * cnt;
             if (d == 1)
                 store_q<8>(dst, v, a.size_log2 - lv);
             else if (d == 2)
@@ -122,24 +122,33 @@ __device__ __forceinline__ float col_chunk16(float (&v)[16], int ch, int c, cons
     }
     return v[0];
 }
+// One wave = 64 adjacent rows.  Stores: a row's bytes of level lvl_in + d are NG >> d <= 128 bytes, so a lane that
+// stored its own row's pieces straight to HBM wrote 1 .. 8 bytes at a time, 32 .. 128 bytes apart (measured: 129 MB
+// written per 256 frames of cfg3 for 33 MB of output, 457 MB for 67 MB at 2^22 points).  The wave's 64 rows of one
+// level are ONE contiguous piece of the level-major buffer: they are collected in LDS and go out as whole lines.
 template <int NG>
 __global__ __launch_bounds__(64) void k_col_tail(ColTailArgs a) {
     static_assert(NG % 32 == 0 && NG <= 256, "groups per row");
     constexpr int NC = NG / 16, LOGNG = NG == 64 ? 6 : (NG == 128 ? 7 : 8);
-    const int c = blockIdx.x * 64 + threadIdx.x, f = blockIdx.y;
-    if (c >= a.L) return;
+    __shared__ __attribute__((aligned(16))) int8_t sq[64 * NG];
+    const int cl = threadIdx.x, c0 = blockIdx.x * 64, c = c0 + cl, f = blockIdx.y;
     const float *Pf = a.Pin + (size_t)f * a.in_stride;
     int8_t *Qf = a.Q + (size_t)f * a.q_stride;
     size_t qoff[12];  // byte offset of level lvl_in + d
+    int soff[12];     // ... and of its 64-row piece inside sq
     {
         size_t o = 0;
         for (int i = 0; i <= a.lvl_in; i++) o += a.R >> i;
+        int so = 0;
 #pragma unroll
         for (int d = 1; d < 12; d++) {
             qoff[d] = o;
             o += a.R >> (a.lvl_in + d);
+            soff[d] = so;
+            so += d <= LOGNG ? 64 * (NG >> d) : 0;
         }
         qoff[0] = 0;
+        soff[0] = 0;
     }
     float cs[NC];
     if (a.mode == 1) {
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(64) void k_col_tail(ColTailArgs a) {
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) v[i] = Pf[((size_t)(16 * ch + i) << a.l2L) + c];
-            cs[ch] = col_chunk16<NG>(v, ch, c, a, Qf, qoff);
+            cs[ch] = col_chunk16<NG>(v, ch, cl, a, sq, soff);
         }
     } else {
         // one 8-byte load gives the low octet of tile g (group g) and its mirror octet (group NG-1-g)
@@ -161,22 +170,20 @@ __global__ __launch_bounds__(64) void k_col_tail(ColTailArgs a) {
                 lo[i] = t.x;
                 hi[15 - i] = t.y;
             }
-            cs[ch] = col_chunk16<NG>(lo, ch, c, a, Qf, qoff);
-            cs[NC - 1 - ch] = col_chunk16<NG>(hi, NC - 1 - ch, c, a, Qf, qoff);
+            cs[ch] = col_chunk16<NG>(lo, ch, cl, a, sq, soff);
+            cs[NC - 1 - ch] = col_chunk16<NG>(hi, NC - 1 - ch, cl, a, sq, soff);
         }
     }
     // levels +5 .. +log2(NG) over the chunk sums
 #pragma unroll
     for (int d = 5; d <= LOGNG; d++) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int cnt = NG >> d;
 #pragma unroll
         for (int i = 0; i < NC / 2; i++)
             if (i < cnt) cs[i] = __fadd_rn(cs[2 * i], cs[2 * i + 1]);
         const int lv = a.lvl_in + d;
         if (lv < a.nlevels) {
-            int8_t *dst = Qf + qoff[d] + (size_t)c * cnt;
+            int8_t *dst = sq + soff[d] + cl * cnt;
             if (cnt >= 8)
                 store_q<8>(dst, cs, a.size_log2 - lv);
             else if (cnt == 4)
@@ -188,6 +195,15 @@ __global__ __launch_bounds__(64) void k_col_tail(ColTailArgs a) {
         }
     }
     if (a.Pout) a.Pout[(size_t)f * a.out_stride + c] = cs[0];
+    __syncthreads();  // (one wave: orders the LDS bytes of all lanes before the flush)
+#pragma unroll
+    for (int d = 1; d <= LOGNG; d++) {
+        if (a.lvl_in + d >= a.nlevels) break;
+        const int bytes = 64 * (NG >> d);  // >= 64: whole 16-byte pieces
+        int8_t *dst = Qf + qoff[d] + (size_t)c0 * (NG >> d);
+        for (int o = cl * 16; o < bytes; o += 64 * 16)
+            *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(sq + soff[d] + o);
+    }
 }
 
 struct UntangleArgs {
