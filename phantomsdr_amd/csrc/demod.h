@@ -419,7 +419,10 @@ __device__ __forceinline__ void idft_stage_fixed(cf *buf, const cf *Wn, int lane
 //   grid = ceil(nact * nframes / W), W = blockDim.x / 64 items per work-group;
 //   dynamic LDS = (1 + W) * N * 8 bytes
 template <int N, int R0, int R1, int R2>
-__global__ __launch_bounds__(256, 5) void k_demod_idft_fixed(DemodArgs a, int nact) {
+#ifndef PSDR_IDFT_WPE
+#define PSDR_IDFT_WPE 5
+#endif
+__global__ __launch_bounds__(256, PSDR_IDFT_WPE) void k_demod_idft_fixed(DemodArgs a, int nact) {
     static_assert(R0 * R1 * R2 == N, "plan");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, W = blockDim.x >> 6;

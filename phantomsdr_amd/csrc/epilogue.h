@@ -126,8 +126,11 @@ __device__ __forceinline__ float col_chunk16(float (&v)[16], int ch, int cl, con
 // stored its own row's pieces straight to HBM wrote 1 .. 8 bytes at a time, 32 .. 128 bytes apart (measured: 129 MB
 // written per 256 frames of cfg3 for 33 MB of output, 457 MB for 67 MB at 2^22 points).  The wave's 64 rows of one
 // level are ONE contiguous piece of the level-major buffer: they are collected in LDS and go out as whole lines.
+#ifndef PSDR_CT_WPE
+#define PSDR_CT_WPE 1
+#endif
 template <int NG>
-__global__ __launch_bounds__(64) void k_col_tail(ColTailArgs a) {
+__global__ __launch_bounds__(64, PSDR_CT_WPE) void k_col_tail(ColTailArgs a) {
     static_assert(NG % 32 == 0 && NG <= 256, "groups per row");
     constexpr int NC = NG / 16, LOGNG = NG == 64 ? 6 : (NG == 128 ? 7 : 8);
     __shared__ __attribute__((aligned(16))) int8_t sq[64 * NG];
