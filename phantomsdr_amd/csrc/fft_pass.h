@@ -362,6 +362,7 @@ struct TileQueue {
     unsigned pending;      // owner thread: ticket drawn, not yet examined
     unsigned ptx;          // ... and the XCD whose counter it came from
     unsigned owner;        // the thread that draws (0 unless the kernel has a loader wave)
+    unsigned level;        // 0: drawing from the own XCD's queue, k: from the queue of XCD x ^ k
     bool dynamic, global, own_done;
     // global_: ONE counter for the whole chip (perfect balance, no XCD affinity)
     __device__ __forceinline__ void init(unsigned *t, unsigned total_, bool global_ = false, unsigned owner_ = 0) {
@@ -373,6 +374,7 @@ struct TileQueue {
         pending = 0;
         ptx = blockIdx.x & 7u;
         own_done = false;
+        level = 0;
         dynamic = t != nullptr && 2u * gridDim.x < total_;
     }
     // thread 0: start drawing (no wait)
@@ -387,7 +389,7 @@ struct TileQueue {
             // passes (pass 2 moves 4.9 GB per 256 frames at 5.6 TB/s - it waits for memory either way),
             // -3 % on the fused real-input pass 2 together with the scalar twiddle load there.
             typedef __attribute__((address_space(1))) unsigned gu32;  // global, not flat: flat returns out of order
-            ptx = own_done ? (blockIdx.x & 7u) ^ 1u : blockIdx.x & 7u;
+            ptx = (blockIdx.x & 7u) ^ level;
             gu32 *p = (gu32 *)(tickets + (global ? 0u : ptx));
             asm volatile("" : "+v"(p));
             pending = __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -411,14 +413,18 @@ struct TileQueue {
             } else if (dynamic) {
                 s = global ? pending + 2u * gridDim.x : (pending + base) * 8u + ptx;
 #ifndef PSDR_NO_PARTNER_STEAL
-                if (!global && s >= total && !own_done) {
+#ifndef PSDR_STEAL_LEVELS
+#define PSDR_STEAL_LEVELS 1  // queues of other XCDs a work-group goes on with after its own: x^1 (, x^2, x^3 ...)
+#endif
+                while (!global && s >= total && level < PSDR_STEAL_LEVELS) {
                     // The own queue is empty: go on with the queue of the neighbouring XCD (x ^ 1).  Pass 1's
                     // even XCDs are consistently ~2 % slower than the odd ones (tools/trace_phases.py, every
                     // box seen), which left the chip half idle for the last 12-17 us of every launch.  One
                     // synchronous draw per work-group (its result is needed now), asynchronous ones after.
                     // (Probing all seven other counters was tried in round 1: +27 us per launch.)
+                    level++;
                     own_done = true;
-                    ptx = (blockIdx.x & 7u) ^ 1u;
+                    ptx = (blockIdx.x & 7u) ^ level;
                     typedef __attribute__((address_space(1))) unsigned gu32;
                     gu32 *p = (gu32 *)(tickets + ptx);
                     asm volatile("" : "+v"(p));
