@@ -416,33 +416,10 @@ __device__ __forceinline__ void idft_stage_fixed(cf *buf, const cf *Wn, int lane
     }
 }
 
-//   grid = ceil(nact * nframes / W), W = blockDim.x / 64 items per work-group;
-//   dynamic LDS = (1 + W) * N * 8 bytes
+// the transform of ONE (client, frame) item by one wave: slice load, mode-specific bin copy, c2r symmetry, the
+// stages.  Leaves the n outputs in buf (before reversal / sign flip) and returns the slice power (all lanes).
 template <int N, int R0, int R1, int R2>
-#ifndef PSDR_IDFT_WPE
-#define PSDR_IDFT_WPE 5
-#endif
-__global__ __launch_bounds__(256, PSDR_IDFT_WPE) void k_demod_idft_fixed(DemodArgs a, int nact) {
-    static_assert(R0 * R1 * R2 == N, "plan");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, W = blockDim.x >> 6;
-    cf *Wn = reinterpret_cast<cf *>(smem);
-    for (int i = threadIdx.x; i < N; i += blockDim.x) Wn[i] = a.Wn[i];
-    __syncthreads();  // the only work-group barrier: the shared twiddle table
-    // everything about the item is wave-uniform: keep it in scalar registers (the mode
-    // branches become scalar branches, the range tests compare against scalars)
-    const int item = __builtin_amdgcn_readfirstlane((int)blockIdx.x * W + wv);
-    if (item >= nact * a.nframes) return;
-    const int ci = item / a.nframes, f = item - ci * a.nframes;
-    ClientParams cp = a.clients[ci];
-    cp.l = __builtin_amdgcn_readfirstlane(cp.l);
-    cp.r = __builtin_amdgcn_readfirstlane(cp.r);
-    cp.m_floor = __builtin_amdgcn_readfirstlane(cp.m_floor);
-    cp.mode = __builtin_amdgcn_readfirstlane(cp.mode);
-    cp.slot = __builtin_amdgcn_readfirstlane(cp.slot);
-    const unsigned long long frame_num = a.first_frame_num + (unsigned long long)f;
-    cf *buf = Wn + N + (size_t)wv * N;
-
+__device__ __forceinline__ float idft_item_fixed(const DemodArgs &a, const ClientParams &cp, int f, cf *buf, const cf *Wn, int lane) {
     const int len = cp.r - cp.l;
     const int m = cp.m_floor - cp.l;  // audio_m
     const cf *S = a.spec + (size_t)f * a.spec_stride;  // slice bin t at lay.pos(cp.l + t)
@@ -478,7 +455,6 @@ __global__ __launch_bounds__(256, PSDR_IDFT_WPE) void k_demod_idft_fixed(DemodAr
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) pw += __shfl_xor(pw, d, 64);
-    if (lane == 0) a.pwr[(size_t)cp.slot * a.max_batch + f] = pw;
     if (cp.mode < 2) {  // c2r semantics, see k_demod_idft
         wave_lds_sync();
 #pragma unroll
@@ -503,6 +479,39 @@ __global__ __launch_bounds__(256, PSDR_IDFT_WPE) void k_demod_idft_fixed(DemodAr
         idft_stage_fixed<N, R2, R0 * R1>(buf, Wn, lane);
         wave_lds_sync();
     }
+    return pw;
+}
+
+//   grid = ceil(nact * nframes / W), W = blockDim.x / 64 items per work-group;
+//   dynamic LDS = (1 + W) * N * 8 bytes
+template <int N, int R0, int R1, int R2>
+#ifndef PSDR_IDFT_WPE
+#define PSDR_IDFT_WPE 5
+#endif
+__global__ __launch_bounds__(256, PSDR_IDFT_WPE) void k_demod_idft_fixed(DemodArgs a, int nact) {
+    static_assert(R0 * R1 * R2 == N, "plan");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, W = blockDim.x >> 6;
+    cf *Wn = reinterpret_cast<cf *>(smem);
+    for (int i = threadIdx.x; i < N; i += blockDim.x) Wn[i] = a.Wn[i];
+    __syncthreads();  // the only work-group barrier: the shared twiddle table
+    // everything about the item is wave-uniform: keep it in scalar registers (the mode
+    // branches become scalar branches, the range tests compare against scalars)
+    const int item = __builtin_amdgcn_readfirstlane((int)blockIdx.x * W + wv);
+    if (item >= nact * a.nframes) return;
+    const int ci = item / a.nframes, f = item - ci * a.nframes;
+    ClientParams cp = a.clients[ci];
+    cp.l = __builtin_amdgcn_readfirstlane(cp.l);
+    cp.r = __builtin_amdgcn_readfirstlane(cp.r);
+    cp.m_floor = __builtin_amdgcn_readfirstlane(cp.m_floor);
+    cp.mode = __builtin_amdgcn_readfirstlane(cp.mode);
+    cp.slot = __builtin_amdgcn_readfirstlane(cp.slot);
+    const unsigned long long frame_num = a.first_frame_num + (unsigned long long)f;
+    cf *buf = Wn + N + (size_t)wv * N;
+
+    const float pw = idft_item_fixed<N, R0, R1, R2>(a, cp, f, buf, Wn, lane);
+    if (lane == 0) a.pwr[(size_t)cp.slot * a.max_batch + f] = pw;
+    constexpr int NR = (N + 63) / 64;
     const bool flip = flip_frame(frame_num, cp.m_floor, a.is_real);
     const float sg = flip ? -1.f : 1.f;
     cf *yp = a.ypost + ((size_t)cp.slot * a.max_batch + f) * N;
@@ -611,6 +620,157 @@ __global__ __launch_bounds__(256) void k_demod_ola(DemodArgs a, int nact) {
         }
         const int any_nan = __any(s_nan);
         if (tid == 0) a.nan_flags[srow * a.max_batch + f] = any_nan ? 1 : 0;
+    }
+}
+
+// ---- transform + overlap-add + demodulation in ONE kernel (compile-time plans) -------------------------------
+// One wave walks a CHAIN of K consecutive frames of one client: the second half of frame f-1's transform stays in
+// registers until frame f adds it (src/signal.cpp:171-172, 235-237), so the n complex values per item that
+// k_demod_idft_fixed writes for k_demod_ola to read back (2.9 KB at n = 360: 190 MB per step at 256 clients x 256
+// frames) never leave the CU, and k_demod_ola's three dependent round trips per wave disappear with it.  A chain
+// that does not start the batch first repeats the transform of the frame before it (FM: of the two frames before
+// it - its first sample needs B'_{f0-1}[h-1] = y_{f0-1}[h-1] + y_{f0-2}[n-1]) as warm-up: 1 or 2 transforms more per K.
+// Same operations in the same order as the two-kernel path (explicit __fmul_rn / __fadd_rn where the fused form
+// would otherwise let the compiler contract what used to be split across two kernels): bit-identical outputs.
+//   grid = ceil(nact * ceil(nframes / K) / W), W = blockDim.x / 64; dynamic LDS = (1 + W) * N * 8 bytes
+template <int N, int R0, int R1, int R2>
+__global__ __launch_bounds__(256, N <= 512 ? PSDR_IDFT_WPE : PSDR_IDFT_WPE - 1) void k_demod_chain_fixed(DemodArgs a, int nact, int K) {
+    static_assert(R0 * R1 * R2 == N, "plan");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int h = N / 2, NH = (h + 63) / 64;
+    const int lane_ = threadIdx.x & 63, wv = threadIdx.x >> 6, W = blockDim.x >> 6;
+    cf *Wn = reinterpret_cast<cf *>(smem);
+    for (int i = threadIdx.x; i < N; i += blockDim.x) Wn[i] = a.Wn[i];
+    __syncthreads();
+    const int F = a.nframes, nch = (F + K - 1) / K;
+    const int item = __builtin_amdgcn_readfirstlane((int)blockIdx.x * W + wv);
+    if (item >= nact * nch) return;
+    const int ci = item / nch, f0 = (item - ci * nch) * K;
+    const int f1 = f0 + K < F ? f0 + K : F;
+    ClientParams cp = a.clients[ci];
+    cp.l = __builtin_amdgcn_readfirstlane(cp.l);
+    cp.r = __builtin_amdgcn_readfirstlane(cp.r);
+    cp.m_floor = __builtin_amdgcn_readfirstlane(cp.m_floor);
+    cp.mode = __builtin_amdgcn_readfirstlane(cp.mode);
+    cp.slot = __builtin_amdgcn_readfirstlane(cp.slot);
+    cp.state_cur = __builtin_amdgcn_readfirstlane(cp.state_cur);
+    cf *buf = Wn + N + (size_t)wv * N;
+    const size_t srow = (size_t)cp.slot;
+    const int cur = cp.state_cur, nxt = cur ^ 1;
+    const float *rp_old = a.real_prev + ((size_t)cur * a.slots + srow) * h;
+    float *rp_new = a.real_prev + ((size_t)nxt * a.slots + srow) * h;
+    const cf *bt_old = a.bb_tail + ((size_t)cur * a.slots + srow) * h;
+    cf *bt_new = a.bb_tail + ((size_t)nxt * a.slots + srow) * h;
+    const bool ssb = cp.mode < 2;
+    auto sign_of = [&](int f) { return flip_frame(a.first_frame_num + (unsigned long long)f, cp.m_floor, a.is_real) ? -1.f : 1.f; };
+    cf tail[NH];                         // y_{f-1}[h + j], j = lane + 64 u
+    cf blast = make_float2(0.f, 0.f);    // FM: B'_{f-1}[h-1] (wave-uniform)
+    // warm-up frames (transformed, nothing written): one before the chain, two for FM; ONE loop body for both kinds
+    // of frame (three inlined copies of the transform cost 100 VGPRs more)
+    const int fs = f0 == 0 ? 0 : (f0 - (cp.mode == 3 ? 2 : 1) > 0 ? f0 - (cp.mode == 3 ? 2 : 1) : 0);
+#pragma unroll
+    for (int u = 0; u < NH; u++) {
+        const int j = lane_ + 64 * u;
+        tail[u] = make_float2(0.f, 0.f);
+        // the batch's first frame: the carried state (src/signal.h:86-101)
+        if (fs == 0 && j < h) tail[u] = ssb ? make_float2(rp_old[j], 0.f) : bt_old[j];
+    }
+    if (fs == 0 && cp.mode == 3) blast = a.bb_last[(size_t)cur * a.slots + srow];
+    for (int f = fs; f < f1; f++) {
+        const bool emit = f >= f0;
+        // (an opaque copy per iteration: with the loop-invariant lane the compiler keeps every address of every stage
+        // in registers across the loop - 100 VGPRs more than the transform itself needs, or 300-700 bytes of scratch)
+        int ln = lane_;
+        asm volatile("" : "+v"(ln));
+        const int lane = ln;
+        const float pw = idft_item_fixed<N, R0, R1, R2>(a, cp, f, buf, Wn, lane);
+        if (emit && lane == 0) a.pwr[srow * a.max_batch + f] = pw;
+        const float sg = sign_of(f);
+        float *out = a.audio + (srow * a.max_batch + f) * h;
+        const bool last = (f == F - 1);
+        int s_nan = 0;
+        cf carry = blast;  // FM: b of sample j-1 for the lane that holds j = 64 u (lane 0)
+        // y_f[j] and y_f[h + j] of the two-kernel path: the transform output after reversal (LSB) and sign flip.
+        // (mode is a scalar: one plain loop per mode - the three-way select inside one unrolled loop is miscompiled
+        // by this toolchain, see k_demod_idft_fixed)
+        cf yv[NH], yn[NH];
+        if (cp.mode == 0) {
+#pragma unroll
+            for (int u = 0; u < NH; u++) {
+                const int j = lane + 64 * u;
+                yv[u] = yn[u] = make_float2(0.f, 0.f);
+                if (j < h) {
+                    yv[u].x = __fmul_rn(buf[j].x, sg);
+                    yn[u].x = __fmul_rn(buf[h + j].x, sg);
+                }
+            }
+        } else if (cp.mode == 1) {
+#pragma unroll
+            for (int u = 0; u < NH; u++) {
+                const int j = lane + 64 * u;
+                yv[u] = yn[u] = make_float2(0.f, 0.f);
+                if (j < h) {
+                    yv[u].x = __fmul_rn(buf[N - 1 - j].x, sg);  // std::reverse :155
+                    yn[u].x = __fmul_rn(buf[N - 1 - h - j].x, sg);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NH; u++) {
+                const int j = lane + 64 * u;
+                yv[u] = yn[u] = make_float2(0.f, 0.f);
+                if (j < h) {
+                    const cf v0 = buf[j], v1 = buf[h + j];
+                    yv[u] = make_float2(__fmul_rn(v0.x, sg), __fmul_rn(v0.y, sg));
+                    yn[u] = make_float2(__fmul_rn(v1.x, sg), __fmul_rn(v1.y, sg));
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NH; u++) {
+            const int j = lane + 64 * u;
+            const bool ok = j < h;
+            const cf y = yv[u], ynext = yn[u];
+            float v = 0.f;
+            cf b = make_float2(0.f, 0.f);
+            if (ssb) {
+                v = __fadd_rn(y.x, tail[u].x);  // dsp_add_float :171
+            } else {
+                b = make_float2(__fadd_rn(y.x, tail[u].x), __fadd_rn(y.y, tail[u].y));  // dsp_add_complex :235
+                if (cp.mode == 2) {
+                    v = sqrtf(fmaf(b.x, b.x, b.y * b.y));  // dsp_am_demod
+                } else {
+                    // previous sample: lane-1 of this round; lane 0 takes the last sample of the round before
+                    cf pr = make_float2(__shfl_up(b.x, 1, 64), __shfl_up(b.y, 1, 64));
+                    if (lane == 0) pr = carry;
+                    // arg(b * conj(pr)), src/utils/dsp.cpp:32
+                    const float re = fmaf(b.x, pr.x, b.y * pr.y);
+                    const float im = fmaf(b.x, -pr.y, b.y * pr.x);
+                    v = atan2f(im, re);
+                    carry = make_float2(__shfl(b.x, 63, 64), __shfl(b.y, 63, 64));
+                    if (u == (h - 1) / 64) blast = make_float2(__shfl(b.x, (h - 1) & 63, 64), __shfl(b.y, (h - 1) & 63, 64));
+                }
+            }
+            if (ok && emit) {
+                out[j] = v;
+                if (isnan(v)) s_nan = 1;
+                if (last) {  // the state the next batch starts from (:200-203, :273-275); the other mode family's is kept
+                    if (ssb) {
+                        rp_new[j] = ynext.x;
+                        bt_new[j] = bt_old[j];
+                    } else {
+                        bt_new[j] = ynext;
+                        rp_new[j] = rp_old[j];
+                        if (j == h - 1) a.bb_last[(size_t)nxt * a.slots + srow] = b;
+                    }
+                }
+            }
+            tail[u] = ynext;
+        }
+        if (last && ssb && lane == 0) a.bb_last[(size_t)nxt * a.slots + srow] = a.bb_last[(size_t)cur * a.slots + srow];
+        const int any_nan = __any(s_nan);
+        if (emit && lane == 0) a.nan_flags[srow * a.max_batch + f] = any_nan ? 1 : 0;
+        wave_lds_sync();  // buf is read out: the next frame's transform may overwrite it
     }
 }
 

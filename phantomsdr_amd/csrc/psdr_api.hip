@@ -215,6 +215,8 @@ struct psdr_ctx {
     int nstages = 0;
     int radix[PSDR_MAX_STAGES];
     int lds_mode = 0;
+    bool demod_chain = true;  // PSDR_DEMOD_CHAIN=0: the two-kernel path (k_demod_idft_fixed + k_demod_ola) for n = 360 / 720 too
+    int demod_chain_k = 0;    // PSDR_DEMOD_K: frames per chain (0: 16, fewer when there are few clients)
     size_t idft_lds = 0;
     int4 *d_stage_tab = nullptr;
     int idft_threads = 256;
@@ -1101,6 +1103,8 @@ int build(psdr_ctx *c) {
             c->idft_threads = n <= 512 ? 128 : 256;
             c->idft_block = getenv("PSDR_IDFT_BLOCK") != nullptr;
             c->idft_generic = getenv("PSDR_IDFT_GENERIC") != nullptr;
+            if (const char *e = getenv("PSDR_DEMOD_CHAIN")) c->demod_chain = atoi(e) != 0;
+            if (const char *e = getenv("PSDR_DEMOD_K")) c->demod_chain_k = std::max(1, atoi(e));
         }
         const size_t S = (size_t)std::max(1, g.max_clients);
         c->aslots.resize(S);
@@ -1659,10 +1663,28 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     a.bb_tail = c->d_bb_tail;
     a.bb_last = c->d_bb_last;
     a.slots = (int)c->aslots.size();
+    bool ola_done = false;
     {
         ProfScope ps(c, K_IDFT, c->side);
         const bool fixed_plan = (c->n == 360 || c->n == 720) && !c->idft_block && !c->idft_generic;
-        if (fixed_plan) {
+        if (fixed_plan && c->demod_chain) {
+            // transform + overlap-add + demodulation in one kernel, one wave per chain of K consecutive frames of a
+            // client (demod.h): long chains repeat fewer transforms (1 or 2 per chain), short ones give few clients
+            // enough waves
+            int K = c->demod_chain_k > 0 ? c->demod_chain_k : 16;
+            if (c->demod_chain_k <= 0)
+                while (K > 4 && (unsigned)nact * (unsigned)((nframes + K - 1) / K) < 1024u) K >>= 1;
+            const unsigned items = (unsigned)nact * (unsigned)((nframes + K - 1) / K);
+            const unsigned W = c->n == 360 ? 4u : 1u;
+            const size_t lds = (size_t)(1 + W) * c->n * sizeof(cf);
+            if (c->n == 360)
+                hipLaunchKernelGGL((k_demod_chain_fixed<360, 8, 9, 5>), dim3((items + W - 1) / W), dim3(64 * W), lds,
+                                   c->side, a, nact, K);
+            else
+                hipLaunchKernelGGL((k_demod_chain_fixed<720, 8, 9, 10>), dim3((items + W - 1) / W), dim3(64 * W), lds,
+                                   c->side, a, nact, K);
+            ola_done = true;
+        } else if (fixed_plan) {
             // compile-time plans (demod.h): 360 = 8*9*5, 720 = 8*9*10; W items per work-group in
             // the 15 KiB of LDS an FFT pass leaves free on a CU
             const unsigned items = (unsigned)nact * (unsigned)nframes;
@@ -1686,7 +1708,7 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
         }
         HIPCHK(hipGetLastError());
     }
-    {
+    if (!ola_done) {
         ProfScope ps(c, K_OLA, c->side);
         const unsigned items = (unsigned)nact * (unsigned)((nframes + PSDR_OLA_FG - 1) / PSDR_OLA_FG);
         hipLaunchKernelGGL(k_demod_ola, dim3((items + 3) / 4), dim3(256), 0, c->side, a, nact);
