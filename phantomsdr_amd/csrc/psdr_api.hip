@@ -216,7 +216,7 @@ struct psdr_ctx {
     int radix[PSDR_MAX_STAGES];
     int lds_mode = 0;
     bool demod_chain = true;  // PSDR_DEMOD_CHAIN=0: the two-kernel path (k_demod_idft_fixed + k_demod_ola) for n = 360 / 720 too
-    int demod_chain_k = 0;    // PSDR_DEMOD_K: frames per chain (0: 16, fewer when there are few clients)
+    int demod_chain_k = 0;    // PSDR_DEMOD_K: frames per chain (0: 8, 4 when there are few clients)
     size_t idft_lds = 0;
     int4 *d_stage_tab = nullptr;
     int idft_threads = 256;
@@ -1671,7 +1671,9 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
             // transform + overlap-add + demodulation in one kernel, one wave per chain of K consecutive frames of a
             // client (demod.h): long chains repeat fewer transforms (1 or 2 per chain), short ones give few clients
             // enough waves
-            int K = c->demod_chain_k > 0 ? c->demod_chain_k : 16;
+            // (256 clients x 256 frames, same box: K = 4 / 8 / 16 / 32 -> 5.81 / 5.77 / 5.93 / 6.04 us per frame, the
+            // two-kernel path 5.99)
+            int K = c->demod_chain_k > 0 ? c->demod_chain_k : 8;
             if (c->demod_chain_k <= 0)
                 while (K > 4 && (unsigned)nact * (unsigned)((nframes + K - 1) / K) < 1024u) K >>= 1;
             const unsigned items = (unsigned)nact * (unsigned)((nframes + K - 1) / K);
