@@ -535,3 +535,52 @@ def test_post_chain_skips_nan_frames():
         ctx.dev_free(d)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,F", [(360, 7), (720, 9), (360, 1)])
+def test_chain_demodulation_is_bit_identical_to_the_two_kernel_path(n, F, monkeypatch):
+    """k_demod_chain_fixed (transform + overlap-add + AM / FM in one kernel, one wave per chain of K frames, the
+    previous frame's tail in registers, warm-up transforms at chain starts) against k_demod_idft_fixed + k_demod_ola
+    on the same samples: audio, power and NaN flags of USB / LSB / AM / FM clients over two batches, for chains of
+    1, 2, 3 frames (every chain start inside the batch needs its warm-up; FM needs two frames of it) and the default."""
+    from phantomsdr_amd import SpectrumEngine
+    N, nb = 1 << 17, 2
+    x = synth_stream((nb * F + 1) * (N // 2), False, seed=5, fft_size=N)
+    raw = quantize_raw(x, "s16", False)
+
+    def run(chain, k):
+        monkeypatch.setenv("PSDR_DEMOD_CHAIN", "1" if chain else "0")
+        if k:
+            monkeypatch.setenv("PSDR_DEMOD_K", str(k))
+        else:
+            monkeypatch.delenv("PSDR_DEMOD_K", raising=False)
+        eng = SpectrumEngine(4369067, N, False, input_format="s16", max_batch=F, max_clients=8,
+                             audio_sps=12000 if n == 360 else 24000)
+        try:
+            assert eng.params["audio_fft_size"] == n
+            cl = [eng.add_audio_client(1000 + 3000 * i, 1000 + 3000 * i + (0 if m == "USB" else 120), 1000 + 3000 * i + 240, m)
+                  for i, m in enumerate(["USB", "LSB", "AM", "FM", "FM", "AM"])]
+            d = eng.ctx.dev_alloc(raw.nbytes)
+            eng.ctx.h2d(d, raw)
+            hb = eng.ctx.half_frame_bytes()
+            out = []
+            for b in range(nb):
+                eng.ctx.process_batch(d, F, offset_bytes=b * F * hb)
+                eng.ctx.demod_batch(b * F)
+                eng.ctx.synchronize()
+                out.append([c.read_audio(F) for c in cl])
+            eng.ctx.dev_free(d)
+            return out
+        finally:
+            eng.close()
+    ref = run(False, 0)
+    assert np.abs(np.asarray(ref[1][3][0])).max() > 0
+    for k in (0, 1, 2, 3):
+        got = run(True, k)
+        for b in range(nb):
+            for ci in range(6):
+                for name, u, v in zip(("audio", "pwr", "nan"), ref[b][ci], got[b][ci]):
+                    u, v = np.asarray(u), np.asarray(v)
+                    same = np.array_equal(u.view(np.uint32), v.view(np.uint32)) if u.dtype == np.float32 else np.array_equal(u, v)
+                    assert same, f"K={k} batch {b} client {ci} {name}"
