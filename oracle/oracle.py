@@ -332,6 +332,11 @@ class AudioClient:
         # FM's first sample pairs with the previous frame's last baseband sample (src/signal.cpp:258-262):
         # kept for the tests' conditioned FM bound (tests/helpers.py fm_tolerance)
         self.bb_prev = complex(self.baseband()[self.n // 2 - 1])
+        # ... and the scale of what the FORWARD transform's rounding contributes to this frame's baseband: rms of the
+        # whole spectrum (f32 butterfly errors are proportional to what flows through them, the strong carriers
+        # included) times sqrt(bins summed); the previous frame's is kept beside it (FM pairs across the frame edge)
+        self.fwd_scale_prev = getattr(self, "fwd_scale", 0.0)
+        self.fwd_scale = float(np.sqrt(np.mean(np.abs(spectrum[: self.R].astype(np.complex128)) ** 2)) * np.sqrt(max(self.r - self.l, 1)))
         rc = lib().orc_client_send_audio(self.h, _p(buf), int(frame_num), _p(audio),
                                          C.byref(pwr), _p(pcm) if post else None)
         return audio, pwr.value, pcm, bool(rc)

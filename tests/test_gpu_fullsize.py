@@ -22,7 +22,7 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import check_fm, quantize_raw, rel_err, rel_l2, synth_stream
+from helpers import check_fm, pwr_tolerance, quantize_raw, rel_err, rel_l2, synth_stream
 from oracle import oracle as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -52,11 +52,11 @@ def _oracle_clients(clients, is_real, n, R):
 def _check_audio(tag, mode, a_g, p_g, nan_g, a_o, p_o, dropped, oc=None):
     """oc: the oracle client right after its send_audio (FM: its baseband conditions the bound)"""
     assert not dropped and nan_g == 0, tag
-    assert abs(p_g - p_o) <= 1e-4 * max(abs(p_o), 1e-30), f"{tag}: pwr {p_g} vs {p_o}"
+    assert abs(p_g - p_o) <= pwr_tolerance(p_o, oc.fwd_scale if oc is not None else 0.0), f"{tag}: pwr {p_g} vs {p_o}"
     if mode == O.FM:
-        # SURVEY B.6: 1e-4 rad where the discriminator input is at least 1e-2 of its peak, scaled by
-        # the conditioning |B|max / |B[i]| below that (helpers.fm_tolerance)
-        check_fm(a_g, a_o, oc.baseband()[: oc.n // 2], oc.bb_prev, tag)
+        # SURVEY B.6: 1e-4 rad where both discriminator inputs are at least 5 % of the peak, scaled by the
+        # conditioning below that (helpers.fm_tolerance)
+        check_fm(a_g, a_o, oc.baseband()[: oc.n // 2], oc.bb_prev, tag, fwd_scale=max(oc.fwd_scale, oc.fwd_scale_prev))
     else:
         assert rel_l2(a_g, a_o) < AUDIO_TOL, f"{tag}: rel L2 {rel_l2(a_g, a_o):.2e}"
         assert np.abs(a_g - a_o).max() <= 2e-4 * max(np.abs(a_o).max(), 1e-30), tag

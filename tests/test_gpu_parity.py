@@ -5,7 +5,7 @@ the GPU's own spectrum, and >= 99.9 % identical (rest +-1) against the oracle's.
 import numpy as np
 import pytest
 
-from helpers import check_fm, quantize_raw, rel_err, rel_l2, synth_stream
+from helpers import check_fm, pwr_tolerance, quantize_raw, rel_err, rel_l2, synth_stream
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -163,11 +163,11 @@ def run_demod_case(N, is_real, n, clients, nbatches, F, seed, fmt="s16", mode_ch
                     a_g, p_g, nan_g = got[ci][0][f], got[ci][1][f], got[ci][2][f]
                     assert not dropped and nan_g == 0
                     tag = f"client {ci} {clients[ci]} frame {frame}"
-                    assert abs(p_g - p_o) <= 1e-4 * max(abs(p_o), 1e-30), tag
+                    assert abs(p_g - p_o) <= pwr_tolerance(p_o, o.fwd_scale), tag
                     scale = max(np.abs(a_o).max(), 1e-30)
                     if o.mode == O.FM:
                         # 1e-4 rad, conditioned by |B|max / |B[i]| (helpers.fm_tolerance)
-                        check_fm(a_g, a_o, o.baseband()[: o.n // 2], o.bb_prev, tag)
+                        check_fm(a_g, a_o, o.baseband()[: o.n // 2], o.bb_prev, tag, fwd_scale=max(o.fwd_scale, o.fwd_scale_prev))
                     else:
                         assert rel_l2(a_g, a_o) < AUDIO_TOL, f"{tag}: rel L2 {rel_l2(a_g, a_o):.2e}"
                         assert np.abs(a_g - a_o).max() <= 2e-4 * scale, tag

@@ -11,7 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from helpers import check_fm, quantize_raw, rel_err, rel_l2, synth_stream  # noqa: E402
+from helpers import check_fm, pwr_tolerance, quantize_raw, rel_err, rel_l2, synth_stream  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 from phantomsdr_amd import AudioClient, Context, WaterfallClient  # noqa: E402
 
@@ -132,10 +132,10 @@ def one_case(rng, case):
                     a_g, p_g, nan_g = got[ci][0][f], got[ci][1][f], got[ci][2][f]
                     tag = desc + f" client {ci} frame {frame}"
                     assert not dropped and nan_g == 0, tag
-                    assert abs(p_g - p_o) <= 1e-4 * max(abs(p_o), 1e-30) + 1e-30, tag
+                    assert abs(p_g - p_o) <= pwr_tolerance(p_o, o.fwd_scale), tag + f": pwr {p_g} vs {p_o}"
                     scale = max(np.abs(a_o).max(), 1e-30)
                     if o.mode == O.FM:
-                        check_fm(a_g, a_o, o.baseband()[: o.n // 2], o.bb_prev, tag)
+                        check_fm(a_g, a_o, o.baseband()[: o.n // 2], o.bb_prev, tag, fwd_scale=max(o.fwd_scale, o.fwd_scale_prev))
                     else:
                         # relative to the larger of the audio's own peak and the slice's amplitude sqrt(w*pwr):
                         # a one-bin slice whose phase sits near +-90 degrees demodulates (c2r: only Re of
