@@ -40,6 +40,7 @@ typedef float q_v2f __attribute__((ext_vector_type(2)));
 struct QConst {
     q_v2f c21, c0k, s20;  // (-0.3448.., 2.0246..), (-0.6748.., 0.30103), (20, 127)
     unsigned mmask, mone; // 0x807FFFFF (keeps the sign bit like the reference's &= ~(255<<23)), 127<<23
+    unsigned magic;       // 0x4B000000 >> 9: the high word of v_alignbit that leaves 2^23's bit pattern above bits >> 23
     float lo, hi;         // -128, 127
 };
 __device__ __forceinline__ QConst qconst() {
@@ -49,6 +50,7 @@ __device__ __forceinline__ QConst qconst() {
     k.s20 = q_v2f{20.f, 127.f};
     k.mmask = 0x807FFFFFu;
     k.mone = 127u << 23;
+    k.magic = 0x4B000000u >> 9;
     k.lo = -128.f;
     k.hi = 127.f;
     return k;
@@ -57,8 +59,19 @@ __device__ __forceinline__ QConst qconst() {
 __device__ __forceinline__ q_v2f quantize2(float a, float b, float koff, const QConst &k) {
     const unsigned ba = __float_as_uint(a), bb = __float_as_uint(b);
     // exponent: (float)((bits >> 23) & 255) + (power_offset - 128), exact in either order
+#ifdef PSDR_Q_ALIGNBIT
+    // ONE instruction per value instead of bfe + cvt: (0x4B000000 | bits >> 23) is the float 2^23 + exponent (a
+    // power is never negative: bit 31 is clear, so bits >> 23 IS the exponent field), and 2^23 leaves again in the
+    // packed add below - sums of small integers, exact in any order
+    unsigned ea, eb;
+    asm("v_alignbit_b32 %0, %1, %2, 23" : "=v"(ea) : "v"(k.magic), "v"(ba));
+    asm("v_alignbit_b32 %0, %1, %2, 23" : "=v"(eb) : "v"(k.magic), "v"(bb));
+    q_v2f lf = {__uint_as_float(ea), __uint_as_float(eb)};
+    const q_v2f kk = {koff - 8388608.f, koff - 8388608.f};
+#else
     q_v2f lf = {(float)((ba >> 23) & 0xFFu), (float)((bb >> 23) & 0xFFu)};
     const q_v2f kk = {koff, koff};
+#endif
     unsigned ma, mb;
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ma) : "v"(ba), "v"(k.mmask), "v"(k.mone));
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(mb) : "v"(bb), "v"(k.mmask), "v"(k.mone));
