@@ -170,16 +170,17 @@ int psdr_pack_band(psdr_ctx *ctx, int nframes, uint32_t first_bin, uint32_t nbin
                    size_t out_stride_bins);
 int psdr_demod_batch_from_band(psdr_ctx *ctx, const float *d_band, size_t frame_stride_bins, uint32_t first_bin,
                                uint32_t nbins, int nframes, uint64_t first_frame_num);
-/* Band sharding WITHOUT the pack pass (2^20-point IQ contexts; PSDR_ERR_UNSUPPORTED otherwise - use psdr_pack_band).
+/* Band sharding WITHOUT the pack pass (2^20- and 2^21-point IQ contexts; PSDR_ERR_UNSUPPORTED otherwise - use
+ * psdr_pack_band).
  * After psdr_set_band_layout(ctx, nbands, halo_bins) the second FFT pass writes the spectrum as nbands (a power of two,
  * <= 16) band REGIONS: region b holds bins [b*R/nbands, (b+1)*R/nbands + halo) - the halo, rounded up to whole
- * columns of 1024 bins, repeats the start of band b+1 - of ALL frames of the batch in one contiguous piece (frames
+ * columns of M1 = N / 1024 bins, repeats the start of band b+1 - of ALL frames of the batch in one contiguous piece (frames
  * frame_stride_bins apart), in device order.  psdr_band_region gives the piece of the LAST processed batch: that is
  * what is sent to peer b, as it is.  Two result sets alternate from batch to batch (also on a caller's stream), so a
  * region stays valid until the batch after the next one is processed.  Everything else (demodulation, pyramid,
  * psdr_read_spectrum, psdr_pack_band) works unchanged on the root; psdr_spectrum_device_ptr does not (a frame is no
  * longer one piece).  Call before the first batch; reallocates the spectrum buffers.
- * psdr_demod_batch_from_band_region: psdr_demod_batch_from_band on a received region (any 2^20-point IQ context). */
+ * psdr_demod_batch_from_band_region: psdr_demod_batch_from_band on a received region (an IQ context of the same size). */
 int psdr_set_band_layout(psdr_ctx *ctx, int nbands, uint32_t halo_bins);
 int psdr_band_region(psdr_ctx *ctx, int band, const float **d_region, size_t *frame_stride_bins, uint32_t *first_bin,
                      uint32_t *nbins);

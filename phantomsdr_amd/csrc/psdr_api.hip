@@ -681,7 +681,8 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
             a2.lbmask = (1 << c->lay.l2Lb) - 1;
             a2.Lw = c->lay.Lw;
             a2.band_stride = c->lay.band_stride;
-            rc = launch_pass2_t<1024, 16, true, 16, false, true>(c, a2, a2.total_slots);
+            rc = a2.TW == 16 ? launch_pass2_t<1024, 16, true, 16, false, true>(c, a2, a2.total_slots)
+                             : launch_pass2_t<1024, 16, true, 8, false, true>(c, a2, a2.total_slots);
             if (rc) return rc;
             if (c->band_H > 0) {  // the first columns of band b+1 once more, behind band b's own
                 const size_t n16 = (size_t)c->nbands * nframes * (c->M1 / 16) * c->band_H * 8;  // 16-byte pieces
@@ -1987,8 +1988,8 @@ extern "C" int psdr_demod_batch_from_band(psdr_ctx *c, const float *d_band, size
 // ---- band sharding without the pack: pass 2 writes band regions ------------------------------------------------
 extern "C" int psdr_set_band_layout(psdr_ctx *c, int nbands, uint32_t halo_bins) {
     if (!c) return fail(PSDR_ERR_INVALID, "null argument");
-    if (c->is_real || c->lay.mode == 0 || c->lay.mode == 2 || c->M1 != 1024 || c->M2 != 1024 || c->p1_wave)
-        return fail(PSDR_ERR_UNSUPPORTED, "banded spectrum: 2^20-point IQ frames only (use psdr_pack_band)");
+    if (c->is_real || c->lay.mode == 0 || c->lay.mode == 2 || (c->M1 != 1024 && c->M1 != 2048) || c->M2 != 1024 || c->p1_wave)
+        return fail(PSDR_ERR_UNSUPPORTED, "banded spectrum: 2^20- and 2^21-point IQ frames only (use psdr_pack_band)");
     if (nbands < 1 || nbands > 16 || (nbands & (nbands - 1))) return fail(PSDR_ERR_INVALID, "nbands %d: a power of two <= 16", nbands);
     if (halo_bins > (uint32_t)c->M) return fail(PSDR_ERR_INVALID, "halo of %u bins", halo_bins);
     HIPCHK(hipSetDevice(c->device));

@@ -413,14 +413,15 @@ class HipBandBackend:
         self.stream = torch.cuda.Stream(device=device)
         assert self.stream.cuda_stream != 0
         check(ctx.lib.psdr_set_stream(ctx.h, C.c_void_p(self.stream.cuda_stream)))
-        can = (not ctx.is_real) and ctx.N == 1 << 20 and world <= 16 and world & (world - 1) == 0
+        can = (not ctx.is_real) and ctx.N in (1 << 20, 1 << 21) and world <= 16 and world & (world - 1) == 0
         if banded is None:
             banded = can
         if banded and not can:
-            raise ValueError("banded band sharding: 2^20-point IQ frames and a power-of-two world <= 16")
+            raise ValueError("banded band sharding: 2^20- or 2^21-point IQ frames and a power-of-two world <= 16")
         self.banded = banded
         if banded:
-            self.first, self.bins = banded_bounds(rank, self.R, world, halo)
+            self.column = ctx.N >> 10  # bins per column of the (c1, c2) grid: M1
+            self.first, self.bins = banded_bounds(rank, self.R, world, halo, self.column)
             if rank == root:  # (a receiver's context keeps its own layout: it never transforms)
                 check(ctx.lib.psdr_set_band_layout(ctx.h, world, halo))
             self.send = None
@@ -449,7 +450,7 @@ class HipBandBackend:
         for g in range(self.world):
             p, fs, fb, nb = C.c_void_p(), C.c_size_t(), C.c_uint32(), C.c_uint32()
             check(self.ctx.lib.psdr_band_region(self.ctx.h, g, C.byref(p), C.byref(fs), C.byref(fb), C.byref(nb)))
-            assert (fb.value, nb.value) == banded_bounds(g, self.R, self.world, self.halo) and fs.value == nb.value
+            assert (fb.value, nb.value) == banded_bounds(g, self.R, self.world, self.halo, self.column) and fs.value == nb.value
             t = alias_device_f32(self.torch, p.value, self.F * nb.value * 2, self.device)
             out.append(self.torch.view_as_complex(t.view(self.F, nb.value, 2)))
         return out

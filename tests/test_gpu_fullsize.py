@@ -239,7 +239,8 @@ def test_cfg4_share_demod_from_matches_unsharded_and_oracle():
 
 
 @pytest.mark.parametrize("wl_name,world,g,banded", [("cfg4", 8, 5, True), ("cfg4", 8, 7, True), ("cfg4", 8, 0, True),
-                                                    ("cfg4", 16, 9, True), ("cfg4", 2, 1, True), ("cfg4", 8, 5, False),
+                                                    ("cfg4", 16, 9, True), ("cfg4", 2, 1, True), ("cfg4_2M", 8, 7, True),
+                                                    ("cfg4_2M", 4, 1, True), ("cfg4", 8, 5, False),
                                                     ("cfg4", 8, 7, False), ("cfg3", 4, 3, False), ("cfg3", 4, 0, False)])
 def test_band_sharding_matches_unsharded(wl_name, world, g, banded):
     """SURVEY 8e variant (ii) on ONE GPU.  banded: the root's second FFT pass writes the spectrum as one region per
@@ -254,7 +255,8 @@ def test_band_sharding_matches_unsharded(wl_name, world, g, banded):
     from phantomsdr_amd._lib import check
     from phantomsdr_amd.distributed import HipBandBackend, assign_clients_by_band, band_bounds, banded_bounds
     B = _bench()
-    wl = B.WORKLOADS[wl_name]
+    # (cfg4_2M: cfg4's stream with 2^21-point frames - 2048-bin columns, the 8-column pass-1 tiles, n = 720)
+    wl = dict(B.WORKLOADS["cfg4"], fft_size=1 << 21) if wl_name == "cfg4_2M" else B.WORKLOADS[wl_name]
     N, F, nb_, is_real = wl["fft_size"], 3, 3, wl["is_real"]
     dev = torch.device("cuda", 0)
     x = synth_stream((nb_ * F + 1) * (N // 2), is_real, seed=17, fft_size=N)
@@ -284,7 +286,7 @@ def test_band_sharding_matches_unsharded(wl_name, world, g, banded):
         root = HipBandBackend(torch, engR.ctx, dev, ring.data_ptr(), nb_, F, 0, world, n, banded=banded)
         recv = HipBandBackend(torch, engG.ctx, dev, 0, nb_, F, g, world, n, root=-1, banded=banded)
         assert root.banded == banded and recv.banded == banded
-        assert (recv.first, recv.bins) == (banded_bounds(g, R, world, n) if banded else (first, bins))
+        assert (recv.first, recv.bins) == (banded_bounds(g, R, world, n, N >> 10) if banded else (first, bins))
         assert recv.first <= first and first + bins <= recv.first + recv.bins
         if banded:  # the root serves clients of its own too, from the banded buffer
             gR = [engR.add_audio_client(l, m, r, mode) for mode, l, m, r in mine]
