@@ -170,6 +170,7 @@ struct psdr_ctx {
     // re-zeroed (in stream order) whenever the other half starts being used
     unsigned *d_tickets[2] = {nullptr, nullptr};
     unsigned ticket_pos[2] = {0, 0};
+    bool no_col_tail = false;  // tuning (PSDR_NO_COL_TAIL=1)
     bool static_tiles = false, no_p1_stream = true;  // tuning knobs (PSDR_STATIC_TILES, PSDR_P1_STREAM)
     unsigned p1_grid = 0, p2_grid = 0;  // PSDR_P1_GRID / PSDR_P2_GRID: work-groups of each pass (0: all CUs)
     bool input_on_main = false;  // level-1 H2D staging was enqueued on the main stream
@@ -621,7 +622,9 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     a1.trace = c->d_trace;
     a1.kclk = next_kclk(c, 0);
     a1.ymask = ~0u;
-    if (const char *e = getenv("PSDR_Y_ALIAS")) a1.ymask = (unsigned)atoi(e) - 1u;  // timing-only: WRONG results (frames share Y)
+#ifdef PSDR_TUNING_BUILD  // never in the shipped library: a timing-only experiment with WRONG results (frames share Y)
+    if (const char *e = getenv("PSDR_Y_ALIAS")) a1.ymask = (unsigned)atoi(e) - 1u;
+#endif
     {
         int rc = next_tickets(c, 0, c->p1, &a1.tickets);
         if (rc) return rc;
@@ -770,7 +773,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     // levels inside a row (k_col_tail), the generic kernel the few above
     const int ng = (int)(len >> c->log2M2);  // groups per output row
     const bool col_tail = c->recmap.mapped && c->M2 == 1024 && c->recmap.l2gpt == 0 && (ng == 64 || ng == 128 || ng == 256) &&
-                          getenv("PSDR_NO_COL_TAIL") == nullptr;
+                          !c->no_col_tail;
     if (col_tail && lvl + 1 < c->levels) {
         ColTailArgs t{};
         t.Pin = c->d_pscr[0];
@@ -939,6 +942,7 @@ int build(psdr_ctx *c) {
     c->stream = c->own_stream;
     c->side = c->own_side;
     c->static_tiles = getenv("PSDR_STATIC_TILES") != nullptr;
+    c->no_col_tail = getenv("PSDR_NO_COL_TAIL") != nullptr;
     // pass 1 on its own stream overlaps the two passes of consecutive batches; it pays only when
     // both batches' intermediates fit the 256 MiB MALL together (measured: F=16 2^20-point frames
     // lose 12 %, F>=32 gain nothing), so it is opt-in
