@@ -2004,11 +2004,21 @@ extern "C" int psdr_set_band_layout(psdr_ctx *c, int nbands, uint32_t halo_bins)
     HIPCHK(hipDeviceSynchronize());
     const int H = (int)((halo_bins + (uint32_t)c->M1 - 1) >> c->log2M1), Lb = c->M2 / nbands, Lw = Lb + H;
     const size_t F = (size_t)c->max_batch, fs = (size_t)c->M1 * Lw;
-    for (int s = 0; s < 2; s++) {
-        if (c->spec_pool[s]) HIPCHK(hipFree(c->spec_pool[s]));
-        c->spec_pool[s] = nullptr;
-        HIPCHK(hipMalloc((void **)&c->spec_pool[s], (size_t)nbands * F * fs * sizeof(cf)));
-        HIPCHK(hipMemset(c->spec_pool[s], 0, (size_t)nbands * F * fs * sizeof(cf)));
+    {  // the new buffers first: a failed allocation leaves the context as it was
+        cf *fresh[2] = {nullptr, nullptr};
+        for (int s = 0; s < 2; s++) {
+            if (hipMalloc((void **)&fresh[s], (size_t)nbands * F * fs * sizeof(cf)) != hipSuccess ||
+                hipMemset(fresh[s], 0, (size_t)nbands * F * fs * sizeof(cf)) != hipSuccess) {
+                (void)hipGetLastError();
+                for (int t = 0; t <= s; t++)
+                    if (fresh[t]) (void)hipFree(fresh[t]);
+                return fail(PSDR_ERR_NOMEM, "banded spectrum: %zu bytes per result set", (size_t)nbands * F * fs * sizeof(cf));
+            }
+        }
+        for (int s = 0; s < 2; s++) {
+            if (c->spec_pool[s]) (void)hipFree(c->spec_pool[s]);
+            c->spec_pool[s] = fresh[s];
+        }
     }
     c->nbands = nbands;
     c->band_H = H;

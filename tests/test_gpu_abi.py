@@ -208,6 +208,65 @@ def test_band_calls_refuse_bad_arguments():
         ctx.close()
 
 
+def test_band_layout_calls_refuse_bad_arguments():
+    """psdr_set_band_layout / psdr_band_region / psdr_demod_batch_from_band_region: what the banded layout does not
+    support comes back as PSDR_ERR_UNSUPPORTED (the caller falls back to psdr_pack_band), bad arguments as
+    PSDR_ERR_INVALID, nothing is launched and the context keeps working"""
+    from phantomsdr_amd import Context
+    p, sz, u32 = C.c_void_p(), C.c_size_t(), C.c_uint32()
+    small = Context(1 << 14, False, _levels(1 << 14), audio_fft_size=60, audio_rate=12000, input_format="s16", max_batch=2,
+                    max_clients=2, max_waterfall_clients=1, skip_num=1)
+    try:
+        assert small.lib.psdr_set_band_layout(small.h, 2, 60) == -6       # natural-order spectrum: unsupported
+        assert b"psdr_pack_band" in small.lib.psdr_last_error()
+        assert small.lib.psdr_band_region(small.h, 0, C.byref(p), C.byref(sz), C.byref(u32), C.byref(u32)) == -4
+        assert small.lib.psdr_demod_batch_from_band_region(small.h, C.c_void_p(16), 1024, 0, 1024, 1, 0) == -6
+    finally:
+        small.close()
+    real = Context(1 << 21, True, _levels(1 << 20), audio_fft_size=360, audio_rate=12000, input_format="s16", max_batch=2,
+                   max_clients=2, max_waterfall_clients=1, skip_num=1)
+    try:
+        assert real.lib.psdr_set_band_layout(real.h, 4, 360) == -6        # fused real layout: bands share lines
+    finally:
+        real.close()
+    N, F = 1 << 20, 2
+    ctx = Context(N, False, _levels(N), audio_fft_size=360, audio_rate=12000, input_format="s16", max_batch=F, max_clients=2,
+                  max_waterfall_clients=1, skip_num=1)
+    try:
+        L = ctx.lib
+        for bad in (0, 3, 32, -1):
+            assert L.psdr_set_band_layout(ctx.h, bad, 360) == -1
+        assert L.psdr_set_band_layout(ctx.h, 8, N + 1) == -1
+        assert L.psdr_set_band_layout(ctx.h, 8, 360) == 0
+        assert L.psdr_band_region(ctx.h, 8, C.byref(p), C.byref(sz), C.byref(u32), C.byref(u32)) == -1
+        fb, nb = C.c_uint32(), C.c_uint32()
+        assert L.psdr_band_region(ctx.h, 3, C.byref(p), C.byref(sz), C.byref(fb), C.byref(nb)) == 0
+        assert (fb.value, nb.value, sz.value) == (3 * (N // 8), N // 8 + 1024, N // 8 + 1024) and p.value
+        dp, nbins = C.c_void_p(), C.c_size_t()
+        assert L.psdr_spectrum_device_ptr(ctx.h, 0, C.byref(dp), C.byref(nbins)) == -6   # a frame is not one piece any more
+        reg = C.c_void_p(p.value)
+        assert L.psdr_demod_batch_from_band_region(ctx.h, reg, nb.value, fb.value + 8, nb.value, F, 0) == -1   # not a whole column
+        assert L.psdr_demod_batch_from_band_region(ctx.h, reg, nb.value, fb.value, nb.value - 8, F, 0) == -1
+        assert L.psdr_demod_batch_from_band_region(ctx.h, reg, nb.value - 1024, fb.value, nb.value, F, 0) == -1  # stride < bins
+        assert L.psdr_demod_batch_from_band_region(ctx.h, reg, nb.value, fb.value, nb.value, F + 1, 0) == -1
+        assert L.psdr_demod_batch_from_band_region(ctx.h, None, nb.value, fb.value, nb.value, F, 0) == -1
+        # the context still transforms and answers in k order
+        x = synth_stream((F + 1) * (N // 2), False, seed=3, fft_size=N)
+        raw = quantize_raw(x, "s16", False)
+        d = ctx.dev_alloc(raw.nbytes)
+        ctx.h2d(d, raw)
+        ctx.process_batch(d, F)
+        fo = O.FFT(N, False, _levels(N), 0, 360)
+        conv = O.convert(raw, "s16").view(np.complex64).reshape(F + 1, N // 2)
+        fo.load(conv[1], conv[2])
+        fo.execute()
+        got, want = ctx.read_spectrum(1), fo.output()
+        assert np.abs(got[:N] - want[:N]).max() <= 1e-4 * np.abs(want[:N]).max()
+        ctx.dev_free(d)
+    finally:
+        ctx.close()
+
+
 def test_fetch_batch_matches_per_client_reads_and_guards_late_clients():
     """psdr_fetch_batch + psdr_fetched_audio (one synchronisation, at most four copies per batch for ALL clients: the
     granularity of src/websocket.cpp:156-185's one pass over signal_slices) hand out exactly what psdr_read_audio /
