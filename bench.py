@@ -41,6 +41,11 @@ WORKLOADS = {
     "cfg5": dict(sps=70_000_000, fft_size=1 << 22, is_real=True, fmt="s16", audio=128, waterfall=8,
                  modes=("USB", "LSB", "AM", "FM"),
                  desc="70 MSPS real s16, 2^22-pt R2C, 128 audio clients + 8 zoomed waterfalls per GPU"),
+    # the target's own wording: 256 concurrent (mixed) audio clients on one MI355X, cfg2's stream (the `clients256`
+    # sub-object of the default line is this workload; here it can be profiled on its own)
+    "clients256": dict(sps=35_000_000, fft_size=1 << 20, is_real=False, fmt="s16", audio=256, waterfall=4,
+                       modes=("USB", "LSB", "AM", "FM"),
+                       desc="35 MSPS IQ cs16, 2^20-pt C2C, 256 mixed USB/LSB/AM/FM audio + 4 waterfall clients"),
 }
 SAMPLE_BYTES = {"u8": 1, "s8": 1, "u16": 2, "s16": 2, "f32": 4, "f64": 8}
 

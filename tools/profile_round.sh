@@ -15,6 +15,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- $B > $O
 case $WL in
   cfg3) K="python $R/tools/kernel_times.py --fft 21 --real --clients 64 --batch 256 --steps 4";;
   cfg5) K="python $R/tools/kernel_times.py --fft 22 --real --clients 128 --batch 256 --steps 3 --ring-mib 2100";;
+  clients256) K="python $R/tools/kernel_times.py --fft 20 --clients 256 --batch 256 --steps 4";;
   *)    K="python $R/tools/kernel_times.py --fft 20 --clients 16 --batch 256 --steps 4";;
 esac
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- $K > $O/pmc_fetch.log 2>&1
