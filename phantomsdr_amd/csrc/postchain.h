@@ -69,6 +69,19 @@ struct PostArgs {
 
 typedef float pc_f4 __attribute__((ext_vector_type(4)));
 
+#ifndef PSDR_PC_RING
+#define PSDR_PC_RING 16  // register sets of 16 samples in the two recurrence kernels (even, >= 6)
+#endif
+// floats of padding behind every client's stream rows: the recurrence kernels read whole blocks ahead of the stream's end
+#define PSDR_PC_PAD (16 * (PSDR_PC_RING + 4))
+template <int I, int N, typename F>
+__device__ __forceinline__ void pc_static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        pc_static_for<I + 1, N>(f);
+    }
+}
+
 // one wave per client: where each surviving frame starts in the client's stream (a ballot per 64
 // frames: the count of surviving frames below a lane is a popcount)
 __global__ __launch_bounds__(64) void k_pc_index(PostArgs a) {
@@ -143,7 +156,13 @@ __global__ __launch_bounds__(64) void k_pc_ma2(PostArgs a) {
     if (ci >= a.nact) return;
     const ClientParams cp = a.clients[ci];
     const int slot = cp.slot;
-    constexpr int KB = 16, D = 32, AHEAD = 3;
+    // RING register sets of one 16-step block each: blocks b-2, b-1 (evicted values), b, and AHEAD = RING - 3 blocks of
+    // loads in flight.  Round 3: 13 blocks ahead instead of 3 - vmcnt is ONE in-order counter for loads and stores,
+    // so waiting for a load also waits for every store issued before it, and beside the FFT passes a store is
+    // acknowledged thousands of cycles after issue: the distance has to cover THAT, not the load latency.  A single-wave
+    // kernel has the registers (RING must be even: the two m1 sets alternate).
+    constexpr int KB = 16, D = 32, RING = PSDR_PC_RING, AHEAD = RING - 3;
+    static_assert(RING % 2 == 0 && RING >= 6, "ring of x blocks");
     // one wave next to the FFT passes' eight issue-bound waves: let it issue first
     __builtin_amdgcn_s_setprio(3);
     const bool fresh = cp.agc_reset == 2;  // zero sums (k_pc_index zeroed the history rows)
@@ -161,12 +180,12 @@ __global__ __launch_bounds__(64) void k_pc_ma2(PostArgs a) {
     // ever copied from set to set - the ring is indexed at compile time, six blocks per trip.  ms: the first
     // running SUM of the steps whose average the second sum evicts, two alternating sets (s1 = 32 * m1 exactly,
     // so the eviction and the insertion are one fma each).
-    pc_f4 xr[6][4];
+    pc_f4 xr[RING][4];
     float ms[2][KB];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        xr[4][q] = reinterpret_cast<const pc_f4 *>(X)[q];          // block -2
-        xr[5][q] = reinterpret_cast<const pc_f4 *>(X + KB)[q];     // block -1
+        xr[RING - 2][q] = reinterpret_cast<const pc_f4 *>(X)[q];          // block -2
+        xr[RING - 1][q] = reinterpret_cast<const pc_f4 *>(X + KB)[q];     // block -1
     }
 #pragma unroll
     for (int i = 0; i < KB; i++) {
@@ -175,11 +194,12 @@ __global__ __launch_bounds__(64) void k_pc_ma2(PostArgs a) {
     }
     auto fetch = [&](auto kc, int blk) {
         constexpr int k = decltype(kc)::value;
-        if (blk < nfull) {
-            const pc_f4 *src = reinterpret_cast<const pc_f4 *>(X + D + blk * KB);  // D, KB, px: multiples of 4
+        // UNCONDITIONAL (round 3): a load under `if (blk < nfull)` is a load under an exec mask, and behind those the
+        // compiler waits with s_waitcnt vmcnt(0) at the top of every block.  Blocks up to nfull + AHEAD are read:
+        // inside the row's PC_PAD floats of padding (psdr_set_post_chain: px, pv), values never used.
+        const pc_f4 *src = reinterpret_cast<const pc_f4 *>(X + D + blk * KB);  // D, KB, px: multiples of 4
 #pragma unroll
-            for (int q = 0; q < 4; q++) xr[k][q] = src[q];
-        }
+        for (int q = 0; q < 4; q++) xr[k][q] = src[q];
     };
     // m1 = s1 / 32 is exact (a power of two), so rounding (s2 - m1_old) + m1 and x - s2 / 32 after the exact
     // products is the reference's arithmetic with three fused operations instead of five:
@@ -187,7 +207,7 @@ __global__ __launch_bounds__(64) void k_pc_ma2(PostArgs a) {
     // (the loop is bound by its own instruction stream: 7 -> 5 operations per sample, and no moves)
     const float nrD = -rD;
     auto block = [&](auto jc, int t0) {
-        constexpr int J = decltype(jc)::value, E = (J + 4) % 6, N1 = (J + 5) % 6, P = J & 1;
+        constexpr int J = decltype(jc)::value, E = (J + RING - 2) % RING, N1 = (J + RING - 1) % RING, P = J & 1;
         pc_f4 o[4];
 #pragma unroll
         for (int i = 0; i < KB; i++) {
@@ -201,53 +221,25 @@ __global__ __launch_bounds__(64) void k_pc_ma2(PostArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; q++) reinterpret_cast<pc_f4 *>(V1 + t0)[q] = o[q];
     };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
-    using I4 = std::integral_constant<int, 4>;
-    using I5 = std::integral_constant<int, 5>;
-    fetch(I0{}, 0);
-    fetch(I1{}, 1);
-    fetch(I2{}, 2);
+    pc_static_for<0, AHEAD>([&](auto kc) { fetch(kc, decltype(kc)::value); });
     int b = 0;
-    for (; b + 6 <= nfull; b += 6) {
-        fetch(I3{}, b + 3);
-        block(I0{}, b * KB);
-        fetch(I4{}, b + 4);
-        block(I1{}, (b + 1) * KB);
-        fetch(I5{}, b + 5);
-        block(I2{}, (b + 2) * KB);
-        fetch(I0{}, b + 6);
-        block(I3{}, (b + 3) * KB);
-        fetch(I1{}, b + 7);
-        block(I4{}, (b + 4) * KB);
-        fetch(I2{}, b + 8);
-        block(I5{}, (b + 5) * KB);
-    }
-    // up to five more whole blocks (b is a multiple of 6: block b + j lives in set j)
-    if (b < nfull) {
-        fetch(I3{}, b + 3);
-        block(I0{}, b * KB);
-        b++;
-        if (b < nfull) {
-            fetch(I4{}, b + 3);
-            block(I1{}, b * KB);
-            b++;
-            if (b < nfull) {
-                fetch(I5{}, b + 3);
-                block(I2{}, b * KB);
-                b++;
-                if (b < nfull) {
-                    block(I3{}, b * KB);
-                    b++;
-                    if (b < nfull) {
-                        block(I4{}, b * KB);
-                        b++;
-                    }
-                }
+    for (; b + RING <= nfull; b += RING)
+        pc_static_for<0, RING>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            fetch(std::integral_constant<int, (J + AHEAD) % RING>{}, b + J + AHEAD);
+            block(jc, (b + J) * KB);
+        });
+    // up to RING - 1 more whole blocks (b is a multiple of RING: block b + j lives in set j)
+    {
+        const int b0 = b;
+        pc_static_for<0, RING - 1>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            if (b0 + J < nfull) {
+                fetch(std::integral_constant<int, (J + AHEAD) % RING>{}, b0 + J + AHEAD);
+                block(jc, (b0 + J) * KB);
+                b = b0 + J + 1;
             }
-        }
+        });
     }
     // now (b even) ms[0] is the older set of m1 values, else ms[1]: the window of m1 values in time
     // order goes to rows t1.. of M1 for the remaining T - nfull*KB (< KB) steps, one by one
@@ -336,6 +328,7 @@ __global__ __launch_bounds__(256) void k_pc_want(PostArgs a) {
 // the gain recurrence (src/utils/audioprocessing.cpp:55-66); g_t -> P[t] (0 while the
 // look-ahead buffer is still filling: the reference outputs 0 there and leaves the gain alone;
 // an active gain is never 0: w_t > 0)
+template <bool ATT_FASTER>
 __global__ __launch_bounds__(64) void k_pc_gain(PostArgs a) {
     const int lane = threadIdx.x, ci = blockIdx.x * 64 + lane;
     if (ci >= a.nact) return;
@@ -348,7 +341,7 @@ __global__ __launch_bounds__(64) void k_pc_gain(PostArgs a) {
         gain = 0.f;
         n0 = 0;
     }
-    constexpr int KB = 16, AHEAD = 3;
+    constexpr int KB = 16, GR = PSDR_PC_RING, AHEAD = GR - 1;  // blocks of loads in flight: see k_pc_ma2
     __builtin_amdgcn_s_setprio(3);
     const float *__restrict__ W = a.S + (size_t)slot * a.pv;
     float *__restrict__ G = a.P + (size_t)slot * a.pv;
@@ -359,11 +352,17 @@ __global__ __launch_bounds__(64) void k_pc_gain(PostArgs a) {
     // go through VCC, and VCC -> v_cndmask costs two wait states on this part in a loop that is nothing but
     // its own instruction stream.  (d = -0 picks the attack coefficient where the reference picks release:
     // the product is a zero either way and the sum is the same.)
+    // Round 3: the loop is ONE wave's dependent chain (~8 cycles from an instruction to the next that needs its
+    // result: 36 cycles per sample measured), so what counts is the DEPTH per sample.  Both candidates are computed
+    // side by side and the choice is a min / max: with attack > release (the reference's 50 ms against 300 ms)
+    // d < 0 makes attack * d the smaller product and d > 0 the larger, and fma rounds monotonically - min(A, R) IS
+    // the reference's pick, bit for bit (d = 0: both are the gain).  sub -> fma, fma -> min: depth 3 instead of 4.
+    // (ATT_FASTER = attack >= release, a template parameter: as a run-time flag the compiler computed min AND max and
+    // selected - six instructions and depth 4 again)
     auto step = [&](float w) -> float {
         const float d = __fsub_rn(w, gain);
-        int mk = __float_as_int(d) >> 31, cbits;
-        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(cbits) : "v"(mk), "v"(__float_as_int(att)), "v"(__float_as_int(rel)));
-        gain = __fmaf_rn(__int_as_float(cbits), d, gain);
+        const float ga = __fmaf_rn(att, d, gain), gr = __fmaf_rn(rel, d, gain);
+        gain = ATT_FASTER ? fminf(ga, gr) : fmaxf(ga, gr);
         return gain;
     };
     // while the look-ahead buffer is filling (only right after a reset / for a new client) the
@@ -373,14 +372,13 @@ __global__ __launch_bounds__(64) void k_pc_gain(PostArgs a) {
     for (; t < T && n0 + t + 1 < L; t++) G[t] = 0.f;
     for (; t < T && (t & 3); t++) G[t] = step(W[t]);
     const int nblk = (T - t) / KB;
-    pc_f4 w[AHEAD + 1][4];
+    pc_f4 w[GR][4];
     auto fetch = [&](auto kc, int blk) {
         constexpr int k = decltype(kc)::value;
-        if (blk < nblk) {
-            const pc_f4 *src = reinterpret_cast<const pc_f4 *>(W + t + blk * KB);
+        // (unconditional, like k_pc_ma2's: blocks up to nblk + AHEAD stay inside the row's padding)
+        const pc_f4 *src = reinterpret_cast<const pc_f4 *>(W + t + blk * KB);
 #pragma unroll
-            for (int q = 0; q < 4; q++) w[k][q] = src[q];
-        }
+        for (int q = 0; q < 4; q++) w[k][q] = src[q];
     };
     auto block = [&](const pc_f4 (&wv)[4], int blk) {
         pc_f4 g[4];
@@ -389,35 +387,23 @@ __global__ __launch_bounds__(64) void k_pc_gain(PostArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; q++) reinterpret_cast<pc_f4 *>(G + t + blk * KB)[q] = g[q];
     };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>;
-    fetch(I0{}, 0);
-    fetch(I1{}, 1);
-    fetch(I2{}, 2);
+    pc_static_for<0, AHEAD>([&](auto kc) { fetch(kc, decltype(kc)::value); });
     int b = 0;
-    for (; b + 4 <= nblk; b += 4) {
-        fetch(I3{}, b + 3);
-        block(w[0], b);
-        fetch(I0{}, b + 4);
-        block(w[1], b + 1);
-        fetch(I1{}, b + 5);
-        block(w[2], b + 2);
-        fetch(I2{}, b + 6);
-        block(w[3], b + 3);
-    }
-    if (b < nblk) {
-        block(w[0], b);
-        b++;
-    }
-    if (b < nblk) {
-        block(w[1], b);
-        b++;
-    }
-    if (b < nblk) {
-        block(w[2], b);
-        b++;
+    for (; b + GR <= nblk; b += GR)
+        pc_static_for<0, GR>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            fetch(std::integral_constant<int, (J + AHEAD) % GR>{}, b + J + AHEAD);
+            block(w[J], b + J);
+        });
+    {
+        const int b0 = b;
+        pc_static_for<0, GR - 1>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            if (b0 + J < nblk) {
+                fetch(std::integral_constant<int, (J + AHEAD) % GR>{}, b0 + J + AHEAD);
+                block(w[J], b0 + J);
+            }
+        });
     }
     for (t += nblk * KB; t < T; t++) G[t] = step(W[t]);
     a.agc_gain[slot] = gain;

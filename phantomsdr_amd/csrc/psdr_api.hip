@@ -232,7 +232,15 @@ struct psdr_ctx {
     // batch b+1 runs on `side` while stage 2 (look-ahead peak, gain, int16) of batch b runs on
     // `side2`; what the stages share is double-buffered (V1, frame offsets, stream lengths)
     hipStream_t side2 = nullptr;
+    // ... and stage 1 has a stream of its own too (round 3): on `side` its sequential kernel (k_pc_ma2, ~0.9 ms beside
+    // the passes) sat between this batch's demodulation and the NEXT batch's tails and demodulation - the side
+    // stream, not the GPU, set the step (1.88 ms of serial work per 1.4 ms of passes)
+    hipStream_t side3 = nullptr;
+    hipEvent_t ev_want[2] = {nullptr, nullptr};  // w_t of this parity is ready (the gain recurrence may start)
+    hipEvent_t ev_demod = nullptr, ev_gather = nullptr;  // demodulation done (stage 1 may read); audio rows read (the next demodulation may write)
+    bool gather_pending = false;
     float *post_v1[2] = {nullptr, nullptr};
+    float *post_p[2] = {nullptr, nullptr}, *post_s[2] = {nullptr, nullptr};  // prefix / suffix maxima, then w_t / g_t
     int *post_fstart[2] = {nullptr, nullptr}, *post_len[2] = {nullptr, nullptr};
     hipEvent_t ev_s1[2] = {nullptr, nullptr}, ev_s2[2] = {nullptr, nullptr};
     uint64_t chain_seq = 0;
@@ -330,6 +338,7 @@ void resolve_pending(psdr_ctx *c) {
     hipStreamSynchronize(c->stream);
     hipStreamSynchronize(c->side);
     if (c->side2) hipStreamSynchronize(c->side2);
+    if (c->side3) hipStreamSynchronize(c->side3);
     for (auto &p : c->pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -916,6 +925,11 @@ void free_all(psdr_ctx *c) {
     }
     if (c->own_side) hipStreamDestroy(c->own_side);
     if (c->side2) hipStreamDestroy(c->side2);
+    if (c->side3) hipStreamDestroy(c->side3);
+    if (c->ev_demod) hipEventDestroy(c->ev_demod);
+    if (c->ev_gather) hipEventDestroy(c->ev_gather);
+    for (int i = 0; i < 2; i++)
+        if (c->ev_want[i]) hipEventDestroy(c->ev_want[i]);
     for (int i = 0; i < 2; i++) {
         if (c->ev_s1[i]) hipEventDestroy(c->ev_s1[i]);
         if (c->ev_s2[i]) hipEventDestroy(c->ev_s2[i]);
@@ -1508,6 +1522,7 @@ static int drain(psdr_ctx *c) {
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->side != c->stream) HIPCHK(hipStreamSynchronize(c->side));
     if (c->side2) HIPCHK(hipStreamSynchronize(c->side2));
+    if (c->side3) HIPCHK(hipStreamSynchronize(c->side3));
     return PSDR_OK;
 }
 static int check_slot(psdr_ctx *c, int id) {
@@ -1668,6 +1683,10 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     a.bb_tail = c->d_bb_tail;
     a.bb_last = c->d_bb_last;
     a.slots = (int)c->aslots.size();
+    if (c->gather_pending && c->side3) {  // post chain: the previous batch's audio rows are still being gathered
+        HIPCHK(hipStreamWaitEvent(c->side, c->ev_gather, 0));
+        c->gather_pending = false;
+    }
     bool ola_done = false;
     {
         ProfScope ps(c, K_IDFT, c->side);
@@ -1725,7 +1744,7 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     if (c->post_on && nact > 0) {
         const int par = (int)(c->chain_seq & 1);
         const bool piped = c->side != c->stream && c->side2 != nullptr;
-        hipStream_t s2 = piped ? c->side2 : c->side;
+        hipStream_t s2 = piped ? c->side2 : c->side, s1 = piped ? c->side3 : c->side;
         PostArgs pa = c->post;
         pa.clients = d_clients;
         pa.nact = nact;
@@ -1734,40 +1753,63 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
         pa.V1n = c->post_v1[par ^ 1];
         pa.fstart = c->post_fstart[par];
         pa.len = c->post_len[par];
+        pa.P = c->post_p[par];
+        pa.S = c->post_s[par];
         const unsigned cb = (unsigned)((nact + 63) / 64);
         const size_t Tb = (size_t)nframes * pa.h;  // longest possible stream of this batch
         const unsigned nblk = (unsigned)((pa.L - 1 + Tb + pa.L - 1) / pa.L);
-        {  // ---- stage 1 on `side`
-            if (piped && c->chain_seq >= 2) HIPCHK(hipStreamWaitEvent(c->side, c->ev_s2[par], 0));  // stage 2 of batch b-2 read this set
-            ProfScope ps(c, K_POST, c->side);
-            hipLaunchKernelGGL(k_pc_index, dim3(nact), dim3(64), 0, c->side, pa);
-            hipLaunchKernelGGL(k_pc_gather, dim3(nact, nframes), dim3(256), 0, c->side, pa);
+        {  // ---- stage 1 (its own stream when the consumers have theirs)
+            if (piped) {
+                HIPCHK(hipEventRecord(c->ev_demod, c->side));
+                HIPCHK(hipStreamWaitEvent(s1, c->ev_demod, 0));
+                if (c->chain_seq >= 2) HIPCHK(hipStreamWaitEvent(s1, c->ev_s2[par], 0));  // stage 2 of batch b-2 read this set
+            }
+            ProfScope ps(c, K_POST, s1);
+            hipLaunchKernelGGL(k_pc_index, dim3(nact), dim3(64), 0, s1, pa);
+            hipLaunchKernelGGL(k_pc_gather, dim3(nact, nframes), dim3(256), 0, s1, pa);
+            if (piped) {  // the audio rows and NaN flags are read: the next batch's demodulation may overwrite them
+                HIPCHK(hipEventRecord(c->ev_gather, s1));
+                c->gather_pending = true;
+            }
             pa.ma_fused = pa.D == 32 ? 1 : 0;  // both averages in one loop (postchain.h)
             if (pa.ma_fused) {
-                hipLaunchKernelGGL(k_pc_ma2, dim3(cb), dim3(64), 0, c->side, pa);
+                hipLaunchKernelGGL(k_pc_ma2, dim3(cb), dim3(64), 0, s1, pa);
             } else if ((pa.D & (pa.D - 1)) == 0) {
-                hipLaunchKernelGGL((k_pc_ma<false, true>), dim3(cb), dim3(64), 0, c->side, pa);
-                hipLaunchKernelGGL((k_pc_ma<true, true>), dim3(cb), dim3(64), 0, c->side, pa);
+                hipLaunchKernelGGL((k_pc_ma<false, true>), dim3(cb), dim3(64), 0, s1, pa);
+                hipLaunchKernelGGL((k_pc_ma<true, true>), dim3(cb), dim3(64), 0, s1, pa);
             } else {
-                hipLaunchKernelGGL((k_pc_ma<false, false>), dim3(cb), dim3(64), 0, c->side, pa);
-                hipLaunchKernelGGL((k_pc_ma<true, false>), dim3(cb), dim3(64), 0, c->side, pa);
+                hipLaunchKernelGGL((k_pc_ma<false, false>), dim3(cb), dim3(64), 0, s1, pa);
+                hipLaunchKernelGGL((k_pc_ma<true, false>), dim3(cb), dim3(64), 0, s1, pa);
             }
             pa.hist_sel = 0;
-            hipLaunchKernelGGL(k_pc_history, dim3(nact), dim3(256), (size_t)pa.D * sizeof(float), c->side, pa);
+            hipLaunchKernelGGL(k_pc_history, dim3(nact), dim3(256), (size_t)pa.D * sizeof(float), s1, pa);
+            // the look-ahead maxima and w_t are parallel work: they ride in this stage (P and S exist per parity), so
+            // that stage 2 is nothing but the gain recurrence and the output - the two sequential kernels (k_pc_ma2
+            // here, k_pc_gain there: ~1.1 ms each beside the FFT passes) sit in different stages
+            hipLaunchKernelGGL(k_pc_scan, dim3(nact, nblk, 2), dim3(64), 0, s1, pa);
+            hipLaunchKernelGGL(k_pc_want, dim3(nact, (unsigned)((Tb + 255) / 256)), dim3(256), 0, s1, pa);
+            // w_t is all the gain recurrence needs: it must not wait for the history copy below, which in turn waits
+            // for the previous batch's output kernel (gain -> out -> history -> gain would be one serial chain per batch)
+            if (piped) HIPCHK(hipEventRecord(c->ev_want[par], s1));
+            // V1's tail -> the other parity's history rows (a plain copy, no LDS).  The other parity's stage 2 (the
+            // previous batch: k_pc_out reads those rows) must be done with them
+            if (piped && c->chain_seq >= 1) HIPCHK(hipStreamWaitEvent(s1, c->ev_s2[par ^ 1], 0));
+            pa.hist_sel = 1;
+            hipLaunchKernelGGL(k_pc_history, dim3(nact), dim3(256), 0, s1, pa);
             HIPCHK(hipGetLastError());
         }
         if (piped) {
-            HIPCHK(hipEventRecord(c->ev_s1[par], c->side));
-            HIPCHK(hipStreamWaitEvent(s2, c->ev_s1[par], 0));
+            HIPCHK(hipEventRecord(c->ev_s1[par], s1));
+            HIPCHK(hipStreamWaitEvent(s2, c->ev_want[par], 0));
         }
         {  // ---- stage 2
             ProfScope ps(c, K_POST, s2);
-            hipLaunchKernelGGL(k_pc_scan, dim3(nact, nblk, 2), dim3(64), 0, s2, pa);
-            hipLaunchKernelGGL(k_pc_want, dim3(nact, (unsigned)((Tb + 255) / 256)), dim3(256), 0, s2, pa);
-            hipLaunchKernelGGL(k_pc_gain, dim3(cb), dim3(64), 0, s2, pa);
+            if (pa.attack >= pa.release)
+                hipLaunchKernelGGL(k_pc_gain<true>, dim3(cb), dim3(64), 0, s2, pa);
+            else
+                hipLaunchKernelGGL(k_pc_gain<false>, dim3(cb), dim3(64), 0, s2, pa);
+            if (piped) HIPCHK(hipStreamWaitEvent(s2, c->ev_s1[par], 0));  // k_pc_out reads V1's history rows
             hipLaunchKernelGGL(k_pc_out, dim3(nact, nframes), dim3(256), 0, s2, pa);
-            pa.hist_sel = 1;
-            hipLaunchKernelGGL(k_pc_history, dim3(nact), dim3(256), 0, s2, pa);  // (V1 -> V1n: a plain copy, no LDS)
             HIPCHK(hipGetLastError());
         }
         if (piped) {
@@ -1893,14 +1935,16 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
         };
         // client-major streams (postchain.h): pitches are multiples of 4 floats, + padding for the
         // blocked kernels' look-ahead
-        a.px = ((size_t)a.D + Tm + 64 + 3) & ~(size_t)3;
+        a.px = ((size_t)a.D + Tm + PSDR_PC_PAD + 3) & ~(size_t)3;
         a.vo = (4 - ((a.L - 1) & 3)) & 3;
-        a.pv = ((size_t)a.vo + (size_t)a.L - 1 + Tm + 64 + 3) & ~(size_t)3;
+        a.pv = ((size_t)a.vo + (size_t)a.L - 1 + Tm + PSDR_PC_PAD + 3) & ~(size_t)3;
         int rc = 0;
         for (int i = 0; i < 2; i++) {
             rc |= alloc((void **)&c->post_fstart[i], S * c->max_batch * sizeof(int));
             rc |= alloc((void **)&c->post_len[i], S * sizeof(int));
             rc |= alloc((void **)&c->post_v1[i], a.pv * S * sizeof(float));
+            rc |= alloc((void **)&c->post_p[i], a.pv * S * sizeof(float));
+            rc |= alloc((void **)&c->post_s[i], a.pv * S * sizeof(float));
             if (!c->ev_s1[i]) HIPCHK(hipEventCreateWithFlags(&c->ev_s1[i], hipEventDisableTiming));
             if (!c->ev_s2[i]) HIPCHK(hipEventCreateWithFlags(&c->ev_s2[i], hipEventDisableTiming));
         }
@@ -1908,11 +1952,13 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
             int lo = 0, hi = 0;
             HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
             HIPCHK(hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, hi));
+            HIPCHK(hipStreamCreateWithPriority(&c->side3, hipStreamNonBlocking, hi));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_demod, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_gather, hipEventDisableTiming));
+            for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_want[i], hipEventDisableTiming));
         }
         rc |= alloc((void **)&a.X, a.px * S * sizeof(float));
         rc |= alloc((void **)&a.M1, a.px * S * sizeof(float));
-        rc |= alloc((void **)&a.P, a.pv * S * sizeof(float));
-        rc |= alloc((void **)&a.S, a.pv * S * sizeof(float));
         rc |= alloc((void **)&a.pcm, S * Tm * sizeof(int32_t));
         rc |= alloc((void **)&a.dc_s1, S * sizeof(float));
         rc |= alloc((void **)&a.dc_s2, S * sizeof(float));
