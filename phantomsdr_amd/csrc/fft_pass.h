@@ -1445,7 +1445,13 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                     if (side && seg_first) {  // no carry-in: the octet is completed by k_real_seam
                         reinterpret_cast<float4 *>(seamP)[2 * c2i] = v0[j];
                         reinterpret_cast<float4 *>(seamP)[2 * c2i + 1] = v1[j];
-                    } else {
+                    }
+                    // The record is written by EVERY lane (a segment's first tile: with a stale carried row in the
+                    // high octets - k_real_seam, which runs before any consumer, writes those records again).  With
+                    // the stores under `else` the whole store could be skipped (s_cbranch_execz) as far as the
+                    // compiler knew, so it could not count them and waited for the next tile's loads with
+                    // s_waitcnt vmcnt(0) - i.e. for the acknowledgement of these stores, at the top of every tile.
+                    {
                         const size_t rp = (size_t)g * (2 * L) + q;  // RecMap mode 2
                         uint4 rec;
                         pyr_record8(pw, a.size_log2, rec);
