@@ -737,7 +737,9 @@ def main():
     F = args.batch
     run = SingleGpuRun(torch, device, local_rank, wl_name, wl, F, args.ring_mib)
     eng, params, clients, waterfalls, N = run.eng, run.params, run.clients, run.waterfalls, run.N
-    times = run.timed(args.steps, args.warmup)
+    # >= 3 s of timed steps (a 5-second utilisation sampler around the run should see the GPU busy at least once;
+    # the value is still the median repetition of exactly K steps)
+    times = run.timed(args.steps, args.warmup, min_total_s=3.0, max_reps=400)
     head = run.summary(times, args.steps)
 
     # per-kernel durations: profiled replay of the same steps (the events do not perturb `value`)
