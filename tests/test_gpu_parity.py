@@ -565,8 +565,21 @@ def test_chain_demodulation_is_bit_identical_to_the_two_kernel_path(n, F, monkey
             eng.ctx.h2d(d, raw)
             hb = eng.ctx.half_frame_bytes()
             out = []
+            import ctypes as C
+            from phantomsdr_amd._lib import check
+            poison = np.full(2, np.nan, np.float32)
             for b in range(nb):
                 eng.ctx.process_batch(d, F, offset_bytes=b * F * hb)
+                if b == 0 and F > 2:
+                    # NaN into one bin of the LSB and the FM client's windows, in a frame inside a chain and in the
+                    # batch's last frame (its tail is the next batch's carried state): the NaN guard's flags
+                    # (src/signal.cpp:266-271) and the poisoned overlap of the frame after must come out the same
+                    eng.ctx.synchronize()
+                    for f in (2, F - 1):
+                        for bin_ in (1000 + 3000 * 1 + 50, 1000 + 3000 * 3 + 130):
+                            p, nbytes = C.c_void_p(), C.c_size_t()
+                            check(eng.ctx.lib.psdr_spectrum_device_ptr(eng.ctx.h, f, C.byref(p), C.byref(nbytes)))
+                            eng.ctx.h2d(p, poison, offset=bin_ * 8)  # (2^17 points: the device keeps client order as it is)
                 eng.ctx.demod_batch(b * F)
                 eng.ctx.synchronize()
                 out.append([c.read_audio(F) for c in cl])
@@ -575,12 +588,18 @@ def test_chain_demodulation_is_bit_identical_to_the_two_kernel_path(n, F, monkey
         finally:
             eng.close()
     ref = run(False, 0)
-    assert np.abs(np.asarray(ref[1][3][0])).max() > 0
+    assert np.abs(np.nan_to_num(np.asarray(ref[1][3][0]))).max() > 0
+    if F > 2:
+        assert ref[0][1][2][2] == 1 and ref[0][3][2][F - 1] == 1 and ref[0][0][2].sum() == 0  # flags where the NaNs went
     for k in (0, 1, 2, 3):
         got = run(True, k)
         for b in range(nb):
             for ci in range(6):
                 for name, u, v in zip(("audio", "pwr", "nan"), ref[b][ci], got[b][ci]):
                     u, v = np.asarray(u), np.asarray(v)
-                    same = np.array_equal(u.view(np.uint32), v.view(np.uint32)) if u.dtype == np.float32 else np.array_equal(u, v)
+                    if u.dtype == np.float32:  # NaNs in the same places (payloads may differ), every other value bit for bit
+                        nu, nv = np.isnan(u), np.isnan(v)
+                        same = np.array_equal(nu, nv) and np.array_equal(u[~nu].view(np.uint32), v[~nv].view(np.uint32))
+                    else:
+                        same = np.array_equal(u, v)
                     assert same, f"K={k} batch {b} client {ci} {name}"
