@@ -149,6 +149,13 @@ int psdr_client_set_audio_range(psdr_ctx *ctx, int id, int l, double audio_mid, 
 int psdr_client_on_window_message(psdr_ctx *ctx, int id, int l, double audio_mid, int r);
 /* AudioClient::set_audio_demodulation / on_demodulation_message (src/signal.cpp:95-97,316-328) */
 int psdr_client_set_audio_demodulation(psdr_ctx *ctx, int id, int mode);
+/* signal_loop's slow-client rule (src/websocket.cpp:170-176): the reference does not call send_audio at all for a
+ * client with more than 50 kB queued on its socket, so NOTHING of that client moves for the frame - overlap-add tails and
+ * FM's last sample (src/signal.cpp:200-203, 273-275), DC blocker and AGC (:277-284).  A paused client sits out every
+ * psdr_demod_batch* until it is resumed (paused = 0): its state is frozen bit for bit, and its results read as
+ * PSDR_ERR_NO_DATA for those batches.  A Level-2 caller evaluates the backlog BEFORE the frame is demodulated
+ * (phantomsdr_amd/host/hip_level2.h). */
+int psdr_client_set_paused(psdr_ctx *ctx, int id, int paused);
 /* signal_loop + send_audio (src/websocket.cpp:156-185, src/signal.cpp:102-275) for every
  * active client over the frames of the last psdr_process_batch.  first_frame_num is the
  * server's frame counter of the first frame (flip parity, src/signal.cpp:160-168,223). */
@@ -206,6 +213,10 @@ int psdr_read_audio(psdr_ctx *ctx, int id, int nframes, float *audio, float *pwr
 int psdr_fetch_batch(psdr_ctx *ctx);
 int psdr_fetched_audio(psdr_ctx *ctx, int id, int frame, const float **audio, float *pwr, int32_t *nan_flag,
                        const int32_t **pcm);
+/* the window [l, r) and audio_mid client `id` was DEMODULATED with in the fetched batch (set_audio_range may have run on
+ * another thread since, or have been refused): what the packet labels of src/signal.cpp:104-105, 287 must be computed
+ * from.  Same error behaviour as psdr_fetched_audio. */
+int psdr_fetched_window(psdr_ctx *ctx, int id, int *l, double *audio_mid, int *r);
 /* device-resident results (no copy): audio of client slot `id` */
 int psdr_audio_device_ptr(psdr_ctx *ctx, int id, const float **d_audio, const float **d_pwr);
 

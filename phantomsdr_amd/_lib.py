@@ -65,6 +65,7 @@ SYMBOLS = [
     ("psdr_client_set_audio_range", _i, [_vp, _i, _i, C.c_double, _i]),
     ("psdr_client_on_window_message", _i, [_vp, _i, _i, C.c_double, _i]),
     ("psdr_client_set_audio_demodulation", _i, [_vp, _i, _i]),
+    ("psdr_client_set_paused", _i, [_vp, _i, _i]),
     ("psdr_demod_batch", _i, [_vp, _u64]),
     ("psdr_demod_batch_from", _i, [_vp, _vp, _sz, _i, _u64]),
     ("psdr_pack_band", _i, [_vp, _i, C.c_uint32, C.c_uint32, _vp, _sz]),
@@ -93,6 +94,7 @@ SYMBOLS = [
     ("psdr_fetch_batch", _i, [_vp]),
     ("psdr_fetched_audio", _i, [_vp, _i, _i, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_float), C.POINTER(C.c_int32),
                                 C.POINTER(C.POINTER(C.c_int32))]),
+    ("psdr_fetched_window", _i, [_vp, _i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     ("psdr_get_kernel_samples", _i, [_vp, C.c_char_p, C.POINTER(C.c_double), _i, C.POINTER(_i)]),
     ("psdr_reset_kernel_stats", _i, [_vp]),
     ("psdr_timer_start", _i, [_vp]),

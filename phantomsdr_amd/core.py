@@ -322,6 +322,11 @@ class AudioClient:
         check(self.ctx.lib.psdr_client_set_audio_demodulation(self.ctx.h, self.id, mode))
         self.demodulation = mode
 
+    def set_paused(self, paused):
+        """signal_loop's slow-client rule (src/websocket.cpp:170-176): a paused client gets no send_audio call -
+        it sits out the demodulation batches with all of its state frozen."""
+        check(self.ctx.lib.psdr_client_set_paused(self.ctx.h, self.id, 1 if paused else 0))
+
     def on_window_message(self, l, m, r):
         """returns False where the reference silently returns (src/signal.cpp:302-311)."""
         if m is None:

@@ -39,6 +39,8 @@ struct ClientParams {
     int state_cur;  // which half of the double-buffered state is current
     int agc_reset;  // post chain: 1 = the demodulation changed since the last batch (AGC::reset),
                     // 2 = a new client took this slot (all chain state starts from zero)
+    int paused;     // psdr_client_set_paused: listed BEHIND the batch's active clients, for the post chain only (its
+                    // double-buffered streams must carry the client's history across the batch it sits out)
 };
 
 struct DemodArgs {
@@ -573,17 +575,32 @@ __global__ __launch_bounds__(256) void k_demod_ola(DemodArgs a, int nact) {
         int s_nan = 0;  // per lane; combined by a wave vote at the end
         const bool last = (f == F - 1);
         if (cp.mode < 2) {
+            // the half to add is the second half of the latest EARLIER frame that survived the NaN guard: a dropped
+            // frame throws at src/signal.cpp:266-271, before audio_real_prev is replaced (:273-275).  A transform has a
+            // NaN in every output or in none (each output sums all inputs), so "frame g was dropped" is read off the
+            // half that is loaded anyway; the carried tail is clean by the same rule.
+            int g = f - 1;
+            while (g >= 0) {
+                int d = 0;
+                for (int j = tid; j < h; j += NT) d |= isnan(yp[(size_t)g * n + h + j].x) ? 1 : 0;
+                if (!__any(d)) break;
+                g--;
+            }
             for (int j = tid; j < h; j += NT) {
-                const float prev = (f == 0) ? rp_old[j] : yp[(size_t)(f - 1) * n + h + j].x;
+                const float prev = (g < 0) ? rp_old[j] : yp[(size_t)g * n + h + j].x;
                 const float v = y[j].x + prev;  // dsp_add_float :171
                 out[j] = v;
                 if (isnan(v)) s_nan = 1;
-                if (last) {
-                    rp_new[j] = y[h + j].x;  // :273-275
+            }
+            if (last) {
+                const int dropped = __any(s_nan);
+                for (int j = tid; j < h; j += NT) {
+                    // :273-275, unless this frame was dropped: then the tail it would have added stays
+                    rp_new[j] = dropped ? ((g < 0) ? rp_old[j] : yp[(size_t)g * n + h + j].x) : y[h + j].x;
                     bt_new[j] = bt_old[j];
                 }
+                if (tid == 0) a.bb_last[(size_t)nxt * a.slots + srow] = a.bb_last[(size_t)cur * a.slots + srow];
             }
-            if (last && tid == 0) a.bb_last[(size_t)nxt * a.slots + srow] = a.bb_last[(size_t)cur * a.slots + srow];
         } else {
             for (int j = tid; j < h; j += NT) {
                 const cf pv = (f == 0) ? bt_old[j] : yp[(size_t)(f - 1) * n + h + j];
@@ -676,7 +693,8 @@ __global__ __launch_bounds__(256, N <= 512 ? PSDR_IDFT_WPE : PSDR_IDFT_WPE - 1) 
         if (fs == 0 && j < h) tail[u] = ssb ? make_float2(rp_old[j], 0.f) : bt_old[j];
     }
     if (fs == 0 && cp.mode == 3) blast = a.bb_last[(size_t)cur * a.slots + srow];
-    for (int f = fs; f < f1; f++) {
+    int f = fs;
+    while (f < f1) {
         const bool emit = f >= f0;
         // (an opaque copy per iteration: with the loop-invariant lane the compiler keeps every address of every stage
         // in registers across the loop - 100 VGPRs more than the transform itself needs, or 300-700 bytes of scratch)
@@ -751,26 +769,53 @@ __global__ __launch_bounds__(256, N <= 512 ? PSDR_IDFT_WPE : PSDR_IDFT_WPE - 1) 
                     if (u == (h - 1) / 64) blast = make_float2(__shfl(b.x, (h - 1) & 63, 64), __shfl(b.y, (h - 1) & 63, 64));
                 }
             }
+            if (ok && isnan(v)) s_nan = 1;
             if (ok && emit) {
                 out[j] = v;
-                if (isnan(v)) s_nan = 1;
-                if (last) {  // the state the next batch starts from (:200-203, :273-275); the other mode family's is kept
-                    if (ssb) {
-                        rp_new[j] = ynext.x;
-                        bt_new[j] = bt_old[j];
-                    } else {
-                        bt_new[j] = ynext;
-                        rp_new[j] = rp_old[j];
-                        if (j == h - 1) a.bb_last[(size_t)nxt * a.slots + srow] = b;
-                    }
+                if (last && !ssb) {  // the state the next batch starts from (:200-203); the other mode family's is kept
+                    bt_new[j] = ynext;
+                    rp_new[j] = rp_old[j];
+                    if (j == h - 1) a.bb_last[(size_t)nxt * a.slots + srow] = b;
                 }
             }
-            tail[u] = ynext;
+            if (!ssb) tail[u] = ynext;  // (:200-203 precede the NaN guard: the complex modes' state always moves)
         }
-        if (last && ssb && lane == 0) a.bb_last[(size_t)nxt * a.slots + srow] = a.bb_last[(size_t)cur * a.slots + srow];
         const int any_nan = __any(s_nan);
+        if (ssb) {
+            // A dropped USB / LSB frame throws at src/signal.cpp:266-271, BEFORE audio_real_prev is replaced (:273-275):
+            // the next frame adds the tail of the latest frame that survived.  (A transform has a NaN in every output
+            // or in none, so for a warm-up frame - whose own tail is unknown here - "y + 0 has a NaN" says the same.)
+            if (!emit) {
+                // the warm-up frame of a chain that does not start the batch: if it was dropped, look further back
+                if (any_nan && f > 0) {
+                    f--;
+                    wave_lds_sync();
+                    continue;
+                }
+#pragma unroll
+                for (int u = 0; u < NH; u++) {
+                    const int j = lane + 64 * u;
+                    tail[u] = yn[u];
+                    if (any_nan && j < h) tail[u] = make_float2(rp_old[j], 0.f);  // nothing survived before the chain: the carried tail
+                }
+                f = f0;
+                wave_lds_sync();
+                continue;
+            }
+#pragma unroll
+            for (int u = 0; u < NH; u++) {
+                const int j = lane + 64 * u;
+                if (!any_nan) tail[u] = yn[u];
+                if (last && j < h) {  // :273-275
+                    rp_new[j] = tail[u].x;
+                    bt_new[j] = bt_old[j];
+                }
+            }
+            if (last && lane == 0) a.bb_last[(size_t)nxt * a.slots + srow] = a.bb_last[(size_t)cur * a.slots + srow];
+        }
         if (emit && lane == 0) a.nan_flags[srow * a.max_batch + f] = any_nan ? 1 : 0;
         wave_lds_sync();  // buf is read out: the next frame's transform may overwrite it
+        f++;
     }
 }
 

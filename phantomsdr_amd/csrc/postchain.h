@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64) void k_pc_index(PostArgs a) {
     int cnt = 0;
     for (int f0 = 0; f0 < a.nframes; f0 += 64) {
         const int f = f0 + lane;
-        const bool alive = f < a.nframes && nf[f] == 0;
+        const bool alive = f < a.nframes && nf[f] == 0 && !cp.paused;  // a paused client: an empty stream, state untouched
         const unsigned long long m = __ballot(alive);
         const int before = __popcll(m & ((1ull << lane) - 1ull));
         if (f < a.nframes) fs[f] = alive ? (cnt + before) * a.h : -1;

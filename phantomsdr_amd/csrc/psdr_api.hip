@@ -64,7 +64,12 @@ struct AudioSlot {
     int mode = PSDR_USB;
     int state_cur = 0;
     int agc_reset = 2;  // post chain: 1 = AGC::reset pending (set_audio_demodulation), 2 = fresh client
+    bool paused = false;  // psdr_client_set_paused: sits out the demodulation batches, all state frozen
     uint64_t last_seq = 0;  // the demodulation batch (ctx->demod_seq) that last included this slot; 0: none yet
+    int b_l = 0, b_r = 0;   // the window that batch was demodulated with ...
+    double b_mid = 0;
+    int f_l = 0, f_r = 0;   // ... and the one of the batch psdr_fetch_batch copied
+    double f_mid = 0;
 };
 struct WfSlot {
     bool active = false;
@@ -1590,6 +1595,17 @@ extern "C" int psdr_client_on_window_message(psdr_ctx *c, int id, int l, double 
     if (r - l > c->n) return fail(PSDR_ERR_INVALID, "window wider than audio_fft_size");
     return psdr_client_set_audio_range(c, id, l, mid, r);
 }
+// signal_loop's slow-client rule (src/websocket.cpp:170-176): a client with more than 50 kB queued on its socket gets no
+// send_audio call for the frame - nothing of its state moves (src/signal.cpp:200-203, 273-284).  A paused client sits
+// out every demodulation batch until it is resumed; its results read as PSDR_ERR_NO_DATA meanwhile.
+extern "C" int psdr_client_set_paused(psdr_ctx *c, int id, int paused) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mtx);
+    int rc = check_slot(c, id);
+    if (rc) return rc;
+    c->aslots[id].paused = paused != 0;
+    return PSDR_OK;
+}
 extern "C" int psdr_client_set_audio_demodulation(psdr_ctx *c, int id, int mode) {
     if (!c) return fail(PSDR_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(c->mtx);
@@ -1607,7 +1623,7 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
                       const uint32_t *band = nullptr, bool band_tiled = false) {
     if (c->n <= 0) return fail(PSDR_ERR_STATE, "context created with audio_fft_size 0");
     HIPCHK(hipSetDevice(c->device));
-    int nact = 0;
+    int nact = 0, npaused = 0;
     const int ring = c->client_ring.acquire();
     if (ring < 0) return fail(PSDR_ERR_HIP, "client parameter ring: event wait failed");
     ClientParams *h_clients = (ClientParams *)c->client_ring.host(ring);
@@ -1618,7 +1634,7 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
             for (size_t i = 0; i < c->aslots.size(); i++) {
                 const AudioSlot &s = c->aslots[i];
                 // an empty window (a client between psdr_client_add and its first set_audio_range) reads no bin
-                if (s.active && s.r > s.l && ((uint32_t)s.l < band[0] || (uint64_t)s.r > (uint64_t)band[0] + band[1])) {
+                if (s.active && !s.paused && s.r > s.l && ((uint32_t)s.l < band[0] || (uint64_t)s.r > (uint64_t)band[0] + band[1])) {
                     c->client_ring.idx = (c->client_ring.idx + ParamRing::K - 1) % ParamRing::K;  // hand the slot back
                     return fail(PSDR_ERR_INVALID, "client %zu: window [%d, %d) outside the band [%u, %u)", i, s.l, s.r,
                                 band[0], band[0] + band[1]);
@@ -1628,8 +1644,9 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
         c->demod_seq++;
         for (size_t i = 0; i < c->aslots.size(); i++) {
             AudioSlot &s = c->aslots[i];
-            if (!s.active) continue;
+            if (!s.active || s.paused) continue;
             s.last_seq = c->demod_seq;
+            s.b_l = s.l, s.b_r = s.r, s.b_mid = s.mid;
             ClientParams &p = h_clients[nact++];
             p.l = s.l;
             p.r = s.r;
@@ -1639,12 +1656,28 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
             p.state_cur = s.state_cur;
             s.state_cur ^= 1;
             p.agc_reset = c->post_on ? s.agc_reset : 0;
+            p.paused = 0;
             if (c->post_on) s.agc_reset = 0;
         }
+        // Paused clients (psdr_client_set_paused) are not demodulated: signal_loop never calls send_audio for a client
+        // whose socket is backed up (src/websocket.cpp:170-176), so its overlap-add tails, FM sample, DC blocker and
+        // AGC stand still (src/signal.cpp:273-284).  The post chain lists them BEHIND the active ones with an empty
+        // stream: its double-buffered histories alternate per batch for every listed client, state unchanged.  A
+        // pending AGC reset stays pending until the client's next batch (it only takes effect there anyway).
+        if (c->post_on && nact > 0)
+            for (size_t i = 0; i < c->aslots.size(); i++) {
+                const AudioSlot &s = c->aslots[i];
+                if (!s.active || !s.paused || s.agc_reset == 2) continue;  // (a client that never ran has no history)
+                ClientParams &p = h_clients[nact + npaused++];
+                p = ClientParams{};
+                p.slot = (int)i;
+                p.state_cur = s.state_cur;
+                p.paused = 1;
+            }
     }
     c->last_demod_frames = nframes;
     if (nact == 0) return PSDR_OK;
-    HIPCHK(hipMemcpyAsync(d_clients, h_clients, (size_t)nact * sizeof(ClientParams),
+    HIPCHK(hipMemcpyAsync(d_clients, h_clients, (size_t)(nact + npaused) * sizeof(ClientParams),
                           hipMemcpyHostToDevice, c->side));
     DemodArgs a{};
     a.spec = spec;
@@ -1747,7 +1780,7 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
         hipStream_t s2 = piped ? c->side2 : c->side, s1 = piped ? c->side3 : c->side;
         PostArgs pa = c->post;
         pa.clients = d_clients;
-        pa.nact = nact;
+        pa.nact = nact + npaused;
         pa.nframes = nframes;
         pa.V1 = c->post_v1[par];
         pa.V1n = c->post_v1[par ^ 1];
@@ -1755,7 +1788,8 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
         pa.len = c->post_len[par];
         pa.P = c->post_p[par];
         pa.S = c->post_s[par];
-        const unsigned cb = (unsigned)((nact + 63) / 64);
+        const int nall = nact + npaused;
+        const unsigned cb = (unsigned)((nall + 63) / 64);
         const size_t Tb = (size_t)nframes * pa.h;  // longest possible stream of this batch
         const unsigned nblk = (unsigned)((pa.L - 1 + Tb + pa.L - 1) / pa.L);
         {  // ---- stage 1 (its own stream when the consumers have theirs)
@@ -1765,8 +1799,8 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
                 if (c->chain_seq >= 2) HIPCHK(hipStreamWaitEvent(s1, c->ev_s2[par], 0));  // stage 2 of batch b-2 read this set
             }
             ProfScope ps(c, K_POST, s1);
-            hipLaunchKernelGGL(k_pc_index, dim3(nact), dim3(64), 0, s1, pa);
-            hipLaunchKernelGGL(k_pc_gather, dim3(nact, nframes), dim3(256), 0, s1, pa);
+            hipLaunchKernelGGL(k_pc_index, dim3(nall), dim3(64), 0, s1, pa);
+            hipLaunchKernelGGL(k_pc_gather, dim3(nall, nframes), dim3(256), 0, s1, pa);
             if (piped) {  // the audio rows and NaN flags are read: the next batch's demodulation may overwrite them
                 HIPCHK(hipEventRecord(c->ev_gather, s1));
                 c->gather_pending = true;
@@ -1782,12 +1816,12 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
                 hipLaunchKernelGGL((k_pc_ma<true, false>), dim3(cb), dim3(64), 0, s1, pa);
             }
             pa.hist_sel = 0;
-            hipLaunchKernelGGL(k_pc_history, dim3(nact), dim3(256), (size_t)pa.D * sizeof(float), s1, pa);
+            hipLaunchKernelGGL(k_pc_history, dim3(nall), dim3(256), (size_t)pa.D * sizeof(float), s1, pa);
             // the look-ahead maxima and w_t are parallel work: they ride in this stage (P and S exist per parity), so
             // that stage 2 is nothing but the gain recurrence and the output - the two sequential kernels (k_pc_ma2
             // here, k_pc_gain there: ~1.1 ms each beside the FFT passes) sit in different stages
-            hipLaunchKernelGGL(k_pc_scan, dim3(nact, nblk, 2), dim3(64), 0, s1, pa);
-            hipLaunchKernelGGL(k_pc_want, dim3(nact, (unsigned)((Tb + 255) / 256)), dim3(256), 0, s1, pa);
+            hipLaunchKernelGGL(k_pc_scan, dim3(nall, nblk, 2), dim3(64), 0, s1, pa);
+            hipLaunchKernelGGL(k_pc_want, dim3(nall, (unsigned)((Tb + 255) / 256)), dim3(256), 0, s1, pa);
             // w_t is all the gain recurrence needs: it must not wait for the history copy below, which in turn waits
             // for the previous batch's output kernel (gain -> out -> history -> gain would be one serial chain per batch)
             if (piped) HIPCHK(hipEventRecord(c->ev_want[par], s1));
@@ -1795,7 +1829,7 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
             // previous batch: k_pc_out reads those rows) must be done with them
             if (piped && c->chain_seq >= 1) HIPCHK(hipStreamWaitEvent(s1, c->ev_s2[par ^ 1], 0));
             pa.hist_sel = 1;
-            hipLaunchKernelGGL(k_pc_history, dim3(nact), dim3(256), 0, s1, pa);
+            hipLaunchKernelGGL(k_pc_history, dim3(nall), dim3(256), 0, s1, pa);
             HIPCHK(hipGetLastError());
         }
         if (piped) {
@@ -1809,7 +1843,7 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
             else
                 hipLaunchKernelGGL(k_pc_gain<false>, dim3(cb), dim3(64), 0, s2, pa);
             if (piped) HIPCHK(hipStreamWaitEvent(s2, c->ev_s1[par], 0));  // k_pc_out reads V1's history rows
-            hipLaunchKernelGGL(k_pc_out, dim3(nact, nframes), dim3(256), 0, s2, pa);
+            hipLaunchKernelGGL(k_pc_out, dim3(nall, nframes), dim3(256), 0, s2, pa);
             HIPCHK(hipGetLastError());
         }
         if (piped) {
@@ -1848,11 +1882,10 @@ extern "C" int psdr_fetch_batch(psdr_ctx *c) {
     const size_t F = (size_t)c->last_demod_frames, h = (size_t)c->n / 2, mb = (size_t)c->max_batch, S = c->aslots.size();
     if (F == 0 || c->demod_seq == 0) return fail(PSDR_ERR_STATE, "no demodulated batch to fetch");
     HIPCHK(hipSetDevice(c->device));
-    if (!c->h_audio) {
-        HIPCHK(hipHostMalloc((void **)&c->h_audio, S * mb * h * sizeof(float), hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void **)&c->h_pwr, S * mb * sizeof(float), hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void **)&c->h_nan, S * mb * sizeof(int32_t), hipHostMallocDefault));
-    }
+    // (each block on its own: a failed allocation leaves nothing half-initialised behind for the next call)
+    if (!c->h_audio) HIPCHK(hipHostMalloc((void **)&c->h_audio, S * mb * h * sizeof(float), hipHostMallocDefault));
+    if (!c->h_pwr) HIPCHK(hipHostMalloc((void **)&c->h_pwr, S * mb * sizeof(float), hipHostMallocDefault));
+    if (!c->h_nan) HIPCHK(hipHostMalloc((void **)&c->h_nan, S * mb * sizeof(int32_t), hipHostMallocDefault));
     if (c->post_on && !c->h_pcm) HIPCHK(hipHostMalloc((void **)&c->h_pcm, S * mb * h * sizeof(int32_t), hipHostMallocDefault));
     {
         int rc = drain(c);
@@ -1869,9 +1902,27 @@ extern "C" int psdr_fetch_batch(psdr_ctx *c) {
         HIPCHK(hipMemcpy2DAsync(c->h_pcm, mb * h * sizeof(int32_t), c->post.pcm, mb * h * sizeof(int32_t), F * h * sizeof(int32_t), S,
                                 hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->fetched_frames = (int)F;
-    c->fetched_seq = c->demod_seq;
-    c->fetched_pcm = c->post_on;
+    {
+        std::lock_guard<std::mutex> lk(c->mtx);
+        for (auto &s : c->aslots)
+            if (s.last_seq == c->demod_seq) s.f_l = s.b_l, s.f_r = s.b_r, s.f_mid = s.b_mid;
+        c->fetched_frames = (int)F;
+        c->fetched_seq = c->demod_seq;
+        c->fetched_pcm = c->post_on;
+    }
+    return PSDR_OK;
+}
+extern "C" int psdr_fetched_window(psdr_ctx *c, int id, int *l, double *audio_mid, int *r) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mtx);
+    int rc = check_slot(c, id);
+    if (rc) return rc;
+    if (c->fetched_seq == 0) return fail(PSDR_ERR_STATE, "psdr_fetch_batch() first");
+    const AudioSlot &s = c->aslots[id];
+    if (s.last_seq != c->fetched_seq) return fail(PSDR_ERR_NO_DATA, "client %d was not part of the fetched batch", id);
+    if (l) *l = s.f_l;
+    if (audio_mid) *audio_mid = s.f_mid;
+    if (r) *r = s.f_r;
     return PSDR_OK;
 }
 extern "C" int psdr_fetched_audio(psdr_ctx *c, int id, int frame, const float **audio, float *pwr, int32_t *nan_flag,
@@ -2042,13 +2093,19 @@ extern "C" int psdr_set_band_layout(psdr_ctx *c, int nbands, uint32_t halo_bins)
         return fail(PSDR_ERR_UNSUPPORTED, "banded spectrum: 2^20- and 2^21-point IQ frames only (use psdr_pack_band)");
     if (nbands < 1 || nbands > 16 || (nbands & (nbands - 1))) return fail(PSDR_ERR_INVALID, "nbands %d: a power of two <= 16", nbands);
     if (halo_bins > (uint32_t)c->M) return fail(PSDR_ERR_INVALID, "halo of %u bins", halo_bins);
+    const int H = (int)((halo_bins + (uint32_t)c->M1 - 1) >> c->log2M1), Lb = c->M2 / nbands, Lw = Lb + H;
+    // k_band_halo repeats the first H columns of band b+1 behind band b: they must be band b+1's OWN columns (a halo
+    // longer than a band would reach into band b+2's, which band b+1's region only holds as its own halo - written
+    // by the same launch)
+    if (H > Lb)
+        return fail(PSDR_ERR_INVALID, "halo of %u bins = %d columns of %d bins exceeds a band of %d columns (%d bands)", halo_bins, H,
+                    c->M1, Lb, nbands);
     HIPCHK(hipSetDevice(c->device));
     {
         int rc = drain(c);
         if (rc) return rc;
     }
     HIPCHK(hipDeviceSynchronize());
-    const int H = (int)((halo_bins + (uint32_t)c->M1 - 1) >> c->log2M1), Lb = c->M2 / nbands, Lw = Lb + H;
     const size_t F = (size_t)c->max_batch, fs = (size_t)c->M1 * Lw;
     {  // the new buffers first: a failed allocation leaves the context as it was
         cf *fresh[2] = {nullptr, nullptr};

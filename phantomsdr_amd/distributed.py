@@ -386,7 +386,10 @@ def banded_bounds(g, R, world, halo, column=1024):
     """(first bin, bins) of rank g's band REGION in a banded spectrum (psdr_set_band_layout): whole columns of
     `column` bins, the halo rounded up to columns.  Contains band_bounds(g, ...) for every g."""
     per = R // world
-    return g * per, per + -(-halo // column) * column
+    hcols = -(-halo // column)
+    if hcols * column > per:  # (psdr_set_band_layout refuses it too: a halo must be the NEXT band's own columns)
+        raise ValueError(f"halo of {halo} bins exceeds a band of {per} bins ({world} bands)")
+    return g * per, per + hcols * column
 
 
 class HipBandBackend:

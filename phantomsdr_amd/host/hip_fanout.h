@@ -65,6 +65,12 @@ class HipFanout {
         chk(psdr_host_alloc(ctx, (psdr_half_frame_bytes(ctx) + 3) / 4, &p));
         return p;
     }
+    // (the reference frees its input_buffers when fft_task ends, src/fft.cpp:116-118; every copy out of the buffer has
+    // left the host first)
+    void free_half(void *buf) {
+        psdr_synchronize(ctx);
+        psdr_host_free(ctx, (float *)buf);
+    }
     // a new half-frame has been read: its copy to HBM starts at once and overlaps the GPU work on the
     // previous frame (the reference overlaps the read of half k+2 with the FFT of (k, k+1), src/fft.cpp:56-67)
     void push_half(const void *raw_half) { chk(psdr_ring_write_async(ctx, next_half++, raw_half)); }
@@ -99,13 +105,27 @@ class HipFanout {
         return id >= 0 && psdr_client_on_window_message(ctx, id, l, m, r) == PSDR_OK;  // false: the reference returns silently
     }
     bool set_audio_demodulation(int id, psdr_mode mode) { return id >= 0 && psdr_client_set_audio_demodulation(ctx, id, mode) == PSDR_OK; }
+    // signal_loop's slow-client rule (src/websocket.cpp:170-176): no send_audio call at all for a client whose socket is
+    // backed up - its overlap-add tails, FM sample, DC blocker and AGC stand still.  Called by the frame loop BEFORE
+    // process_frame() for every audio client (hip_level2.h).
+    bool set_audio_paused(int id, bool paused) { return id >= 0 && psdr_client_set_paused(ctx, id, paused ? 1 : 0) == PSDR_OK; }
     // the tail of send_audio for one client (asio pool): pointers into the block process_frame() fetched; no device
     // call.  Returns false when there is nothing to send: the reference would have dropped the frame (NaN guard,
-    // src/signal.cpp:266-271), or the client attached after this frame was demodulated.  audio: audio_max_fft_size/2
-    // floats; pcm: as many int32, nullptr unless the post chain runs on the GPU.
-    bool fetch_audio(int id, const float **audio, const int32_t **pcm, float *average_power) {
+    // src/signal.cpp:266-271), the client was paused for this frame, or it attached after the frame was demodulated.
+    // audio: audio_max_fft_size/2 floats; pcm: as many int32, nullptr unless the post chain runs on the GPU; l, m, r: the
+    // window this frame was DEMODULATED with (the labels of src/signal.cpp:104-105, 287 must describe the samples they
+    // travel with: the CPU-side l / audio_mid / r may have moved since, or hold a window the GPU refused).
+    struct AudioFrame {
+        const float *audio = nullptr;
+        const int32_t *pcm = nullptr;
+        float average_power = 0;
+        int l = 0, r = 0;
+        double m = 0;
+    };
+    bool fetch_audio(int id, AudioFrame *out) {
         int32_t nan = 0;
-        if (!have_audio || id < 0 || psdr_fetched_audio(ctx, id, 0, audio, average_power, &nan, pcm) != PSDR_OK) return false;
+        if (!have_audio || id < 0 || psdr_fetched_audio(ctx, id, 0, &out->audio, &out->average_power, &nan, &out->pcm) != PSDR_OK) return false;
+        if (psdr_fetched_window(ctx, id, &out->l, &out->m, &out->r) != PSDR_OK) return false;
         return nan == 0;
     }
 

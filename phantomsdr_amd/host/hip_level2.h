@@ -36,24 +36,24 @@ struct Access {
     template <class AudioClientT, class Fanout>
     static void send_audio(AudioClientT &c, Fanout &fo, size_t frame_num) {
         try {
-            const float *audio = nullptr;
-            const int32_t *pcm = nullptr;
-            float average_power = 0;
-            // false: the NaN guard dropped this frame (src/signal.cpp:266-271), or this client attached after the
-            // frame was demodulated - nothing is sent, as in the reference
-            if (!fo.fetch_audio(c.psdr_id, &audio, &pcm, &average_power)) return;
+            typename Fanout::AudioFrame fr;
+            // false: the NaN guard dropped this frame (src/signal.cpp:266-271), the client was paused for it (slow
+            // socket, src/websocket.cpp:170-176), or it attached after the frame was demodulated - nothing is sent
+            if (!fo.fetch_audio(c.psdr_id, &fr)) return;
             const int half = c.audio_fft_size / 2;
-            if (pcm) {
-                std::copy(pcm, pcm + half, c.audio_real_int16.begin());
+            if (fr.pcm) {
+                std::copy(fr.pcm, fr.pcm + half, c.audio_real_int16.begin());
             } else {
-                std::copy(audio, audio + half, c.audio_real.begin());
+                std::copy(fr.audio, fr.audio + half, c.audio_real.begin());
                 c.dc.removeDC(c.audio_real.data(), half);                                        // :278
                 c.agc.process(c.audio_real.data(), half);                                        // :281
                 dsp_float_to_int16(c.audio_real.data(), c.audio_real_int16.data(), 65536 / 4, half);  // :283-284
             }
-            const int audio_l = c.l - c.l, audio_r = c.r - c.l;  // :104-105
-            c.encoder->set_data(frame_num, audio_l, c.audio_mid, audio_r, average_power);  // :287
-            c.encoder->process(c.audio_real_int16.data(), half);                           // :291
+            // :104-105 with the window the samples were demodulated with (the client's own l / audio_mid / r may have
+            // moved since the frame was transformed, or hold a window the GPU refused)
+            const int audio_l = fr.l - fr.l, audio_r = fr.r - fr.l;
+            c.encoder->set_data(frame_num, audio_l, fr.m, audio_r, fr.average_power);  // :287
+            c.encoder->process(c.audio_real_int16.data(), half);                       // :291
         } catch (const std::exception &) {  // :295
         }
     }
@@ -86,7 +86,10 @@ struct Access {
         const int skip_num = std::max(1, (int)std::floor(((float)srv.sps / srv.fft_size) / 10.) * 2);  // src/fft.cpp:33
         std::vector<std::future<void>> signal_futures, waterfall_futures;
         uint64_t half = 0;
-        if (raw.read(bufs[0], half_bytes) != half_bytes) return;
+        if (raw.read(bufs[0], half_bytes) != half_bytes) {
+            for (void *b : bufs) fo.free_half(b);
+            return;
+        }
         fo.push_half(bufs[0]);
         half++;
         while (srv.running) {
@@ -105,16 +108,25 @@ struct Access {
             signal_futures.clear();
             waterfall_futures.clear();
             const size_t frame_num = (size_t)srv.frame_num;
-            fo.process_frame(frame_num);  // FFT + pyramid + all clients + one copy of their results to the host
+            // signal_loop decides per client and frame whether send_audio is called AT ALL (src/websocket.cpp:170-176):
+            // a client with more than 50 kB queued is passed over, and since send_audio is what advances its overlap-add
+            // tails, FM sample, DC blocker and AGC (src/signal.cpp:200-203, 273-284), all of that stands still.  On the
+            // GPU the frame is demodulated for everybody at once, so the decision comes FIRST: slow clients are paused
+            // for this frame, the others are the ones whose task is posted below.
+            std::vector<decltype(srv.signal_slices.begin()->second)> to_send;
             {
                 std::scoped_lock lg(srv.signal_slice_mtx);          // src/websocket.cpp:161
-                signal_futures.reserve(srv.signal_slices.size());
+                to_send.reserve(srv.signal_slices.size());
                 for (auto &[slice, client] : srv.signal_slices) {
-                    if (backlog(client->hdl) > 50000) continue;     // :174-177
-                    auto cl = client;                                // (keeps the client alive inside the task)
-                    signal_futures.emplace_back(post([cl, &fo, frame_num] { cl->send_audio_hip(&fo, frame_num); }));
+                    const bool slow = backlog(client->hdl) > 50000;  // :174-177
+                    fo.set_audio_paused(client->psdr_id, slow);
+                    if (!slow) to_send.push_back(client);            // (keeps the client alive inside the task)
                 }
             }
+            fo.process_frame(frame_num);  // FFT + pyramid + all clients + one copy of their results to the host
+            signal_futures.reserve(to_send.size());
+            for (auto &cl : to_send)
+                signal_futures.emplace_back(post([cl, &fo, frame_num] { cl->send_audio_hip(&fo, frame_num); }));
             if (frame_num % (size_t)skip_num == 0) {                // src/fft.cpp:101-103
                 for (int i = 0; i < srv.downsample_levels; i++) {
                     std::scoped_lock lg(srv.waterfall_slice_mtx[i]);  // src/websocket.cpp:217
@@ -129,6 +141,7 @@ struct Access {
         }
         for (auto &f : signal_futures) f.wait();
         for (auto &f : waterfall_futures) f.wait();
+        for (void *b : bufs) fo.free_half(b);  // src/fft.cpp:116-118
     }
 };
 

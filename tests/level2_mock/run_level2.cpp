@@ -71,14 +71,39 @@ class MockFanout {
         cur = frame_num;
         return true;
     }
-    // client 0: always data; client 1: NaN-dropped on frame 1; client 2 (id -1): never attached
-    bool fetch_audio(int id, const float **a, const int32_t **p, float *pwr) {
+    // what the frame loop decided for (client id, frame) BEFORE the frame was processed (src/websocket.cpp:170-176)
+    std::vector<std::pair<int, bool>> pause_calls;   // (id, paused), in call order
+    std::vector<int> pause_calls_at_frame;           // frames processed when the call was made
+    std::vector<bool> paused_now = std::vector<bool>(8, false);
+    bool set_audio_paused(int id, bool paused) {
+        pause_calls.push_back({id, paused});
+        pause_calls_at_frame.push_back(frames);
+        if (id >= 0) paused_now[id] = paused;
+        return id >= 0;
+    }
+    int freed = 0;
+    void free_half(void *) { freed++; }
+    struct AudioFrame {
+        const float *audio = nullptr;
+        const int32_t *pcm = nullptr;
+        float average_power = 0;
+        int l = 0, r = 0;
+        double m = 0;
+    };
+    // client 0: always data; client 1: NaN-dropped on frame 1; client 2 (id -1): never attached; client 3: paused on the
+    // frames its socket is backed up.  The window reported is the one the GPU demodulated with - for client 0 NOT the
+    // one its CPU-side members hold on frame 5 (a set_audio_range the GPU refused)
+    bool fetch_audio(int id, AudioFrame *fr) {
         if (id < 0) return false;
         if (id == 1 && cur == 1) return false;
+        if (paused_now[id]) return false;
         for (int i = 0; i < 8; i++) audio[i] = (float)(i + 10 * id), pcm[i] = 100 * id + i + (int)cur;
-        *a = audio.data();
-        *p = post_chain_on ? pcm.data() : nullptr;
-        *pwr = 0.5f + (float)id;
+        fr->audio = audio.data();
+        fr->pcm = post_chain_on ? pcm.data() : nullptr;
+        fr->average_power = 0.5f + (float)id;
+        static const int L[4] = {20000, 41000, 0, 300}, R[4] = {20090, 41160, 0, 420};
+        static const double M[4] = {20000.5, 41080.0, 0, 360.25};
+        fr->l = L[id], fr->r = R[id], fr->m = M[id];
         return true;
     }
     bool fetch_waterfall(int id, std::vector<int8_t> &row, int *l, int *r) {
@@ -129,9 +154,11 @@ struct TestSetup {
             srv.signal_slices.insert({{l, r}, c});
             return c;
         };
-        mk_audio(0, 20000, 20000.5, 20090);
+        mk_audio(0, 20000, 20000.5, 20090)->r = 20111;  // (a window the GPU refused: the labels must still be the demodulated one's)
         mk_audio(1, 41000, 41080.0, 41160);
         mk_audio(-1, 100, 150.0, 200);  // every GPU slot taken: psdr_attach got -1
+        auto slow_audio = mk_audio(3, 300, 360.25, 420);  // its socket is backed up on frames 2, 3 and 6
+        void *slow_audio_hdl = cons.back().get();
         auto w = std::make_shared<WaterfallClient>();
         cons.push_back(std::make_shared<int>(9));
         w->hdl = cons.back();
@@ -148,13 +175,29 @@ struct TestSetup {
         void *slow_hdl = cons.back().get();
         psdr_level2::Access::fft_task(
             srv, raw, [](auto fn) { return std::async(std::launch::async, fn); },
-            [&](connection_hdl h) -> size_t { return h.lock().get() == slow_hdl ? 60000 : 0; });
+            [&](connection_hdl h) -> size_t {
+                if (h.lock().get() == slow_audio_hdl) return (srv.frame_num == 2 || srv.frame_num == 3 || srv.frame_num == 6) ? 50001 : 50000;
+                return h.lock().get() == slow_hdl ? 60000 : 0;
+            });
         auto &fo = *srv.fanout;
         assert(fo.halves_pushed == 9 && fo.frames == 8 && srv.frame_num == 8);
         for (int f = 0; f < 8; f++) assert(fo.frame_nums[f] == (uint64_t)f);
         assert(g_ring_waits.size() == 7 && g_ring_waits[0] == 0 && g_ring_waits[6] == 6);  // a buffer is reused from the 4th read on, once its copy has left the host
-        int na0 = 0, na1 = 0, nw = 0;
+        // every audio client's pause decision was made BEFORE its frame was processed, once per client and frame
+        assert(fo.pause_calls.size() == 4 * 8 && fo.freed == 3);
+        for (size_t i = 0; i < fo.pause_calls.size(); i++) {
+            const int f = (int)i / 4;
+            assert(fo.pause_calls_at_frame[i] == f);
+            const bool want = fo.pause_calls[i].first == 3 && (f == 2 || f == 3 || f == 6);
+            assert(fo.pause_calls[i].second == want);
+        }
+        int na0 = 0, na1 = 0, na3 = 0, nw = 0;
         for (auto &c : g_calls) {
+            if (c.what == "audio" && c.m == 360.25) {
+                assert(c.frame_num != 2 && c.frame_num != 3 && c.frame_num != 6 && c.l == 0 && c.r == 120 && c.pwr == 3.5);
+                na3++;
+                continue;
+            }
             if (c.what == "audio") {
                 const bool c0 = c.m == 20000.5;
                 assert(c0 || c.m == 41080.0);  // the client without a slot never sends
@@ -175,7 +218,7 @@ struct TestSetup {
                 nw++;
             }
         }
-        assert(na0 == 8 && na1 == 7 && nw == 2);  // waterfall frames 0 and 6; the backed-up client got nothing
+        assert(na0 == 8 && na1 == 7 && na3 == 5 && nw == 2);  // waterfall frames 0 and 6; the backed-up client got nothing
         return 0;
     }
     static int run_without_users() {  // src/fft.cpp:70-80: the input is still read (and shipped), nothing is transformed

@@ -139,7 +139,7 @@ def signal_h(L):
 def signal_cpp(L):
     # every state change is forwarded to the GPU-side client
     L = after(L, "void AudioClient::set_audio_range(int l, double m, int r) {", H([
-        "    if (psdr_fo) (void)psdr_fo->set_audio_range(psdr_id, l, m, r);  // never throws; a rejected window keeps the old one on the GPU"]))
+        "    if (psdr_fo) (void)psdr_fo->set_audio_range(psdr_id, l, m, r);  // never throws; a rejected window keeps the old one on the GPU, and the packets carry the labels of the window that was demodulated (hip_level2.h)"]))
     L = after(L, "void AudioClient::set_audio_demodulation(demodulation_mode demodulation) {", H([
         "    if (psdr_fo) (void)psdr_fo->set_audio_demodulation(psdr_id, (psdr_mode)demodulation);"]))
     L = after(L, "    this->agc.reset();", H([
