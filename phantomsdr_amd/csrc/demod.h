@@ -26,22 +26,11 @@
 
 #include "butterfly.h"
 #include "quantize.h"
+#include "types.h"
 
 namespace psdr {
 
-#define PSDR_MAX_STAGES 12
 
-struct ClientParams {
-    int l, r;       // [l, r) in client bin coordinates
-    int m_floor;    // floor(audio_mid)
-    int mode;       // psdr_mode
-    int slot;       // persistent slot (state + output rows)
-    int state_cur;  // which half of the double-buffered state is current
-    int agc_reset;  // post chain: 1 = the demodulation changed since the last batch (AGC::reset),
-                    // 2 = a new client took this slot (all chain state starts from zero)
-    int paused;     // psdr_client_set_paused: listed BEHIND the batch's active clients, for the post chain only (its
-                    // double-buffered streams must carry the client's history across the batch it sits out)
-};
 
 struct DemodArgs {
     const cf *spec;  // [nframes][spec_stride]; IQ: client order, real: k order, through `lay`

@@ -1,0 +1,447 @@
+// demod.hip - the audio clients (AudioClient, src/signal.h:53-123) and their batched demodulation: signal_loop +
+// AudioClient::send_audio up to the NaN guard (src/websocket.cpp:156-185, src/signal.cpp:102-275) for every client and
+// every frame of a batch, and the read-back of its results.
+#include "ctx.h"
+#include "demod.h"
+
+static int check_slot(psdr_ctx *c, int id) {
+    if (id < 0 || id >= (int)c->aslots.size() || !c->aslots[id].active)
+        return fail(PSDR_ERR_INVALID, "no audio client with id %d", id);
+    return PSDR_OK;
+}
+extern "C" int psdr_client_add(psdr_ctx *c, int *id_out) {
+    if (!c || !id_out) return fail(PSDR_ERR_INVALID, "null argument");
+    if (c->n <= 0) return fail(PSDR_ERR_STATE, "context created with audio_fft_size 0");
+    std::lock_guard<std::mutex> lk(c->mtx);
+    HIPCHK(hipSetDevice(c->device));
+    for (size_t i = 0; i < c->aslots.size(); i++)
+        if (!c->aslots[i].active) {
+            AudioSlot &s = c->aslots[i];
+            s = AudioSlot();
+            s.active = true;
+            // a fresh AudioClient starts from zeroed buffers (src/signal.h:42-51)
+            const size_t S = c->aslots.size(), h = (size_t)c->n / 2;
+            for (int b = 0; b < 2; b++) {
+                HIPCHK(hipMemsetAsync(c->d_real_prev + ((size_t)b * S + i) * h, 0, h * sizeof(float),
+                                      c->side));
+                HIPCHK(hipMemsetAsync(c->d_bb_tail + ((size_t)b * S + i) * h, 0, h * sizeof(cf),
+                                      c->side));
+                HIPCHK(hipMemsetAsync(c->d_bb_last + ((size_t)b * S + i), 0, sizeof(cf), c->side));
+            }
+            *id_out = (int)i;
+            return PSDR_OK;
+        }
+    return fail(PSDR_ERR_NOMEM, "all %zu audio client slots are in use", c->aslots.size());
+}
+extern "C" int psdr_client_remove(psdr_ctx *c, int id) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mtx);
+    int rc = check_slot(c, id);
+    if (rc) return rc;
+    c->aslots[id].active = false;
+    return PSDR_OK;
+}
+extern "C" int psdr_client_set_audio_range(psdr_ctx *c, int id, int l, double mid, int r) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mtx);
+    int rc = check_slot(c, id);
+    if (rc) return rc;
+    // the reference does not validate here (src/signal.cpp:81-94); a range outside the
+    // spectrum would read out of bounds there, so it is refused here
+    if (l < 0 || r < l || (size_t)r > c->R || r - l > c->n)
+        return fail(PSDR_ERR_INVALID, "range [%d,%d) outside the spectrum or wider than %d", l, r, c->n);
+    AudioSlot &s = c->aslots[id];
+    s.l = l;
+    s.r = r;
+    s.mid = mid;
+    return PSDR_OK;
+}
+extern "C" int psdr_client_on_window_message(psdr_ctx *c, int id, int l, double mid, int r) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    {
+        std::lock_guard<std::mutex> lk(c->mtx);
+        int rc = check_slot(c, id);
+        if (rc) return rc;
+    }
+    const int R = (int)c->R;  // src/signal.cpp:305-311
+    if (l < 0 || l >= R || r < 0 || r >= R || l > r)
+        return fail(PSDR_ERR_INVALID, "window [%d,%d] rejected", l, r);
+    if (r - l > c->n) return fail(PSDR_ERR_INVALID, "window wider than audio_fft_size");
+    return psdr_client_set_audio_range(c, id, l, mid, r);
+}
+// signal_loop's slow-client rule (src/websocket.cpp:170-176): a client with more than 50 kB queued on its socket gets no
+// send_audio call for the frame - nothing of its state moves (src/signal.cpp:200-203, 273-284).  A paused client sits
+// out every demodulation batch until it is resumed; its results read as PSDR_ERR_NO_DATA meanwhile.
+extern "C" int psdr_client_set_paused(psdr_ctx *c, int id, int paused) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mtx);
+    int rc = check_slot(c, id);
+    if (rc) return rc;
+    c->aslots[id].paused = paused != 0;
+    return PSDR_OK;
+}
+extern "C" int psdr_client_set_audio_demodulation(psdr_ctx *c, int id, int mode) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mtx);
+    int rc = check_slot(c, id);
+    if (rc) return rc;
+    if (mode < PSDR_USB || mode > PSDR_FM) return fail(PSDR_ERR_INVALID, "unknown mode %d", mode);
+    c->aslots[id].mode = mode;
+    if (c->aslots[id].agc_reset == 0) c->aslots[id].agc_reset = 1;  // src/signal.cpp:316-328: resets the AGC
+    return PSDR_OK;
+}
+
+// band != nullptr: `spec` is a window of bins [band[0], band[0] + band[1]) per frame - linear, or (band_tiled) one
+// band region of a banded spectrum (SpecLayout mode 4)
+static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nframes, uint64_t first_frame_num,
+                      const uint32_t *band = nullptr, bool band_tiled = false) {
+    if (c->n <= 0) return fail(PSDR_ERR_STATE, "context created with audio_fft_size 0");
+    HIPCHK(hipSetDevice(c->device));
+    int nact = 0, npaused = 0;
+    const int ring = c->client_ring.acquire();
+    if (ring < 0) return fail(PSDR_ERR_HIP, "client parameter ring: event wait failed");
+    ClientParams *h_clients = (ClientParams *)c->client_ring.host(ring);
+    ClientParams *d_clients = (ClientParams *)c->client_ring.dev(ring);
+    {
+        std::lock_guard<std::mutex> lk(c->mtx);
+        if (band) {  // checked under the same lock that fixes the windows this batch is demodulated with
+            for (size_t i = 0; i < c->aslots.size(); i++) {
+                const AudioSlot &s = c->aslots[i];
+                // an empty window (a client between psdr_client_add and its first set_audio_range) reads no bin
+                if (s.active && !s.paused && s.r > s.l && ((uint32_t)s.l < band[0] || (uint64_t)s.r > (uint64_t)band[0] + band[1])) {
+                    c->client_ring.idx = (c->client_ring.idx + ParamRing::K - 1) % ParamRing::K;  // hand the slot back
+                    return fail(PSDR_ERR_INVALID, "client %zu: window [%d, %d) outside the band [%u, %u)", i, s.l, s.r,
+                                band[0], band[0] + band[1]);
+                }
+            }
+        }
+        c->demod_seq++;
+        for (size_t i = 0; i < c->aslots.size(); i++) {
+            AudioSlot &s = c->aslots[i];
+            if (!s.active || s.paused) continue;
+            s.last_seq = c->demod_seq;
+            s.b_l = s.l, s.b_r = s.r, s.b_mid = s.mid;
+            ClientParams &p = h_clients[nact++];
+            p.l = s.l;
+            p.r = s.r;
+            p.m_floor = (int)std::floor(s.mid);
+            p.mode = s.mode;
+            p.slot = (int)i;
+            p.state_cur = s.state_cur;
+            s.state_cur ^= 1;
+            p.agc_reset = c->post_on ? s.agc_reset : 0;
+            p.paused = 0;
+            if (c->post_on) s.agc_reset = 0;
+        }
+        // Paused clients (psdr_client_set_paused) are not demodulated: signal_loop never calls send_audio for a client
+        // whose socket is backed up (src/websocket.cpp:170-176), so its overlap-add tails, FM sample, DC blocker and
+        // AGC stand still (src/signal.cpp:273-284).  The post chain lists them BEHIND the active ones with an empty
+        // stream: its double-buffered histories alternate per batch for every listed client, state unchanged.  A
+        // pending AGC reset stays pending until the client's next batch (it only takes effect there anyway).
+        if (c->post_on && nact > 0)
+            for (size_t i = 0; i < c->aslots.size(); i++) {
+                const AudioSlot &s = c->aslots[i];
+                if (!s.active || !s.paused || s.agc_reset == 2) continue;  // (a client that never ran has no history)
+                ClientParams &p = h_clients[nact + npaused++];
+                p = ClientParams{};
+                p.slot = (int)i;
+                p.state_cur = s.state_cur;
+                p.paused = 1;
+            }
+    }
+    c->last_demod_frames = nframes;
+    if (nact == 0) return PSDR_OK;
+    HIPCHK(hipMemcpyAsync(d_clients, h_clients, (size_t)(nact + npaused) * sizeof(ClientParams),
+                          hipMemcpyHostToDevice, c->side));
+    DemodArgs a{};
+    a.spec = spec;
+    a.spec_stride = spec_stride;
+    a.is_real = c->is_real ? 1 : 0;
+    a.lay = c->lay;
+    if (band) {
+        a.lay = SpecLayout{};
+        a.lay.k0 = (int)band[0];
+        if (band_tiled) {
+            a.lay.mode = 4;
+            a.lay.m1 = c->M1;
+            a.lay.l2m1 = c->log2M1;
+            a.lay.L = c->M2;
+            a.lay.l2L = c->log2M2;
+            a.lay.Lw = (int)(band[1] >> c->log2M1);
+            a.lay.c2_0 = (int)(band[0] >> c->log2M1);
+        }
+    }
+    a.n = c->n;
+    a.nframes = nframes;
+    a.max_batch = c->max_batch;
+    a.first_frame_num = first_frame_num;
+    a.clients = d_clients;
+    a.Wn = c->d_Wn;
+    a.nstages = c->nstages;
+    for (int i = 0; i < c->nstages; i++) a.radix[i] = c->radix[i];
+    a.stage_tab = c->d_stage_tab;
+    a.ypost = c->d_ypost;
+    a.pwr = c->d_pwr;
+    a.gscratch = c->d_gscratch;
+    a.lds_mode = c->lds_mode;
+    a.audio = c->d_audio;
+    a.nan_flags = c->d_nan;
+    a.real_prev = c->d_real_prev;
+    a.bb_tail = c->d_bb_tail;
+    a.bb_last = c->d_bb_last;
+    a.slots = (int)c->aslots.size();
+    if (c->gather_pending && c->side3) {  // post chain: the previous batch's audio rows are still being gathered
+        HIPCHK(hipStreamWaitEvent(c->side, c->ev_gather, 0));
+        c->gather_pending = false;
+    }
+    bool ola_done = false;
+    {
+        ProfScope ps(c, K_IDFT, c->side);
+        const bool fixed_plan = (c->n == 360 || c->n == 720) && !c->idft_block && !c->idft_generic;
+        if (fixed_plan && c->demod_chain) {
+            // transform + overlap-add + demodulation in one kernel, one wave per chain of K consecutive frames of a
+            // client (demod.h): long chains repeat fewer transforms (1 or 2 per chain), short ones give few clients
+            // enough waves
+            // (256 clients x 256 frames, same box: K = 4 / 8 / 16 / 32 -> 5.81 / 5.77 / 5.93 / 6.04 us per frame, the
+            // two-kernel path 5.99)
+            int K = c->demod_chain_k > 0 ? c->demod_chain_k : 8;
+            if (c->demod_chain_k <= 0)
+                while (K > 4 && (unsigned)nact * (unsigned)((nframes + K - 1) / K) < 1024u) K >>= 1;
+            const unsigned items = (unsigned)nact * (unsigned)((nframes + K - 1) / K);
+            const unsigned W = c->n == 360 ? 4u : 1u;
+            const size_t lds = (size_t)(1 + W) * c->n * sizeof(cf);
+            if (c->n == 360)
+                hipLaunchKernelGGL((k_demod_chain_fixed<360, 8, 9, 5>), dim3((items + W - 1) / W), dim3(64 * W), lds,
+                                   c->side, a, nact, K);
+            else
+                hipLaunchKernelGGL((k_demod_chain_fixed<720, 8, 9, 10>), dim3((items + W - 1) / W), dim3(64 * W), lds,
+                                   c->side, a, nact, K);
+            ola_done = true;
+        } else if (fixed_plan) {
+            // compile-time plans (demod.h): 360 = 8*9*5, 720 = 8*9*10; W items per work-group in
+            // the 15 KiB of LDS an FFT pass leaves free on a CU
+            const unsigned items = (unsigned)nact * (unsigned)nframes;
+            const unsigned W = c->n == 360 ? 4u : 1u;
+            const size_t lds = (size_t)(1 + W) * c->n * sizeof(cf);
+            if (c->n == 360)
+                hipLaunchKernelGGL((k_demod_idft_fixed<360, 8, 9, 5>), dim3((items + W - 1) / W), dim3(64 * W), lds,
+                                   c->side, a, nact);
+            else
+                hipLaunchKernelGGL((k_demod_idft_fixed<720, 8, 9, 10>), dim3((items + W - 1) / W), dim3(64 * W), lds,
+                                   c->side, a, nact);
+        } else if (c->n <= 512 && !c->idft_block) {
+            // one wave per (client, frame), no work-group barriers (demod.h)
+            const unsigned items = (unsigned)nact * (unsigned)nframes;
+            const size_t lds = (size_t)(2 * PSDR_IDFT_WAVES + 1) * c->n * sizeof(cf);
+            hipLaunchKernelGGL(k_demod_idft_wave, dim3((items + PSDR_IDFT_WAVES - 1) / PSDR_IDFT_WAVES),
+                               dim3(64 * PSDR_IDFT_WAVES), lds, c->side, a, nact);
+        } else {
+            if (c->idft_lds > 64 * 1024 && c->lds_attr_done.insert((const void *)k_demod_idft).second)
+                HIPCHK(hipFuncSetAttribute((const void *)k_demod_idft, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->idft_lds));
+            hipLaunchKernelGGL(k_demod_idft, dim3(nact, nframes), dim3(c->idft_threads), c->idft_lds, c->side,
+                               a);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    if (!ola_done) {
+        ProfScope ps(c, K_OLA, c->side);
+        const unsigned items = (unsigned)nact * (unsigned)((nframes + PSDR_OLA_FG - 1) / PSDR_OLA_FG);
+        hipLaunchKernelGGL(k_demod_ola, dim3((items + 3) / 4), dim3(256), 0, c->side, a, nact);
+        HIPCHK(hipGetLastError());
+    }
+    hipStream_t last_user = c->side;
+    if (c->post_on && nact > 0) {
+        int rc = post_chain_enqueue(c, d_clients, nact, npaused, nframes, &last_user);
+        if (rc) return rc;
+    }
+    HIPCHK(c->client_ring.release(ring, last_user));
+    if (c->side != c->stream) {
+        HIPCHK(hipEventRecord(c->ev_side_done, c->side));
+        c->side_pending = true;
+        HIPCHK(hipEventRecord(c->ev_set_done[c->cur_set], c->side));
+        c->set_pending[c->cur_set] = true;
+    }
+    return PSDR_OK;
+}
+
+// A slot whose client attached AFTER the last demodulation batch holds the previous occupant's results (or
+// nothing): the reference's per-client task would not exist for that frame either (src/websocket.cpp:156-185 walks
+// signal_slices at the time of the frame).  PSDR_ERR_NO_DATA, nothing is copied.
+static int slot_in_last_batch(psdr_ctx *c, int id) {
+    std::lock_guard<std::mutex> lk(c->mtx);
+    if (c->demod_seq == 0 || c->aslots[id].last_seq != c->demod_seq)
+        return fail(PSDR_ERR_NO_DATA, "client %d was not part of the last demodulation batch", id);
+    return PSDR_OK;
+}
+
+// ---- batched read-back: ONE synchronisation and at most four copies per batch for ALL clients ----------------
+// (src/websocket.cpp:156-185 makes one pass over signal_slices per frame; per-client psdr_read_audio would pay a
+// synchronisation and three copies per client and frame)
+extern "C" int psdr_fetch_batch(psdr_ctx *c) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    if (c->n <= 0) return fail(PSDR_ERR_STATE, "context created with audio_fft_size 0");
+    const size_t F = (size_t)c->last_demod_frames, h = (size_t)c->n / 2, mb = (size_t)c->max_batch, S = c->aslots.size();
+    if (F == 0 || c->demod_seq == 0) return fail(PSDR_ERR_STATE, "no demodulated batch to fetch");
+    HIPCHK(hipSetDevice(c->device));
+    // (each block on its own: a failed allocation leaves nothing half-initialised behind for the next call)
+    if (!c->h_audio) HIPCHK(hipHostMalloc((void **)&c->h_audio, S * mb * h * sizeof(float), hipHostMallocDefault));
+    if (!c->h_pwr) HIPCHK(hipHostMalloc((void **)&c->h_pwr, S * mb * sizeof(float), hipHostMallocDefault));
+    if (!c->h_nan) HIPCHK(hipHostMalloc((void **)&c->h_nan, S * mb * sizeof(int32_t), hipHostMallocDefault));
+    if (c->post_on && !c->h_pcm) HIPCHK(hipHostMalloc((void **)&c->h_pcm, S * mb * h * sizeof(int32_t), hipHostMallocDefault));
+    {
+        int rc = drain(c);
+        if (rc) return rc;
+    }
+    // rows [slot][0..F) of the device arrays [slot][max_batch][...]: one strided copy each
+    HIPCHK(hipMemcpy2DAsync(c->h_audio, mb * h * sizeof(float), c->d_audio, mb * h * sizeof(float), F * h * sizeof(float), S,
+                            hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpy2DAsync(c->h_pwr, mb * sizeof(float), c->d_pwr, mb * sizeof(float), F * sizeof(float), S,
+                            hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpy2DAsync(c->h_nan, mb * sizeof(int32_t), c->d_nan, mb * sizeof(int), F * sizeof(int32_t), S,
+                            hipMemcpyDeviceToHost, c->stream));
+    if (c->post_on)
+        HIPCHK(hipMemcpy2DAsync(c->h_pcm, mb * h * sizeof(int32_t), c->post.pcm, mb * h * sizeof(int32_t), F * h * sizeof(int32_t), S,
+                                hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    {
+        std::lock_guard<std::mutex> lk(c->mtx);
+        for (auto &s : c->aslots)
+            if (s.last_seq == c->demod_seq) s.f_l = s.b_l, s.f_r = s.b_r, s.f_mid = s.b_mid;
+        c->fetched_frames = (int)F;
+        c->fetched_seq = c->demod_seq;
+        c->fetched_pcm = c->post_on;
+    }
+    return PSDR_OK;
+}
+extern "C" int psdr_fetched_window(psdr_ctx *c, int id, int *l, double *audio_mid, int *r) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mtx);
+    int rc = check_slot(c, id);
+    if (rc) return rc;
+    if (c->fetched_seq == 0) return fail(PSDR_ERR_STATE, "psdr_fetch_batch() first");
+    const AudioSlot &s = c->aslots[id];
+    if (s.last_seq != c->fetched_seq) return fail(PSDR_ERR_NO_DATA, "client %d was not part of the fetched batch", id);
+    if (l) *l = s.f_l;
+    if (audio_mid) *audio_mid = s.f_mid;
+    if (r) *r = s.f_r;
+    return PSDR_OK;
+}
+extern "C" int psdr_fetched_audio(psdr_ctx *c, int id, int frame, const float **audio, float *pwr, int32_t *nan_flag,
+                                  const int32_t **pcm) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    {
+        std::lock_guard<std::mutex> lk(c->mtx);
+        int rc = check_slot(c, id);
+        if (rc) return rc;
+        if (c->fetched_seq == 0) return fail(PSDR_ERR_STATE, "psdr_fetch_batch() first");
+        if (c->aslots[id].last_seq != c->fetched_seq)
+            return fail(PSDR_ERR_NO_DATA, "client %d was not part of the fetched batch", id);
+    }
+    if (frame < 0 || frame >= c->fetched_frames) return fail(PSDR_ERR_INVALID, "frame %d not in the fetched batch of %d", frame, c->fetched_frames);
+    const size_t h = (size_t)c->n / 2, mb = (size_t)c->max_batch, row = (size_t)id * mb + (size_t)frame;
+    if (audio) *audio = c->h_audio + row * h;
+    if (pwr) *pwr = c->h_pwr[row];
+    if (nan_flag) *nan_flag = c->h_nan[row];
+    if (pcm) *pcm = c->fetched_pcm ? c->h_pcm + row * h : nullptr;
+    return PSDR_OK;
+}
+
+extern "C" int psdr_read_pcm(psdr_ctx *c, int id, int nframes, int32_t *pcm, int *nframes_out) {
+    if (!c || !pcm) return fail(PSDR_ERR_INVALID, "null argument");
+    {
+        std::lock_guard<std::mutex> lk(c->mtx);
+        int rc = check_slot(c, id);
+        if (rc) return rc;
+    }
+    if (!c->post_on) return fail(PSDR_ERR_STATE, "post chain not enabled (psdr_set_post_chain)");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t F = (size_t)c->last_demod_frames, h = (size_t)c->n / 2, mb = (size_t)c->max_batch;
+    if (F == 0) return fail(PSDR_ERR_STATE, "no demodulated batch to read");
+    if (nframes < (int)F) return fail(PSDR_ERR_INVALID, "buffer holds %d frames, the last batch has %zu", nframes, F);
+    {
+        int rc = slot_in_last_batch(c, id);
+        if (rc) return rc;
+        rc = drain(c);
+        if (rc) return rc;
+    }
+    HIPCHK(hipMemcpy(pcm, c->post.pcm + (size_t)id * mb * h, F * h * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (nframes_out) *nframes_out = (int)F;
+    return PSDR_OK;
+}
+
+extern "C" int psdr_demod_batch(psdr_ctx *c, uint64_t first_frame_num) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    if (c->last_nframes < 1) return fail(PSDR_ERR_STATE, "demod_batch before process_batch/execute");
+    return demod_impl(c, c->d_spec, c->spec_stride, c->last_nframes, first_frame_num);
+}
+extern "C" int psdr_demod_batch_from(psdr_ctx *c, const float *d_spec, size_t frame_stride_bins,
+                                     int nframes, uint64_t first_frame_num) {
+    if (!c || !d_spec) return fail(PSDR_ERR_INVALID, "null argument");
+    if (nframes < 1 || nframes > c->max_batch)
+        return fail(PSDR_ERR_INVALID, "nframes %d outside [1, max_batch=%d]", nframes, c->max_batch);
+    if (frame_stride_bins < (c->is_real ? c->N / 2 + 1 : c->N))
+        return fail(PSDR_ERR_INVALID, "frame stride smaller than one spectrum");
+    return demod_impl(c, (const cf *)d_spec, frame_stride_bins, nframes, first_frame_num);
+}
+extern "C" int psdr_demod_batch_from_band(psdr_ctx *c, const float *d_band, size_t frame_stride_bins, uint32_t first_bin,
+                                          uint32_t nbins, int nframes, uint64_t first_frame_num) {
+    if (!c || !d_band) return fail(PSDR_ERR_INVALID, "null argument");
+    if (nframes < 1 || nframes > c->max_batch)
+        return fail(PSDR_ERR_INVALID, "nframes %d outside [1, max_batch=%d]", nframes, c->max_batch);
+    if (nbins < 1 || frame_stride_bins < nbins) return fail(PSDR_ERR_INVALID, "frame stride smaller than the band");
+    const uint32_t band[2] = {first_bin, nbins};
+    return demod_impl(c, (const cf *)d_band, frame_stride_bins, nframes, first_frame_num, band);
+}
+extern "C" int psdr_demod_batch_from_band_region(psdr_ctx *c, const float *d_region, size_t frame_stride_bins, uint32_t first_bin,
+                                                 uint32_t nbins, int nframes, uint64_t first_frame_num) {
+    if (!c || !d_region) return fail(PSDR_ERR_INVALID, "null argument");
+    if (c->is_real || c->M2 != 1024) return fail(PSDR_ERR_UNSUPPORTED, "band regions: IQ frames with 1024-point rows only");
+    if (nframes < 1 || nframes > c->max_batch)
+        return fail(PSDR_ERR_INVALID, "nframes %d outside [1, max_batch=%d]", nframes, c->max_batch);
+    const uint32_t m1 = (uint32_t)c->M1;
+    if (nbins < m1 || (nbins & (m1 - 1)) || (first_bin & (m1 - 1)) || first_bin >= (uint32_t)c->M)
+        return fail(PSDR_ERR_INVALID, "band region [%u, +%u): whole columns of %u bins", first_bin, nbins, m1);
+    if (frame_stride_bins < nbins) return fail(PSDR_ERR_INVALID, "frame stride smaller than the band");
+    const uint32_t band[2] = {first_bin, nbins};
+    return demod_impl(c, (const cf *)d_region, frame_stride_bins, nframes, first_frame_num, band, true);
+}
+
+extern "C" int psdr_read_audio(psdr_ctx *c, int id, int nframes, float *audio, float *pwr, int32_t *nan_flags,
+                               int *nframes_out) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    {
+        std::lock_guard<std::mutex> lk(c->mtx);
+        int rc = check_slot(c, id);
+        if (rc) return rc;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    const size_t F = (size_t)c->last_demod_frames, h = (size_t)c->n / 2, mb = (size_t)c->max_batch;
+    if (F == 0) return fail(PSDR_ERR_STATE, "no demodulated batch to read");
+    if (nframes < (int)F) return fail(PSDR_ERR_INVALID, "buffers hold %d frames, the last batch has %zu", nframes, F);
+    if (nframes_out) *nframes_out = (int)F;
+    {
+        int rc = slot_in_last_batch(c, id);
+        if (rc) return rc;
+        rc = drain(c);
+        if (rc) return rc;
+    }
+    if (audio)
+        HIPCHK(hipMemcpyAsync(audio, c->d_audio + (size_t)id * mb * h, F * h * sizeof(float),
+                              hipMemcpyDeviceToHost, c->stream));
+    if (pwr)
+        HIPCHK(hipMemcpyAsync(pwr, c->d_pwr + (size_t)id * mb, F * sizeof(float), hipMemcpyDeviceToHost,
+                              c->stream));
+    if (nan_flags)
+        HIPCHK(hipMemcpyAsync(nan_flags, c->d_nan + (size_t)id * mb, F * sizeof(int),
+                              hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return PSDR_OK;
+}
+extern "C" int psdr_audio_device_ptr(psdr_ctx *c, int id, const float **d_audio, const float **d_pwr) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    if (id < 0 || id >= (int)c->aslots.size()) return fail(PSDR_ERR_INVALID, "bad id %d", id);
+    const size_t h = (size_t)c->n / 2, mb = (size_t)c->max_batch;
+    if (d_audio) *d_audio = c->d_audio + (size_t)id * mb * h;
+    if (d_pwr) *d_pwr = c->d_pwr + (size_t)id * mb;
+    return PSDR_OK;
+}

@@ -14,6 +14,7 @@
 
 #include "butterfly.h"
 #include "quantize.h"
+#include "types.h"
 
 namespace psdr {
 
@@ -412,12 +413,6 @@ __global__ __launch_bounds__(256) void k_band_halo(cf *X, size_t spec_stride, Sp
     dst[piece] = src[piece];
 }
 
-struct WfClient {
-    int level, l, r;
-    int active;
-    size_t qoff;     // byte offset of `level` inside a frame's level-major int8 buffer
-    size_t out_off;  // byte offset of this client's output block
-};
 
 // one work-group row per (client, sent frame): copies q_level[l..r).  Levels <= tiled_lt live
 // in the tiled records (quantize.h), the upper levels in the level-major buffer.

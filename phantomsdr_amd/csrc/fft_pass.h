@@ -608,9 +608,16 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
 #ifndef PSDR_TW_P1_MASK
 #define PSDR_TW_P1_MASK 1
 #endif
+    // ... and the PAIR kernels (real input) have their own setting: they carry 13 more VGPRs than the IQ kernels
+    // (210 / 220 against 197), and with the twiddles on top the consumers of the previous batch (88 - 127 VGPRs) do not
+    // fit beside a pass-1 work-group's two waves per SIMD at all
+#ifndef PSDR_TW_P1_MASK_PAIR
+#define PSDR_TW_P1_MASK_PAIR PSDR_TW_P1_MASK
+#endif
+    constexpr int TWM = PAIR ? PSDR_TW_P1_MASK_PAIR : PSDR_TW_P1_MASK;
     StageTw<L> stw;
-    if (PSDR_TW_P1_MASK) stw.load(Wl, i0_);
-    const StageTw<L> *stw_front = (Plan<L>::NS == 3 && (PSDR_TW_P1_MASK & 1)) ? &stw : nullptr, *stw_last = (PSDR_TW_P1_MASK & 2) ? &stw : nullptr;
+    if (TWM) stw.load(Wl, i0_);
+    const StageTw<L> *stw_front = (Plan<L>::NS == 3 && (TWM & 1)) ? &stw : nullptr, *stw_last = (TWM & 2) ? &stw : nullptr;
 
     int it = 0;
     for (; s < total; it++) {

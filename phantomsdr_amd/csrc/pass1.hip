@@ -1,0 +1,79 @@
+// pass1.hip - launchers of the first FFT pass (fft_pass.h: convert + Hann + column transform + inter-pass twiddle)
+#include "ctx.h"
+#include "fft_pass.h"
+#ifdef PSDR_TUNING_BUILD
+#include "fft_pass1w.h"  // the barrier-free first pass of round 3 (measured slower: DESIGN.md 5.2) lives in tuning builds only
+#endif
+
+namespace psdr {
+
+template <int L, int T, int SB, bool PAIR = false>
+static int launch_pass1_t(psdr_ctx *c, const Pass1Args &a, unsigned blocks) {
+    // tile + W_L (= first twiddle factor) + second twiddle factor (M2 entries)
+    const size_t lds = (size_t)L * T * sizeof(cf) + (size_t)L * sizeof(cf) + (size_t)a.M2 * sizeof(cf);
+    // (per context = per device: the attribute is a property of the function ON a device)
+    if (c->lds_attr_done.insert((const void *)k_fft_pass1<L, T, SB, PAIR>).second)
+        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass1<L, T, SB, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    ProfScope ps(c, K_PASS1, c->p1);
+    // persistent: as many work-groups per CU as their LDS admits (a 128 KiB tile: one)
+    unsigned grid = persistent_grid(c, blocks, lds);
+    if (c->p1_grid && c->p1_grid < grid) grid = c->p1_grid;
+    hipLaunchKernelGGL((k_fft_pass1<L, T, SB, PAIR>), dim3(grid), dim3(L * T / 32), lds, c->p1, a);
+    HIPCHK(hipGetLastError());
+    return PSDR_OK;
+}
+#ifdef PSDR_TUNING_BUILD
+// pass 1 with wave-owned column couples (fft_pass1w.h): 2^20-point IQ frames of 8/16-bit samples
+template <int SB>
+static int launch_pass1_w(psdr_ctx *c, const Pass1Args &a, unsigned blocks) {
+    constexpr size_t lds = pass1w_lds_bytes<SB>();
+    if (c->lds_attr_done.insert((const void *)k_fft_pass1_w<SB>).second)
+        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass1_w<SB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ProfScope ps(c, K_PASS1, c->p1);
+    unsigned grid = persistent_grid(c, blocks, lds);
+    if (c->p1_grid && c->p1_grid < grid) grid = c->p1_grid;
+    hipLaunchKernelGGL((k_fft_pass1_w<SB>), dim3(grid), dim3(kPass1wThreads), lds, c->p1, a);
+    HIPCHK(hipGetLastError());
+    return PSDR_OK;
+}
+#endif
+
+#define P1CASE(L_, T_)                                                   \
+    if (L == L_ && T == T_) {                                            \
+        if (sb == 2) return launch_pass1_t<L_, T_, 2>(c, a, blocks);     \
+        if (sb == 4) return launch_pass1_t<L_, T_, 4>(c, a, blocks);     \
+        return launch_pass1_t<L_, T_, 8>(c, a, blocks);                  \
+    }
+#define P1PAIR(L_, T_)                                                         \
+    if (L == L_ && T == T_) {                                                  \
+        if (sb == 2) return launch_pass1_t<L_, T_, 2, true>(c, a, blocks);     \
+        if (sb == 4) return launch_pass1_t<L_, T_, 4, true>(c, a, blocks);     \
+        return launch_pass1_t<L_, T_, 8, true>(c, a, blocks);                  \
+    }
+// sb: bytes per complex sample slot of the raw image (2, 4, 8); pair: the real-input form feeding k_fft_pass2_real;
+// wave: the wave-owned kernel (tuning builds)
+int launch_pass1(psdr_ctx *c, int L, int T, int sb, const Pass1Args &a, unsigned blocks, bool pair, bool wave) {
+    if (wave) {
+#ifdef PSDR_TUNING_BUILD
+        return sb == 2 ? launch_pass1_w<2>(c, a, blocks) : launch_pass1_w<4>(c, a, blocks);
+#else
+        return fail(PSDR_ERR_UNSUPPORTED, "the wave-owned first pass exists in tuning builds only");
+#endif
+    }
+    if (pair) {
+        P1PAIR(1024, 16)
+        P1PAIR(2048, 8)
+        return fail(PSDR_ERR_UNSUPPORTED, "no paired pass-1 kernel for L=%d T=%d", L, T);
+    }
+    P1CASE(64, 64)
+    P1CASE(128, 64)
+    P1CASE(128, 128)
+    P1CASE(256, 64)
+    P1CASE(512, 32)
+    P1CASE(1024, 16)
+    P1CASE(1024, 8)
+    P1CASE(2048, 8)
+    return fail(PSDR_ERR_UNSUPPORTED, "no pass-1 kernel for L=%d T=%d", L, T);
+}
+
+}  // namespace psdr

@@ -37,43 +37,14 @@
 
 #include <type_traits>
 
-#include "demod.h"
+#include "butterfly.h"
+#include "types.h"
 
 namespace psdr {
 
-struct PostArgs {
-    const ClientParams *clients;  // active clients (compact), .slot = row block
-    int nact, nframes, max_batch, h;  // h = n/2 samples per frame
-    int slots;
-    int D, L;                         // DC delay, AGC look-ahead (samples)
-    float desired, attack, release;   // AGC
-    const float *audio;               // [slots][max_batch][h]
-    const int *nan_flags;             // [slots][max_batch]
-    int *fstart;                      // [slots][max_batch] stream offset of a frame, -1 = dropped
-    int *len;                         // [slots] samples of this batch's stream
-    size_t px, pv;                    // row pitches (floats per client) of X/M1 and of V1/P/S, multiples of 4
-    int vo;                           // V1 only: leading pad so that its NEW rows (from row L-1) are 16-byte aligned
-    float *X;                         // [slots][px]: demodulated audio, rows < D history          (D + T + pad)
-    float *M1;                        // [slots][px]: first moving average, rows < D history
-    float *V1;                        // [slots][pv]: DC-blocked stream, rows < L-1 history         (L-1 + T + pad)
-    float *V1n;                       // the NEXT batch's V1 (double-buffered: k_pc_history moves the tail there)
-    int hist_sel;                     // k_pc_history: 0 = X and M1, 1 = V1 -> V1n
-    float *P, *S;                     // like V1: prefix / suffix maxima; then S = w_t, P = g_t
-    int32_t *pcm;                     // [slots][max_batch][h]
-    // carried state
-    float *dc_s1, *dc_s2;             // [slots] running sums
-    float *agc_gain;
-    int *agc_n0;  // samples pushed since the last reset, saturating at L
-    int ma_fused;  // k_pc_ma2 keeps M1's history itself (k_pc_history leaves M1 alone)
-};
 
 typedef float pc_f4 __attribute__((ext_vector_type(4)));
 
-#ifndef PSDR_PC_RING
-#define PSDR_PC_RING 16  // register sets of 16 samples in the two recurrence kernels (even, >= 6)
-#endif
-// floats of padding behind every client's stream rows: the recurrence kernels read whole blocks ahead of the stream's end
-#define PSDR_PC_PAD (16 * (PSDR_PC_RING + 4))
 template <int I, int N, typename F>
 __device__ __forceinline__ void pc_static_for(F &&f) {
     if constexpr (I < N) {
