@@ -54,6 +54,8 @@ def lib():
         L.orc_fft_use_library.argtypes = [C.c_char_p]
         L.orc_fft_use_library.restype = i32
         L.orc_fft_library.restype = C.c_char_p
+        L.orc_fft_library_threads.argtypes = [i32]
+        L.orc_fft_library_threads.restype = i32
         L.orc_fft_create.argtypes = [sz, i32, i32, i32, i32]
         L.orc_fft_create.restype = vp
         L.orc_fft_destroy.argtypes = [vp]
@@ -167,6 +169,12 @@ def use_fft_library(path=None):
 
 def fft_library():
     return lib().orc_fft_library().decode()
+
+
+def fft_library_threads(n):
+    """plans created from now on use n threads inside the FFT library (fftwf_plan_with_nthreads, src/fft_impl.cpp:82-88);
+    False when the loaded library has no threads API"""
+    return lib().orc_fft_library_threads(int(n)) == 0
 
 
 def convert(raw, fmt):
@@ -315,9 +323,10 @@ class AudioClient:
             self.l, self.m, self.r = int(l), float(m), int(r)
         return bool(ok)
 
-    def send_audio(self, spectrum, frame_num, fft: "FFT" = None, post=False):
+    def send_audio(self, spectrum, frame_num, fft: "FFT" = None, post=False, stats=True):
         """spectrum: the reference's output buffer (k order, with wrap copy).  Returns
-        (audio_pre[n/2], pwr, pcm[n/2] or None, dropped)."""
+        (audio_pre[n/2], pwr, pcm[n/2] or None, dropped).  stats=False skips the bookkeeping the tests' conditioned
+        bounds use (bb_prev, fwd_scale: a pass over the whole spectrum) - the timed CPU baseline is the C call alone."""
         spectrum = np.ascontiguousarray(spectrum, np.complex64)
         if fft is not None:
             start = fft.slice_ptr_index(self.l)
@@ -331,15 +340,19 @@ class AudioClient:
         pcm = np.zeros(self.n // 2, np.int32) if post else None
         # FM's first sample pairs with the previous frame's last baseband sample (src/signal.cpp:258-262):
         # kept for the tests' conditioned FM bound (tests/helpers.py fm_tolerance)
+        if stats:
+            self._stats(spectrum)
+        rc = lib().orc_client_send_audio(self.h, _p(buf), int(frame_num), _p(audio),
+                                         C.byref(pwr), _p(pcm) if post else None)
+        return audio, pwr.value, pcm, bool(rc)
+
+    def _stats(self, spectrum):
         self.bb_prev = complex(self.baseband()[self.n // 2 - 1])
         # ... and the scale of what the FORWARD transform's rounding contributes to this frame's baseband: rms of the
         # whole spectrum (f32 butterfly errors are proportional to what flows through them, the strong carriers
         # included) times sqrt(bins summed); the previous frame's is kept beside it (FM pairs across the frame edge)
         self.fwd_scale_prev = getattr(self, "fwd_scale", 0.0)
         self.fwd_scale = float(np.sqrt(np.mean(np.abs(spectrum[: self.R].astype(np.complex128)) ** 2)) * np.sqrt(max(self.r - self.l, 1)))
-        rc = lib().orc_client_send_audio(self.h, _p(buf), int(frame_num), _p(audio),
-                                         C.byref(pwr), _p(pcm) if post else None)
-        return audio, pwr.value, pcm, bool(rc)
 
     def real_prev(self):
         addr = lib().orc_client_real_prev(self.h)

@@ -500,6 +500,20 @@ int orc_fft_use_library(const char *path) {
     return 0;
 }
 const char *orc_fft_library(void) { return g_fftlib.handle ? g_fftlib.name : ""; }
+/* Plans created from now on use n threads inside the library, as the reference's FFTW back-end does with
+ * fftwf_init_threads() + fftwf_plan_with_nthreads(nthreads) (src/fft_impl.cpp:82-88).  Returns 0, or -1 when the loaded
+ * library does not export the threads API (MKL's wrappers do; they additionally follow MKL_NUM_THREADS). */
+int orc_fft_library_threads(int n) {
+    if (!g_fftlib.handle) return -1;
+    int (*init_threads)(void) = (int (*)(void))dlsym(g_fftlib.handle, "fftwf_init_threads");
+    void (*with_nthreads)(int) = (void (*)(int))dlsym(g_fftlib.handle, "fftwf_plan_with_nthreads");
+    if (!init_threads || !with_nthreads) return -1;
+    pthread_mutex_lock(&g_plan_mtx);
+    init_threads();
+    with_nthreads(n < 1 ? 1 : n);
+    pthread_mutex_unlock(&g_plan_mtx);
+    return 0;
+}
 
 /* FFT::FFT src/fft_impl.cpp:63-70 + FFTW::plan_c2c :89-103 / plan_r2c :104-117 */
 orc_fft *orc_fft_create(size_t size, int is_real, int downsample_levels,

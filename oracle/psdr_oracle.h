@@ -65,6 +65,7 @@ typedef struct orc_fft orc_fft;
  * forward transform of FFT objects created afterwards; NULL/"" = the built-in transform.  0 = ok. */
 int orc_fft_use_library(const char *path);
 const char *orc_fft_library(void);
+int orc_fft_library_threads(int n);
 orc_fft *orc_fft_create(size_t size, int is_real, int downsample_levels,
                         int brightness_offset, int additional_size);
 void orc_fft_destroy(orc_fft *f);
