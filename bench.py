@@ -473,6 +473,61 @@ def kernel_roofline(ctx, step, first_step, nsteps, wl, wl_name, params, clients,
     return roofline, kernels, ab
 
 
+def c_group_bench(ngpus, steps, warmup, F, ring_mib):
+    """SURVEY 8e from C in ONE process: psdr_group_* (phantomsdr_amd/csrc/group.hip) over `ngpus` devices, RCCL called by
+    the library itself - what the C++ server links (HipFanout with a device list).  cfg4's per-GPU shape (32 clients per
+    GPU); the three shardings of the group, each with its achieved bytes per second over ONE root-to-peer link.
+    With one device the communicator and the collectives are forced (PSDR_SHARD_FORCE_COMM): a plumbing run."""
+    import ctypes as C
+    from phantomsdr_amd import Group
+    from phantomsdr_amd.core import derived_params
+    wl = WORKLOADS["cfg4"]
+    N = wl["fft_size"]
+    p = derived_params(wl["sps"], N, wl["is_real"])
+    nclients = wl["audio"] * ngpus
+    clients = make_clients(dict(wl, audio=nclients), p, seed=0x5D5D0004)
+    rng = np.random.default_rng(4)
+    out = {"devices": ngpus, "frames_per_step": F, "audio_clients": nclients, "forced_single_device": ngpus == 1,
+           "what": "one process, psdr_group_step: root transform -> RCCL exchange -> every device demodulates its clients", "by_shard": {}}
+    for shard in ("band", "clients", "raw"):
+        try:
+            g = Group(list(range(ngpus)), shard, N, wl["is_real"], p["downsample_levels"], force_comm=ngpus == 1,
+                      additional_size=p["audio_fft_size"], audio_fft_size=p["audio_fft_size"], input_format=wl["fmt"], max_batch=F,
+                      max_clients=max(2 * wl["audio"], 1) if shard == "band" else wl["audio"], max_waterfall_clients=1, skip_num=p["skip_num"])
+            root = g.root
+            hb = root.half_frame_bytes()
+            nb = max(2, (ring_mib << 20) // (hb * F))
+            raw = rng.integers(-64, 64, size=(nb * F + 1) * hb // 2, dtype=np.int16)
+            d = root.dev_alloc(raw.nbytes)
+            root.h2d(d, raw)
+            placed = 0
+            for mode, l, m, r in clients:
+                try:
+                    g.client_add(l, m, r, mode)
+                    placed += 1
+                except Exception:
+                    pass  # (band sharding: a band's device is full - the uniformly drawn windows do not split evenly)
+            for i in range(warmup):
+                g.step(d, F, i * F, offset_bytes=(i % nb) * F * hb)
+            g.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                g.step(d, F, (warmup + i) * F, offset_bytes=(i % nb) * F * hb)
+            g.synchronize()
+            dt = time.perf_counter() - t0
+            link_bytes, ex_ms = g.link_stats()
+            out["by_shard"][shard] = {
+                "value": round(steps * F * (N // 2) / dt / 1e6, 2), "ms_per_step": round(dt / steps * 1e3, 4), "clients_placed": placed,
+                "link_bytes_per_step": int(link_bytes), "exchange_ms_last_step": round(ex_ms, 4),
+                "GB_per_s_per_link_during_exchange": round(link_bytes / (ex_ms * 1e-3) / 1e9, 2) if ex_ms > 0 else None,
+                "GB_per_s_per_link_over_the_step": round(link_bytes * steps / dt / 1e9, 2), "link_peak_GB_per_s": 153.0}
+            root.dev_free(d)
+            g.close()
+        except Exception as e:
+            out["by_shard"][shard] = {"error": repr(e)}
+    return out
+
+
 def run_sharded_bench(args, torch, rank, world, local_rank):
     """N > 1, one process per GPU over RCCL.  Three ways to shard the path are measured in the same run;
     `value` is the one --shard names (default: BASELINE.json configs[3]):
@@ -638,7 +693,10 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
         torch.cuda.empty_cache()
         return res
 
-    main_mode = args.shard
+    # `value`: band sharding for IQ workloads (per link and frame 8N/G bytes, pack-free at 2^20 / 2^21 points: the one
+    # client sharding whose ceiling grows with G); the north star's spectrum broadcast (BASELINE.json configs[3], link-bound
+    # at ~9.5 GS/s by construction) is measured in the same run and reported as `north_star_sharding`
+    main_mode = args.shard or ("clients" if WORKLOADS[args.workload or "cfg4"]["is_real"] else "band")
     results = {}
     for m in (main_mode,) + tuple(x for x in ("clients", "clients_pipelined", "raw", "band", "time") if x != main_mode):
         try:
@@ -656,6 +714,29 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
             raise SystemExit("every sharding failed: " + json.dumps(results))
         results["_requested"] = {"shard": main_mode, "error": results[main_mode]["error"]}
         main_mode = ok[0]
+    # SURVEY 8e from C, in the same run: rank 0 starts ONE extra process that drives all N devices through psdr_group_*
+    # (RCCL called by the library).  A child with a timeout: whatever happens to it, this line is still printed; the
+    # other ranks wait on the rendezvous store (host side - a RCCL barrier would keep a kernel spinning on their GPUs).
+    c_group = None
+    if not one_device:
+        try:
+            store = dist.distributed_c10d._get_default_store()
+            if rank == 0:
+                import subprocess
+                try:
+                    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                                           "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+                    rr = subprocess.run([sys.executable, os.path.abspath(__file__), "--c-group-only", str(world), "--steps", "10", "--warmup", "3",
+                                         "--batch", str(args.batch)], capture_output=True, text=True, timeout=240, env=env)
+                    line = [ln for ln in rr.stdout.splitlines() if ln.startswith("{")]
+                    c_group = json.loads(line[-1]) if line else {"error": (rr.stderr or "")[-400:]}
+                except Exception as e:
+                    c_group = {"error": repr(e)}
+                store.set("psdr_c_group_done", "1")
+            else:
+                store.wait(["psdr_c_group_done"])
+        except Exception as e:
+            c_group = {"error": repr(e)}
     if rank == 0:
         r = results[main_mode]
         out = {
@@ -673,6 +754,8 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
             "sharding": {m: {k: v for k, v in results[m].items() if k in ("value", "ms_per_step", "steps", "audio_clients",
                                                                            "parallelism", "xgmi", "error", "workload", "shard")}
                          for m in results},
+            "north_star_sharding": {k: v for k, v in results.get("clients", {}).items() if k in ("value", "ms_per_step", "xgmi", "error")},
+            "c_group": c_group,
             "cpu_baseline": None,
         }
     else:
@@ -818,8 +901,10 @@ def main():
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the clients256 / cfg3 sub-objects (profiling runs of one workload)")
     ap.add_argument("--ring-mib", type=int, default=512)
-    ap.add_argument("--shard", default="clients", choices=["clients", "clients_pipelined", "time", "raw", "band"],
-                    help="N > 1: shard the clients with a spectrum broadcast (BASELINE.json configs[3], default), "
+    ap.add_argument("--shard", default=None, choices=["clients", "clients_pipelined", "time", "raw", "band"],
+                    help="N > 1 (default: band for IQ workloads - the client sharding whose link bytes shrink with N - and "
+                         "clients for real input; every other sharding is measured and reported beside it): "
+                         "shard the clients with a spectrum broadcast (BASELINE.json configs[3]), "
                          "the clients with a RAW half-frame broadcast + replicated FFT, the clients by frequency band "
                          "with a scatter of one band per rank, or the stream (no collective)")
     ap.add_argument("--force-sharded", action="store_true",
@@ -830,6 +915,8 @@ def main():
     ap.add_argument("--cpu-threaded-only", default=None, metavar="WORKLOAD",
                     help="(internal) one CPU pipeline with the FFT library's own threads (--cpu-threads)")
     ap.add_argument("--cpu-threads", type=int, default=8)
+    ap.add_argument("--c-group-only", type=int, default=0, metavar="NGPUS",
+                    help="(internal) ONE process over NGPUS devices through psdr_group_* (RCCL called by the library): prints its JSON")
     args = ap.parse_args()
 
     if args.cpu_baseline_only:
@@ -846,6 +933,10 @@ def main():
         wl = WORKLOADS[args.cpu_threaded_only]
         p = O.derived_params(wl["sps"], wl["fft_size"], wl["is_real"])
         print(json.dumps(cpu_threaded_pipeline(wl, p, args.cpu_threads)), flush=True)
+        return
+
+    if args.c_group_only:
+        print(json.dumps(c_group_bench(args.c_group_only, max(args.steps, 1), args.warmup, args.batch or 256, args.ring_mib)), flush=True)
         return
 
     if args.gpus < 1:
@@ -963,6 +1054,20 @@ def main():
         except Exception as e:
             scaling = {"error": repr(e)}
 
+    # SURVEY 8e from C on this box's one GPU: psdr_group_* with the communicator and the collectives forced (a child
+    # process: RCCL stays out of this one) - shows that the library's own RCCL path runs here; its rates mean nothing
+    # (a broadcast to oneself).  The N > 1 line carries the real thing (`c_group`).
+    c_group = None
+    if not args.no_extra and wl_name == "cfg2":
+        import subprocess
+        try:
+            rr = subprocess.run([sys.executable, os.path.abspath(__file__), "--c-group-only", "1", "--steps", "5", "--warmup", "2",
+                                 "--batch", str(F)], capture_output=True, text=True, timeout=180)
+            line = [ln for ln in rr.stdout.splitlines() if ln.startswith("{")]
+            c_group = json.loads(line[-1]) if line else {"error": (rr.stderr or "")[-400:]}
+        except Exception as e:
+            c_group = {"error": repr(e)}
+
     cpu = None
     if not args.no_cpu_baseline:
         cpu = cpu_baseline_subprocess(wl_name)
@@ -991,6 +1096,7 @@ def main():
         "cfg3": extra.get("cfg3"),
         "cfg5_share": extra.get("cfg5_share"),
         "real_input_client_scaling": scaling,
+        "c_group_single_device_plumbing": c_group,
         "post_chain": post,
         "cpu_baseline": cpu,
     }

@@ -269,6 +269,47 @@ int psdr_quantized_device_ptr(psdr_ctx *ctx, int frame, const int8_t **d_q, size
 int psdr_read_spectrum(psdr_ctx *ctx, int frame, float *out_k_order);
 int psdr_read_quantized(psdr_ctx *ctx, int frame, int8_t *out);
 
+/* ---- multi-GPU from C: ONE process, n devices of a node ---------------------------------------------
+ * Device devices[0] is the root: it owns the raw ring, the forward FFT and the waterfall clients (use
+ * psdr_group_ctx(g, 0) with the psdr_ring_* and psdr_waterfall_* calls above); the audio clients are spread over all n
+ * contexts and every batch is exchanged ONCE over xGMI through RCCL, called directly (librccl.so is dlopen()ed when a
+ * group of more than one device is created; a single-device group never loads it and issues no collective):
+ *   PSDR_SHARD_CLIENTS  ncclBroadcast of the spectrum (BASELINE.json configs[3]); client i lives on device i mod n
+ *   PSDR_SHARD_RAW      ncclBroadcast of the raw half-frames, every device runs the forward FFT itself
+ *   PSDR_SHARD_BAND     device b receives band b of the spectrum + a halo of one maximal window (ncclSend / ncclRecv of
+ *                       1/n of the bytes; n a power of two); a client lives on the device of the band its window starts in
+ * | PSDR_SHARD_FORCE_COMM: create the communicator and issue the collectives even for ONE device (testing the RCCL
+ * plumbing on a single-GPU box).  Everything of a rank is ordered on one stream per device; psdr_group_step returns
+ * without synchronising.  The process-per-GPU twin of this (torch.distributed over RCCL) is phantomsdr_amd/distributed.py.
+ * Time sharding (batch g on device g mod n, no collective) needs no group: n independent contexts. */
+typedef struct psdr_group psdr_group;
+enum { PSDR_SHARD_CLIENTS = 0, PSDR_SHARD_RAW = 1, PSDR_SHARD_BAND = 2, PSDR_SHARD_FORCE_COMM = 0x100 };
+int psdr_group_create(const psdr_config *cfg, const int *devices, int ndevices, int shard, psdr_group **out);
+void psdr_group_destroy(psdr_group *g);
+int psdr_group_size(const psdr_group *g);
+psdr_ctx *psdr_group_ctx(psdr_group *g, int rank);
+/* audio clients: the group picks the device; *gid_out names the client in every psdr_group_client_* / _fetched_* call.
+ * psdr_group_client_set_audio_range: band sharding moves a client whose window now starts in another band to that
+ * band's device (*gid changes; the overlap-add tail does not travel: one frame starts from silence). */
+int psdr_group_client_add(psdr_group *g, int l, double audio_mid, int r, int mode, int *gid_out);
+int psdr_group_client_remove(psdr_group *g, int gid);
+int psdr_group_client_set_audio_range(psdr_group *g, int *gid, int l, double audio_mid, int r);
+int psdr_group_client_set_audio_demodulation(psdr_group *g, int gid, int mode);
+int psdr_group_client_set_paused(psdr_group *g, int gid, int paused);
+/* one batch: the root transforms nframes frames (d_halves_root: nframes + 1 raw half-frames on the ROOT device; _ring:
+ * the root context's ingest ring from first_half on), the exchange, every device demodulates its clients, the root
+ * gathers the waterfall rows (psdr_demod_batch + psdr_waterfall_batch of a single context, for the whole group) */
+int psdr_group_step(psdr_group *g, const void *d_halves_root, int nframes, uint64_t first_frame_num);
+int psdr_group_step_ring(psdr_group *g, uint64_t first_half, int nframes, uint64_t first_frame_num);
+int psdr_group_synchronize(psdr_group *g);
+/* bytes that crossed ONE root-to-peer link in the last step, and the exchange's duration on the root's stream */
+int psdr_group_link_stats(psdr_group *g, double *bytes_per_link, double *exchange_ms);
+/* psdr_fetch_batch on every device, then psdr_fetched_audio / psdr_fetched_window by gid */
+int psdr_group_fetch(psdr_group *g);
+int psdr_group_fetched_audio(psdr_group *g, int gid, int frame, const float **audio, float *pwr, int32_t *nan_flag,
+                             const int32_t **pcm);
+int psdr_group_fetched_window(psdr_group *g, int gid, int *l, double *audio_mid, int *r);
+
 /* ---- wire formats of the reference's packets (host side) ----------------------- */
 /* The CBOR map nlohmann::json::to_cbor produces in AudioEncoder::send (src/audio.cpp:17-36):
  * {"data": payload, "frame_num", "l", "m", "pwr", "r"} (keys in std::map order, shortest integer

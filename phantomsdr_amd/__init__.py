@@ -8,7 +8,7 @@ Importing this package requires the built HIP library (phantomsdr_amd/libpsdr_hi
 there is no CPU implementation behind it.
 """
 from ._lib import PsdrError, load  # noqa: F401
-from .core import (AM, FM, LSB, MODES, USB, AudioClient, Context, HipFFT,  # noqa: F401
+from .core import (AM, FM, LSB, MODES, USB, AudioClient, Context, Group, HipFFT,  # noqa: F401
                    SpectrumEngine, WaterfallClient, derived_params)
 
 load()  # fail loudly at import time if the extension is missing

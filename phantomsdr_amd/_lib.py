@@ -101,6 +101,23 @@ SYMBOLS = [
     ("psdr_timer_stop_ms", _i, [_vp, C.POINTER(C.c_double)]),
     ("psdr_stream", _vp, [_vp]),
     ("psdr_set_stream", _i, [_vp, _vp]),
+    ("psdr_group_create", _i, [C.POINTER(psdr_config), C.POINTER(_i), _i, _i, _pp]),
+    ("psdr_group_destroy", None, [_vp]),
+    ("psdr_group_size", _i, [_vp]),
+    ("psdr_group_ctx", _vp, [_vp, _i]),
+    ("psdr_group_client_add", _i, [_vp, _i, C.c_double, _i, _i, C.POINTER(_i)]),
+    ("psdr_group_client_remove", _i, [_vp, _i]),
+    ("psdr_group_client_set_audio_range", _i, [_vp, C.POINTER(_i), _i, C.c_double, _i]),
+    ("psdr_group_client_set_audio_demodulation", _i, [_vp, _i, _i]),
+    ("psdr_group_client_set_paused", _i, [_vp, _i, _i]),
+    ("psdr_group_step", _i, [_vp, _vp, _i, _u64]),
+    ("psdr_group_step_ring", _i, [_vp, _u64, _i, _u64]),
+    ("psdr_group_synchronize", _i, [_vp]),
+    ("psdr_group_link_stats", _i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("psdr_group_fetch", _i, [_vp]),
+    ("psdr_group_fetched_audio", _i, [_vp, _i, _i, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_float), C.POINTER(C.c_int32),
+                                      C.POINTER(C.POINTER(C.c_int32))]),
+    ("psdr_group_fetched_window", _i, [_vp, _i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 ]
 
 _lib = None

@@ -8,8 +8,9 @@ from concurrent.futures import ThreadPoolExecutor
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 # context: lifetime / Level 1 / ingest / instrumentation; pass1, pass2: the FFT pass launchers; forward: the frame loop,
-# read-back, band layout, waterfall; demod: audio clients; postchain: DC blocker / AGC / int16; wire: packet formats
-UNITS = ["context", "pass1", "pass2", "forward", "demod", "postchain", "wire"]
+# read-back, band layout, waterfall; demod: audio clients; postchain: DC blocker / AGC / int16; group: n GPUs from one
+# process over RCCL; wire: packet formats
+UNITS = ["context", "pass1", "pass2", "forward", "demod", "postchain", "group", "wire"]
 OUT = os.path.join(_HERE, "libpsdr_hip.so")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-fPIC"]

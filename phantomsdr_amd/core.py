@@ -47,10 +47,10 @@ def _ptr(a):
 class Context:
     """Owns one psdr_ctx."""
 
-    def __init__(self, fft_size, is_real, downsample_levels, brightness_offset=0,
-                 additional_size=0, audio_fft_size=0, audio_rate=12000, input_format="f32",
-                 device=0, max_batch=1, max_clients=1, max_waterfall_clients=1, skip_num=1, waterfall_size=0):
-        self.lib = _lib.load()
+    @staticmethod
+    def _config(fft_size, is_real, downsample_levels, brightness_offset=0,
+                additional_size=0, audio_fft_size=0, audio_rate=12000, input_format="f32",
+                device=0, max_batch=1, max_clients=1, max_waterfall_clients=1, skip_num=1, waterfall_size=0):
         cfg = psdr_config()
         cfg.struct_size = C.sizeof(psdr_config)
         cfg.fft_size = fft_size
@@ -67,27 +67,52 @@ class Context:
         cfg.max_waterfall_clients = max_waterfall_clients
         cfg.skip_num = skip_num
         cfg.waterfall_size = waterfall_size
-        self.cfg = cfg
+        return cfg
+
+    def __init__(self, fft_size, is_real, downsample_levels, brightness_offset=0,
+                 additional_size=0, audio_fft_size=0, audio_rate=12000, input_format="f32",
+                 device=0, max_batch=1, max_clients=1, max_waterfall_clients=1, skip_num=1, waterfall_size=0):
+        self.lib = _lib.load()
+        cfg = Context._config(fft_size, is_real, downsample_levels, brightness_offset, additional_size, audio_fft_size,
+                              audio_rate, input_format, device, max_batch, max_clients, max_waterfall_clients, skip_num,
+                              waterfall_size)
         self.h = C.c_void_p()
         check(self.lib.psdr_create(C.byref(cfg), C.byref(self.h)))
+        self._owned = True
+        self._describe(cfg)
+
+    @classmethod
+    def _view(cls, lib, handle, cfg):
+        """a Context object over a psdr_ctx somebody else owns (a psdr_group's member): close() leaves it alone"""
+        self = cls.__new__(cls)
+        self.lib = lib
+        self.h = C.c_void_p(handle)
+        self._owned = False
+        self._describe(cfg)
+        return self
+
+    def _describe(self, cfg):
+        self.cfg = cfg
+        fft_size, is_real = cfg.fft_size, bool(cfg.is_real)
         self.N = fft_size
-        self.is_real = bool(is_real)
+        self.is_real = is_real
         self.R = fft_size // 2 if is_real else fft_size
-        self.levels = downsample_levels
-        self.n = audio_fft_size
-        self.max_batch = max_batch
-        self.q_len = sum(self.R >> i for i in range(downsample_levels))
+        self.levels = cfg.downsample_levels
+        self.n = cfg.audio_fft_size
+        self.max_batch = cfg.max_batch
+        self.q_len = sum(self.R >> i for i in range(cfg.downsample_levels))
         self.nbins = fft_size // 2 + 1 if is_real else fft_size
         self.last_nframes = 0
         self.last_demod_frames = 0
-        self.input_format = input_format
+        self.input_format = cfg.input_format
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
             for p in getattr(self, "_pinned", []):
                 self.lib.psdr_host_free(self.h, p)
             self._pinned = []
-            self.lib.psdr_destroy(self.h)
+            if getattr(self, "_owned", True):
+                self.lib.psdr_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -415,6 +440,77 @@ class WaterfallClient:
         if self.id >= 0 and self.ctx.h:
             check(self.ctx.lib.psdr_waterfall_remove(self.ctx.h, self.id))
             self.id = -1
+
+
+class Group:
+    """psdr_group (include/psdr.h): one process, n GPUs, the batch exchanged over xGMI through RCCL called from C.
+    shard: "clients" | "raw" | "band"; force_comm: issue the collectives even with one device (testing)."""
+    SHARDS = {"clients": 0, "raw": 1, "band": 2}
+
+    def __init__(self, devices, shard, fft_size, is_real, downsample_levels, force_comm=False, **ctx_kwargs):
+        # a throw-away Context object only to build the psdr_config the same way Context does
+        self.lib = _lib.load()
+        cfg = Context._config(fft_size, is_real, downsample_levels, **ctx_kwargs)
+        devs = (C.c_int * len(devices))(*devices)
+        self.h = C.c_void_p()
+        flag = self.SHARDS[shard] | (0x100 if force_comm else 0)
+        check(self.lib.psdr_group_create(C.byref(cfg), devs, len(devices), flag, C.byref(self.h)))
+        self.n = len(devices)
+        self.cfg = cfg
+        self.h_audio = cfg.audio_fft_size // 2
+        self.root = Context._view(self.lib, self.lib.psdr_group_ctx(self.h, 0), cfg)
+
+    def client_add(self, l, mid, r, mode):
+        gid = C.c_int(-1)
+        mode = MODES[mode] if isinstance(mode, str) else int(mode)
+        check(self.lib.psdr_group_client_add(self.h, int(l), float(mid), int(r), mode, C.byref(gid)))
+        return gid.value
+
+    def client_set_audio_range(self, gid, l, mid, r):
+        g = C.c_int(gid)
+        check(self.lib.psdr_group_client_set_audio_range(self.h, C.byref(g), int(l), float(mid), int(r)))
+        return g.value
+
+    def client_set_paused(self, gid, paused):
+        check(self.lib.psdr_group_client_set_paused(self.h, gid, 1 if paused else 0))
+
+    def step(self, d_halves, nframes, first_frame_num, offset_bytes=0):
+        base = d_halves.value if isinstance(d_halves, C.c_void_p) else int(d_halves)
+        check(self.lib.psdr_group_step(self.h, C.c_void_p(base + offset_bytes), nframes, first_frame_num))
+        self.root.last_nframes = self.root.last_demod_frames = nframes
+
+    def step_ring(self, first_half, nframes, first_frame_num):
+        check(self.lib.psdr_group_step_ring(self.h, first_half, nframes, first_frame_num))
+        self.root.last_nframes = self.root.last_demod_frames = nframes
+
+    def synchronize(self):
+        check(self.lib.psdr_group_synchronize(self.h))
+
+    def fetch(self):
+        check(self.lib.psdr_group_fetch(self.h))
+
+    def fetched_audio(self, gid, frame):
+        """(audio[n/2] copy, pwr, nan flag) of one frame of the fetched batch"""
+        a = C.POINTER(C.c_float)()
+        pw, nan = C.c_float(0), C.c_int32(0)
+        check(self.lib.psdr_group_fetched_audio(self.h, gid, frame, C.byref(a), C.byref(pw), C.byref(nan), None))
+        return np.ctypeslib.as_array(a, shape=(self.h_audio,)).copy(), pw.value, nan.value
+
+    def link_stats(self):
+        b, ms = C.c_double(0), C.c_double(0)
+        check(self.lib.psdr_group_link_stats(self.h, C.byref(b), C.byref(ms)))
+        return b.value, ms.value
+
+    def close(self):
+        if self.h:
+            self.lib.psdr_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class SpectrumEngine:

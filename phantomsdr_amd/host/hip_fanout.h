@@ -30,6 +30,12 @@ class HipFanout {
         int max_audio_clients, max_waterfall_clients;
         bool post_chain;           // DC blocker + AGC + int16 on the GPU too
         int ring_halves;           // half-frames of raw samples kept in HBM (>= 3)
+        // more than one GPU of the node: devices[0] owns the ring, the FFT and the waterfall clients, the
+        // audio clients are spread over all of them and every frame's spectrum crosses xGMI once (psdr_group_*,
+        // RCCL called from the library).  Empty = device 0 alone.
+        std::vector<int> devices;
+        int shard = PSDR_SHARD_CLIENTS;  // PSDR_SHARD_CLIENTS | _RAW | _BAND
+        bool force_group = false;        // the group path (and RCCL) even with one device: testing
     };
     // (the constructor and the frame loop's own calls throw std::runtime_error on failure: they run on the server's
     // main / fft_task threads, where the reference's own set-up throws too)
@@ -49,11 +55,24 @@ class HipFanout {
         cfg.max_waterfall_clients = p.max_waterfall_clients;
         cfg.skip_num = p.skip_num;
         cfg.waterfall_size = p.min_waterfall_fft;
-        chk(psdr_create(&cfg, &ctx));
+        if (p.devices.size() > 1 || p.force_group) {
+            const std::vector<int> devs = p.devices.empty() ? std::vector<int>{0} : p.devices;
+            chk(psdr_group_create(&cfg, devs.data(), (int)devs.size(), p.shard | (p.force_group ? PSDR_SHARD_FORCE_COMM : 0), &grp));
+            ctx = psdr_group_ctx(grp, 0);
+        } else {
+            cfg.device = p.devices.empty() ? 0 : p.devices[0];
+            chk(psdr_create(&cfg, &ctx));
+        }
         chk(psdr_ring_create(ctx, p.ring_halves));
-        if (p.post_chain) chk(psdr_set_post_chain(ctx, 1));
+        if (p.post_chain)
+            for (int r = 0; r < ranks(); r++) chk(psdr_set_post_chain(rank_ctx(r), 1));
     }
-    ~HipFanout() { psdr_destroy(ctx); }
+    ~HipFanout() {
+        if (grp)
+            psdr_group_destroy(grp);
+        else
+            psdr_destroy(ctx);
+    }
     HipFanout(const HipFanout &) = delete;
     HipFanout &operator=(const HipFanout &) = delete;
 
@@ -82,6 +101,11 @@ class HipFanout {
         if (next_half < 2) return false;
         const uint64_t first = next_half - 2;
         // a frame window must not cross the ring end more than by the guard half-frame
+        if (grp) {  // the root transforms, the spectrum crosses xGMI, every GPU demodulates its clients
+            chk(psdr_group_step_ring(grp, first, 1, frame_num));
+            have_audio = psdr_group_fetch(grp) == PSDR_OK;
+            return true;
+        }
         chk(psdr_process_ring(ctx, first, 1));
         chk(psdr_demod_batch(ctx, frame_num));                                         // signal_loop()
         if (frame_num % (uint64_t)prm.skip_num == 0) chk(psdr_waterfall_batch(ctx, frame_num));  // waterfall_loop()
@@ -93,22 +117,43 @@ class HipFanout {
     // The hooks below run on websocket / asio handler threads inside AudioClient::set_audio_range and
     // ::set_audio_demodulation, which never throw in the reference: they report failure through their return value
     // (the previous window / mode stays in force on the GPU) instead of an exception.
+    // (with more than one GPU the id is the group's: it names the device as well; band sharding needs the window to pick
+    // the device, so a client is created at its first set_audio_range there)
     int add_audio_client() {
         int id = -1;
+        if (grp) return psdr_group_client_add(grp, 0, 0.0, 0, PSDR_USB, &id) == PSDR_OK ? id : -1;
         return psdr_client_add(ctx, &id) == PSDR_OK ? id : -1;
     }
     void remove_audio_client(int id) {
-        if (id >= 0) psdr_client_remove(ctx, id);
+        if (id < 0) return;
+        if (grp)
+            psdr_group_client_remove(grp, id);
+        else
+            psdr_client_remove(ctx, id);
     }
-    bool set_audio_range(int id, int l, double m, int r) { return id >= 0 && psdr_client_set_audio_range(ctx, id, l, m, r) == PSDR_OK; }
-    bool on_audio_window_message(int id, int l, double m, int r) {
-        return id >= 0 && psdr_client_on_window_message(ctx, id, l, m, r) == PSDR_OK;  // false: the reference returns silently
+    // (group: the id may CHANGE when band sharding moves the client to another GPU - the caller keeps the returned one)
+    bool set_audio_range(int &id, int l, double m, int r) {
+        if (id < 0) return false;
+        return (grp ? psdr_group_client_set_audio_range(grp, &id, l, m, r) : psdr_client_set_audio_range(ctx, id, l, m, r)) == PSDR_OK;
     }
-    bool set_audio_demodulation(int id, psdr_mode mode) { return id >= 0 && psdr_client_set_audio_demodulation(ctx, id, mode) == PSDR_OK; }
+    bool on_audio_window_message(int &id, int l, double m, int r) {
+        if (id < 0) return false;
+        if (!grp) return psdr_client_on_window_message(ctx, id, l, m, r) == PSDR_OK;  // false: the reference returns silently
+        const int R = (int)(prm.is_real ? prm.fft_size / 2 : prm.fft_size);           // src/signal.cpp:305-311
+        if (l < 0 || l >= R || r < 0 || r >= R || l > r || r - l > prm.audio_max_fft_size) return false;
+        return psdr_group_client_set_audio_range(grp, &id, l, m, r) == PSDR_OK;
+    }
+    bool set_audio_demodulation(int id, psdr_mode mode) {
+        if (id < 0) return false;
+        return (grp ? psdr_group_client_set_audio_demodulation(grp, id, mode) : psdr_client_set_audio_demodulation(ctx, id, mode)) == PSDR_OK;
+    }
     // signal_loop's slow-client rule (src/websocket.cpp:170-176): no send_audio call at all for a client whose socket is
     // backed up - its overlap-add tails, FM sample, DC blocker and AGC stand still.  Called by the frame loop BEFORE
     // process_frame() for every audio client (hip_level2.h).
-    bool set_audio_paused(int id, bool paused) { return id >= 0 && psdr_client_set_paused(ctx, id, paused ? 1 : 0) == PSDR_OK; }
+    bool set_audio_paused(int id, bool paused) {
+        if (id < 0) return false;
+        return (grp ? psdr_group_client_set_paused(grp, id, paused ? 1 : 0) : psdr_client_set_paused(ctx, id, paused ? 1 : 0)) == PSDR_OK;
+    }
     // the tail of send_audio for one client (asio pool): pointers into the block process_frame() fetched; no device
     // call.  Returns false when there is nothing to send: the reference would have dropped the frame (NaN guard,
     // src/signal.cpp:266-271), the client was paused for this frame, or it attached after the frame was demodulated.
@@ -124,7 +169,13 @@ class HipFanout {
     };
     bool fetch_audio(int id, AudioFrame *out) {
         int32_t nan = 0;
-        if (!have_audio || id < 0 || psdr_fetched_audio(ctx, id, 0, &out->audio, &out->average_power, &nan, &out->pcm) != PSDR_OK) return false;
+        if (!have_audio || id < 0) return false;
+        if (grp) {
+            if (psdr_group_fetched_audio(grp, id, 0, &out->audio, &out->average_power, &nan, &out->pcm) != PSDR_OK) return false;
+            if (psdr_group_fetched_window(grp, id, &out->l, &out->m, &out->r) != PSDR_OK) return false;
+            return nan == 0;
+        }
+        if (psdr_fetched_audio(ctx, id, 0, &out->audio, &out->average_power, &nan, &out->pcm) != PSDR_OK) return false;
         if (psdr_fetched_window(ctx, id, &out->l, &out->m, &out->r) != PSDR_OK) return false;
         return nan == 0;
     }
@@ -151,11 +202,14 @@ class HipFanout {
         *r_label = r << lv;
         return true;
     }
-    psdr_ctx *context() { return ctx; }
+    psdr_ctx *context() { return ctx; }  // (the root's: ring, FFT, waterfall clients)
     bool post_chain() const { return prm.post_chain; }
+    int ranks() const { return grp ? psdr_group_size(grp) : 1; }
 
   private:
+    psdr_ctx *rank_ctx(int r) { return grp ? psdr_group_ctx(grp, r) : ctx; }
     psdr_ctx *ctx;
+    psdr_group *grp = nullptr;
     Params prm;
     uint64_t next_half;
     bool have_audio = false;

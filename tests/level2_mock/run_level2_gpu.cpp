@@ -103,7 +103,7 @@ struct Event {
 struct TestSetup {
     static int run(const char *script, const char *rawfile, const char *outfile) {
         // ---- the script
-        int log2n = 16, is_real = 0, sps = 2048000, post_chain = 0, brightness = 0, audio_sps = 12000, wf_size = 1024;
+        int log2n = 16, is_real = 0, sps = 2048000, post_chain = 0, brightness = 0, audio_sps = 12000, wf_size = 1024, group = 0, shard = 0;
         std::string fmt = "s16";
         struct CSpec {
             int mode, l, r;
@@ -119,7 +119,7 @@ struct TestSetup {
                 std::istringstream ss(line);
                 std::string w;
                 if (!(ss >> w) || w[0] == '#') continue;
-                if (w == "config") ss >> log2n >> is_real >> sps >> fmt >> post_chain >> brightness >> audio_sps >> wf_size;
+                if (w == "config") ss >> log2n >> is_real >> sps >> fmt >> post_chain >> brightness >> audio_sps >> wf_size >> group >> shard;
                 else if (w == "client") {
                     CSpec c{};
                     ss >> c.mode >> c.l >> c.m >> c.r;
@@ -160,6 +160,8 @@ struct TestSetup {
         hp.max_audio_clients = 16, hp.max_waterfall_clients = 8;
         hp.post_chain = post_chain != 0;
         hp.ring_halves = 8;
+        hp.force_group = group != 0;  // the multi-GPU path (psdr_group_*, RCCL from the library) on the one device of the box
+        hp.shard = shard;
         srv.fanout = std::make_unique<HipFanout>(hp);
         HipFanout &fo = *srv.fanout;
         // ---- clients, attached the way the patched server does it (integration/level2.patch: psdr_attach + the hooks

@@ -1,0 +1,164 @@
+"""psdr_group_* (include/psdr.h): SURVEY 8e from C - one process, n GPUs, the batch exchanged through RCCL called
+directly (phantomsdr_amd/csrc/group.hip).  Whatever the sharding, every client's audio must be the SAME BITS as on a
+single plain context (the same kernels run on the same spectra; only where they run differs).
+
+* one device with PSDR_SHARD_FORCE_COMM: the whole group path including librccl.so's dlopen, ncclCommInitAll and the
+  collectives (a broadcast to oneself; the band path's pack) - what a single-GPU box can exercise;
+* two and more devices: skipped unless the box has them."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import quantize_raw, synth_stream
+from test_gpu_parity import levels_for
+
+pytestmark = pytest.mark.gpu
+
+
+def _ndev():
+    hip = C.CDLL("libamdhip64.so")
+    n = C.c_int(0)
+    return n.value if hip.hipGetDeviceCount(C.byref(n)) == 0 else 0
+
+
+def _clients(N, R, n, count):
+    rng = np.random.default_rng(5)
+    out = []
+    for i in range(count):
+        mode = ("USB", "LSB", "AM", "FM")[i % 4]
+        # spread over the whole spectrum so that every band / every rank gets some
+        m = int((i + 0.5) * R / count + rng.integers(-50, 50))
+        m = min(max(m, 200), R - 200)
+        w = 60
+        l, r = (m, m + w) if mode == "USB" else (m - w, m) if mode == "LSB" else (m - w, m + w)
+        out.append((mode, l, float(m) + (0.5 if i % 3 == 0 else 0.0), r))
+    return out
+
+
+def _run_plain(N, is_real, n, F, nb, raw, clients, levels):
+    from phantomsdr_amd import AudioClient, Context
+    ctx = Context(N, is_real, levels, additional_size=n, audio_fft_size=n, input_format="s16", max_batch=F,
+                  max_clients=len(clients), max_waterfall_clients=2)
+    try:
+        d = ctx.dev_alloc(raw.nbytes)
+        ctx.h2d(d, raw)
+        gcl = []
+        for mode, l, m, r in clients:
+            g = AudioClient(ctx)
+            g.set_audio_demodulation(mode)
+            g.set_audio_range(l, m, r)
+            gcl.append(g)
+        hb = ctx.half_frame_bytes()
+        out = []
+        for b in range(nb):
+            ctx.process_batch(d, F, offset_bytes=b * F * hb)
+            ctx.demod_batch(b * F)
+            out.append([g.read_audio(F) for g in gcl])
+        spec = ctx.read_spectrum(F - 1)
+        q = ctx.read_quantized(F - 1)
+        ctx.dev_free(d)
+        return out, spec, q
+    finally:
+        ctx.close()
+
+
+def _run_group(devices, shard, force, N, is_real, n, F, nb, raw, clients, levels):
+    from phantomsdr_amd import Group
+    g = Group(devices, shard, N, is_real, levels, force_comm=force, additional_size=n, audio_fft_size=n, input_format="s16",
+              max_batch=F, max_clients=len(clients), max_waterfall_clients=2)
+    try:
+        root = g.root
+        d = root.dev_alloc(raw.nbytes)
+        root.h2d(d, raw)
+        gids = [g.client_add(l, m, r, mode) for mode, l, m, r in clients]
+        ranks = sorted({gid >> 16 for gid in gids})
+        hb = root.half_frame_bytes()
+        out = []
+        links = []
+        for b in range(nb):
+            g.step(d, F, b * F, offset_bytes=b * F * hb)
+            g.fetch()
+            links.append(g.link_stats())
+            batch = []
+            for gid in gids:
+                rows = [g.fetched_audio(gid, f) for f in range(F)]
+                batch.append((np.stack([x[0] for x in rows]), np.array([x[1] for x in rows], np.float32),
+                              np.array([x[2] for x in rows], np.int32)))
+            out.append(batch)
+        g.synchronize()
+        spec = root.read_spectrum(F - 1)
+        q = root.read_quantized(F - 1)
+        root.dev_free(d)
+        return out, spec, q, ranks, links
+    finally:
+        g.close()
+
+
+def _same(a, b, tag):
+    for bi, (ba, bb) in enumerate(zip(a, b)):
+        for ci, (ca, cb) in enumerate(zip(ba, bb)):
+            for name, u, v in zip(("audio", "pwr", "nan"), ca, cb):
+                u, v = np.asarray(u), np.asarray(v)
+                assert np.array_equal(u.view(np.uint32) if u.dtype == np.float32 else u, v.view(np.uint32) if v.dtype == np.float32 else v), \
+                    f"{tag}: batch {bi} client {ci} {name} differs"
+
+
+CASES = [(1 << 16, 0, 248), (1 << 20, 0, 360), (1 << 17, 1, 248)]
+
+
+@pytest.mark.parametrize("shard", ["clients", "raw", "band"])
+@pytest.mark.parametrize("N,is_real,n", CASES)
+def test_single_device_group_with_forced_rccl_matches_a_plain_context(shard, N, is_real, n):
+    F, nb = 4, 3
+    R = N // 2 if is_real else N
+    levels = levels_for(R)
+    x = synth_stream((nb * F + 1) * (N // 2), bool(is_real), seed=21, fft_size=N)
+    raw = quantize_raw(x, "s16", bool(is_real))
+    clients = _clients(N, R, n, 12)
+    ref, spec_r, q_r = _run_plain(N, is_real, n, F, nb, raw, clients, levels)
+    got, spec_g, q_g, ranks, links = _run_group([0], shard, True, N, is_real, n, F, nb, raw, clients, levels)
+    _same(ref, got, f"{shard} N=2^{N.bit_length() - 1}")
+    assert np.array_equal(spec_r.view(np.uint32), spec_g.view(np.uint32)) and np.array_equal(q_r, q_g)
+    assert ranks == [0]
+    if shard != "band":  # (a one-device band group has nothing to send)
+        assert links[-1][0] > 0 and links[-1][1] > 0, links  # bytes crossed the (self) link, the exchange took time: RCCL ran
+
+
+@pytest.mark.skipif(_ndev() < 2, reason="needs two HIP devices")
+@pytest.mark.parametrize("ndev", [2, 4, 8])
+@pytest.mark.parametrize("shard", ["clients", "raw", "band"])
+@pytest.mark.parametrize("N,is_real,n", CASES)
+def test_multi_device_group_matches_a_plain_context(shard, N, is_real, n, ndev):
+    if _ndev() < ndev:
+        pytest.skip(f"needs {ndev} HIP devices")
+    F, nb = 4, 3
+    R = N // 2 if is_real else N
+    levels = levels_for(R)
+    x = synth_stream((nb * F + 1) * (N // 2), bool(is_real), seed=21, fft_size=N)
+    raw = quantize_raw(x, "s16", bool(is_real))
+    clients = _clients(N, R, n, 24)
+    ref, spec_r, q_r = _run_plain(N, is_real, n, F, nb, raw, clients, levels)
+    got, spec_g, q_g, ranks, links = _run_group(list(range(ndev)), shard, False, N, is_real, n, F, nb, raw, clients, levels)
+    _same(ref, got, f"{shard} x{ndev} N=2^{N.bit_length() - 1}")
+    assert np.array_equal(spec_r.view(np.uint32), spec_g.view(np.uint32)) and np.array_equal(q_r, q_g)
+    assert ranks == list(range(ndev)), "every device serves clients"
+    assert links[-1][0] > 0 and links[-1][1] > 0
+
+
+def test_group_argument_errors():
+    from phantomsdr_amd import Group, PsdrError
+    with pytest.raises(PsdrError) as e:
+        Group([0, 0], "clients", 1 << 16, False, 7, audio_fft_size=248, additional_size=248)
+    assert e.value.code == -1 and "twice" in str(e.value)
+    if _ndev() >= 3:
+        with pytest.raises(PsdrError) as e:
+            Group([0, 1, 2], "band", 1 << 16, False, 7, audio_fft_size=248, additional_size=248)
+        assert e.value.code == -1
+    g = Group([0], "band", 1 << 16, False, 7, audio_fft_size=248, additional_size=248, max_clients=4)
+    try:
+        gid = g.client_add(100, 100.0, 160, "USB")
+        assert gid >> 16 == 0
+        assert g.client_set_audio_range(gid, 60000, 60000.0, 60060) == gid  # one band: nothing to migrate to
+    finally:
+        g.close()

@@ -56,12 +56,17 @@ def _parse(path):
 MODE = {"USB": 0, "LSB": 1, "AM": 2, "FM": 3}
 
 
-@pytest.mark.parametrize("log2n,is_real,sps,fmt,post_chain,brightness", [
-    (16, 0, 2_048_000, "s16", 1, 0),   # DC blocker + AGC + int16 on the GPU
-    (16, 0, 2_048_000, "u8", 0, 3),    # ... on the CPU (the mock server's chain = the reference's classes), brightness_offset 3
-    (17, 1, 4_096_000, "s16", 1, -2),  # real input
+@pytest.mark.parametrize("log2n,is_real,sps,fmt,post_chain,brightness,group", [
+    (16, 0, 2_048_000, "s16", 1, 0, None),   # DC blocker + AGC + int16 on the GPU
+    (16, 0, 2_048_000, "u8", 0, 3, None),    # ... on the CPU (the mock server's chain = the reference's classes), brightness_offset 3
+    (17, 1, 4_096_000, "s16", 1, -2, None),  # real input
+    # HipFanout's multi-GPU path (psdr_group_*: RCCL called from the library) on the one device of the box, communicator
+    # and collectives forced: spectrum broadcast, raw broadcast, band sharding
+    (16, 0, 2_048_000, "s16", 1, 0, 0),
+    (16, 0, 2_048_000, "s16", 0, 0, 1),
+    (17, 1, 4_096_000, "s16", 1, 0, 2),
 ])
-def test_level2_adapters_on_the_gpu_match_the_oracle(log2n, is_real, sps, fmt, post_chain, brightness):
+def test_level2_adapters_on_the_gpu_match_the_oracle(log2n, is_real, sps, fmt, post_chain, brightness, group):
     from oracle import oracle as O
     d = _mkdtemp()
     exe = _build(d, os.path.join(ROOT, "tests", "level2_mock", "run_level2_gpu.cpp"), "run_level2_gpu")
@@ -84,7 +89,7 @@ def test_level2_adapters_on_the_gpu_match_the_oracle(log2n, is_real, sps, fmt, p
     mode_ev = {(4, 30): "AM", (1, 44): "AM"}                       # (client, frame) -> new mode
     win_ev = {(4, 40): (am + 7, am + 40.5, am + 120), (0, 52): (R - 10, float(R), R + 40)}  # the second is refused by the GPU
     with open(os.path.join(d, "script.txt"), "w") as f:
-        f.write(f"config {log2n} {is_real} {sps} {fmt} {post_chain} {brightness} 12000 1024\n")
+        f.write(f"config {log2n} {is_real} {sps} {fmt} {post_chain} {brightness} 12000 1024 {0 if group is None else 1} {group or 0}\n")
         for mode, l, m, r in clients:
             f.write(f"client {MODE[mode]} {l} {m!r} {r}\n")
         for l, r in wfs:
