@@ -47,6 +47,10 @@ WORKLOADS = {
                        modes=("USB", "LSB", "AM", "FM"),
                        desc="35 MSPS IQ cs16, 2^20-pt C2C, 256 mixed USB/LSB/AM/FM audio + 4 waterfall clients"),
 }
+# frames per step: the latency / throughput knob (batch-size table).  A step of the two persistent passes has
+# ~60-80 us of fixed cost (ramp, prologue, tail, the gaps between the kernels) whatever F is: 96.5 GS/s at F = 256, 99.9 at 512, 100.5
+# at 1024 on one box.  512 frames of cfg2 are 7.7 s of a 35 MSPS stream and 13 GB of the 288 GB of HBM.
+DEFAULT_BATCH = 512
 SAMPLE_BYTES = {"u8": 1, "s8": 1, "u16": 2, "s16": 2, "f32": 4, "f64": 8}
 
 
@@ -891,7 +895,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=0,
-                    help="frames per step (F); default 256: a step of the two persistent passes has ~60 us of "
+                    help="frames per step (F); default 512 (DEFAULT_BATCH): a step of the two persistent passes has ~60 us of "
                          "fixed cost (ramp, prologue, tail, launch gaps) whatever F is (DESIGN.md, batch-size table)")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -936,7 +940,7 @@ def main():
         return
 
     if args.c_group_only:
-        print(json.dumps(c_group_bench(args.c_group_only, max(args.steps, 1), args.warmup, args.batch or 256, args.ring_mib)), flush=True)
+        print(json.dumps(c_group_bench(args.c_group_only, max(args.steps, 1), args.warmup, args.batch or DEFAULT_BATCH, args.ring_mib)), flush=True)
         return
 
     if args.gpus < 1:
@@ -955,7 +959,7 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s): refusing to report a "
                              f"{world}-GPU run as a {args.gpus}-GPU one")
     if args.batch <= 0:
-        args.batch = 256
+        args.batch = DEFAULT_BATCH
 
     import torch
     if not torch.cuda.is_available():

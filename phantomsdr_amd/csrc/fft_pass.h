@@ -467,6 +467,47 @@ struct Pass1Args {
 // the raw words of two adjacent complex samples (columns 2p, 2p+1 of one row) -> c2
 // (src/samplereader.cpp:29-40): unsigned formats flip the MSB, integers are divided by
 // 2^(bits-1) (exact: multiply by the reciprocal).
+// One instruction per component: v_cvt_f32_i32 with an SDWA source selector picks the (sign-extended) byte or half-word
+// itself - the plain C form is a bit-field extract plus a conversion per component, and the conversion of a tile's raw
+// words was a sixth of pass 1's vector instructions.
+template <int HALF>
+__device__ __forceinline__ float cvt_s16(unsigned x) {
+    float f;
+    if constexpr (HALF == 0)
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(f) : "v"(x));
+    else
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f) : "v"(x));
+    return f;
+}
+template <int B>
+__device__ __forceinline__ float cvt_s8(unsigned x) {
+    float f;
+    if constexpr (B == 0)
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(f) : "v"(x));
+    else if constexpr (B == 1)
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(f) : "v"(x));
+    else if constexpr (B == 2)
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(f) : "v"(x));
+    else
+        asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(f) : "v"(x));
+    return f;
+}
+// the raw words of a couple -> c2, UNSCALED integers as floats (the caller folds 2^-(bits-1) into its window weights).
+// FLIP: the unsigned formats' MSB flip (src/samplereader.cpp:29-40) - a template parameter so that the signed formats
+// (the BASELINE configurations' s16) pay nothing for it
+template <int SB, bool FLIP>
+__device__ __forceinline__ c2 words_to_c2_fast(const unsigned (&w)[SB / 2]) {
+    if constexpr (SB == 2) {
+        const unsigned v = FLIP ? (w[0] ^ 0x80808080u) : w[0];
+        return c2{make_float2(cvt_s8<0>(v), cvt_s8<1>(v)), make_float2(cvt_s8<2>(v), cvt_s8<3>(v))};
+    } else if constexpr (SB == 4) {
+        const unsigned x = FLIP ? (w[0] ^ 0x80008000u) : w[0], y = FLIP ? (w[1] ^ 0x80008000u) : w[1];
+        return c2{make_float2(cvt_s16<0>(x), cvt_s16<1>(x)), make_float2(cvt_s16<0>(y), cvt_s16<1>(y))};
+    } else {
+        return c2{make_float2(__uint_as_float(w[0]), __uint_as_float(w[1])),
+                  make_float2(__uint_as_float(w[2]), __uint_as_float(w[3]))};
+    }
+}
 template <int SB, bool SCALED>
 __device__ __forceinline__ c2 words_to_c2(const unsigned (&w)[SB / 2], int fmt) {
     if constexpr (SB == 2) {
@@ -487,6 +528,7 @@ __device__ __forceinline__ c2 words_to_c2(const unsigned (&w)[SB / 2], int fmt) 
 }
 // the integer formats' 2^-(bits-1) (a power of two: folding it into the window weight
 // instead of the sample changes no bit of the product)
+enum { PSDR_FMT_U8_ = 0, PSDR_FMT_U16_ = 2 };  // psdr_format (include/psdr.h)
 template <int SB>
 __device__ __forceinline__ constexpr float image_scale() {
     return SB == 2 ? 1.0f / 128.0f : (SB == 4 ? 1.0f / 32768.0f : 1.0f);
@@ -619,6 +661,9 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
     if (TWM) stw.load(Wl, i0_);
     const StageTw<L> *stw_front = (Plan<L>::NS == 3 && (TWM & 1)) ? &stw : nullptr, *stw_last = (TWM & 2) ? &stw : nullptr;
 
+    const cf wl0 = Wl[i0_];  // W_L^{i0}: the thread's part of every row's window angle (PSDR_HANN_ROT)
+    (void)wl0;
+
     int it = 0;
     for (; s < total; it++) {
         PSDR_TRACE(a.trace, it, 0);
@@ -652,7 +697,60 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
         // exp(-i*2*pi*n/M) = W_M1^{n1} * W_M^{n2}
         const unsigned nA = tl * T + 2u * (unsigned)p, nB = nA + 1u;  // n2 of the two columns
         c2 u[16];
-        {
+#ifndef PSDR_HANN_ROT
+#define PSDR_HANN_ROT 1
+#endif
+        if constexpr (PSDR_HANN_ROT != 0) {
+            // The thread's rows are i0 + e L/16: exp(-i 2 pi row / L) = W_L^{i0} W_16^e - a per-thread constant times a
+            // sixteenth root of unity known at compile time.  With z0 = W_L^{i0} W_M^{n2} (one complex product per column
+            // and tile) the Hann weight of row e is 0.5 - 0.5 Re(z0 W_16^e) = 0.5 - 0.5 (z0.x cos t_e + z0.y sin t_e),
+            // t_e = 2 pi e / 16: two packed FMAs with literal coefficients per row and column couple, no table read per
+            // row (round 3: a stage-table read, two packed products and two FMAs per row for IQ; four complex products
+            // per row for real input, whose odd samples need a second angle)
+            cf wbA, wbB;  // W_M^{n2}: window angle of the columns
+            tw2(nA, nB, wbA, wbB);
+            cf z0A, z0B;
+            cmul_pair(z0A, wl0, wbA, z0B, wl0, wbB);
+            constexpr float C16[16] = {1.f, PSDR_C1_16, PSDR_SQRT1_2, PSDR_S1_16, 0.f, -PSDR_S1_16, -PSDR_SQRT1_2, -PSDR_C1_16,
+                                       -1.f, -PSDR_C1_16, -PSDR_SQRT1_2, -PSDR_S1_16, 0.f, PSDR_S1_16, PSDR_SQRT1_2, PSDR_C1_16};
+            constexpr float S16[16] = {0.f, PSDR_S1_16, PSDR_SQRT1_2, PSDR_C1_16, 1.f, PSDR_C1_16, PSDR_SQRT1_2, PSDR_S1_16,
+                                       0.f, -PSDR_S1_16, -PSDR_SQRT1_2, -PSDR_C1_16, -1.f, -PSDR_C1_16, -PSDR_SQRT1_2, -PSDR_S1_16};
+            // the integer formats' 2^-(bits-1) rides in the weights (a power of two: no bit of the product changes)
+            constexpr float hk = 0.5f * image_scale<SB>();
+            const bool flip = SB <= 4 && (fmt == PSDR_FMT_U8_ || fmt == PSDR_FMT_U16_);  // uniform: one branch per tile
+            auto fill = [&](auto flipc) {
+                constexpr bool FLIP = decltype(flipc)::value;
+                if (a.is_real) {
+                    // even samples: angle of z0; odd samples: one sample further, z0 W_N^1
+                    cf z1A, z1B;
+                    cmul_pair(z1A, z0A, a.wdelta, z1B, z0B, a.wdelta);
+                    const v2f zxA = {z0A.x, z1A.x}, zyA = {z0A.y, z1A.y}, zxB = {z0B.x, z1B.x}, zyB = {z0B.y, z1B.y};
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const c2 x = words_to_c2_fast<SB, FLIP>(rq[e]);
+                        const v2f kc = {-hk * C16[e], -hk * C16[e]}, ks = {-hk * S16[e], -hk * S16[e]}, hf = {hk, hk};
+                        const v2f wA = __builtin_elementwise_fma(zxA, kc, __builtin_elementwise_fma(zyA, ks, hf));
+                        const v2f wB = __builtin_elementwise_fma(zxB, kc, __builtin_elementwise_fma(zyB, ks, hf));
+                        u[e].a = from_v2f(to_v2f(x.a) * wA);
+                        u[e].b = from_v2f(to_v2f(x.b) * wB);
+                    }
+                } else {
+                    const v2f zx = {z0A.x, z0B.x}, zy = {z0A.y, z0B.y};
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const c2 x = words_to_c2_fast<SB, FLIP>(rq[e]);
+                        const v2f kc = {-hk * C16[e], -hk * C16[e]}, ks = {-hk * S16[e], -hk * S16[e]}, hf = {hk, hk};
+                        const v2f w2 = __builtin_elementwise_fma(zx, kc, __builtin_elementwise_fma(zy, ks, hf));
+                        u[e].a = scale_lo(x.a, w2);
+                        u[e].b = scale_hi(x.b, w2);
+                    }
+                }
+            };
+            if (flip)
+                fill(std::true_type{});
+            else
+                fill(std::false_type{});
+        } else {
             cf wbA, wbB;  // W_M^{n2}: window angle of the columns
             tw2(nA, nB, wbA, wbB);
             if (a.is_real) {

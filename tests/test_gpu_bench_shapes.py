@@ -73,17 +73,19 @@ def _default_seg_len(M1, nframes, num_cus=256):
 
 def test_bench_seg_len_is_what_the_chain_tests_cover():
     assert _default_seg_len(1024, 256) == 32 and _default_seg_len(2048, 256) == 64
+    assert _default_seg_len(1024, 512) == 64 and _default_seg_len(2048, 512) == 128  # bench.DEFAULT_BATCH: whole frames
 
 
 @pytest.mark.parametrize("wl_name", ["cfg2", "cfg3"])
 def test_bench_launch_256_frames_vs_oracle(wl_name):
-    """bench.py's own launch: SingleGpuRun.step() twice with F = 256, then frames {0, 2, 127, 255} of the second
-    launch against the oracle (which runs frames g-2, g-1, g: the overlap-add tail and FM's last sample are
+    """bench.py's own launch: SingleGpuRun.step() twice with F = bench.DEFAULT_BATCH (512; 256 up to round 3), then
+    frames {0, 2, F/2 - 1, F - 1} of the second launch against the oracle (which runs frames g-2, g-1, g: the overlap-add tail and FM's last sample are
     functions of the two preceding frames)."""
     import torch
     B = _bench()
     wl = B.WORKLOADS[wl_name]
-    F = 256
+    import bench
+    F = bench.DEFAULT_BATCH
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     N, is_real = wl["fft_size"], wl["is_real"]
@@ -102,7 +104,7 @@ def test_bench_launch_256_frames_vs_oracle(wl_name):
         sent = [f for f in range(F) if (first + f) % skip == 0]
         for wi, w in enumerate(wrows):
             assert w.shape[0] == len(sent)
-        check = [0, 2, 127, 255]
+        check = [0, 2, F // 2 - 1, F - 1]
         assert any(f in sent for f in check) or not run.waterfalls
         nb = N // 2 if is_real else N
         fo = O.FFT(N, is_real, levels, 0, n)
@@ -118,7 +120,7 @@ def test_bench_launch_256_frames_vs_oracle(wl_name):
                 fo.execute()
                 spec_o = fo.output().copy()
                 res = [o.send_audio(spec_o, g - 2 + k, fft=fo) for o in ocl]
-            tag = f"{wl_name} frame {f} of the second 256-frame launch"
+            tag = f"{wl_name} frame {f} of the second {F}-frame launch"
             Xg = eng.ctx.read_spectrum(f)
             assert rel_err(Xg[:nb], spec_o[:nb]) < SPEC_TOL, tag
             assert rel_l2(Xg[:nb], spec_o[:nb]) < SPEC_L2, tag
