@@ -107,6 +107,10 @@ def spectrumserver_cpp(L):
         '        hp.max_waterfall_clients = config["limits"]["waterfall"].value_or(1000);',
         '        hp.post_chain = config["input"]["hip_post_chain"].value_or(true);',
         "        hp.ring_halves = 8;",
+        "        // more than one GPU of the node: input.hip_devices = [0, 1, ...] (device 0 keeps the ring, the FFT and the waterfall",
+        "        // clients, the audio clients are spread over all of them, the spectrum crosses xGMI once per frame: psdr_group_*)",
+        '        if (auto *devs = config["input"]["hip_devices"].as_array())',
+        "            for (auto &d : *devs) hp.devices.push_back((int)d.value_or<int64_t>(0));",
         "        fanout = std::make_unique<HipFanout>(hp);",
         "    }"]))
 
