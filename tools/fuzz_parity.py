@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Randomised parity fuzz: random transform sizes, sample formats, batch splits, client slices
-(all modes, edges, empty and widest slices, odd/fractional mids), mode switches and waterfall
-windows, every frame compared with the oracle the way tests/test_gpu_parity.py does.
+(all modes, edges, empty and widest slices, odd/fractional mids), mode switches, clients that sit out
+whole batches (psdr_client_set_paused: the oracle's client gets no send_audio call, src/websocket.cpp:170-176)
+and waterfall windows, every frame compared with the oracle the way tests/test_gpu_parity.py does.
     tools/fuzz_parity.py [cases] [seed]"""
 import os
 import sys
@@ -105,16 +106,21 @@ def one_case(rng, case):
         fo = O.FFT(N, is_real, levels, 0, n)
         hb = ctx.half_frame_bytes()
         frame = 0
+        pause_case = rng.random() < 0.34
         for bi, nf in enumerate(splits):
             if bi == 1 and rng.integers(0, 2):  # a mode switch between batches
                 ci = int(rng.integers(0, ncl))
                 mode = MODES[int(rng.integers(0, 4))]
                 gcl[ci].set_audio_demodulation(mode)
                 ocl[ci].set_audio_demodulation(mode)
+            # a third of the cases: every client sits out this batch with probability 1/4
+            paused = [pause_case and rng.random() < 0.25 for _ in gcl]
+            for g, pz in zip(gcl, paused):
+                g.set_paused(pz)
             ctx.process_batch(d, nf, offset_bytes=frame * hb)
             ctx.demod_batch(frame)
             ctx.waterfall_batch(frame)
-            got = [g.read_audio(nf) for g in gcl]
+            got = [None if pz else g.read_audio(nf) for g, pz in zip(gcl, paused)]
             sent = [f for f in range(nf) if (frame + f) % skip == 0]
             wgot = [w.read_waterfall() for w in wcl]
             for f in range(nf):
@@ -128,6 +134,8 @@ def one_case(rng, case):
                 dq = np.abs(qg.astype(np.int16) - qo.astype(np.int16))
                 assert dq.max() <= 1 and (dq != 0).mean() <= 2e-3, desc + f" frame {frame}: pyramid {dq.max()} {(dq != 0).mean()}"
                 for ci, o in enumerate(ocl):
+                    if paused[ci]:
+                        continue
                     a_o, p_o, _, dropped = o.send_audio(spec, frame, fft=fo)
                     a_g, p_g, nan_g = got[ci][0][f], got[ci][1][f], got[ci][2][f]
                     tag = desc + f" client {ci} frame {frame}"
