@@ -1308,9 +1308,22 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         tile_of(sg, j, f, g);
         nxt = a.Y + (size_t)(f & a.ymask) * a.yframe + (size_t)g * a.ytile + lane_off;
     };
+    // SPLIT (as in pass2_body): register i holds the tile's load number i ^ 8, so that the loads issued FIRST (i < 8) are
+    // the upper half of the LDS tile (n2 >= L/2).  The octet loop reads the staging rows (the lower half) and the carried
+    // row only: a wave that has finished its octets fills the upper half of the NEXT tile at once, and the "tile is free
+    // again" barrier sits between the two half-fills instead of at the end of the loop, where the waves of a work-group
+    // arrived up to 2200 cycles apart (tools/trace_real.py, round 4: 9 % of a tile).
+    // Same box, interleaved, F = 512: cfg3 (TWC = 16) 180.3 -> 183.4 GS/s; cfg5's share (TWC = 8: 1 KiB chunks of Y) 167.7 ->
+    // 165.5 - there the end barrier costs less than the permuted load order, so it keeps the plain order.
+#ifdef PSDR_P2R_SPLITFILL
+    constexpr bool SPLIT = PSDR_P2R_SPLITFILL != 0;
+#else
+    constexpr bool SPLIT = TWC == 16;
+#endif
     auto issue = [&](auto qc) {
         constexpr int i = decltype(qc)::value;
-        const cf *q = nxt + (size_t)((2 * i * NT) >> lc) * a.yjs + ((2 * i * NT) & (chunk - 1));
+        constexpr int ip = SPLIT ? (i ^ (NLD / 2)) : i;  // which sixteenth of the tile
+        const cf *q = nxt + (size_t)((2 * ip * NT) >> lc) * a.yjs + ((2 * ip * NT) & (chunk - 1));
         r[i] = *reinterpret_cast<const float4 *>(q);
     };
     __shared__ unsigned s_next[2];
@@ -1377,12 +1390,18 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         // transposing fill (as pass2_body)
 #pragma unroll
         for (int i = 0; i < NLD; i++) {
-            const int w = ((2 * i * NT) & (chunk - 1)) + ((2 * tidx) & (chunk - 1));
+            const int ip = SPLIT ? (i ^ (NLD / 2)) : i;
+            const int w = ((2 * ip * NT) & (chunk - 1)) + ((2 * tidx) & (chunk - 1));
             const int rr = w >> log2TW, cc = w & (TW - 1);
-            const int n2 = (((2 * i * NT) >> lc) + ((2 * tidx) >> lc)) * TW + cc;  // even
+            const int n2 = (((2 * ip * NT) >> lc) + ((2 * tidx) >> lc)) * TW + cc;  // even
             const int slot0 = lds_slot<H, true>(n2, rr & 7);  // couple p = (row p, row 8 + p of the tile)
             tile_cf[2 * slot0 + (rr >> 3)] = make_float2(r[i].x, r[i].y);
             tile_cf[2 * (slot0 + H) + (rr >> 3)] = make_float2(r[i].z, r[i].w);
+            if (SPLIT && i == NLD / 2 - 1) {
+                PSDR_SCHED_FENCE();
+                __syncthreads();  // every wave has finished the previous tile's octet loop: the lower half is free
+                PSDR_SCHED_FENCE();
+            }
         }
         PSDR_SCHED_FENCE();
         if (more) static_for<0, EARLY>(issue);
@@ -1568,7 +1587,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             }
         }
         PSDR_TRACE(a.trace, it, 12);
-        __syncthreads();  // the tile is free again
+        if (!SPLIT) __syncthreads();  // the tile is free again (SPLIT: between the next tile's two half-fills)
         PSDR_TRACE(a.trace, it, 13);
         if (seg_last) {
             const unsigned s2 = s_next[segit & 1];
