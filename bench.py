@@ -722,7 +722,7 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
     # (RCCL called by the library).  A child with a timeout: whatever happens to it, this line is still printed; the
     # other ranks wait on the rendezvous store (host side - a RCCL barrier would keep a kernel spinning on their GPUs).
     c_group = None
-    if not one_device:
+    if True:  # (PSDR_BENCH_ONE_DEVICE: the child drives the one device with forced collectives - the orchestration is what is tested)
         try:
             store = dist.distributed_c10d._get_default_store()
             if rank == 0:
@@ -730,7 +730,7 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
                 try:
                     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
                                                                            "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
-                    rr = subprocess.run([sys.executable, os.path.abspath(__file__), "--c-group-only", str(world), "--steps", "10", "--warmup", "3",
+                    rr = subprocess.run([sys.executable, os.path.abspath(__file__), "--c-group-only", str(1 if one_device else world), "--steps", "10", "--warmup", "3",
                                          "--batch", str(args.batch)], capture_output=True, text=True, timeout=240, env=env)
                     line = [ln for ln in rr.stdout.splitlines() if ln.startswith("{")]
                     c_group = json.loads(line[-1]) if line else {"error": (rr.stderr or "")[-400:]}

@@ -210,3 +210,10 @@ def test_bench_gpus_2_runs_every_sharding_as_two_processes():
     assert set(d["sharding"]) == {"clients", "clients_pipelined", "raw", "band", "time"}
     for mode, v in d["sharding"].items():
         assert v.get("error") is None and v["value"] > 0, (mode, v)
+    # band sharding is `value` for IQ workloads, the north star's broadcast sits beside it, and the C-side group leg
+    # (one child process through psdr_group_*; here: the one device with forced collectives) reported its three shardings
+    assert d["shard"] == "band" and d["north_star_sharding"]["value"] > 0
+    cg = d["c_group"]
+    assert cg and "by_shard" in cg, cg
+    for shard, v in cg["by_shard"].items():
+        assert v.get("error") is None and v["value"] > 0, (shard, v)
