@@ -721,26 +721,26 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
     # SURVEY 8e from C, in the same run: rank 0 starts ONE extra process that drives all N devices through psdr_group_*
     # (RCCL called by the library).  A child with a timeout: whatever happens to it, this line is still printed; the
     # other ranks wait on the rendezvous store (host side - a RCCL barrier would keep a kernel spinning on their GPUs).
+    # (PSDR_BENCH_ONE_DEVICE: the child drives the one device with forced collectives - the orchestration is what is tested)
     c_group = None
-    if True:  # (PSDR_BENCH_ONE_DEVICE: the child drives the one device with forced collectives - the orchestration is what is tested)
-        try:
-            store = dist.distributed_c10d._get_default_store()
-            if rank == 0:
-                import subprocess
-                try:
-                    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
-                                                                           "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
-                    rr = subprocess.run([sys.executable, os.path.abspath(__file__), "--c-group-only", str(1 if one_device else world), "--steps", "10", "--warmup", "3",
-                                         "--batch", str(args.batch)], capture_output=True, text=True, timeout=240, env=env)
-                    line = [ln for ln in rr.stdout.splitlines() if ln.startswith("{")]
-                    c_group = json.loads(line[-1]) if line else {"error": (rr.stderr or "")[-400:]}
-                except Exception as e:
-                    c_group = {"error": repr(e)}
-                store.set("psdr_c_group_done", "1")
-            else:
-                store.wait(["psdr_c_group_done"])
-        except Exception as e:
-            c_group = {"error": repr(e)}
+    try:
+        store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            import subprocess
+            try:
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                                       "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+                rr = subprocess.run([sys.executable, os.path.abspath(__file__), "--c-group-only", str(1 if one_device else world), "--steps", "10", "--warmup", "3",
+                                     "--batch", str(args.batch)], capture_output=True, text=True, timeout=240, env=env)
+                line = [ln for ln in rr.stdout.splitlines() if ln.startswith("{")]
+                c_group = json.loads(line[-1]) if line else {"error": (rr.stderr or "")[-400:]}
+            except Exception as e:
+                c_group = {"error": repr(e)}
+            store.set("psdr_c_group_done", "1")
+        else:
+            store.wait(["psdr_c_group_done"])
+    except Exception as e:
+        c_group = {"error": repr(e)}
     if rank == 0:
         r = results[main_mode]
         out = {

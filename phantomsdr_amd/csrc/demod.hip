@@ -204,7 +204,9 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
             // enough waves
             // (256 clients x 256 frames, same box: K = 4 / 8 / 16 / 32 -> 5.81 / 5.77 / 5.93 / 6.04 us per frame, the
             // two-kernel path 5.99)
-            int K = c->demod_chain_k > 0 ? c->demod_chain_k : 8;
+            // (round 4, 512-frame launches: with 256 clients and more, chains of 16 still leave 8192 waves and repeat half as
+            // many warm-up transforms: 93.4 -> 94.6 GS/s on the 256-client shape, same box, interleaved twice)
+            int K = c->demod_chain_k > 0 ? c->demod_chain_k : (nact >= 256 && (unsigned)nact * (unsigned)((nframes + 15) / 16) >= 8192u ? 16 : 8);
             if (c->demod_chain_k <= 0)
                 while (K > 4 && (unsigned)nact * (unsigned)((nframes + K - 1) / K) < 1024u) K >>= 1;
             const unsigned items = (unsigned)nact * (unsigned)((nframes + K - 1) / K);
