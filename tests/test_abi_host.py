@@ -134,6 +134,17 @@ def test_c_example_compiles_and_links_against_the_header():
         assert r.returncode == 2 and "No HIP devices found" in r.stderr
 
 
+def test_group_example_compiles_and_fails_loudly_without_a_gpu():
+    """examples/group_demo.c: psdr_group_* from plain C, linked against libpsdr_hip.so only (RCCL is the library's business)"""
+    import subprocess
+    _, out = _build_c_example("group_demo")
+    r = subprocess.run([out, "1", "0"], capture_output=True, text=True)
+    if HAVE_GPU:
+        assert r.returncode == 0 and "group demo ok" in r.stdout, r.stdout + r.stderr
+    else:
+        assert r.returncode == 2 and "No HIP devices found" in r.stderr
+
+
 @pytest.mark.gpu
 def test_c_example_runs_on_the_gpu_and_matches_the_oracle():
     """the plain-C caller drives Level 1 like broadcast_server::fft_task (src/fft.cpp:17-30,61-98);

@@ -162,3 +162,44 @@ def test_group_argument_errors():
         assert g.client_set_audio_range(gid, 60000, 60000.0, 60060) == gid  # one band: nothing to migrate to
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("shard", [0, 1, 2])
+def test_plain_c_caller_of_the_group_matches_the_oracle(shard):
+    """examples/group_demo.c: SURVEY 8e from plain C (one process, psdr_group_*; here one device with the collectives
+    forced).  Its dumped per-client audio against the oracle on its dumped stream."""
+    import atexit
+    import os
+    import shutil
+    import subprocess
+    import tempfile
+    from conftest import ROOT
+    from helpers import rel_l2
+    from oracle import oracle as O
+    d = tempfile.mkdtemp(prefix="psdr_grp_")
+    atexit.register(shutil.rmtree, d, ignore_errors=True)
+    exe = os.path.join(d, "group_demo")
+    lib = os.path.join(ROOT, "phantomsdr_amd")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "group_demo.c"),
+                           "-L" + lib, "-lpsdr_hip", "-lm", "-Wl,-rpath," + lib, "-o", exe])
+    r = subprocess.run([exe, "1", str(shard), d], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "group demo ok" in r.stdout, r.stdout + r.stderr
+    N, F, NB, NCL, n, levels = 1 << 16, 4, 3, 8, 248, 7
+    raw = np.fromfile(os.path.join(d, "raw.bin"), np.int16)
+    halves = O.convert(raw, "s16").view(np.complex64).reshape(NB * F + 1, N // 2)
+    fo = O.FFT(N, False, levels, 0, n)
+    ocl = []
+    for i in range(NCL):
+        k = int((i + 0.5) * N / NCL) - N // 2
+        c = (k - (N // 2 + 1)) % N
+        o = O.AudioClient(False, n, 12000, N)
+        o.set_audio_demodulation("USB")
+        o.set_audio_range(c, float(c), c + 60)
+        ocl.append(o)
+    got = [np.fromfile(os.path.join(d, f"client{i}.bin"), np.float32).reshape(NB * F, n // 2) for i in range(NCL)]
+    for f in range(NB * F):
+        fo.load(halves[f], halves[f + 1])
+        fo.execute()
+        for i, o in enumerate(ocl):
+            a_o, _, _, dropped = o.send_audio(fo.output(), f, fft=fo)
+            assert not dropped and rel_l2(got[i][f], a_o) < 1e-4, (shard, i, f, rel_l2(got[i][f], a_o))
