@@ -90,7 +90,7 @@ struct ColTailArgs {
     const float *Pin;  // [nframes][in_stride]
     size_t in_stride;
     int mode;  // RecMap::mapped: 1 = IQ tiles of 16 rows (group i of row c at i*L + c),
-               // 2 = fused real: octet pairs (low octet of tile g, mirror octet of tile g) at (g*L + c)*2
+               // 2 = fused real: low octet of tile g of column c at (2g)*L + c, its mirror octet at (2g+1)*L + c
     int L, l2L;
     int lvl_in, nlevels, size_log2;
     int8_t *Q;
@@ -164,15 +164,20 @@ __global__ __launch_bounds__(64, PSDR_CT_WPE) void k_col_tail(ColTailArgs a) {
             cs[ch] = col_chunk16<NG>(v, ch, cl, a, sq, soff);
         }
     } else {
-        // one 8-byte load gives the low octet of tile g (group g) and its mirror octet (group NG-1-g)
+        // tile g's two rows of sums: the low octets (group g) and the mirror octets (group NG-1-g) of the 64 columns
 #pragma unroll
         for (int ch = 0; ch < NC / 2; ch++) {
             float lo[16], hi[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) {
+#if PSDR_REC_SIDE_MAJOR
+                lo[i] = Pf[((size_t)(2 * (16 * ch + i)) << a.l2L) + c];
+                hi[15 - i] = Pf[((size_t)(2 * (16 * ch + i) + 1) << a.l2L) + c];
+#else
                 const float2 t = reinterpret_cast<const float2 *>(Pf)[((size_t)(16 * ch + i) << a.l2L) + c];
                 lo[i] = t.x;
                 hi[15 - i] = t.y;
+#endif
             }
             cs[ch] = col_chunk16<NG>(lo, ch, cl, a, sq, soff);
             cs[NC - 1 - ch] = col_chunk16<NG>(hi, NC - 1 - ch, cl, a, sq, soff);
@@ -358,7 +363,11 @@ __global__ __launch_bounds__(256) void k_real_seam(SeamArgs a) {
     for (int c = threadIdx.x; c < a.L; c += blockDim.x) {
         const float4 v0 = reinterpret_cast<const float4 *>(P)[2 * c], v1 = reinterpret_cast<const float4 *>(P)[2 * c + 1];
         float pw[8] = {Cc[c], v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z};  // elements 1..7 at [0..7)
+#if PSDR_REC_SIDE_MAJOR
+        const size_t rp = ((size_t)g * 2 + 1) * a.L + c;
+#else
         const size_t rp = ((size_t)g * a.L + c) * 2 + 1;
+#endif
         uint4 rec;
         pyr_record8(pw, a.size_log2, rec);
         *reinterpret_cast<uint4 *>(Qf + rp * 16) = rec;

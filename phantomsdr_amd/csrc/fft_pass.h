@@ -1258,6 +1258,17 @@ __device__ __forceinline__ float bin_power(cf x) {
     return p;
 }
 
+// Octet staging Pst[c2][16] floats (one 64-byte row per column: low octet, then elements 1..7 of the high octet and the
+// tile's carry-out).  Side-major records: the octet loop reads ONE 16-byte quarter per lane with lanes = adjacent
+// rows, 64 bytes apart - a four-way bank conflict in the plain order - so quarter j of row c sits at j ^ ((c >> 2) & 3).
+__device__ __forceinline__ int pst_at(int row, int e) {
+#if PSDR_REC_SIDE_MAJOR
+    return row * 16 + ((((e >> 2) ^ (row >> 2)) & 3) << 2) + (e & 3);
+#else
+    return row * 16 + e;
+#endif
+}
+
 template <int L, int T, int TWC>
 __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
     static_assert(T == 16, "eight (row, mirror) couples per tile");
@@ -1444,8 +1455,8 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             const int cm = L - 1 - c2i;
             Xt[16 * c2i + p] = xk;
             Xt[16 * c2i + 15 - p] = xm;  // mirror row M1-p: element 7-p of the mirror octet
-            Pst[c2i * 16 + p] = bin_power(xk);
-            Pst[cm * 16 + 15 - p] = bin_power(xm);  // (p >= 1 here: element 8-p at [7+8-p])
+            Pst[pst_at(c2i, p)] = bin_power(xk);
+            Pst[pst_at(cm, 15 - p)] = bin_power(xm);  // (p >= 1 here: element 8-p at [7+8-p])
         };
         // Every other tile: two outputs (A, B) per call.  Lane pair (2q, 2q+1): the even lane ends up
         // with rows 8g+2q, 8g+2q+1 of both outputs, the odd lane with the mirror rows M1-8g-2q-1,
@@ -1458,7 +1469,8 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         // row c, the odd lane row L-1-c = (L/16-1-i0) + (L/16)*(15-t): per-thread base and +-4 KiB
         // stride.  (Opaque copies: see the loop-invariant-address note in pass 1.)
         unsigned gofs = (unsigned)((i0_ * 16 + off_) * (int)sizeof(cf));
-        int lbase = ((ev_ ? i0_ : (L16 - 1 - i0_) + 15 * L16) * 16 + off_) * (int)sizeof(float);
+        // (the row moves by +-L/16 = 64 per output: the quarter swizzle of pst_at is the same for all sixteen)
+        int lbase = pst_at(ev_ ? i0_ : (L16 - 1 - i0_) + 15 * L16, off_) * (int)sizeof(float);
         int lstride = (ev_ ? L16 : -L16) * 16 * (int)sizeof(float);
         asm volatile("" : "+v"(gofs), "+v"(lbase), "+v"(lstride));
         char *Xtb = reinterpret_cast<char *>(Xt);
@@ -1516,7 +1528,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                     const cf pz = exA[(L - c2i) & (L - 1)];
                     untangle_pair(exA[c2i], make_float2(pz.x, -pz.y), cmul(w0z, w32(t)), hscale, xk, xm);
                     Xf[16 * c2i] = xk;  // line (0, c2), bin 0
-                    Pst[c2i * 16] = bin_power(xk);
+                    Pst[pst_at(c2i, 0)] = bin_power(xk);
                     // bin N/2 is never normalised by the reference (src/fft_impl.cpp:156-160 visits
                     // k < N/2 only): X[N/2] = Re Z[0] - Im Z[0]
                     if (c2i == 0) Xf[(size_t)L << a.log2M1] = make_float2(exA[0].x - exA[0].y, 0.f);  // after the M bins
@@ -1542,6 +1554,56 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
 #endif
             constexpr int GRP = PSDR_OCT_GROUP;
             static_assert(NG % GRP == 0, "octet groups");
+#if PSDR_REC_SIDE_MAJOR
+            // Octet kk of the thread: side = kk & 1 (known after unrolling: no per-lane selects), column c2 = (kk >> 1) * NT +
+            // tidx - a wave's 64 records of one side are 1 KiB of adjacent records (RecMap mode 2: [tile][side][column]).
+            static_assert(L16 % 4 == 0 && NT % 16 == 0, "quarter swizzle: constant per thread");
+            const float4 *P4 = reinterpret_cast<const float4 *>(Pst);
+            int pbase = 4 * tidx + ((tidx >> 2) & 3);  // quarter j of the thread's row: (pbase ^ j), + 4 * NT per column group
+            asm volatile("" : "+v"(pbase));
+#pragma unroll
+            for (int k0 = 0; k0 < NG; k0 += GRP) {
+                float4 v0[GRP], v1[GRP];
+                float cin[GRP];
+#pragma unroll
+                for (int j = 0; j < GRP; j++) {
+                    const int kk = k0 + j, sd = kk & 1, cg = kk >> 1;
+                    v0[j] = P4[(pbase ^ (2 * sd)) + 4 * NT * cg];
+                    v1[j] = P4[(pbase ^ (2 * sd + 1)) + 4 * NT * cg];
+                    cin[j] = sd ? carry_r[cg * NT + tidx] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < GRP; j++) {
+                    const int kk = k0 + j, sd = kk & 1;
+                    const int c2i = (kk >> 1) * NT + tidx;
+                    float pw[8];
+                    if (sd) {  // high octet: element 0 is the carried row, 1..7 sit at [0..7), and slot 7
+                               // holds this tile's own carry-out (row M1-8g of column c2i)
+                        carry_w[c2i] = v1[j].w;
+                        if (seg_last && g != 0) seamC[c2i] = v1[j].w;
+                        pw[0] = cin[j];
+                        pw[1] = v0[j].x, pw[2] = v0[j].y, pw[3] = v0[j].z, pw[4] = v0[j].w, pw[5] = v1[j].x, pw[6] = v1[j].y, pw[7] = v1[j].z;
+                        if (seg_first) {  // no carry-in: the octet is completed by k_real_seam
+                            reinterpret_cast<float4 *>(seamP)[2 * c2i] = v0[j];
+                            reinterpret_cast<float4 *>(seamP)[2 * c2i + 1] = v1[j];
+                        }
+                    } else {
+                        pw[0] = v0[j].x, pw[1] = v0[j].y, pw[2] = v0[j].z, pw[3] = v0[j].w, pw[4] = v1[j].x, pw[5] = v1[j].y, pw[6] = v1[j].z, pw[7] = v1[j].w;
+                    }
+                    // The record is written by EVERY lane (a segment's first tile: with a stale carried row in the
+                    // high octets - k_real_seam, which runs before any consumer, writes those records again): stores the
+                    // compiler can count, see the note in the lane-alternating form below.
+                    {
+                        const size_t rp = (size_t)g * (2 * L) + (size_t)sd * L + c2i;  // RecMap mode 2
+                        uint4 rec;
+                        pyr_record8(pw, a.size_log2, rec);
+                        *reinterpret_cast<uint4 *>(Qf + rp * 16) = rec;
+                        Pf[rp] = pw[0];
+                    }
+                }
+                PSDR_SCHED_FENCE();
+            }
+#else
             const int side = tidx & 1;  // (NT is even: q = k * NT + tidx keeps its parity)
 #pragma unroll
             for (int k0 = 0; k0 < NG; k0 += GRP) {
@@ -1585,6 +1647,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                 }
                 PSDR_SCHED_FENCE();
             }
+#endif
         }
         PSDR_TRACE(a.trace, it, 12);
         if (!SPLIT) __syncthreads();  // the tile is free again (SPLIT: between the next tile's two half-fills)

@@ -179,6 +179,9 @@ __device__ __forceinline__ void pyr_levels(float (&p)[CH], int8_t *Qf, size_t qo
 // g = c / CH of client-order bin c sits in record
 //   pos(g) = tl * (rows * gpt) + row * gpt + k,  row = g / tpr, tl = (g % tpr) / gpt, k = g % gpt
 // (tpr = M1/CH groups per output row, gpt = T/CH groups per tile and row, rows = M2).
+#ifndef PSDR_REC_SIDE_MAJOR
+#define PSDR_REC_SIDE_MAJOR 1  // 0: round 1-3 order (g * rows + c2) * 2 + side, lanes alternate between the sides
+#endif
 struct RecMap {
     int l2tpr, l2gpt, l2rows;
     int mapped;  // 0: identity (level-major producers: the three-pass real-input path)
@@ -186,7 +189,8 @@ struct RecMap {
                  // 2: fused real-input pass 2 (k_fft_pass2_real): octet o = k / 8 of bin k lives in
                  //    row c2 = o / tpr (tpr = M1/8 octets per row); the lower half of a row's octets
                  //    belongs to tile g = o % tpr as its LOW octet, the upper half to tile
-                 //    g = tpr - 1 - o % tpr as its HIGH octet: pos = (g * rows + c2) * 2 + side
+                 //    g = tpr - 1 - o % tpr as its HIGH octet: pos = (g * 2 + side) * rows + c2 (a tile's low octets,
+                 //    then its high octets: a wave of the octet loop stores 64 adjacent records of ONE side)
     __host__ __device__ __forceinline__ size_t pos(size_t g) const {
         if (!mapped) return g;
         const size_t row = g >> l2tpr, gc = g & (((size_t)1 << l2tpr) - 1);
@@ -194,7 +198,11 @@ struct RecMap {
             const size_t tpr = (size_t)1 << l2tpr;
             const size_t side = gc >= (tpr >> 1) ? 1 : 0;
             const size_t tl = side ? tpr - 1 - gc : gc;
+#if PSDR_REC_SIDE_MAJOR
+            return (((tl << 1) + side) << l2rows) + row;
+#else
             return (((tl << l2rows) + row) << 1) + side;
+#endif
         }
         const size_t tl = gc >> l2gpt, k = gc & (((size_t)1 << l2gpt) - 1);
         return (((tl << l2rows) + row) << l2gpt) + k;
