@@ -26,6 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md)
+COPY_CEILING = 6.29e12  # B/s: the plain device copy SURVEY.md 8(d) measured ("also report vs 6.29 TB/s measured-copy ceiling")
 
 WORKLOADS = {
     # BASELINE.json configs[1]
@@ -867,6 +868,12 @@ class SingleGpuRun:
                "algorithmic_bytes_per_frame": int(ab["total"]), "repetitions": len(times),
                "ms_per_step_min_max": [round(min(times) / steps * 1e3, 4), round(max(times) / steps * 1e3, 4)],
                "timed_s": round(sum(times), 3)}
+        # SURVEY 8d, supplementary: what THIS design moves - the compulsory bytes plus the inter-pass array Y written and read
+        # once (8 B per point of the N- or N/2-point complex transform) - against the copy rate the survey measured on MI355X
+        y_pts = self.N // 2 if self.wl["is_real"] else self.N
+        tp = ab["total"] + 16 * y_pts
+        out["two_pass_model"] = {"bytes_per_frame": int(tp), "GB_per_s": round(tp * frames / med / 1e9, 1),
+                                 "frac_of_measured_copy_6290_GB_per_s": round(tp * frames / med / COPY_CEILING, 4)}
         st = getattr(self, "times_stamped", None)
         if st:
             out["instrumentation"] = {"value_from": "repetitions with psdr_set_profiling(0)",
@@ -1094,7 +1101,8 @@ def main():
                              "a few MB per step against GBs of device traffic)"},
         "roofline": roofline,
         "path": {"algorithmic_bytes_per_frame": head["algorithmic_bytes_per_frame"], "frames_per_s": head["frames_per_s"],
-                 "frac_of_hbm_peak": head["frac_of_hbm_peak"], "ms_per_step_min_max": head["ms_per_step_min_max"],
+                 "frac_of_hbm_peak": head["frac_of_hbm_peak"], "two_pass_model": head.get("two_pass_model"),
+                 "ms_per_step_min_max": head["ms_per_step_min_max"],
                  "instrumentation": head.get("instrumentation"), "kernels": kernels},
         "clients256": extra.get("clients256"),
         "cfg3": extra.get("cfg3"),
