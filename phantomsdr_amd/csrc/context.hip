@@ -139,6 +139,8 @@ void free_all(psdr_ctx *c) {
         F(c->seam_pool[st][0]);
         F(c->seam_pool[st][1]);
     }
+    F(c->d_segflag);
+    for (auto &sp : c->seg_plans) F(sp.d_tab);
     F(c->d_tickets[0]);
     F(c->d_tickets[1]);
     F(c->y_pool[0]);
@@ -296,14 +298,22 @@ int build(psdr_ctx *c) {
         HIPCHK(hipMalloc((void **)&c->d_Z, (c->M + 2) * sizeof(cf)));
         if (const char *e = getenv("PSDR_SEG_LEN")) c->seg_len_env = atoi(e);
         c->y_blocked = psdr_tuning_env("PSDR_REAL_YBLOCKED") != nullptr;
-        size_t cap = 0;
-        for (int nf = 1; nf <= c->max_batch; nf++)
-            cap = std::max(cap, (size_t)nf * (size_t)((c->M1 / 16) / real_seg_len(c, nf)));
+        size_t cap = 0, capc = 0;
+        for (int nf = 1; nf <= c->max_batch; nf++) {
+            unsigned ns, nm;
+            bool ho;
+            seg_plan_counts(c, nf, &ns, &nm, &ho);
+            cap = std::max(cap, (size_t)nm);
+            capc = std::max(capc, (size_t)ns);
+        }
         c->seam_cap = cap;
+        c->seg_cap = capc;
         for (int st = 0; st < 2; st++) {  // part of the double-buffered result sets: k_real_seam is a consumer
             HIPCHK(hipMalloc((void **)&c->seam_pool[st][0], cap * (size_t)c->M2 * 8 * sizeof(float)));
-            HIPCHK(hipMalloc((void **)&c->seam_pool[st][1], cap * (size_t)c->M2 * sizeof(float)));
+            HIPCHK(hipMalloc((void **)&c->seam_pool[st][1], capc * (size_t)c->M2 * sizeof(float)));
         }
+        HIPCHK(hipMalloc((void **)&c->d_segflag, capc * sizeof(unsigned)));
+        HIPCHK(hipMemset(c->d_segflag, 0, capc * sizeof(unsigned)));
     }
     for (int s = 0; s < 2; s++) {
         HIPCHK(hipMalloc((void **)&c->spec_pool[s], F * c->spec_stride * sizeof(cf)));

@@ -144,10 +144,20 @@ struct psdr_ctx {
     SpecLayout lay{};                // device layout of the spectrum (natural unless real_fused)
     int nbands = 0, band_H = 0;      // psdr_set_band_layout: band regions (SpecLayout mode 3), halo columns per band
     bool y_blocked = false;          // PSDR_REAL_YBLOCKED (tuning)
-    int seg_len_env = 0;             // PSDR_SEG_LEN (tuning): tiles per chain segment
+    int seg_len_env = 0;             // PSDR_SEG_LEN: tiles per chain segment (uniform segments, every one with a seam)
     float *d_seamP = nullptr, *d_seamC = nullptr;  // of the current result set
     float *seam_pool[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    size_t seam_cap = 0;             // segments the seam buffers hold
+    size_t seam_cap = 0, seg_cap = 0;  // segments without a carry-in the seamP buffers hold; segments (seamC, flags)
+    // chain segments of the fused real second pass for a batch of `nframes` frames (forward.hip: seg_plan)
+    struct SegPlan {
+        int nframes = 0;
+        unsigned nsegs = 0, nseam = 0;  // the nseam segments without a carry-in come first
+        bool handoff = false;           // the others get their carried row through memory inside the launch
+        uint4 *d_tab = nullptr;
+    };
+    std::vector<SegPlan> seg_plans;  // one per batch size seen
+    unsigned *d_segflag = nullptr;   // [seg_cap] epoch of the launch that last published the segment's carry-out
+    unsigned seg_epoch = 0;
     int size_log2 = 0;
     int levels = 0;
     size_t spec_stride = 0;  // complex elements per frame
@@ -353,6 +363,7 @@ int reset_kclock(psdr_ctx *c);
 // forward.hip
 void select_set(psdr_ctx *c, int set);
 int real_seg_len(const psdr_ctx *c, int nframes);
+void seg_plan_counts(const psdr_ctx *c, int nframes, unsigned *nsegs, unsigned *nseam, bool *handoff);
 int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipEvent_t ev_raw_consumed = nullptr);
 // pass1.hip / pass2.hip (Pass1Args / Pass2Args: fft_pass.h)
 struct Pass1Args;

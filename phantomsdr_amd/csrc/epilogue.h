@@ -342,11 +342,12 @@ __global__ __launch_bounds__(256) void k_untangle_real(UntangleArgs a) {
 // ---- fused real-input path (k_fft_pass2_real, fft_pass.h) -------------------------------------
 // Completes the high octets a segment's first tile could not finish: element 0 of the octet comes
 // from the carry-out of the segment above (the LAST segment's from tile 0: row M1/2), elements
-// 1..7 from the tile's own partial rows.  grid = (segments per frame, nframes).
+// 1..7 from the tile's own partial rows.  grid = the segments without a carry-in (the first entries of the table).
 struct SeamArgs {
-    const float *seamP;  // [nframes][S][L][8]: elements 1..7 of the octet at [0..7)
-    const float *seamC;  // [nframes][S][L]
-    int S, SL, L;        // segments per frame, tiles per segment, row length (M2)
+    const float *seamP;  // [seam segments][L][8]: elements 1..7 of the octet at [0..7)
+    const float *seamC;  // [segments][L]
+    const uint4 *segtab; // Pass2Args::segtab: the segments without a carry-in come first
+    int L;               // row length (M2)
     int size_log2;
     int8_t *Qt;
     size_t qt_stride;
@@ -354,10 +355,11 @@ struct SeamArgs {
     size_t p_stride;
 };
 __global__ __launch_bounds__(256) void k_real_seam(SeamArgs a) {
-    const int si = blockIdx.x, f = blockIdx.y;
-    const int g = (si + 1) * a.SL - 1;  // the segment's first tile
-    const float *P = a.seamP + ((size_t)f * a.S + si) * a.L * 8;
-    const float *Cc = a.seamC + ((size_t)f * a.S + (si + 1) % a.S) * a.L;
+    const uint4 se = a.segtab[blockIdx.x];
+    const int f = (int)se.x;
+    const int g = (int)(se.y & 0xFFFFu);  // the segment's first tile
+    const float *P = a.seamP + (size_t)blockIdx.x * a.L * 8;
+    const float *Cc = a.seamC + (size_t)se.z * a.L;  // carry-out of the segment above (the top segment: row M1/2 from tile 0)
     int8_t *Qf = a.Qt + (size_t)f * a.qt_stride;
     float *Pf = a.Pscr + (size_t)f * a.p_stride;
     for (int c = threadIdx.x; c < a.L; c += blockDim.x) {

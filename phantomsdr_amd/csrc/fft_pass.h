@@ -359,6 +359,7 @@ __device__ __forceinline__ unsigned xcd_slot(unsigned bid, unsigned total) {
 struct TileQueue {
     unsigned *tickets;
     unsigned total, base;  // indices below 2*gridDim.x are the static first tiles
+    unsigned first_dyn;    // index of ticket 0 of the chip-wide counter (2*gridDim.x; 0: everything is drawn)
     unsigned pending;      // owner thread: ticket drawn, not yet examined
     unsigned ptx;          // ... and the XCD whose counter it came from
     unsigned owner;        // the thread that draws (0 unless the kernel has a loader wave)
@@ -371,6 +372,7 @@ struct TileQueue {
         tickets = t;
         total = total_;
         base = gridDim.x >> 2;  // 2*gridDim.x / 8
+        first_dyn = 2u * gridDim.x;
         pending = 0;
         ptx = blockIdx.x & 7u;
         own_done = false;
@@ -411,7 +413,7 @@ struct TileQueue {
             if (!tickets) {  // static round-robin
                 if (prev2 < total) s = prev2 + 2u * gridDim.x;
             } else if (dynamic) {
-                s = global ? pending + 2u * gridDim.x : (pending + base) * 8u + ptx;
+                s = global ? pending + first_dyn : (pending + base) * 8u + ptx;
 #ifndef PSDR_NO_PARTNER_STEAL
 #ifndef PSDR_STEAL_LEVELS
 #define PSDR_STEAL_LEVELS 1  // queues of other XCDs a work-group goes on with after its own: x^1 (, x^2, x^3 ...)
@@ -462,6 +464,10 @@ struct Pass1Args {
     unsigned long long *trace;
     unsigned long long *kclk;  // device-clock stamps of this launch (kclk_begin / kclk_end) or nullptr
     unsigned ymask;            // frame index mask of Y (~0u; a timing-only experiment aliases frames: PSDR_Y_ALIAS)
+    float yscale;              // a power of two carried by the window weights, so that Y - and with it the second pass's
+                               // outputs - arrive scaled: 1/N for IQ input, 0.5/N for the fused real path (the untangle's
+                               // 1/2 with it), 1 for the three-pass real path.  Scaling by a power of two commutes with every
+                               // rounding of the transform (src/fft_impl.cpp:156-160 divides last): no bit of X changes.
 };
 
 // the raw words of two adjacent complex samples (columns 2p, 2p+1 of one row) -> c2
@@ -661,8 +667,8 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
     if (TWM) stw.load(Wl, i0_);
     const StageTw<L> *stw_front = (Plan<L>::NS == 3 && (TWM & 1)) ? &stw : nullptr, *stw_last = (TWM & 2) ? &stw : nullptr;
 
-    const cf wl0 = Wl[i0_];  // W_L^{i0}: the thread's part of every row's window angle (PSDR_HANN_ROT)
-    (void)wl0;
+    // W_L^{i0}: the thread's part of every row's window angle, times the output scale (Pass1Args::yscale)
+    const cf wl0 = make_float2(Wl[i0_].x * a.yscale, Wl[i0_].y * a.yscale);
 
     int it = 0;
     for (; s < total; it++) {
@@ -697,95 +703,57 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
         // exp(-i*2*pi*n/M) = W_M1^{n1} * W_M^{n2}
         const unsigned nA = tl * T + 2u * (unsigned)p, nB = nA + 1u;  // n2 of the two columns
         c2 u[16];
-#ifndef PSDR_HANN_ROT
-#define PSDR_HANN_ROT 1
-#endif
-        if constexpr (PSDR_HANN_ROT != 0) {
-            // The thread's rows are i0 + e L/16: exp(-i 2 pi row / L) = W_L^{i0} W_16^e - a per-thread constant times a
-            // sixteenth root of unity known at compile time.  With z0 = W_L^{i0} W_M^{n2} (one complex product per column
-            // and tile) the Hann weight of row e is 0.5 - 0.5 Re(z0 W_16^e) = 0.5 - 0.5 (z0.x cos t_e + z0.y sin t_e),
-            // t_e = 2 pi e / 16: two packed FMAs with literal coefficients per row and column couple, no table read per
-            // row (round 3: a stage-table read, two packed products and two FMAs per row for IQ; four complex products
-            // per row for real input, whose odd samples need a second angle)
-            cf wbA, wbB;  // W_M^{n2}: window angle of the columns
-            tw2(nA, nB, wbA, wbB);
-            cf z0A, z0B;
-            cmul_pair(z0A, wl0, wbA, z0B, wl0, wbB);
-            constexpr float C16[16] = {1.f, PSDR_C1_16, PSDR_SQRT1_2, PSDR_S1_16, 0.f, -PSDR_S1_16, -PSDR_SQRT1_2, -PSDR_C1_16,
-                                       -1.f, -PSDR_C1_16, -PSDR_SQRT1_2, -PSDR_S1_16, 0.f, PSDR_S1_16, PSDR_SQRT1_2, PSDR_C1_16};
-            constexpr float S16[16] = {0.f, PSDR_S1_16, PSDR_SQRT1_2, PSDR_C1_16, 1.f, PSDR_C1_16, PSDR_SQRT1_2, PSDR_S1_16,
-                                       0.f, -PSDR_S1_16, -PSDR_SQRT1_2, -PSDR_C1_16, -1.f, -PSDR_C1_16, -PSDR_SQRT1_2, -PSDR_S1_16};
-            // the integer formats' 2^-(bits-1) rides in the weights (a power of two: no bit of the product changes)
-            constexpr float hk = 0.5f * image_scale<SB>();
-            const bool flip = SB <= 4 && (fmt == PSDR_FMT_U8_ || fmt == PSDR_FMT_U16_);  // uniform: one branch per tile
-            auto fill = [&](auto flipc) {
-                constexpr bool FLIP = decltype(flipc)::value;
-                if (a.is_real) {
-                    // even samples: angle of z0; odd samples: one sample further, z0 W_N^1
-                    cf z1A, z1B;
-                    cmul_pair(z1A, z0A, a.wdelta, z1B, z0B, a.wdelta);
-                    const v2f zxA = {z0A.x, z1A.x}, zyA = {z0A.y, z1A.y}, zxB = {z0B.x, z1B.x}, zyB = {z0B.y, z1B.y};
-#pragma unroll
-                    for (int e = 0; e < 16; e++) {
-                        const c2 x = words_to_c2_fast<SB, FLIP>(rq[e]);
-                        const v2f kc = {-hk * C16[e], -hk * C16[e]}, ks = {-hk * S16[e], -hk * S16[e]}, hf = {hk, hk};
-                        const v2f wA = __builtin_elementwise_fma(zxA, kc, __builtin_elementwise_fma(zyA, ks, hf));
-                        const v2f wB = __builtin_elementwise_fma(zxB, kc, __builtin_elementwise_fma(zyB, ks, hf));
-                        u[e].a = from_v2f(to_v2f(x.a) * wA);
-                        u[e].b = from_v2f(to_v2f(x.b) * wB);
-                    }
-                } else {
-                    const v2f zx = {z0A.x, z0B.x}, zy = {z0A.y, z0B.y};
-#pragma unroll
-                    for (int e = 0; e < 16; e++) {
-                        const c2 x = words_to_c2_fast<SB, FLIP>(rq[e]);
-                        const v2f kc = {-hk * C16[e], -hk * C16[e]}, ks = {-hk * S16[e], -hk * S16[e]}, hf = {hk, hk};
-                        const v2f w2 = __builtin_elementwise_fma(zx, kc, __builtin_elementwise_fma(zy, ks, hf));
-                        u[e].a = scale_lo(x.a, w2);
-                        u[e].b = scale_hi(x.b, w2);
-                    }
-                }
-            };
-            if (flip)
-                fill(std::true_type{});
-            else
-                fill(std::false_type{});
-        } else {
-            cf wbA, wbB;  // W_M^{n2}: window angle of the columns
-            tw2(nA, nB, wbA, wbB);
+        // The thread's rows are i0 + e L/16: exp(-i 2 pi row / L) = W_L^{i0} W_16^e - a per-thread constant times a
+        // sixteenth root of unity known at compile time.  With z0 = W_L^{i0} W_M^{n2} (one complex product per column
+        // and tile) the Hann weight of row e is 0.5 - 0.5 Re(z0 W_16^e) = 0.5 - 0.5 (z0.x cos t_e + z0.y sin t_e),
+        // t_e = 2 pi e / 16: two packed FMAs with literal coefficients per row and column couple, no table read per
+        // row (round 3: a stage-table read, two packed products and two FMAs per row for IQ; four complex products
+        // per row for real input, whose odd samples need a second angle)
+        cf wbA, wbB;  // W_M^{n2}: window angle of the columns
+        tw2(nA, nB, wbA, wbB);
+        cf z0A, z0B;
+        cmul_pair(z0A, wl0, wbA, z0B, wl0, wbB);
+        constexpr float C16[16] = {1.f, PSDR_C1_16, PSDR_SQRT1_2, PSDR_S1_16, 0.f, -PSDR_S1_16, -PSDR_SQRT1_2, -PSDR_C1_16,
+                                   -1.f, -PSDR_C1_16, -PSDR_SQRT1_2, -PSDR_S1_16, 0.f, PSDR_S1_16, PSDR_SQRT1_2, PSDR_C1_16};
+        constexpr float S16[16] = {0.f, PSDR_S1_16, PSDR_SQRT1_2, PSDR_C1_16, 1.f, PSDR_C1_16, PSDR_SQRT1_2, PSDR_S1_16,
+                                   0.f, -PSDR_S1_16, -PSDR_SQRT1_2, -PSDR_C1_16, -1.f, -PSDR_C1_16, -PSDR_SQRT1_2, -PSDR_S1_16};
+        // the integer formats' 2^-(bits-1) rides in the weights (a power of two: no bit of the product changes); so does the
+        // output scale: z0 carries it through wl0, the constant term through hs
+        constexpr float hk = 0.5f * image_scale<SB>();
+        const float hs = hk * a.yscale;
+        const bool flip = SB <= 4 && (fmt == PSDR_FMT_U8_ || fmt == PSDR_FMT_U16_);  // uniform: one branch per tile
+        auto fill = [&](auto flipc) {
+            constexpr bool FLIP = decltype(flipc)::value;
             if (a.is_real) {
+                // even samples: angle of z0; odd samples: one sample further, z0 W_N^1
+                cf z1A, z1B;
+                cmul_pair(z1A, z0A, a.wdelta, z1B, z0B, a.wdelta);
+                const v2f zxA = {z0A.x, z1A.x}, zyA = {z0A.y, z1A.y}, zxB = {z0B.x, z1B.x}, zyB = {z0B.y, z1B.y};
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
-                    const int row = i0 + e * L16;
-                    u[e] = words_to_c2<SB, true>(rq[e], fmt);
-                    const cf wl = Wl[row];
-                    const cf zA = cmul(wl, wbA), zB = cmul(wl, wbB);
-                    u[e].a.x *= fmaf(-0.5f, zA.x, 0.5f);
-                    u[e].a.y *= fmaf(-0.5f, cmul(zA, a.wdelta).x, 0.5f);
-                    u[e].b.x *= fmaf(-0.5f, zB.x, 0.5f);
-                    u[e].b.y *= fmaf(-0.5f, cmul(zB, a.wdelta).x, 0.5f);
+                    const c2 x = words_to_c2_fast<SB, FLIP>(rq[e]);
+                    const v2f kc = {-hk * C16[e], -hk * C16[e]}, ks = {-hk * S16[e], -hk * S16[e]}, hf = {hs, hs};
+                    const v2f wA = __builtin_elementwise_fma(zxA, kc, __builtin_elementwise_fma(zyA, ks, hf));
+                    const v2f wB = __builtin_elementwise_fma(zxB, kc, __builtin_elementwise_fma(zyB, ks, hf));
+                    u[e].a = from_v2f(to_v2f(x.a) * wA);
+                    u[e].b = from_v2f(to_v2f(x.b) * wB);
                 }
             } else {
-                // both columns' weights in one packed pair:
-                //   w = k*(0.5 - 0.5*(wl.x*wb.x - wl.y*wb.y)),  k = the format's 2^-(bits-1)
-                const v2f wx = {wbA.x, wbB.x}, wy = {wbA.y, wbB.y};
-                constexpr float hk = 0.5f * image_scale<SB>();
+                const v2f zx = {z0A.x, z0B.x}, zy = {z0A.y, z0B.y};
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
-                    const int row = i0 + e * L16;
-                    const c2 x = words_to_c2<SB, false>(rq[e], fmt);
-                    const cf wl = Wl[row];
-                    v2f t, t2;
-                    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t) : "v"(to_v2f(wl)), "v"(wy));
-                    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]"
-                        : "=v"(t2)
-                        : "v"(to_v2f(wl)), "v"(wx), "v"(t));
-                    const v2f w2 = {fmaf(-hk, t2.x, hk), fmaf(-hk, t2.y, hk)};
+                    const c2 x = words_to_c2_fast<SB, FLIP>(rq[e]);
+                    const v2f kc = {-hk * C16[e], -hk * C16[e]}, ks = {-hk * S16[e], -hk * S16[e]}, hf = {hs, hs};
+                    const v2f w2 = __builtin_elementwise_fma(zx, kc, __builtin_elementwise_fma(zy, ks, hf));
                     u[e].a = scale_lo(x.a, w2);
                     u[e].b = scale_hi(x.b, w2);
                 }
             }
-        }
+        };
+        if (flip)
+            fill(std::true_type{});
+        else
+            fill(std::false_type{});
         PSDR_SCHED_FENCE();
         if (more) static_for<0, EARLY>(issue);  // the raw registers are free again
         PSDR_SCHED_FENCE();
@@ -927,10 +895,19 @@ struct Pass2Args {
     const cf *UA, *UB;  // W_N^{h << log2UB}, W_N^{l}: untangle twiddles
     const cf *UG;       // W_N^{8g}, g < M1/16: the tile's factor of the untangle twiddle
     int log2UB;
-    int seg_len;        // tiles of one frame a work-group walks in a chain (divides tiles_per_frame)
-    float *seamP;       // [nframes][segs][L][8]: partial octets of every segment's first tile
-    float *seamC;       // [nframes][segs][L]: carry-out of every segment's last tile
+    // chain segments of the fused real pass (forward.hip, build_seg_table): entry sg = { frame, first (highest) tile | tiles
+    // << 16, the segment ABOVE it in the frame (whose last tile carries into this one's first; the top segment's: the
+    // frame's bottom segment, whose tile 0 holds row M1/2), flags }
+    const uint4 *segtab;
+    float *seamP;       // [seam segments][L][8]: partial octets of the first tile of a segment without a carry-in
+    float *seamC;       // [segments][L]: carry-out of every segment's last tile
+    unsigned *segflag;  // [segments]: == epoch once the segment's carry-out row is in memory (hand-off mode)
+    unsigned epoch;     // of this launch (never 0)
+    unsigned ticket_base;  // first index handed out by the ticket counter: 2 * grid (two static segments per work-group) or
+                           // 0 (hand-off mode: a segment is only ever held by a RUNNING work-group, so that nobody spins on
+                           // the flag of a segment whose owner has not been dispatched yet)
 };
+enum { PSDR_SEG_CARRY_MEM = 1 };  // segtab flags: the first tile's carry-in comes from seamC[above] behind segflag[above]
 
 // pass 2: row FFT (length L = M2) of T adjacent rows c1 (T/2 couples); FUSED adds /N,
 // |X|^2, int8 level 0..LT of the pyramid.  L*T/32 threads.
@@ -1086,10 +1063,7 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
             [&](int bb, int ss, int c2i, c2 x) {
                 (void)bb, (void)ss;
                 if (FUSED) {
-                    x.a.x *= a.inv_n;
-                    x.a.y *= a.inv_n;
-                    x.b.x *= a.inv_n;
-                    x.b.y *= a.inv_n;
+                    // (/N, src/fft_impl.cpp:29-31, came in with the first pass's window weights: Pass1Args::yscale)
                     // src/fft_impl.cpp:36-38
                     *reinterpret_cast<float2 *>(Pst + c2i * T + 2 * p) =
                         make_float2(fmaf(x.a.x, x.a.x, x.a.y * x.a.y), fmaf(x.b.x, x.b.x, x.b.y * x.b.y));
@@ -1240,13 +1214,14 @@ __device__ __forceinline__ cf w32(int t) {
     const int u = t <= 8 ? 8 - t : t - 8;
     return make_float2(C[t], -C[u]);
 }
-// the two bins of a pair from a = Z[k], b = conj(Z[M-k]); w = W_N^k; h = 0.5/N (a power of two:
-// scaling last changes no bit).  xm is X[M-k].
-__device__ __forceinline__ void untangle_pair(cf a, cf b, cf w, float h, cf &xk, cf &xm) {
+// the two bins of a pair from a = Z[k], b = conj(Z[M-k]); w = W_N^k.  The 0.5/N of the reference's untangle and
+// normalisation came in with the first pass's window weights (Pass1Args::yscale: a power of two, no bit changes).
+// xm is X[M-k].
+__device__ __forceinline__ void untangle_pair(cf a, cf b, cf w, cf &xk, cf &xm) {
     const cf s = cadd(a, b), d = csub(a, b);
     const cf wo = cmul(w, make_float2(d.y, -d.x));  // W_N^k * (-i)(a-b)
-    xk = make_float2((s.x + wo.x) * h, (s.y + wo.y) * h);
-    xm = make_float2((s.x - wo.x) * h, (wo.y - s.y) * h);
+    xk = make_float2(s.x + wo.x, s.y + wo.y);
+    xm = make_float2(s.x - wo.x, wo.y - s.y);
 }
 // |x|^2 as the reference rounds it (src/fft_impl.cpp:36-38: fma(re, re, im*im)).  Two plain VALU
 // instructions: left to itself the compiler packs two of these into v_pk_mul/v_pk_fma and pays four
@@ -1298,26 +1273,20 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
     static_assert(TWC == 16 || TWC == 8, "pass-1 tile width");
     const int chunk = T * TW;
     const int lc = log2TW + 4;  // log2(chunk)
-    const int SL = a.seg_len;
-    const unsigned S = a.tiles_per_frame / (unsigned)SL;  // segments per frame
     float4 r[NLD];
     const cf *nxt = nullptr;
     // element idx of the tile = (pass-1 tile j, row rr, column cc), idx = j*chunk + rr*TW + cc: chunk j of
     // pass-2 tile g starts at g*ytile + j*yjs (tile-major Y: yjs = chunk, the tile is one linear block)
     const unsigned lane_off = (unsigned)((size_t)((2 * tid) >> lc) * a.yjs + ((2 * tid) & (chunk - 1)));
-    // tile j of segment sg: frame sg / S, g = (sg % S + 1) * SL - 1 - j (S, SL powers of two; the
-    // segment index is wave-uniform: keep the tile's coordinates and addresses in scalar registers)
-    const int l2S = 31 - __builtin_clz(S);
-    auto tile_of = [&](unsigned sg, int j, unsigned &f, int &g) {
-        sg = __builtin_amdgcn_readfirstlane(sg);
-        f = sg >> l2S;
-        g = (int)((sg - (f << l2S) + 1u) * (unsigned)SL) - 1 - j;
-    };
+    // tile j of segment sg: frame and first tile from the segment table, g = first - j (the segment index is
+    // wave-uniform: the entry comes through the scalar cache, the tile's coordinates and addresses stay in scalar registers)
+    typedef unsigned seg_u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) seg_u32x4 seg_entry_t;
+    auto seg_entry = [&](unsigned sg) -> seg_u32x4 { return ((seg_entry_t *)a.segtab)[__builtin_amdgcn_readfirstlane(sg)]; };
     auto point_at = [&](unsigned sg, int j) {
-        unsigned f;
-        int g;
-        tile_of(sg, j, f, g);
-        nxt = a.Y + (size_t)(f & a.ymask) * a.yframe + (size_t)g * a.ytile + lane_off;
+        const seg_u32x4 e = seg_entry(sg);
+        const int g = (int)(e.y & 0xFFFFu) - j;
+        nxt = a.Y + (size_t)(e.x & a.ymask) * a.yframe + (size_t)g * a.ytile + lane_off;
     };
     // SPLIT (as in pass2_body): register i holds the tile's load number i ^ 8, so that the loads issued FIRST (i < 8) are
     // the upper half of the LDS tile (n2 >= L/2).  The octet loop reads the staging rows (the lower half) and the carried
@@ -1340,15 +1309,45 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
     __shared__ unsigned s_next[2];
     TileQueue tq;
     tq.init(a.tickets, total, true);
+    tq.first_dyn = a.ticket_base;
+    tq.dynamic = a.tickets != nullptr && a.ticket_base < total;
     unsigned s = blockIdx.x, snext = blockIdx.x + gridDim.x;
+    if (a.ticket_base == 0) {
+        // hand-off mode: the first two segments are drawn too (Pass2Args::ticket_base)
+        if (tid == 0) s_next[0] = __hip_atomic_fetch_add(a.tickets, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        s = s_next[0];
+        snext = s + 1u;
+        __syncthreads();  // (s_next is written again by the first draw_end)
+    }
     if (s < total) {
         point_at(s, 0);
         static_for<0, NLD>(issue);
     }
     for (int i = tid; i < L; i += NT) Wl[i] = a.Wl[i];  // visible after the loop's first barrier
     tq.draw_first();
+    // Hand-off of the carried row between chain segments through memory (Pass2Args::segflag != nullptr): the LAST tile of
+    // a segment stores its carry-out row write-through (sc1: the reader sits on another XCD), every wave waits for its
+    // own stores with a COUNTED wait two stages into the next tile (tick 2: by then they are ~10 k cycles old and only the
+    // next tile's seven youngest loads are allowed to be outstanding), the barrier of that stage follows, thread 0
+    // publishes the launch's epoch in segflag[segment] (tick 3).  The FIRST tile of a segment whose table entry says
+    // PSDR_SEG_CARRY_MEM reads the flag of the segment above asynchronously at the top of the tile, looks at it at tick 3
+    // (after its own pending publication: a work-group never spins while it owes one), polls if it has to - with the
+    // level-major ticket order of build_seg_table() the producer finished a round of segments ago - fetches the row
+    // with sc1 loads behind the observed flag and drops it into the carry buffer before the octet loop's barrier.
+    // (cdna_hip_programming.md: in-launch hand-off, sc1 form - relaxed agent-scope accesses, one counted drain per
+    // publication, never a fence per tile.)
+    constexpr unsigned NOSEG = 0xFFFFFFFFu;
+    unsigned post_seg = NOSEG;  // segment whose carry-out row is stored but not published yet
+    // The flag and the row are CONDITIONAL loads whose results are used in other conditional blocks: at the joins the
+    // compiler has to assume them pending, and wherever it then re-used their registers it put a conservative wait on the
+    // path EVERY tile takes (vmcnt(4) before the last stage: a drain of the next tile's loads per tile).  They live in
+    // registers of their own for the whole loop instead (never re-initialised, a dummy use at the loop's end, where
+    // thirty younger operations make any such wait a formality).
+    unsigned fl = 0;
+    unsigned long long cin_mem = 0, cin_late = 0;  // carry-in row, floats 2 tid and 2 tid + 1: fetched at tick 1 / after a poll
 
-    const float hscale = 0.5f * a.inv_n;
+    const float unscale = 2.0f / a.inv_n;  // 1 / Pass1Args::yscale: bin N/2 is never normalised by the reference
     const unsigned ubm = (1u << a.log2UB) - 1u;
     // Untangle twiddle of the thread's first output: W_N^{c1 + M1*i0}, c1 = 8g + p.  The (p, i0) part
     // is a per-thread constant; the tile's part W_N^{8g} is wave-uniform and comes through the
@@ -1356,10 +1355,11 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
     // in-order vmcnt queue and waiting for it drains them all, once per tile.
     // Lane roles of the pair exchange below: even lanes keep the low-side bin X[k] ("mine") and pass
     // the mirror-side bin X[M-k] on ("send"), odd lanes the other way round.  With sigma = +1 / -1:
-    //   mine = (s + sigma*wo) * (h, sigma*h)      send = (s - sigma*wo) * (h, -sigma*h)
+    //   mine = (s + sigma*wo) * (1, sigma)      send = (s - sigma*wo) * (1, -sigma)
     // (s = a+b, wo = W_N^k * (-i)(a-b); the signed second component is the conjugation of X[M-k]),
-    // so the roles cost no select: sigma rides in the thread's twiddle constant and in two
-    // per-thread scale pairs.
+    // so the roles cost no select: sigma rides in the thread's twiddle constant and in two per-thread sign
+    // masks for the imaginary parts (one v_xor each; rounds 2-4 multiplied by (h, +-h) pairs here - the
+    // 0.5/N now comes in with the first pass's window weights, Pass1Args::yscale).
     const bool ev_ = (p_ & 1) == 0;
     cf wc;
     {
@@ -1367,25 +1367,26 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         wc = cmul(a.UA[e >> a.log2UB], a.UB[e & ubm]);
         if (!ev_) wc = make_float2(-wc.x, -wc.y);
     }
-    const v2f hm = {hscale, ev_ ? hscale : -hscale}, hs = {hscale, ev_ ? -hscale : hscale};
+    const unsigned sgn_mine = ev_ ? 0u : 0x80000000u, sgn_send = ev_ ? 0x80000000u : 0u;
     const int off_ = ev_ ? (p_ & ~1) : 14 - (p_ & ~1);  // bin of the lane's pair inside the 16-bin line
     const int xflip_ = ev_ ? 0 : L - 1;                 // mirror-side values of column c belong to column L-1-c
     int j = 0, segit = 0;
     for (int it = 0; s < total; it++) {
-        unsigned f;
-        int g;
-        tile_of(s, j, f, g);
+        const seg_u32x4 se = seg_entry(s);
+        const unsigned f = se.x;
+        const int g = (int)(se.y & 0xFFFFu) - j;
         PSDR_TRACE(a.trace, it, 0);
-        const bool seg_first = j == 0, seg_last = j == SL - 1;
-        const unsigned si = s - f * S;
-        bool more;
-        if (!seg_last) {
-            more = true;
+        const bool seg_first = j == 0, seg_last = j == (int)(se.y >> 16) - 1;
+        const bool carry_mem = seg_first && (se.w & PSDR_SEG_CARRY_MEM) != 0;  // carry-in through memory (uniform)
+        const bool seam_in = seg_first && !carry_mem;                          // no carry-in: k_real_seam completes the octets
+        // The next tile's loads are issued UNCONDITIONALLY: a work-group's very last tile fetches its own block once more
+        // (nxt stays where it is; 128 KiB per work-group and launch).  With the loads under `if (more)` every wait the
+        // compiler places behind them inside the same tile - the flag and the carried row of the hand-off below - has a
+        // path with nothing younger in flight and degenerates to vmcnt(0).
+        if (!seg_last)
             point_at(s, j + 1);
-        } else {
-            more = snext < total;
-            if (more) point_at(snext, 0);
-        }
+        else if (snext < total)
+            point_at(snext, 0);
         if (seg_first) {
             tq.draw_end(&s_next[segit & 1], s);
             tq.draw_begin();
@@ -1415,8 +1416,11 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             }
         }
         PSDR_SCHED_FENCE();
-        if (more) static_for<0, EARLY>(issue);
+        asm volatile("" ::"v"(fl), "v"(cin_mem), "v"(cin_late));  // (see their declaration; behind the fill's own waits)
+        static_for<0, EARLY>(issue);
         PSDR_SCHED_FENCE();
+        // the flag of the segment above, asynchronously (looked at at tick 1)
+        if (carry_mem) fl = __hip_atomic_load(a.segflag + se.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         PSDR_TRACE(a.trace, it, 1);
         __syncthreads();
         PSDR_TRACE(a.trace, it, 2);
@@ -1429,20 +1433,62 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         float *Pst = reinterpret_cast<float *>(smem);             // [L][16]: low octet, high octet
         cf *exA = tile_cf + (size_t)L * 8, *exB = exA + L;        // tile 0: rows 0 and M1/2 (beyond Pst)
         float *carry_w = carry + (it & 1) * L, *carry_r = carry + ((it & 1) ^ 1) * L;
-        float *seamC = a.seamC + ((size_t)f * S + si) * L;
+        float *seamC = a.seamC + (size_t)s * L;
+        bool cin_ok = false;  // the carried row was fetched at tick 1 (the flag was up when the tile began)
+        static_assert(NTICK == 4 && LPT == 1, "the counted drain below knows what the ticks issue");
         run_front_stages<L, T, true>(
             tile, Wl, i0, p, u,
             [&](int k) {
-                if (more)
-                    static_switch<0, NTICK>(k, [&](auto kc) {
-                        constexpr int K = decltype(kc)::value;
-                        constexpr int lo = EARLY + K * LPT < NFRONT ? EARLY + K * LPT : NFRONT;
-                        constexpr int hi = lo + LPT < NFRONT ? lo + LPT : NFRONT;
-                        static_for<lo, hi>(issue);
-                    });
+                static_switch<0, NTICK>(k, [&](auto kc) {
+                    constexpr int K = decltype(kc)::value;
+                    constexpr int lo = EARLY + K * LPT < NFRONT ? EARLY + K * LPT : NFRONT;
+                    constexpr int hi = lo + LPT < NFRONT ? lo + LPT : NFRONT;
+                    static_for<lo, hi>(issue);
+                });
+                if (k == 2 && post_seg != NOSEG) {
+                    // this wave's carry-out stores of the previous tile: older than the EARLY + 3 loads of the next tile
+                    // issued since (and than the flag load and wave 0's ticket, if any: then the wait is only stricter)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EARLY + 3) : "memory");
+                }
+                if (k == 1 && carry_mem) {
+                    // the usual case: the segment above was published long ago - fetch its row now, a stage and a half
+                    // before it is needed (sc1: from memory, not from this XCD's L2)
+                    asm volatile("" : "+v"(fl));  // (not to be speculated onto the path of the other tiles, wait included)
+                    cin_ok = fl == a.epoch;
+                    if (cin_ok)
+                        cin_mem = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(a.seamC + (size_t)se.z * L) + tid,
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (k == 3) {
+                    if (post_seg != NOSEG) {  // behind the stage's barriers: every wave has drained
+                        if (tid == 0) __hip_atomic_store(a.segflag + post_seg, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        post_seg = NOSEG;
+                    }
+                    if (carry_mem && !cin_ok) {  // not yet: wait for it here, with nothing owed to anybody
+                        do {
+                            __builtin_amdgcn_s_sleep(8);
+                            fl = __hip_atomic_load(a.segflag + se.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } while (fl != a.epoch);
+                        cin_late = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(a.seamC + (size_t)se.z * L) + tid,
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
             },
             [&](int k) { PSDR_TRACE(a.trace, it, k); });
-        if (LATE > 0 && more) static_for<NFRONT, NFRONT + LATE / 2>(issue);
+        if (LATE > 0) static_for<NFRONT, NFRONT + LATE / 2>(issue);
+        // the carried row from memory goes into the carry buffer BEFORE the last stage's stores: behind them the compiler's
+        // wait for it would be a wait for their acknowledgements (the buffer was last read in the previous tile's octet
+        // loop, and every wave is past that: the barriers of this tile)
+        // (two variables, two blocks: one variable with two places of definition makes the usual case wait as if it were
+        // the rare one - for the two loads issued just before)
+        if (carry_mem && cin_ok) {
+            reinterpret_cast<float2 *>(carry_r)[tid] =
+                make_float2(__uint_as_float((unsigned)cin_mem), __uint_as_float((unsigned)(cin_mem >> 32)));
+        }
+        if (carry_mem && !cin_ok) {
+            reinterpret_cast<float2 *>(carry_r)[tid] =
+                make_float2(__uint_as_float((unsigned)cin_late), __uint_as_float((unsigned)(cin_late >> 32)));
+        }
         const cf w0 = cmul(wc, wg);
         cf *Xt = Xf + (size_t)g * (16 * L);  // line (g, c) of the frame starts at Xt + 16 * c
         // Octet staging Pst[c2][16]: [0..8) the low octet of column c2; [8..15) elements 1..7 of the
@@ -1451,7 +1497,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         auto emit_pair = [&](int t, int c2i, c2 x) {
             cf xk, xm;
             const cf w0p = (p & 1) ? make_float2(-w0.x, -w0.y) : w0;  // (w0 carries the lane's sigma)
-            untangle_pair(x.a, x.b, cmul(w0p, w32(t)), hscale, xk, xm);
+            untangle_pair(x.a, x.b, cmul(w0p, w32(t)), xk, xm);
             const int cm = L - 1 - c2i;
             Xt[16 * c2i + p] = xk;
             Xt[16 * c2i + 15 - p] = xm;  // mirror row M1-p: element 7-p of the mirror octet
@@ -1495,7 +1541,9 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             run_last_stage<L>(Wl, i0, u, [&](int b, int sidx, int c2i, c2 x) {
                 const cf sm = cadd(x.a, x.b), d = csub(x.a, x.b);
                 const cf wo = cmul(cmul(w0, w32(b + NBL * sidx)), make_float2(d.y, -d.x));  // sigma * W_N^k * (-i)(a-b)
-                const v2f mine = (to_v2f(sm) + to_v2f(wo)) * hm, send = (to_v2f(sm) - to_v2f(wo)) * hs;
+                v2f mine = to_v2f(sm) + to_v2f(wo), send = to_v2f(sm) - to_v2f(wo);
+                mine.y = __uint_as_float(__float_as_uint(mine.y) ^ sgn_mine);
+                send.y = __uint_as_float(__float_as_uint(send.y) ^ sgn_send);
                 (void)c2i;  // = i0 + (L/16) * (b + NBL * sidx)
                 if ((sidx & 1) == 0) {
                     mineA = from_v2f(mine);
@@ -1526,14 +1574,14 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                     const int c2i = i0 + L16 * t;
                     cf xk, xm;
                     const cf pz = exA[(L - c2i) & (L - 1)];
-                    untangle_pair(exA[c2i], make_float2(pz.x, -pz.y), cmul(w0z, w32(t)), hscale, xk, xm);
+                    untangle_pair(exA[c2i], make_float2(pz.x, -pz.y), cmul(w0z, w32(t)), xk, xm);
                     Xf[16 * c2i] = xk;  // line (0, c2), bin 0
                     Pst[pst_at(c2i, 0)] = bin_power(xk);
                     // bin N/2 is never normalised by the reference (src/fft_impl.cpp:156-160 visits
                     // k < N/2 only): X[N/2] = Re Z[0] - Im Z[0]
-                    if (c2i == 0) Xf[(size_t)L << a.log2M1] = make_float2(exA[0].x - exA[0].y, 0.f);  // after the M bins
+                    if (c2i == 0) Xf[(size_t)L << a.log2M1] = make_float2((exA[0].x - exA[0].y) * unscale, 0.f);  // after the M bins
                     const cf ph = exB[L - 1 - c2i];
-                    untangle_pair(exB[c2i], make_float2(ph.x, -ph.y), cmul(w0h, w32(t)), hscale, xk, xm);
+                    untangle_pair(exB[c2i], make_float2(ph.x, -ph.y), cmul(w0h, w32(t)), xk, xm);
                     Xf[16 * (L - 1 - c2i) + 15] = xk;  // row M1/2 closes tile 0's mirror octet, line (0, L-1-c2)
                     seamC[c2i] = bin_power(xk);  // element 0 of the octet [M1/2, M1/2+8) at column c2
                 }
@@ -1542,11 +1590,11 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         PSDR_TRACE(a.trace, it, 10);
         __syncthreads();  // octet staging (and the carry) complete
         PSDR_TRACE(a.trace, it, 11);
-        if (LATE > 0 && more) static_for<NFRONT + LATE / 2, NLD>(issue);
+        if (LATE > 0) static_for<NFRONT + LATE / 2, NLD>(issue);
         {
             int8_t *Qf = a.Qt + (size_t)f * a.qt_stride;
             float *Pf = a.Pscr + (size_t)f * a.p_stride;
-            float *seamP = a.seamP + ((size_t)f * S + si) * L * 8;
+            float *seamP = a.seamP + (size_t)s * L * 8;  // (seam_in only: those segments come first in the table)
             constexpr int NG = 2 * L / NT;  // octets per thread: chunk q = 2*c2 + side
             // GRP octets at a time: their LDS reads (staging + carried row) are issued together, then the records
 #ifndef PSDR_OCT_GROUP
@@ -1580,10 +1628,13 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                     if (sd) {  // high octet: element 0 is the carried row, 1..7 sit at [0..7), and slot 7
                                // holds this tile's own carry-out (row M1-8g of column c2i)
                         carry_w[c2i] = v1[j].w;
-                        if (seg_last && g != 0) seamC[c2i] = v1[j].w;
+                        // (write-through: in hand-off mode the reader is a work-group on another XCD, inside this launch)
+                        if (seg_last && g != 0)
+                            __hip_atomic_store(reinterpret_cast<unsigned *>(seamC) + c2i, __float_as_uint(v1[j].w), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
                         pw[0] = cin[j];
                         pw[1] = v0[j].x, pw[2] = v0[j].y, pw[3] = v0[j].z, pw[4] = v0[j].w, pw[5] = v1[j].x, pw[6] = v1[j].y, pw[7] = v1[j].z;
-                        if (seg_first) {  // no carry-in: the octet is completed by k_real_seam
+                        if (seam_in) {  // no carry-in: the octet is completed by k_real_seam
                             reinterpret_cast<float4 *>(seamP)[2 * c2i] = v0[j];
                             reinterpret_cast<float4 *>(seamP)[2 * c2i + 1] = v1[j];
                         }
@@ -1624,11 +1675,13 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                     if (side) {  // high octet: element 0 is the carried row, 1..7 sit at [0..7), and slot 7
                                  // holds this tile's own carry-out (row M1-8g of column c2i)
                         carry_w[c2i] = v1[j].w;
-                        if (seg_last && g != 0) seamC[c2i] = v1[j].w;
+                        if (seg_last && g != 0)
+                            __hip_atomic_store(reinterpret_cast<unsigned *>(seamC) + c2i, __float_as_uint(v1[j].w), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
                         pw[0] = cin[j];
                         pw[1] = v0[j].x, pw[2] = v0[j].y, pw[3] = v0[j].z, pw[4] = v0[j].w, pw[5] = v1[j].x, pw[6] = v1[j].y, pw[7] = v1[j].z;
                     }
-                    if (side && seg_first) {  // no carry-in: the octet is completed by k_real_seam
+                    if (side && seam_in) {  // no carry-in: the octet is completed by k_real_seam
                         reinterpret_cast<float4 *>(seamP)[2 * c2i] = v0[j];
                         reinterpret_cast<float4 *>(seamP)[2 * c2i + 1] = v1[j];
                     }
@@ -1653,6 +1706,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         if (!SPLIT) __syncthreads();  // the tile is free again (SPLIT: between the next tile's two half-fills)
         PSDR_TRACE(a.trace, it, 13);
         if (seg_last) {
+            if (a.segflag && g != 0) post_seg = s;  // (tile 0's carry-out, row M1/2, is k_real_seam's: a later kernel)
             const unsigned s2 = s_next[segit & 1];
             s = snext;
             snext = s2;
@@ -1662,6 +1716,11 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         } else {
             j++;
         }
+    }
+    if (post_seg != NOSEG) {  // the work-group's last segment
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.segflag + post_seg, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     PSDR_WGTRACE(a.trace, 7);
     kclk_end(a.kclk);

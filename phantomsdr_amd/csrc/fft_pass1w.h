@@ -261,7 +261,7 @@ __global__ __launch_bounds__(kPass1wThreads) void k_fft_pass1_w(Pass1Args a) {
             cf wbA, wbB;
             tw2(nA, nB, wbA, wbB);
             const v2f wx = {wbA.x, wbB.x}, wy = {wbA.y, wbB.y};
-            constexpr float hk = 0.5f * image_scale<SB>();
+            const float hk = 0.5f * image_scale<SB>() * a.yscale;  // (Pass1Args::yscale: the output scale rides in the weights)
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const c2 x = words_to_c2<SB, false>(rq[e], fmt);

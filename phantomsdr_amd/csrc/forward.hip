@@ -48,6 +48,113 @@ int real_seg_len(const psdr_ctx *c, int nframes) {
     while (sl * 2 <= want && sl * 2 <= G) sl *= 2;
     return sl;
 }
+// Chain segments of a batch (k_fft_pass2_real, fft_pass.h).  Two forms:
+//  * uniform segments of real_seg_len() tiles, frame-major, every segment's first tile WITHOUT a carry-in (it leaves its
+//    partial octets in seamP, k_real_seam completes them): small batches, PSDR_SEG_LEN, static tile hand-out;
+//  * hand-off (batches of at least two frames per work-group): a frame is cut into segments of G/4, G/4, G/4, G/8, ... 2,
+//    1, 1 tiles from the top, handed out LEVEL-major - all frames' top segments first, then all second segments, ... - by
+//    the ticket counter alone.  Only the top segment of a frame has no carry-in (the ring closes through tile 0's row
+//    M1/2: one seam per frame, as with whole-frame segments); every other segment reads the carried row its predecessor -
+//    handed out nframes tickets earlier, i.e. finished about a round of segments ago - left in seamC behind its flag.
+//    What it buys: the work-groups of a launch differ by +-3.5 % in speed (the even XCDs are ~3 % slower: tools/trace_real.py),
+//    and with two whole-frame segments each nothing balanced that - the launch ended with its slowest work-group, 3.4 %
+//    after the median one.  With tickets and segments that shrink to single tiles the spread at the end is one tile, at
+//    a cost of 8 KiB of traffic per hand-off (a seam: 92 KiB and a record written twice).
+// tiles per segment from the top of a frame: G/4, G/4, G/4, G/8, ... 2, 1, 1 (tuning builds: PSDR_SEG_PLAN="32,16,8,8")
+static std::vector<int> seg_plan_lens(const psdr_ctx *c) {
+    const int G = c->M1 / 16;
+    std::vector<int> lens;
+    if (const char *e = psdr_tuning_env("PSDR_SEG_PLAN")) {
+        int sum = 0;
+        for (const char *q = e; *q;) {
+            const int v = atoi(q);
+            if (v > 0) lens.push_back(v), sum += v;
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+        if (sum == G) return lens;
+        lens.clear();
+    }
+    lens = {G / 4, G / 4, G / 4};
+    for (int l = G / 8; l >= 1; l >>= 1) lens.push_back(l);
+    lens.push_back(1);
+    return lens;
+}
+void seg_plan_counts(const psdr_ctx *c, int nframes, unsigned *nsegs, unsigned *nseam, bool *handoff) {
+    const int G = c->M1 / 16;
+    // (round 4: correct - bit-identical to whole-frame segments over 3 x 512 frames of 2^21 and 2^22 points - and SLOWER as
+    // first measured, cfg3 -6 %, cfg5 -10 %; tuning builds switch it on with PSDR_SEG_HANDOFF=1 until that is understood)
+    const bool ho = c->seg_len_env <= 0 && !c->static_tiles && G >= 16 && nframes >= 2 * std::max(c->num_cus, 1) &&
+                    psdr_tuning_env("PSDR_SEG_HANDOFF") != nullptr;
+    if (ho) {
+        const int levels = (int)seg_plan_lens(c).size();
+        *nsegs = (unsigned)(levels * nframes);
+        *nseam = (unsigned)nframes;
+    } else {
+        *nsegs = *nseam = (unsigned)(nframes * (G / real_seg_len(c, nframes)));
+    }
+    *handoff = ho;
+}
+static int seg_plan(psdr_ctx *c, int nframes, const psdr_ctx::SegPlan **out) {
+    for (const auto &sp : c->seg_plans)
+        if (sp.nframes == nframes) {
+            *out = &sp;
+            return PSDR_OK;
+        }
+    psdr_ctx::SegPlan sp;
+    sp.nframes = nframes;
+    seg_plan_counts(c, nframes, &sp.nsegs, &sp.nseam, &sp.handoff);
+    const int G = c->M1 / 16;
+    std::vector<uint4> tab(sp.nsegs);
+    if (sp.handoff) {
+        const std::vector<int> lens = seg_plan_lens(c);
+        const int levels = (int)lens.size();
+        // Frames in the order in which their top segments FINISH: a work-group starts with two consecutive tickets (2k,
+        // 2k + 1: the second is done a segment later than the first), everything from ticket 2 * grid on is drawn in
+        // order.  The levels below walk the frames in that order, so that a segment's predecessor - the same position
+        // one level up, nframes >= 2 * grid tickets earlier - was finished (and published) at least a segment ago.
+        const int grid = std::max(c->num_cus, 1);
+        std::vector<int> perm(nframes), pos(nframes);
+        {
+            int n = 0;
+            const int npair = std::min(nframes, 2 * grid);
+            const bool noperm = psdr_tuning_env("PSDR_SEG_NOPERM") != nullptr;
+            if (noperm) {
+                for (int f = 0; f < nframes; f++) perm[n++] = f;
+            } else {
+                for (int f = 0; f < npair; f += 2) perm[n++] = f;
+                for (int f = 1; f < npair; f += 2) perm[n++] = f;
+                for (int f = npair; f < nframes; f++) perm[n++] = f;
+            }
+            for (int i = 0; i < nframes; i++) pos[perm[i]] = i;
+        }
+        int g = G - 1;
+        for (int lv = 0; lv < levels; lv++) {
+            for (int i = 0; i < nframes; i++) {
+                const int f = lv ? perm[i] : i;
+                const unsigned above = lv == 0 ? (unsigned)((levels - 1) * nframes + pos[f])  // the frame's bottom segment
+                                     : lv == 1 ? (unsigned)f                                       // its top segment
+                                               : (unsigned)((lv - 1) * nframes + i);
+                tab[(size_t)lv * nframes + i] = make_uint4((unsigned)f, (unsigned)g | ((unsigned)lens[lv] << 16), above,
+                                                           lv ? (unsigned)PSDR_SEG_CARRY_MEM : 0u);
+            }
+            g -= lens[lv];
+        }
+    } else {
+        const int SL = real_seg_len(c, nframes), S = G / SL;
+        for (int f = 0; f < nframes; f++)
+            for (int si = 0; si < S; si++)
+                tab[(size_t)f * S + si] = make_uint4((unsigned)f, (unsigned)((si + 1) * SL - 1) | ((unsigned)SL << 16),
+                                                     (unsigned)(f * S + (si + 1) % S), 0u);
+    }
+    if (sp.nseam > c->seam_cap || sp.nsegs > c->seg_cap)
+        return fail(PSDR_ERR_STATE, "seam buffers too small (%u + %u segments, %zu + %zu allocated)", sp.nseam, sp.nsegs, c->seam_cap, c->seg_cap);
+    HIPCHK(hipMalloc((void **)&sp.d_tab, tab.size() * sizeof(uint4)));
+    HIPCHK(hipMemcpy(sp.d_tab, tab.data(), tab.size() * sizeof(uint4), hipMemcpyHostToDevice));  // (once per batch size)
+    c->seg_plans.push_back(sp);
+    *out = &c->seg_plans.back();
+    return PSDR_OK;
+}
 void select_set(psdr_ctx *c, int set) {
     c->cur_set = set;
     c->d_spec = c->spec_pool[set];
@@ -101,6 +208,9 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     a1.trace = c->d_trace;
     a1.kclk = next_kclk(c, 0);
     a1.ymask = ~0u;
+    // /N (src/fft_impl.cpp:29-31) - and the real untangle's 1/2 - as a power of two in the window weights: the fused
+    // second passes store what their last stage leaves; the three-pass real path scales in k_untangle_real as before
+    a1.yscale = !c->is_real ? 1.0f / (float)c->N : (c->real_fused ? 0.5f / (float)c->N : 1.0f);
     // (tuning builds only: a timing-only experiment with WRONG results - all frames of a launch share a few frames of Y)
     if (const char *e = psdr_tuning_env("PSDR_Y_ALIAS")) a1.ymask = (unsigned)atoi(e) - 1u;
     {
@@ -149,7 +259,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     if (c->set_pending[c->cur_set] && c->side != c->stream)
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_set_done[c->cur_set], 0));
     auto run_pass2 = [&](bool fused) -> int { return launch_pass2(c, c->M2, c->T2, fused, a2, a2.total_slots, wave1 /* couple-major Y */); };
-    int seam_S = 0, seam_SL = 0;  // fused real path: the seam kernel runs with the consumers
+    const psdr_ctx::SegPlan *plan = nullptr;  // fused real path: the seam kernel runs with the consumers
     if (!c->is_real) {
         a2.X = c->d_spec;
         a2.spec_stride = c->spec_stride;
@@ -177,17 +287,17 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
         a2.UB = c->d_UB;
         a2.UG = c->d_UG;
         a2.log2UB = c->log2UB;
-        a2.seg_len = real_seg_len(c, nframes);
-        const unsigned S = tiles2 / (unsigned)a2.seg_len;
-        if ((size_t)nframes * S > c->seam_cap)
-            return fail(PSDR_ERR_STATE, "seam buffers too small (%zu segments, %zu allocated)", (size_t)nframes * S, c->seam_cap);
+        rc = seg_plan(c, nframes, &plan);
+        if (rc) return rc;
+        a2.segtab = plan->d_tab;
         a2.seamP = c->d_seamP;
         a2.seamC = c->d_seamC;
-        a2.total_slots = S * (unsigned)nframes;
+        a2.segflag = plan->handoff ? c->d_segflag : nullptr;
+        if (++c->seg_epoch == 0) c->seg_epoch = 1;
+        a2.epoch = c->seg_epoch;
+        a2.total_slots = plan->nsegs;
         rc = launch_pass2_real(c, a2);
         if (rc) return rc;
-        seam_S = (int)S;
-        seam_SL = a2.seg_len;
     } else {
         a2.X = c->d_Z;
         a2.spec_stride = c->M;
@@ -222,12 +332,11 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
         HIPCHK(hipEventRecord(c->ev_fft_done, c->stream));
         HIPCHK(hipStreamWaitEvent(c->side, c->ev_fft_done, 0));
     }
-    if (seam_S) {  // fused real input: the mirror octets of every chain segment's first tile (epilogue.h)
+    if (plan) {  // fused real input: the mirror octets of the first tile of every chain segment without a carry-in (epilogue.h)
         SeamArgs sa{};
         sa.seamP = c->d_seamP;
         sa.seamC = c->d_seamC;
-        sa.S = seam_S;
-        sa.SL = seam_SL;
+        sa.segtab = plan->d_tab;
         sa.L = c->M2;
         sa.size_log2 = c->size_log2;
         sa.Qt = c->d_qt;
@@ -235,7 +344,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
         sa.Pscr = c->d_pscr[0];
         sa.p_stride = c->p_stride;
         ProfScope ps(c, K_SEAM, c->side);
-        hipLaunchKernelGGL(k_real_seam, dim3(seam_S, nframes), dim3(256), 0, c->side, sa);
+        hipLaunchKernelGGL(k_real_seam, dim3(plan->nseam), dim3(256), 0, c->side, sa);
         HIPCHK(hipGetLastError());
     }
     // remaining pyramid levels from the partial level in scratch

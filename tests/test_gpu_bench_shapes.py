@@ -73,7 +73,57 @@ def _default_seg_len(M1, nframes, num_cus=256):
 
 def test_bench_seg_len_is_what_the_chain_tests_cover():
     assert _default_seg_len(1024, 256) == 32 and _default_seg_len(2048, 256) == 64
-    assert _default_seg_len(1024, 512) == 64 and _default_seg_len(2048, 512) == 128  # bench.DEFAULT_BATCH: whole frames
+    assert _default_seg_len(1024, 512) == 64 and _default_seg_len(2048, 512) == 128  # whole frames: PSDR_SEG_LEN = G
+    # bench.DEFAULT_BATCH = 512 frames >= 1.5 per work-group: the hand-off plan (test_real_fused_model.py states it,
+    # test_handoff_plan_bit_identical_to_whole_frame_segments below runs it against the whole-frame segments)
+    import bench
+    from test_real_fused_model import seg_plan
+    assert bench.DEFAULT_BATCH == 512 and seg_plan(64, 512)[1] and not seg_plan(64, 256)[1]
+
+
+@pytest.mark.parametrize("log2n", [21, 22])
+def test_handoff_plan_bit_identical_to_whole_frame_segments(log2n, monkeypatch):
+    """The fused real second pass with the round-4 segment plan (segments of G/4 ... 1 tiles drawn level-major by tickets,
+    the carried row handed from work-group to work-group through memory behind a flag INSIDE the launch) against the same
+    512-frame batches with one whole-frame segment per frame (PSDR_SEG_LEN = G: no hand-off at all): the spectrum and
+    the int8 pyramid of EVERY frame of two consecutive launches (both result sets, two epochs of the flags) must be
+    bit-identical - a stale carried row would show in the mirror-side octets of a segment's first tile."""
+    import hashlib
+    from phantomsdr_amd import Context
+    N, F = 1 << log2n, 512
+    G = (N // 2 // 1024) // 16
+    rng = np.random.default_rng(log2n)
+    raw = rng.integers(-2000, 2000, size=(2 * F + 1) * (N // 2), dtype=np.int16)
+    raw[::7919] = 32767  # spikes: every tile's carried row is its own
+
+    def run(seg_len):
+        if seg_len:
+            monkeypatch.setenv("PSDR_SEG_LEN", str(seg_len))
+        else:
+            monkeypatch.delenv("PSDR_SEG_LEN", raising=False)
+        ctx = Context(N, True, 12 if log2n == 22 else 11, input_format="s16", max_batch=F)
+        try:
+            d = ctx.dev_alloc(raw.nbytes)
+            ctx.h2d(d, raw)
+            out = []
+            hb = ctx.half_frame_bytes()
+            ctx.process_batch(d, F)
+            ctx.process_batch(d, F, offset_bytes=F * hb)  # the second launch's results are what can be read
+            for f in range(F):
+                out.append((hashlib.blake2b(ctx.read_spectrum(f).tobytes(), digest_size=16).digest(),
+                            hashlib.blake2b(ctx.read_quantized(f).tobytes(), digest_size=16).digest()))
+            ctx.process_batch(d, F)  # third launch, first half again: the other result set, a third epoch
+            for f in (0, 1, F // 2, F - 1):
+                out.append((hashlib.blake2b(ctx.read_spectrum(f).tobytes(), digest_size=16).digest(),
+                            hashlib.blake2b(ctx.read_quantized(f).tobytes(), digest_size=16).digest()))
+            ctx.dev_free(d)
+            return out
+        finally:
+            ctx.close()
+    a, b = run(0), run(G)
+    bad_x = [f for f in range(len(a)) if a[f][0] != b[f][0]]
+    bad_q = [f for f in range(len(a)) if a[f][1] != b[f][1]]
+    assert not bad_x and not bad_q, (bad_x[:8], bad_q[:8])
 
 
 @pytest.mark.parametrize("wl_name", ["cfg2", "cfg3"])

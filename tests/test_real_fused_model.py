@@ -63,19 +63,65 @@ def untangle_pair(a, b, w, h):
     return (s + wo) * h, np.conj((s - wo) * h)
 
 
+def seg_plan(G, nframes, num_cus=256, seg_len_env=0, static_tiles=False):
+    """forward.hip: seg_plan_counts / seg_plan.  Returns (table, handoff, nseam): table[sg] = (frame, first tile, tiles,
+    segment above, carry-in through memory)."""
+    handoff = seg_len_env <= 0 and not static_tiles and G >= 16 and nframes >= 2 * num_cus
+    tab = []
+    if handoff:
+        lens = [G // 4] * 3
+        l = G // 8
+        while l >= 1:
+            lens.append(l)
+            l //= 2
+        lens.append(1)
+        npair = min(nframes, 2 * num_cus)   # a work-group's first two tickets are 2k, 2k + 1: the odd one is done later
+        perm = list(range(0, npair, 2)) + list(range(1, npair, 2)) + list(range(npair, nframes))
+        pos = {f: i for i, f in enumerate(perm)}
+        g = G - 1
+        for lv, ln in enumerate(lens):
+            for i in range(nframes):
+                f = perm[i] if lv else i
+                above = (len(lens) - 1) * nframes + pos[f] if lv == 0 else (f if lv == 1 else (lv - 1) * nframes + i)
+                tab.append((f, g, ln, above, lv > 0))
+            g -= ln
+        return tab, True, nframes
+    if seg_len_env > 0:
+        sl = 1
+        while sl * 2 <= seg_len_env and sl * 2 <= G:
+            sl *= 2
+    else:
+        want = G * nframes // (2 * max(num_cus, 1))
+        sl = 1
+        while sl * 2 <= want and sl * 2 <= G:
+            sl *= 2
+    S = G // sl
+    for f in range(nframes):
+        for si in range(S):
+            tab.append((f, (si + 1) * sl - 1, sl, f * S + (si + 1) % S, False))
+    return tab, False, len(tab)
+
+
 def fused_pass2(slots, M1, M2, seg_len):
-    """returns (permuted spectrum [M+1], records dict pos -> 8 powers, level-3 sums dict)"""
-    M, N = M1 * M2, 2 * M1 * M2
+    """uniform segments of seg_len tiles, every one with a seam (small batches, PSDR_SEG_LEN)"""
     G = M1 // 16
     S = G // seg_len
+    return fused_pass2_segments(slots, M1, M2, [((si + 1) * seg_len - 1, seg_len, (si + 1) % S, False) for si in range(S)])
+
+
+def fused_pass2_segments(slots, M1, M2, segs):
+    """One frame.  segs[i] = (first tile, tiles, index of the segment above, carry-in through memory); processed in the
+    order given (a segment with a carry-in through memory needs its predecessor's carry-out: the order must provide it,
+    as the ticket order of the kernel does).  Returns (permuted spectrum [M+1], records dict pos -> 8 powers)."""
+    M, N = M1 * M2, 2 * M1 * M2
     h = 0.5 / N
     X = np.zeros(M + 1, complex)
     rec, seamP, seamC = {}, {}, {}
     c2 = np.arange(M2)
-    for si in range(S):
-        carry = None
+    for si, (g_first, seg_len, above, carry_mem) in enumerate(segs):
+        carry = seamC[above].copy() if carry_mem else None   # (KeyError: the plan handed the segments out in a wrong order)
         for j in range(seg_len):
-            g = (si + 1) * seg_len - 1 - j
+            g = g_first - j
             low = np.zeros((M2, 8))
             high = np.zeros((M2, 8))
             carry_w = np.zeros(M2)
@@ -106,21 +152,22 @@ def fused_pass2(slots, M1, M2, seg_len):
                 else:
                     carry_w[cm] = np.abs(xm) ** 2
                     if j == seg_len - 1:
-                        seamC[si] = carry_w.copy()
+                        seamC[si] = carry_w.copy()      # (hand-off plan: published behind segflag[si])
             for c in range(M2):
                 rec[(g * M2 + c) * 2] = low[c].copy()
-                if j == 0:
+                if carry is None:
                     seamP[si] = high.copy() if c == 0 else seamP[si]
                 else:
                     pw = high[c].copy()
                     pw[0] = carry[c]
                     rec[(g * M2 + c) * 2 + 1] = pw
             carry = carry_w
-    for si in range(S):                          # k_real_seam
-        g = (si + 1) * seg_len - 1
+    for si, (g, _, above, carry_mem) in enumerate(segs):   # k_real_seam: the segments without a carry-in
+        if carry_mem:
+            continue
         for c in range(M2):
             pw = seamP[si][c].copy()
-            pw[0] = seamC[(si + 1) % S][c]
+            pw[0] = seamC[above][c]
             rec[(g * M2 + c) * 2 + 1] = pw
     return X, rec
 
@@ -139,6 +186,62 @@ def test_fused_real_pass2_model_matches_rfft(M1, M2, seg_len):
     got = np.concatenate([Xp[pos], Xp[M:]])
     assert np.abs(got - ref).max() < 1e-12 * np.abs(ref).max() * N
     # octet records in true k order through RecMap mode 2
+    P = np.abs(ref[:M]) ** 2
+    assert len(rec) == M // 8
+    for o in range(M // 8):
+        assert np.allclose(rec[recmap2_pos(o, M1, M2)], P[8 * o: 8 * o + 8], rtol=1e-9, atol=0), o
+
+
+@pytest.mark.parametrize("G,nframes", [(64, 512), (128, 512), (64, 640), (16, 600), (64, 511), (64, 256), (64, 1), (128, 7)])
+def test_segment_plan_partitions_frames_and_orders_the_hand_offs(G, nframes):
+    """the table k_fft_pass2_real walks (forward.hip, seg_plan): every tile of every frame in exactly one segment; the
+    segments without a carry-in first (k_real_seam's grid); in hand-off mode a segment's predecessor is the segment of
+    the SAME frame that ends one tile above it, handed out exactly nframes tickets earlier, and only a frame's top
+    segment needs a seam (the ring closes through tile 0's row M1/2)"""
+    tab, handoff, nseam = seg_plan(G, nframes)
+    assert handoff == (nframes >= 2 * 256)
+    seen = np.zeros((nframes, G), int)
+    for f, g0, ln, above, mem in tab:
+        assert ln >= 1 and g0 - ln + 1 >= 0
+        seen[f, g0 - ln + 1: g0 + 1] += 1
+    assert (seen == 1).all()
+    assert all(not t[4] for t in tab[:nseam]) and all(t[4] for t in tab[nseam:])
+    for sg, (f, g0, ln, above, mem) in enumerate(tab):
+        fa, ga, la, _, _ = tab[above]
+        assert fa == f
+        if g0 == G - 1:
+            assert ga - la + 1 == 0 and not mem      # the top segment: row M1/2 from the segment that holds tile 0
+        else:
+            assert ga - la + 1 == g0 + 1             # the segment above ends one tile above this one's first
+        if mem:
+            assert sg - above >= nframes - 256       # handed out at least nframes - grid tickets earlier ...
+            # ... and not in the time slot right before: a work-group's first two tickets are 2k, 2k + 1 (slots 0 and 1),
+            # ticket t >= 512 is drawn in slot t // 256
+            slot = lambda t: (t & 1) if t < 512 else t // 256
+            assert slot(sg) - slot(above) >= 2
+    if handoff:
+        assert nseam == nframes and max(t[2] for t in tab) == G // 4 and tab[-1][2] == 1
+        assert len(tab) == nframes * (4 + int(np.log2(G // 8)) + 1)
+
+
+@pytest.mark.parametrize("M1,M2", [(256, 8), (512, 4)])
+def test_fused_real_pass2_model_with_the_hand_off_plan(M1, M2):
+    """the hand-off plan's segments of one frame (G/4, G/4, G/4, G/8 ... 1, 1 tiles from the top, carry-in through
+    memory for all but the first) through the model: same spectrum and records as numpy.fft.rfft"""
+    M, N, G = M1 * M2, 2 * M1 * M2, M1 // 16
+    tab, handoff, _ = seg_plan(G, 512)
+    assert handoff
+    mine = [sg for sg, t in enumerate(tab) if t[0] == 0]
+    segs = [(tab[sg][1], tab[sg][2], mine.index(tab[sg][3]), tab[sg][4]) for sg in mine]
+    rng = np.random.default_rng(M1)
+    x = rng.standard_normal(N)
+    z = x[0::2] + 1j * x[1::2]
+    Xp, rec = fused_pass2_segments(pass1_pair(z, M1, M2), M1, M2, segs)
+    ref = np.fft.rfft(x) / N
+    ref[M] *= N
+    pos = np.array([spec_layout_pos(int(k), M1, M2) for k in range(M)])
+    got = np.concatenate([Xp[pos], Xp[M:]])
+    assert np.abs(got - ref).max() < 1e-12 * np.abs(ref).max() * N
     P = np.abs(ref[:M]) ** 2
     assert len(rec) == M // 8
     for o in range(M // 8):
