@@ -312,8 +312,8 @@ int build(psdr_ctx *c) {
             HIPCHK(hipMalloc((void **)&c->seam_pool[st][0], cap * (size_t)c->M2 * 8 * sizeof(float)));
             HIPCHK(hipMalloc((void **)&c->seam_pool[st][1], capc * (size_t)c->M2 * sizeof(float)));
         }
-        HIPCHK(hipMalloc((void **)&c->d_segflag, capc * sizeof(unsigned)));
-        HIPCHK(hipMemset(c->d_segflag, 0, capc * sizeof(unsigned)));
+        HIPCHK(hipMalloc((void **)&c->d_segflag, 2 * capc * sizeof(unsigned)));  // flags, then the fallback marks
+        HIPCHK(hipMemset(c->d_segflag, 0, 2 * capc * sizeof(unsigned)));
     }
     for (int s = 0; s < 2; s++) {
         HIPCHK(hipMalloc((void **)&c->spec_pool[s], F * c->spec_stride * sizeof(cf)));
@@ -819,6 +819,28 @@ extern "C" int psdr_debug_trace(psdr_ctx *c, unsigned long long *out256) {
     if (!c->d_trace) return fail(PSDR_ERR_UNSUPPORTED, "library built without PSDR_TRACE_ON");
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out256, c->d_trace, 4864 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return PSDR_OK;
+}
+// (not in psdr.h: tools/seg_fallbacks.py and the hand-off test) segments of the LAST fused real-input launch, and how many
+// of them did not find their carried row in memory in time and fell back to a seam (fft_pass.h: hand-off); 0 / 0 when the
+// launch used uniform segments
+extern "C" int psdr_debug_seg_fallbacks(psdr_ctx *c, unsigned *nsegs, unsigned *fallbacks, unsigned char *which, unsigned cap) {
+    if (!c || !nsegs || !fallbacks) return fail(PSDR_ERR_INVALID, "null argument");
+    *nsegs = *fallbacks = 0;
+    if (!c->real_fused || !c->d_segflag || c->last_nframes <= 0) return PSDR_OK;
+    const psdr_ctx::SegPlan *plan = nullptr;
+    for (const auto &sp : c->seg_plans)
+        if (sp.nframes == c->last_nframes) plan = &sp;
+    if (!plan || !plan->handoff) return PSDR_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<unsigned> m(plan->nsegs);
+    HIPCHK(hipMemcpy(m.data(), c->d_segflag + c->seg_cap, m.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+    *nsegs = plan->nsegs;
+    for (unsigned i = 0; i < plan->nsegs; i++) {
+        const bool fb = m[i] == c->seg_epoch;
+        *fallbacks += fb;
+        if (which && i < cap) which[i] = fb;  // (level-major: segment i is level i / nframes of frame i % nframes)
+    }
     return PSDR_OK;
 }
 extern "C" int psdr_set_stream(psdr_ctx *c, void *hip_stream) {

@@ -342,11 +342,14 @@ __global__ __launch_bounds__(256) void k_untangle_real(UntangleArgs a) {
 // ---- fused real-input path (k_fft_pass2_real, fft_pass.h) -------------------------------------
 // Completes the high octets a segment's first tile could not finish: element 0 of the octet comes
 // from the carry-out of the segment above (the LAST segment's from tile 0: row M1/2), elements
-// 1..7 from the tile's own partial rows.  grid = the segments without a carry-in (the first entries of the table).
+// 1..7 from the tile's own partial rows.  grid = the segments; those whose carried row arrived inside the launch
+// (hand-off plans: fft_pass.h) have nothing left to do.
 struct SeamArgs {
     const float *seamP;  // [seam segments][L][8]: elements 1..7 of the octet at [0..7)
     const float *seamC;  // [segments][L]
-    const uint4 *segtab; // Pass2Args::segtab: the segments without a carry-in come first
+    const uint4 *segtab; // Pass2Args::segtab
+    const unsigned *segmark;  // hand-off plans: == epoch for a segment whose carry-in was not in memory in time (else nullptr)
+    unsigned epoch;
     int L;               // row length (M2)
     int size_log2;
     int8_t *Qt;
@@ -356,6 +359,7 @@ struct SeamArgs {
 };
 __global__ __launch_bounds__(256) void k_real_seam(SeamArgs a) {
     const uint4 se = a.segtab[blockIdx.x];
+    if ((se.w & 1u) && a.segmark[blockIdx.x] != a.epoch) return;  // (PSDR_SEG_CARRY_MEM) the carried row arrived inside the launch
     const int f = (int)se.x;
     const int g = (int)(se.y & 0xFFFFu);  // the segment's first tile
     const float *P = a.seamP + (size_t)blockIdx.x * a.L * 8;

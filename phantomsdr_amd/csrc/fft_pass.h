@@ -75,6 +75,13 @@
     } while (0)
 #endif
 
+// The passes fetch the NEXT tile while they work on the current one.  PSDR_UNCOND_PREFETCH=1: those loads are issued for a
+// work-group's last tile too (it fetches its own block once more: one tile per work-group and launch) - with the loads
+// under `if (there is a next tile)` the compiler's counted waits degrade wherever a path without them joins.
+#ifndef PSDR_UNCOND_PREFETCH
+#define PSDR_UNCOND_PREFETCH 1
+#endif
+
 namespace psdr {
 
 // Device-clock stamps of a launch (psdr_set_profiling mode 2): k[0] = earliest work-group entry, k[1] = latest
@@ -359,7 +366,7 @@ __device__ __forceinline__ unsigned xcd_slot(unsigned bid, unsigned total) {
 struct TileQueue {
     unsigned *tickets;
     unsigned total, base;  // indices below 2*gridDim.x are the static first tiles
-    unsigned first_dyn;    // index of ticket 0 of the chip-wide counter (2*gridDim.x; 0: everything is drawn)
+    unsigned first_dyn;    // index of ticket 0 of the chip-wide counter (2*gridDim.x)
     unsigned pending;      // owner thread: ticket drawn, not yet examined
     unsigned ptx;          // ... and the XCD whose counter it came from
     unsigned owner;        // the thread that draws (0 unless the kernel has a loader wave)
@@ -683,8 +690,9 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
         cf *Yhi = Yb - (size_t)((i0_ + 7) >> 3) * a.ytile + (8 + ((-i0_) & 7)) * T + 2 * p_;
         (void)Ylo;
         (void)Yhi;
-        const bool more = snext < total;
-        if (more) point_at(snext);
+        const bool has_next = snext < total;
+        if (has_next) point_at(snext);
+        const bool more = PSDR_UNCOND_PREFETCH ? true : has_next;  // (the loads below; nxt stays on this tile without a next one)
         // the index after `snext`: drawn one tile ago, published now, read after the barrier
         tq.draw_end(&s_next[it & 1], s);
         tq.draw_begin();
@@ -901,11 +909,10 @@ struct Pass2Args {
     const uint4 *segtab;
     float *seamP;       // [seam segments][L][8]: partial octets of the first tile of a segment without a carry-in
     float *seamC;       // [segments][L]: carry-out of every segment's last tile
-    unsigned *segflag;  // [segments]: == epoch once the segment's carry-out row is in memory (hand-off mode)
+    unsigned *segflag;  // [segments]: == epoch once the segment's carry-out row is in memory (hand-off plans; else nullptr)
+    unsigned *segmark;  // [segments]: == epoch if the segment's first tile did NOT find its carry-in in time and left its
+                        // partial octets in seamP like a segment without one (k_real_seam completes them)
     unsigned epoch;     // of this launch (never 0)
-    unsigned ticket_base;  // first index handed out by the ticket counter: 2 * grid (two static segments per work-group) or
-                           // 0 (hand-off mode: a segment is only ever held by a RUNNING work-group, so that nobody spins on
-                           // the flag of a segment whose owner has not been dispatched yet)
 };
 enum { PSDR_SEG_CARRY_MEM = 1 };  // segtab flags: the first tile's carry-in comes from seamC[above] behind segflag[above]
 
@@ -1013,8 +1020,9 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
         const unsigned f = slot / a.tiles_per_frame;
         const unsigned tl = slot - f * a.tiles_per_frame;
         const int c1base = tl * T;
-        const bool more = snext < total;
-        if (more) point_at(snext);
+        const bool has_next = snext < total;
+        if (has_next) point_at(snext);
+        const bool more = PSDR_UNCOND_PREFETCH ? true : has_next;  // (the loads below; nxt stays on this tile without a next one)
         // the index after `snext`: drawn one tile ago, published now, read after the barrier
         tq.draw_end(&s_next[it & 1], s);
         tq.draw_begin();
@@ -1283,8 +1291,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
     typedef unsigned seg_u32x4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(4))) seg_u32x4 seg_entry_t;
     auto seg_entry = [&](unsigned sg) -> seg_u32x4 { return ((seg_entry_t *)a.segtab)[__builtin_amdgcn_readfirstlane(sg)]; };
-    auto point_at = [&](unsigned sg, int j) {
-        const seg_u32x4 e = seg_entry(sg);
+    auto point_at = [&](seg_u32x4 e, int j) {
         const int g = (int)(e.y & 0xFFFFu) - j;
         nxt = a.Y + (size_t)(e.x & a.ymask) * a.yframe + (size_t)g * a.ytile + lane_off;
     };
@@ -1306,35 +1313,35 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         const cf *q = nxt + (size_t)((2 * ip * NT) >> lc) * a.yjs + ((2 * ip * NT) & (chunk - 1));
         r[i] = *reinterpret_cast<const float4 *>(q);
     };
-    __shared__ unsigned s_next[2];
+    __shared__ unsigned s_next[4];  // [0..1]: the index after snext (TileQueue); [2]: the carry-in of this segment is in memory
     TileQueue tq;
     tq.init(a.tickets, total, true);
-    tq.first_dyn = a.ticket_base;
-    tq.dynamic = a.tickets != nullptr && a.ticket_base < total;
     unsigned s = blockIdx.x, snext = blockIdx.x + gridDim.x;
-    if (a.ticket_base == 0) {
-        // hand-off mode: the first two segments are drawn too (Pass2Args::ticket_base)
-        if (tid == 0) s_next[0] = __hip_atomic_fetch_add(a.tickets, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        s = s_next[0];
-        snext = s + 1u;
-        __syncthreads();  // (s_next is written again by the first draw_end)
-    }
+    // The table entries of the current and of the next segment live in scalar registers; the entry of a segment is
+    // fetched when its index becomes known, a whole segment before it is used (a first touch misses the scalar cache
+    // AND the L2: fetched where they are needed, two entries cost a work-group ~5 k cycles per segment)
+    seg_u32x4 se = {0u, 0u, 0u, 0u}, sen = se;
     if (s < total) {
-        point_at(s, 0);
+        se = seg_entry(s);
+        if (snext < total) sen = seg_entry(snext);
+        point_at(se, 0);
         static_for<0, NLD>(issue);
     }
     for (int i = tid; i < L; i += NT) Wl[i] = a.Wl[i];  // visible after the loop's first barrier
     tq.draw_first();
-    // Hand-off of the carried row between chain segments through memory (Pass2Args::segflag != nullptr): the LAST tile of
-    // a segment stores its carry-out row write-through (sc1: the reader sits on another XCD), every wave waits for its
-    // own stores with a COUNTED wait two stages into the next tile (tick 2: by then they are ~10 k cycles old and only the
-    // next tile's seven youngest loads are allowed to be outstanding), the barrier of that stage follows, thread 0
-    // publishes the launch's epoch in segflag[segment] (tick 3).  The FIRST tile of a segment whose table entry says
-    // PSDR_SEG_CARRY_MEM reads the flag of the segment above asynchronously at the top of the tile, looks at it at tick 3
-    // (after its own pending publication: a work-group never spins while it owes one), polls if it has to - with the
-    // level-major ticket order of build_seg_table() the producer finished a round of segments ago - fetches the row
-    // with sc1 loads behind the observed flag and drops it into the carry buffer before the octet loop's barrier.
+    // Hand-off of the carried row between chain segments through memory (Pass2Args::segflag != nullptr).
+    // Producer: the LAST tile of a segment stores its carry-out row write-through (sc1: the reader sits on another XCD),
+    // every wave waits for its own stores with a COUNTED wait two stages into the next tile (tick 2: by then they are
+    // ~10 k cycles old and only the next tile's seven youngest loads are allowed to be outstanding), the barrier of that
+    // stage follows, thread 0 publishes the launch's epoch in segflag[segment] (tick 3).
+    // Consumer: thread 0 reads the flag of the segment above a tile EARLY (at the top of the previous segment's last tile,
+    // or before the loop) and says at tick 0 of the segment's first tile - through s_next[2] - whether it was up.  If so,
+    // every thread fetches its piece of the row with sc1 loads at tick 1 (behind the observed flag) and drops it into the
+    // carry buffer before the last stage; the tile is then a tile like any other.  If not, NOBODY WAITS: the tile leaves
+    // its partial octets in seamP as a segment without a carry-in does and marks itself in segmark, k_real_seam completes
+    // them after the launch.  No spinning means no assumption about which work-groups are resident (two contexts on one
+    // device, static first tiles) and no cost when the timing of a launch's first segments is off; with the level-major
+    // ticket order of build_seg_table() the predecessor finished a round of segments earlier and the fallback is rare.
     // (cdna_hip_programming.md: in-launch hand-off, sc1 form - relaxed agent-scope accesses, one counted drain per
     // publication, never a fence per tile.)
     constexpr unsigned NOSEG = 0xFFFFFFFFu;
@@ -1344,8 +1351,10 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
     // path EVERY tile takes (vmcnt(4) before the last stage: a drain of the next tile's loads per tile).  They live in
     // registers of their own for the whole loop instead (never re-initialised, a dummy use at the loop's end, where
     // thirty younger operations make any such wait a formality).
-    unsigned fl = 0;
-    unsigned long long cin_mem = 0, cin_late = 0;  // carry-in row, floats 2 tid and 2 tid + 1: fetched at tick 1 / after a poll
+    unsigned fl = 0;                 // thread 0: flag of the segment above the NEXT segment to start
+    unsigned long long cin_mem = 0;  // carry-in row, floats 2 tid and 2 tid + 1
+    if (a.segflag && tid == 0 && s < total && (se.w & PSDR_SEG_CARRY_MEM))
+        fl = __hip_atomic_load(a.segflag + se.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     const float unscale = 2.0f / a.inv_n;  // 1 / Pass1Args::yscale: bin N/2 is never normalised by the reference
     const unsigned ubm = (1u << a.log2UB) - 1u;
@@ -1372,21 +1381,19 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
     const int xflip_ = ev_ ? 0 : L - 1;                 // mirror-side values of column c belong to column L-1-c
     int j = 0, segit = 0;
     for (int it = 0; s < total; it++) {
-        const seg_u32x4 se = seg_entry(s);
         const unsigned f = se.x;
         const int g = (int)(se.y & 0xFFFFu) - j;
         PSDR_TRACE(a.trace, it, 0);
         const bool seg_first = j == 0, seg_last = j == (int)(se.y >> 16) - 1;
-        const bool carry_mem = seg_first && (se.w & PSDR_SEG_CARRY_MEM) != 0;  // carry-in through memory (uniform)
-        const bool seam_in = seg_first && !carry_mem;                          // no carry-in: k_real_seam completes the octets
+        const bool carry_mem = seg_first && (se.w & PSDR_SEG_CARRY_MEM) != 0;  // carry-in through memory, if it is there (uniform)
         // The next tile's loads are issued UNCONDITIONALLY: a work-group's very last tile fetches its own block once more
         // (nxt stays where it is; 128 KiB per work-group and launch).  With the loads under `if (more)` every wait the
         // compiler places behind them inside the same tile - the flag and the carried row of the hand-off below - has a
         // path with nothing younger in flight and degenerates to vmcnt(0).
         if (!seg_last)
-            point_at(s, j + 1);
+            point_at(se, j + 1);
         else if (snext < total)
-            point_at(snext, 0);
+            point_at(sen, 0);
         if (seg_first) {
             tq.draw_end(&s_next[segit & 1], s);
             tq.draw_begin();
@@ -1416,11 +1423,9 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             }
         }
         PSDR_SCHED_FENCE();
-        asm volatile("" ::"v"(fl), "v"(cin_mem), "v"(cin_late));  // (see their declaration; behind the fill's own waits)
+        asm volatile("" ::"v"(fl), "v"(cin_mem));  // (see their declaration; behind the fill's own waits)
         static_for<0, EARLY>(issue);
         PSDR_SCHED_FENCE();
-        // the flag of the segment above, asynchronously (looked at at tick 1)
-        if (carry_mem) fl = __hip_atomic_load(a.segflag + se.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         PSDR_TRACE(a.trace, it, 1);
         __syncthreads();
         PSDR_TRACE(a.trace, it, 2);
@@ -1434,7 +1439,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         cf *exA = tile_cf + (size_t)L * 8, *exB = exA + L;        // tile 0: rows 0 and M1/2 (beyond Pst)
         float *carry_w = carry + (it & 1) * L, *carry_r = carry + ((it & 1) ^ 1) * L;
         float *seamC = a.seamC + (size_t)s * L;
-        bool cin_ok = false;  // the carried row was fetched at tick 1 (the flag was up when the tile began)
+        bool cin_ok = false;  // the carried row is in memory and was fetched at tick 1 (uniform: thread 0 looked at the flag)
         static_assert(NTICK == 4 && LPT == 1, "the counted drain below knows what the ticks issue");
         run_front_stages<L, T, true>(
             tile, Wl, i0, p, u,
@@ -1450,28 +1455,32 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                     // issued since (and than the flag load and wave 0's ticket, if any: then the wait is only stricter)
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EARLY + 3) : "memory");
                 }
-                if (k == 1 && carry_mem) {
-                    // the usual case: the segment above was published long ago - fetch its row now, a stage and a half
-                    // before it is needed (sc1: from memory, not from this XCD's L2)
-                    asm volatile("" : "+v"(fl));  // (not to be speculated onto the path of the other tiles, wait included)
-                    cin_ok = fl == a.epoch;
-                    if (cin_ok)
+                if (k == 0 && tid == 0) {
+                    if (carry_mem) {
+                        // (a tile old: issued at tick 0 of the previous segment's last tile, or before the loop)
+                        asm volatile("" : "+v"(fl));  // (not to be speculated onto the path of the other tiles, wait included)
+                        bool up = fl == a.epoch;
+                        if (!up) {
+                            // a tile ago it was not: look again, synchronously (the short segments at the end of a frame
+                            // follow their predecessors by a tile or two; ~3 k cycles of wave 0 here against a seam)
+                            const unsigned f2 = __hip_atomic_load(a.segflag + se.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            up = f2 == a.epoch;
+                        }
+                        s_next[2] = up;
+                    }
+                    // ... and the flag the NEXT segment will ask about
+                    if (seg_last && a.segflag && snext < total && (sen.w & PSDR_SEG_CARRY_MEM))
+                        fl = __hip_atomic_load(a.segflag + sen.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (k == 1 && carry_mem) {  // behind stage 0's barriers
+                    cin_ok = s_next[2] != 0;
+                    if (cin_ok)  // sc1: from memory, not from this XCD's L2; a stage and a half before it is needed
                         cin_mem = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(a.seamC + (size_t)se.z * L) + tid,
                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (k == 3) {
-                    if (post_seg != NOSEG) {  // behind the stage's barriers: every wave has drained
-                        if (tid == 0) __hip_atomic_store(a.segflag + post_seg, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        post_seg = NOSEG;
-                    }
-                    if (carry_mem && !cin_ok) {  // not yet: wait for it here, with nothing owed to anybody
-                        do {
-                            __builtin_amdgcn_s_sleep(8);
-                            fl = __hip_atomic_load(a.segflag + se.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        } while (fl != a.epoch);
-                        cin_late = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(a.seamC + (size_t)se.z * L) + tid,
-                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
+                if (k == 3 && post_seg != NOSEG) {  // behind stage 1's barriers: every wave has drained
+                    if (tid == 0) __hip_atomic_store(a.segflag + post_seg, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    post_seg = NOSEG;
                 }
             },
             [&](int k) { PSDR_TRACE(a.trace, it, k); });
@@ -1479,16 +1488,13 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         // the carried row from memory goes into the carry buffer BEFORE the last stage's stores: behind them the compiler's
         // wait for it would be a wait for their acknowledgements (the buffer was last read in the previous tile's octet
         // loop, and every wave is past that: the barriers of this tile)
-        // (two variables, two blocks: one variable with two places of definition makes the usual case wait as if it were
-        // the rare one - for the two loads issued just before)
-        if (carry_mem && cin_ok) {
+        if (cin_ok) {
             reinterpret_cast<float2 *>(carry_r)[tid] =
                 make_float2(__uint_as_float((unsigned)cin_mem), __uint_as_float((unsigned)(cin_mem >> 32)));
         }
-        if (carry_mem && !cin_ok) {
-            reinterpret_cast<float2 *>(carry_r)[tid] =
-                make_float2(__uint_as_float((unsigned)cin_late), __uint_as_float((unsigned)(cin_late >> 32)));
-        }
+        // no carry-in (the table says so, or the segment above was not published in time): k_real_seam completes the octets
+        const bool seam_in = seg_first && !cin_ok;
+        if (seam_in && carry_mem && tid == 0) a.segmark[s] = a.epoch;
         const cf w0 = cmul(wc, wg);
         cf *Xt = Xf + (size_t)g * (16 * L);  // line (g, c) of the frame starts at Xt + 16 * c
         // Octet staging Pst[c2][16]: [0..8) the low octet of column c2; [8..15) elements 1..7 of the
@@ -1710,6 +1716,8 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             const unsigned s2 = s_next[segit & 1];
             s = snext;
             snext = s2;
+            se = sen;
+            if (s2 < total) sen = seg_entry(s2);
             j = 0;
             PSDR_WGTRACE(a.trace, 1 + segit);  // (tuning builds) end of the work-group's segit-th segment
             segit++;

@@ -82,14 +82,14 @@ static std::vector<int> seg_plan_lens(const psdr_ctx *c) {
 }
 void seg_plan_counts(const psdr_ctx *c, int nframes, unsigned *nsegs, unsigned *nseam, bool *handoff) {
     const int G = c->M1 / 16;
-    // (round 4: correct - bit-identical to whole-frame segments over 3 x 512 frames of 2^21 and 2^22 points - and SLOWER as
-    // first measured, cfg3 -6 %, cfg5 -10 %; tuning builds switch it on with PSDR_SEG_HANDOFF=1 until that is understood)
+    // (PSDR_SEG_LEN=n is the way back to uniform segments; tuning builds: PSDR_SEG_HANDOFF=0)
+    const char *off = psdr_tuning_env("PSDR_SEG_HANDOFF");
     const bool ho = c->seg_len_env <= 0 && !c->static_tiles && G >= 16 && nframes >= 2 * std::max(c->num_cus, 1) &&
-                    psdr_tuning_env("PSDR_SEG_HANDOFF") != nullptr;
+                    !(off && atoi(off) == 0);
     if (ho) {
         const int levels = (int)seg_plan_lens(c).size();
         *nsegs = (unsigned)(levels * nframes);
-        *nseam = (unsigned)nframes;
+        *nseam = *nsegs;  // (any segment may fall back to a seam: seamP has room for all of them)
     } else {
         *nsegs = *nseam = (unsigned)(nframes * (G / real_seg_len(c, nframes)));
     }
@@ -109,33 +109,13 @@ static int seg_plan(psdr_ctx *c, int nframes, const psdr_ctx::SegPlan **out) {
     if (sp.handoff) {
         const std::vector<int> lens = seg_plan_lens(c);
         const int levels = (int)lens.size();
-        // Frames in the order in which their top segments FINISH: a work-group starts with two consecutive tickets (2k,
-        // 2k + 1: the second is done a segment later than the first), everything from ticket 2 * grid on is drawn in
-        // order.  The levels below walk the frames in that order, so that a segment's predecessor - the same position
-        // one level up, nframes >= 2 * grid tickets earlier - was finished (and published) at least a segment ago.
-        const int grid = std::max(c->num_cus, 1);
-        std::vector<int> perm(nframes), pos(nframes);
-        {
-            int n = 0;
-            const int npair = std::min(nframes, 2 * grid);
-            const bool noperm = psdr_tuning_env("PSDR_SEG_NOPERM") != nullptr;
-            if (noperm) {
-                for (int f = 0; f < nframes; f++) perm[n++] = f;
-            } else {
-                for (int f = 0; f < npair; f += 2) perm[n++] = f;
-                for (int f = 1; f < npair; f += 2) perm[n++] = f;
-                for (int f = npair; f < nframes; f++) perm[n++] = f;
-            }
-            for (int i = 0; i < nframes; i++) pos[perm[i]] = i;
-        }
+        // Level-major, frames in order: a segment's predecessor - the same frame one level up - is handed out nframes >=
+        // 2 * grid indices earlier, i.e. about two segments of every work-group earlier.
         int g = G - 1;
         for (int lv = 0; lv < levels; lv++) {
-            for (int i = 0; i < nframes; i++) {
-                const int f = lv ? perm[i] : i;
-                const unsigned above = lv == 0 ? (unsigned)((levels - 1) * nframes + pos[f])  // the frame's bottom segment
-                                     : lv == 1 ? (unsigned)f                                       // its top segment
-                                               : (unsigned)((lv - 1) * nframes + i);
-                tab[(size_t)lv * nframes + i] = make_uint4((unsigned)f, (unsigned)g | ((unsigned)lens[lv] << 16), above,
+            for (int f = 0; f < nframes; f++) {
+                const unsigned above = (unsigned)((lv ? lv - 1 : levels - 1) * nframes + f);  // (the top segment's: the bottom one)
+                tab[(size_t)lv * nframes + f] = make_uint4((unsigned)f, (unsigned)g | ((unsigned)lens[lv] << 16), above,
                                                            lv ? (unsigned)PSDR_SEG_CARRY_MEM : 0u);
             }
             g -= lens[lv];
@@ -293,6 +273,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
         a2.seamP = c->d_seamP;
         a2.seamC = c->d_seamC;
         a2.segflag = plan->handoff ? c->d_segflag : nullptr;
+        a2.segmark = c->d_segflag + c->seg_cap;
         if (++c->seg_epoch == 0) c->seg_epoch = 1;
         a2.epoch = c->seg_epoch;
         a2.total_slots = plan->nsegs;
@@ -337,6 +318,8 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
         sa.seamP = c->d_seamP;
         sa.seamC = c->d_seamC;
         sa.segtab = plan->d_tab;
+        sa.segmark = c->d_segflag + c->seg_cap;
+        sa.epoch = c->seg_epoch;
         sa.L = c->M2;
         sa.size_log2 = c->size_log2;
         sa.Qt = c->d_qt;
@@ -344,7 +327,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
         sa.Pscr = c->d_pscr[0];
         sa.p_stride = c->p_stride;
         ProfScope ps(c, K_SEAM, c->side);
-        hipLaunchKernelGGL(k_real_seam, dim3(plan->nseam), dim3(256), 0, c->side, sa);
+        hipLaunchKernelGGL(k_real_seam, dim3(plan->handoff ? plan->nsegs : plan->nseam), dim3(256), 0, c->side, sa);
         HIPCHK(hipGetLastError());
     }
     // remaining pyramid levels from the partial level in scratch

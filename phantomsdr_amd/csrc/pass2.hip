@@ -63,9 +63,7 @@ static int launch_pass2_real_t(psdr_ctx *c, const Pass2Args &a) {
     ProfScope ps(c, K_PASS2);
     unsigned grid = persistent_grid(c, a.total_slots, lds);
     if (c->p2_grid && c->p2_grid < grid) grid = c->p2_grid;
-    Pass2Args b = a;
-    b.ticket_base = a.segflag ? 0u : 2u * grid;  // hand-off mode: every segment is drawn (fft_pass.h, Pass2Args)
-    hipLaunchKernelGGL((k_fft_pass2_real<L, T, TWC>), dim3(grid), dim3(L * T / 32), lds, c->stream, b);
+    hipLaunchKernelGGL((k_fft_pass2_real<L, T, TWC>), dim3(grid), dim3(L * T / 32), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return PSDR_OK;
 }

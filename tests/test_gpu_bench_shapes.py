@@ -116,6 +116,14 @@ def test_handoff_plan_bit_identical_to_whole_frame_segments(log2n, monkeypatch):
             for f in (0, 1, F // 2, F - 1):
                 out.append((hashlib.blake2b(ctx.read_spectrum(f).tobytes(), digest_size=16).digest(),
                             hashlib.blake2b(ctx.read_quantized(f).tobytes(), digest_size=16).digest()))
+            if not seg_len:  # the default plan: it IS the hand-off plan, and the fallback to a seam stays the exception
+                import ctypes as C
+                from phantomsdr_amd import _lib
+                fn = _lib.load().psdr_debug_seg_fallbacks
+                fn.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_void_p, C.c_uint]
+                ns, fb = C.c_uint(0), C.c_uint(0)
+                assert fn(ctx.h, C.byref(ns), C.byref(fb), None, 0) == 0
+                assert ns.value == F * (7 + log2n - 20) and fb.value < ns.value // 4, (ns.value, fb.value)
             ctx.dev_free(d)
             return out
         finally:

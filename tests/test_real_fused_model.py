@@ -75,15 +75,10 @@ def seg_plan(G, nframes, num_cus=256, seg_len_env=0, static_tiles=False):
             lens.append(l)
             l //= 2
         lens.append(1)
-        npair = min(nframes, 2 * num_cus)   # a work-group's first two tickets are 2k, 2k + 1: the odd one is done later
-        perm = list(range(0, npair, 2)) + list(range(1, npair, 2)) + list(range(npair, nframes))
-        pos = {f: i for i, f in enumerate(perm)}
         g = G - 1
         for lv, ln in enumerate(lens):
-            for i in range(nframes):
-                f = perm[i] if lv else i
-                above = (len(lens) - 1) * nframes + pos[f] if lv == 0 else (f if lv == 1 else (lv - 1) * nframes + i)
-                tab.append((f, g, ln, above, lv > 0))
+            for f in range(nframes):
+                tab.append((f, g, ln, ((lv - 1) if lv else len(lens) - 1) * nframes + f, lv > 0))
             g -= ln
         return tab, True, nframes
     if seg_len_env > 0:
@@ -192,7 +187,7 @@ def test_fused_real_pass2_model_matches_rfft(M1, M2, seg_len):
         assert np.allclose(rec[recmap2_pos(o, M1, M2)], P[8 * o: 8 * o + 8], rtol=1e-9, atol=0), o
 
 
-@pytest.mark.parametrize("G,nframes", [(64, 512), (128, 512), (64, 640), (16, 600), (64, 511), (64, 256), (64, 1), (128, 7)])
+@pytest.mark.parametrize("G,nframes", [(64, 512), (128, 512), (64, 640), (16, 600), (64, 513), (64, 511), (64, 256), (64, 1), (128, 7)])
 def test_segment_plan_partitions_frames_and_orders_the_hand_offs(G, nframes):
     """the table k_fft_pass2_real walks (forward.hip, seg_plan): every tile of every frame in exactly one segment; the
     segments without a carry-in first (k_real_seam's grid); in hand-off mode a segment's predecessor is the segment of
@@ -214,11 +209,7 @@ def test_segment_plan_partitions_frames_and_orders_the_hand_offs(G, nframes):
         else:
             assert ga - la + 1 == g0 + 1             # the segment above ends one tile above this one's first
         if mem:
-            assert sg - above >= nframes - 256       # handed out at least nframes - grid tickets earlier ...
-            # ... and not in the time slot right before: a work-group's first two tickets are 2k, 2k + 1 (slots 0 and 1),
-            # ticket t >= 512 is drawn in slot t // 256
-            slot = lambda t: (t & 1) if t < 512 else t // 256
-            assert slot(sg) - slot(above) >= 2
+            assert above == sg - nframes             # the same frame one level up: >= 2 * grid indices earlier
     if handoff:
         assert nseam == nframes and max(t[2] for t in tab) == G // 4 and tab[-1][2] == 1
         assert len(tab) == nframes * (4 + int(np.log2(G // 8)) + 1)
@@ -231,8 +222,7 @@ def test_fused_real_pass2_model_with_the_hand_off_plan(M1, M2):
     M, N, G = M1 * M2, 2 * M1 * M2, M1 // 16
     tab, handoff, _ = seg_plan(G, 512)
     assert handoff
-    mine = [sg for sg, t in enumerate(tab) if t[0] == 0]
-    segs = [(tab[sg][1], tab[sg][2], mine.index(tab[sg][3]), tab[sg][4]) for sg in mine]
+    segs = [(g0, ln, above // 512, mem) for (f, g0, ln, above, mem) in tab if f == 0]
     rng = np.random.default_rng(M1)
     x = rng.standard_normal(N)
     z = x[0::2] + 1j * x[1::2]
