@@ -75,11 +75,12 @@
     } while (0)
 #endif
 
-// The passes fetch the NEXT tile while they work on the current one.  PSDR_UNCOND_PREFETCH=1: those loads are issued for a
-// work-group's last tile too (it fetches its own block once more: one tile per work-group and launch) - with the loads
-// under `if (there is a next tile)` the compiler's counted waits degrade wherever a path without them joins.
+// The passes fetch the NEXT tile while they work on the current one, under `if (there is a next tile)`.  The fused real
+// second pass issues those loads unconditionally (its hand-off needs counted waits behind them: see there).  For the first
+// pass and the IQ second pass the same change (PSDR_UNCOND_PREFETCH=1) measures -1.2 ... -1.4 % on cfg2 (same box, three
+// interleaved repetitions: the IQ second pass goes from 212 to 247 VGPRs and +1.4 %): off.
 #ifndef PSDR_UNCOND_PREFETCH
-#define PSDR_UNCOND_PREFETCH 1
+#define PSDR_UNCOND_PREFETCH 0
 #endif
 
 namespace psdr {
