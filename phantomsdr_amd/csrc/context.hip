@@ -314,6 +314,12 @@ int build(psdr_ctx *c) {
         }
         HIPCHK(hipMalloc((void **)&c->d_segflag, 2 * capc * sizeof(unsigned)));  // flags, then the fallback marks
         HIPCHK(hipMemset(c->d_segflag, 0, 2 * capc * sizeof(unsigned)));
+        {  // the plans of the two batch sizes every caller uses, now rather than in the first batch (a synchronous upload)
+            const psdr_ctx::SegPlan *sp;
+            int rc = seg_plan(c, c->max_batch, &sp);
+            if (!rc && c->max_batch > 1) rc = seg_plan(c, 1, &sp);
+            if (rc) return rc;
+        }
     }
     for (int s = 0; s < 2; s++) {
         HIPCHK(hipMalloc((void **)&c->spec_pool[s], F * c->spec_stride * sizeof(cf)));

@@ -364,6 +364,7 @@ int reset_kclock(psdr_ctx *c);
 void select_set(psdr_ctx *c, int set);
 int real_seg_len(const psdr_ctx *c, int nframes);
 void seg_plan_counts(const psdr_ctx *c, int nframes, unsigned *nsegs, unsigned *nseam, bool *handoff);
+int seg_plan(psdr_ctx *c, int nframes, const psdr_ctx::SegPlan **out);  // (built and uploaded on first use of a batch size)
 int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipEvent_t ev_raw_consumed = nullptr);
 // pass1.hip / pass2.hip (Pass1Args / Pass2Args: fft_pass.h)
 struct Pass1Args;

@@ -1545,10 +1545,24 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         };
         int tA = 0;
         if (g != 0) {
+            static_assert(LastStage<L>::R == 4 && NBL == 4, "outputs t and t + 8 of a thread are two last-stage outputs apart");
+            cf wsv[2];  // sigma * W_N^k of outputs t = b, b + 4
             run_last_stage<L>(Wl, i0, u, [&](int b, int sidx, int c2i, c2 x) {
                 const cf sm = cadd(x.a, x.b), d = csub(x.a, x.b);
-                const cf wo = cmul(cmul(w0, w32(b + NBL * sidx)), make_float2(d.y, -d.x));  // sigma * W_N^k * (-i)(a-b)
-                v2f mine = to_v2f(sm) + to_v2f(wo), send = to_v2f(sm) - to_v2f(wo);
+                const cf e = make_float2(d.y, -d.x);  // (-i)(a-b)
+                v2f mine, send;
+                if (sidx < 2) {
+                    wsv[sidx] = cmul(w0, w32(b + NBL * sidx));
+                    const cf wo = cmul(wsv[sidx], e);  // sigma * W_N^k * (-i)(a-b)
+                    mine = to_v2f(sm) + to_v2f(wo), send = to_v2f(sm) - to_v2f(wo);
+                } else {
+                    // W_32^{t+8} = -i W_32^t exactly (the same table entries; cmul(w0, -i c) = -i cmul(w0, c) bit for bit), and
+                    // a product with -i is a swap and a sign: the twiddle of output t + 8 is not multiplied out, the -i
+                    // rides in the addition's operand selectors.  (The product with (-i)(a-b) rounds its two partial
+                    // products in the other order than before: an ulp of the bin, inside every bound the tests state.)
+                    const cf wb = cmul(wsv[sidx - 2], e);
+                    mine = to_v2f(add_mi(sm, wb)), send = to_v2f(sub_mi(sm, wb));
+                }
                 mine.y = __uint_as_float(__float_as_uint(mine.y) ^ sgn_mine);
                 send.y = __uint_as_float(__float_as_uint(send.y) ^ sgn_send);
                 (void)c2i;  // = i0 + (L/16) * (b + NBL * sidx)

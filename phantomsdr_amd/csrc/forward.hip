@@ -95,7 +95,7 @@ void seg_plan_counts(const psdr_ctx *c, int nframes, unsigned *nsegs, unsigned *
     }
     *handoff = ho;
 }
-static int seg_plan(psdr_ctx *c, int nframes, const psdr_ctx::SegPlan **out) {
+int seg_plan(psdr_ctx *c, int nframes, const psdr_ctx::SegPlan **out) {
     for (const auto &sp : c->seg_plans)
         if (sp.nframes == nframes) {
             *out = &sp;
