@@ -409,18 +409,30 @@ __device__ __forceinline__ void idft_stage_fixed(cf *buf, const cf *Wn, int lane
 
 // the transform of ONE (client, frame) item by one wave: slice load, mode-specific bin copy, c2r symmetry, the
 // stages.  Leaves the n outputs in buf (before reversal / sign flip) and returns the slice power (all lanes).
-template <int N, int R0, int R1, int R2>
-__device__ __forceinline__ float idft_item_fixed(const DemodArgs &a, const ClientParams &cp, int f, cf *buf, const cf *Wn, int lane) {
+// the slice of one (client, frame) item, bin t = lane + 64 u in sv[u] (at most n bins, src/signal.cpp:309-311)
+template <int N>
+__device__ __forceinline__ void idft_load_slice(const DemodArgs &a, const ClientParams &cp, int f, int lane, cf (&sv)[(N + 63) / 64]) {
     const int len = cp.r - cp.l;
-    const int m = cp.m_floor - cp.l;  // audio_m
     const cf *S = a.spec + (size_t)f * a.spec_stride;  // slice bin t at lay.pos(cp.l + t)
-    constexpr int NR = (N + 63) / 64;
-    cf sv[NR];  // the slice (at most n bins, src/signal.cpp:309-311): loads first, LDS after
 #pragma unroll
-    for (int u = 0; u < NR; u++) {
+    for (int u = 0; u < (N + 63) / 64; u++) {
         const int t = lane + 64 * u;
         sv[u] = t < len ? S[a.lay.pos(cp.l + t)] : make_float2(0.f, 0.f);
     }
+}
+template <int N, int R0, int R1, int R2>
+__device__ __forceinline__ float idft_slice_fixed(const ClientParams &cp, const cf (&sv)[(N + 63) / 64], cf *buf, const cf *Wn, int lane);
+template <int N, int R0, int R1, int R2>
+__device__ __forceinline__ float idft_item_fixed(const DemodArgs &a, const ClientParams &cp, int f, cf *buf, const cf *Wn, int lane) {
+    cf sv[(N + 63) / 64];  // loads first, LDS after
+    idft_load_slice<N>(a, cp, f, lane, sv);
+    return idft_slice_fixed<N, R0, R1, R2>(cp, sv, buf, Wn, lane);
+}
+template <int N, int R0, int R1, int R2>
+__device__ __forceinline__ float idft_slice_fixed(const ClientParams &cp, const cf (&sv)[(N + 63) / 64], cf *buf, const cf *Wn, int lane) {
+    const int len = cp.r - cp.l;
+    const int m = cp.m_floor - cp.l;  // audio_m
+    constexpr int NR = (N + 63) / 64;
 #pragma unroll
     for (int u = 0; u < NR; u++) {
         const int i = lane + 64 * u;
@@ -683,6 +695,17 @@ __global__ __launch_bounds__(256, N <= 512 ? PSDR_IDFT_WPE : PSDR_IDFT_WPE - 1) 
     }
     if (fs == 0 && cp.mode == 3) blast = a.bb_last[(size_t)cur * a.slots + srow];
     int f = fs;
+    // PSDR_DEMOD_PREFETCH=1: the slice of the NEXT frame is fetched while this frame is transformed (a wave that walks its
+    // chain frame by frame has one frame's loads in flight at a time).  Measured on the round-4 build, same box, three
+    // interleaved repetitions: 256 clients on cfg2's stream 94.75-94.79 GS/s with it, 94.65-95.06 without; cfg3 and the
+    // cfg5 share inside their spread; n = 720 with it (=2: 128 VGPRs + 48 bytes of scratch) -1 %.  The chain kernel's time
+    // beside the passes is not its own latency: off.
+#ifndef PSDR_DEMOD_PREFETCH
+#define PSDR_DEMOD_PREFETCH 0
+#endif
+    constexpr int NR = (N + 63) / 64;
+    cf svn[NR];
+    int fpre = -1;  // frame whose slice svn holds
     while (f < f1) {
         const bool emit = f >= f0;
         // (an opaque copy per iteration: with the loop-invariant lane the compiler keeps every address of every stage
@@ -690,7 +713,23 @@ __global__ __launch_bounds__(256, N <= 512 ? PSDR_IDFT_WPE : PSDR_IDFT_WPE - 1) 
         int ln = lane_;
         asm volatile("" : "+v"(ln));
         const int lane = ln;
-        const float pw = idft_item_fixed<N, R0, R1, R2>(a, cp, f, buf, Wn, lane);
+        float pw;
+        if (PSDR_DEMOD_PREFETCH && (N <= 512 || PSDR_DEMOD_PREFETCH > 1)) {  // (n = 720: 128 VGPRs + 48 bytes of scratch with it)
+            cf sv[NR];
+            if (f == fpre) {
+#pragma unroll
+                for (int u = 0; u < NR; u++) sv[u] = svn[u];
+            } else {
+                idft_load_slice<N>(a, cp, f, lane, sv);  // the chain's first frame; a warm-up frame looked for further back
+            }
+            if (f + 1 < f1) {
+                idft_load_slice<N>(a, cp, f + 1, lane, svn);
+                fpre = f + 1;
+            }
+            pw = idft_slice_fixed<N, R0, R1, R2>(cp, sv, buf, Wn, lane);
+        } else {
+            pw = idft_item_fixed<N, R0, R1, R2>(a, cp, f, buf, Wn, lane);
+        }
         if (emit && lane == 0) a.pwr[srow * a.max_batch + f] = pw;
         const float sg = sign_of(f);
         float *out = a.audio + (srow * a.max_batch + f) * h;
