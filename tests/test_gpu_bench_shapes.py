@@ -275,3 +275,44 @@ def test_bench_gpus_2_runs_every_sharding_as_two_processes():
     assert cg and "by_shard" in cg, cg
     for shard, v in cg["by_shard"].items():
         assert v.get("error") is None and v["value"] > 0, (shard, v)
+
+
+def test_handoff_two_contexts_interleaved_and_640_frames(monkeypatch):
+    """Two contexts on one device, each with its own streams, flags and epochs, launching 640-frame batches of 2^21-point
+    real frames alternately WITHOUT synchronising in between (their second passes overlap on the chip: neither gets all
+    the CUs, work-groups of both start late - the hand-off never waits, so nothing can lock up), against one context with
+    whole-frame segments.  640 frames: a batch size that is no power of two and no multiple of the work-group count."""
+    import hashlib
+    from phantomsdr_amd import Context
+    N, F = 1 << 21, 640
+    rng = np.random.default_rng(77)
+    raw = rng.integers(-1500, 1500, size=(F + 1) * (N // 2), dtype=np.int16)
+
+    def digest(ctx):
+        return [hashlib.blake2b(ctx.read_quantized(f).tobytes(), digest_size=12).digest() for f in range(0, F, 3)]
+    monkeypatch.setenv("PSDR_SEG_LEN", "64")
+    ref_ctx = Context(N, True, 11, input_format="s16", max_batch=F)
+    try:
+        d = ref_ctx.dev_alloc(raw.nbytes)
+        ref_ctx.h2d(d, raw)
+        ref_ctx.process_batch(d, F)
+        ref = digest(ref_ctx)
+        ref_ctx.dev_free(d)
+    finally:
+        ref_ctx.close()
+    monkeypatch.delenv("PSDR_SEG_LEN")
+    a, b = Context(N, True, 11, input_format="s16", max_batch=F), Context(N, True, 11, input_format="s16", max_batch=F)
+    try:
+        da, db = a.dev_alloc(raw.nbytes), b.dev_alloc(raw.nbytes)
+        a.h2d(da, raw)
+        b.h2d(db, raw)
+        for _ in range(3):  # asynchronous launches: the two contexts' kernels share the device
+            a.process_batch(da, F)
+            b.process_batch(db, F)
+        assert digest(a) == ref
+        assert digest(b) == ref
+        a.dev_free(da)
+        b.dev_free(db)
+    finally:
+        a.close()
+        b.close()
