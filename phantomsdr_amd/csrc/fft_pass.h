@@ -1194,11 +1194,12 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2(Pass2Args a) {
 //
 // Pyramid: octets in TRUE k order.  The low octet [8g, 8g+8) is complete in the tile.  The high
 // octet [M1-8g-8, M1-8g) has seven rows here and its first row (M1-8g-8) in tile g+1 (couple 0), so
-// a work-group walks a SEGMENT of seg_len consecutive tiles of one frame in DEcreasing g and carries
-// that one row of powers (4 KiB of LDS) to the next tile.  The first tile of a segment has no
-// carry-in: it leaves the seven partial rows in seamP; the last tile leaves its carry-out in seamC;
-// k_real_seam (epilogue.h) completes those octets (tile 0's carry-out is row M1/2, which closes the
-// ring at octet [M1/2, M1/2+8) of the LAST tile).  Records: [tile g][c2][low, high] x 16 bytes
+// a work-group walks a SEGMENT of consecutive tiles of one frame (Pass2Args::segtab) in DEcreasing g and
+// carries that one row of powers (4 KiB of LDS) to the next tile.  The first tile of a segment has no
+// carry-in in LDS: either it fetches the row the segment above left in seamC (hand-off plans, see the
+// kernel) or it leaves the seven partial rows in seamP; the last tile leaves its carry-out in seamC;
+// k_real_seam (epilogue.h) completes the octets left open (tile 0's carry-out is row M1/2, which closes
+// the ring at octet [M1/2, M1/2+8) of the LAST tile).  Records: [tile g][c2][low, high] x 16 bytes
 // (RecMap mode 2), level-3 sums in the same order for the tail kernel.
 // W_32^t = exp(-2 pi i t/32), t < 16: a thread's 16 outputs are c2 = i0 + (L/16)*t, and
 // W_N^{M1*c2} = W_{2L}^{c2} = W_{2L}^{i0} * W_32^t
