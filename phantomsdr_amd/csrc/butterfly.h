@@ -54,6 +54,19 @@ __device__ __forceinline__ void cmul_pair(cf &r1, cf a1, cf b1, cf &r2, cf a2, c
     r1 = from_v2f(o1);
     r2 = from_v2f(o2);
 }
+// conj(a1) * b1 and conj(a2) * b2: the same two instructions per product, the conjugation is the other sign selector
+// (t = (a.y*b.y, -a.y*b.x);  r = (a.x*b.x + t.x, a.x*b.y + t.y))
+__device__ __forceinline__ void cmul_cja_pair(cf &r1, cf a1, cf b1, cf &r2, cf a2, cf b2) {
+    v2f t1, t2, o1, o2;
+    asm("v_pk_mul_f32 %0, %4, %5 op_sel:[1,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %6, %7 op_sel:[1,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %2, %4, %5, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %3, %6, %7, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]"
+        : "=&v"(t1), "=&v"(t2), "=&v"(o1), "=&v"(o2)
+        : "v"(to_v2f(a1)), "v"(to_v2f(b1)), "v"(to_v2f(a2)), "v"(to_v2f(b2)));
+    r1 = from_v2f(o1);
+    r2 = from_v2f(o2);
+}
 __device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
 // a + (-i)*d = (a.x + d.y, a.y - d.x)

@@ -770,6 +770,7 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
 
         cf tbA[NBL], tbB[NBL], tsA[RL], tsB[RL], w00A, w00B;  // inter-pass twiddles
         cf cWA = make_float2(1.f, 0.f), cWB = cWA;             // PAIR: W_M2^{n2} of the two columns
+        cf tmA[RL], tmB[RL];                                   // PAIR: conj(ts[q]) * W_M2^{n2}, q >= RL/2 (the mirror rows)
         run_stages<L, T, false>(
             tile, Wl, i0, p, u,
             // ---- inter-pass twiddle W_M^{n2*kappa}, kappa = i0 + b*L/16 + s*P, as
@@ -803,24 +804,35 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
                     tw2(nA * (unsigned)L, nB * (unsigned)L, w00A, w00B);
                     w00B = make_float2(-w00B.x, -w00B.y);
                 }
-                if constexpr (PAIR) tw2(nA * (unsigned)L, nB * (unsigned)L, cWA, cWB);  // W_M^{n2*M1}
+                if constexpr (PAIR) {
+                    tw2(nA * (unsigned)L, nB * (unsigned)L, cWA, cWB);  // W_M^{n2*M1}
+#pragma unroll
+                    for (int q = RL / 2; q < RL; q++) cmul_cja_pair(tmA[q], tsA[q], cWA, tmB[q], tsB[q], cWB);
+                }
             },
             [&](int b, int sidx, int k1, c2 x) {
                 cf wA, wB, yA, yB;
                 const int c1 = a.rot ? ((k1 - 1) & (L - 1)) : k1;
                 (void)c1;
-                if (sidx == 0) {
-                    wA = b == 0 ? w00A : tbA[b];
-                    wB = b == 0 ? w00B : tbB[b];
-                } else {
-                    cmul_pair(wA, tbA[b], tsA[sidx], wB, tbB[b], tsB[sidx]);
+                const bool mirror = PAIR && sidx >= RL / 2;                    // k1 >= L/2 (compile time): mirror form ...
+                const bool maybe_natural = mirror && sidx == RL / 2 && b == 0;  // ... except row L/2 itself (i0 == 0)
+                if (!mirror || maybe_natural) {
+                    if (sidx == 0) {
+                        wA = b == 0 ? w00A : tbA[b];
+                        wB = b == 0 ? w00B : tbB[b];
+                    } else {
+                        cmul_pair(wA, tbA[b], tsA[sidx], wB, tbB[b], tsB[sidx]);
+                    }
+                    cmul_pair(yA, x.a, wA, yB, x.b, wB);
                 }
-                cmul_pair(yA, x.a, wA, yB, x.b, wB);
                 if constexpr (PAIR) {
-                    if (sidx >= RL / 2) {  // k1 >= L/2 (compile time): mirror form, except row L/2 itself
-                        cf mA, mB;
-                        cmul_pair(mA, make_float2(yA.x, -yA.y), cWA, mB, make_float2(yB.x, -yB.y), cWB);
-                        const bool natural = sidx == RL / 2 && b == 0 && i0 == 0;  // k1 == L/2
+                    if (mirror) {
+                        // conj(x w) W_M2^{n2} = conj(x) (conj(tb) (conj(ts) W_M2^{n2})): the last factor once per tile (tm), two
+                        // products per output instead of three (round 3 multiplied x w out and conjugated it)
+                        cf wmA, wmB, mA, mB;
+                        cmul_cja_pair(wmA, tbA[b], tmA[sidx], wmB, tbB[b], tmB[sidx]);
+                        cmul_cja_pair(mA, x.a, wmA, mB, x.b, wmB);
+                        const bool natural = maybe_natural && i0 == 0;  // k1 == L/2
                         yA = natural ? yA : mA;
                         yB = natural ? yB : mB;
                     }
