@@ -312,8 +312,10 @@ int build(psdr_ctx *c) {
             HIPCHK(hipMalloc((void **)&c->seam_pool[st][0], cap * (size_t)c->M2 * 8 * sizeof(float)));
             HIPCHK(hipMalloc((void **)&c->seam_pool[st][1], capc * (size_t)c->M2 * sizeof(float)));
         }
-        HIPCHK(hipMalloc((void **)&c->d_segflag, 2 * capc * sizeof(unsigned)));  // flags, then the fallback marks
-        HIPCHK(hipMemset(c->d_segflag, 0, 2 * capc * sizeof(unsigned)));
+        // flags (inside a launch only), then the fallback marks - ONE ARRAY PER RESULT SET: k_real_seam is a consumer, it may
+        // run after the next batch's second pass has started writing its own marks
+        HIPCHK(hipMalloc((void **)&c->d_segflag, 3 * capc * sizeof(unsigned)));
+        HIPCHK(hipMemset(c->d_segflag, 0, 3 * capc * sizeof(unsigned)));
         {  // the plans of the two batch sizes every caller uses, now rather than in the first batch (a synchronous upload)
             const psdr_ctx::SegPlan *sp;
             int rc = seg_plan(c, c->max_batch, &sp);
@@ -840,7 +842,7 @@ extern "C" int psdr_debug_seg_fallbacks(psdr_ctx *c, unsigned *nsegs, unsigned *
     if (!plan || !plan->handoff) return PSDR_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
     std::vector<unsigned> m(plan->nsegs);
-    HIPCHK(hipMemcpy(m.data(), c->d_segflag + c->seg_cap, m.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(m.data(), c->d_segflag + (size_t)(1 + c->cur_set) * c->seg_cap, m.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
     *nsegs = plan->nsegs;
     for (unsigned i = 0; i < plan->nsegs; i++) {
         const bool fb = m[i] == c->seg_epoch;

@@ -156,7 +156,8 @@ struct psdr_ctx {
         uint4 *d_tab = nullptr;
     };
     std::vector<SegPlan> seg_plans;  // one per batch size seen
-    unsigned *d_segflag = nullptr;   // [seg_cap] epoch of the launch that last published the segment's carry-out
+    unsigned *d_segflag = nullptr;   // [seg_cap] epoch of the launch that last published the segment's carry-out; behind it
+                                     // [2][seg_cap] the fallback marks of the two result sets (fft_pass.h: segmark)
     unsigned seg_epoch = 0;
     int size_log2 = 0;
     int levels = 0;

@@ -273,7 +273,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
         a2.seamP = c->d_seamP;
         a2.seamC = c->d_seamC;
         a2.segflag = plan->handoff ? c->d_segflag : nullptr;
-        a2.segmark = c->d_segflag + c->seg_cap;
+        a2.segmark = c->d_segflag + (size_t)(1 + c->cur_set) * c->seg_cap;  // (of this result set, like seamP / seamC)
         if (++c->seg_epoch == 0) c->seg_epoch = 1;
         a2.epoch = c->seg_epoch;
         a2.total_slots = plan->nsegs;
@@ -318,7 +318,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
         sa.seamP = c->d_seamP;
         sa.seamC = c->d_seamC;
         sa.segtab = plan->d_tab;
-        sa.segmark = c->d_segflag + c->seg_cap;
+        sa.segmark = c->d_segflag + (size_t)(1 + c->cur_set) * c->seg_cap;
         sa.epoch = c->seg_epoch;
         sa.L = c->M2;
         sa.size_log2 = c->size_log2;
