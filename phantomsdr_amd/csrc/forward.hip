@@ -274,7 +274,12 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
         a2.seamC = c->d_seamC;
         a2.segflag = plan->handoff ? c->d_segflag : nullptr;
         a2.segmark = c->d_segflag + (size_t)(1 + c->cur_set) * c->seg_cap;  // (of this result set, like seamP / seamC)
-        if (++c->seg_epoch == 0) c->seg_epoch = 1;
+        if (++c->seg_epoch == 0) {  // 2^32 launches: no flag or mark of the previous cycle may look current
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (c->side != c->stream) HIPCHK(hipStreamSynchronize(c->side));
+            HIPCHK(hipMemset(c->d_segflag, 0, 3 * c->seg_cap * sizeof(unsigned)));
+            c->seg_epoch = 1;
+        }
         a2.epoch = c->seg_epoch;
         a2.total_slots = plan->nsegs;
         rc = launch_pass2_real(c, a2);
