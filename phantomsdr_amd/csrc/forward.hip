@@ -51,7 +51,8 @@ int real_seg_len(const psdr_ctx *c, int nframes) {
 // Chain segments of a batch (k_fft_pass2_real, fft_pass.h).  Two forms:
 //  * uniform segments of real_seg_len() tiles, frame-major, every segment's first tile WITHOUT a carry-in (it leaves its
 //    partial octets in seamP, k_real_seam completes them): small batches, PSDR_SEG_LEN, static tile hand-out;
-//  * hand-off (batches of at least two frames per work-group): a frame is cut into segments of G/4, G/4, G/4, G/8, ... 2,
+//  * hand-off (batches of more than one frame per work-group, and smaller ones that leave a round of work-groups
+//    part empty - seg_plan_counts): a frame is cut into segments of G/4, G/4, G/4, G/8, ... 2,
 //    1, 1 tiles from the top, handed out LEVEL-major - all frames' top segments first, then all second segments, ... - by
 //    the ticket counter alone.  Only the top segment of a frame has no carry-in (the ring closes through tile 0's row
 //    M1/2: one seam per frame, as with whole-frame segments); every other segment reads the carried row its predecessor -
@@ -83,9 +84,21 @@ static std::vector<int> seg_plan_lens(const psdr_ctx *c) {
 void seg_plan_counts(const psdr_ctx *c, int nframes, unsigned *nsegs, unsigned *nseam, bool *handoff) {
     const int G = c->M1 / 16;
     // (PSDR_SEG_LEN=n is the way back to uniform segments; tuning builds: PSDR_SEG_HANDOFF=0)
-    const char *off = psdr_tuning_env("PSDR_SEG_HANDOFF");
-    const bool ho = c->seg_len_env <= 0 && !c->static_tiles && G >= 16 && nframes >= 2 * std::max(c->num_cus, 1) &&
-                    !(off && atoi(off) == 0);
+    // Which batches take the hand-off plan: all of more than one frame per work-group (384 frames of 2^21 points are three
+    // full rounds of uniform 32-tile segments and still 159 GS/s against 178); below that, those whose uniform
+    // segments do not fill the last round of work-groups (the tickets hand a round's leftovers to a part of the chip and
+    // the rest waits: 320 frames of 2^21 points = 640 segments of 32 tiles = 2.5 rounds - 148 GS/s against 186 with the
+    // hand-off plan; 288: 138 / 179; 160: 146 / 170; where the rounds are full - 96, 128, 192, 256 frames - the uniform
+    // plan is 1 ... 4 % ahead, the hand-offs of a batch that small mostly fall back to seams) and that are not tiny
+    // (a single frame's 64 tiles run side by side: nothing to hand over).  profiles/r04b_handoff_vs_uniform_by_batch.jsonl
+    const char *off = psdr_tuning_env("PSDR_SEG_HANDOFF"), *mn = psdr_tuning_env("PSDR_SEG_HANDOFF_MIN");
+    const int W = std::max(c->num_cus, 1);
+    bool want = nframes >= (mn ? atoi(mn) : W + 1);
+    if (!want && !mn && (long long)nframes * G >= 8LL * W) {
+        const long long ns = (long long)nframes * (G / real_seg_len(c, nframes)), rounds = (ns + W - 1) / W;
+        want = 100 * ns < 97 * rounds * W;
+    }
+    const bool ho = c->seg_len_env <= 0 && !c->static_tiles && G >= 16 && want && !(off && atoi(off) == 0);
     if (ho) {
         const int levels = (int)seg_plan_lens(c).size();
         *nsegs = (unsigned)(levels * nframes);

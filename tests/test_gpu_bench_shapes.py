@@ -316,3 +316,47 @@ def test_handoff_two_contexts_interleaved_and_640_frames(monkeypatch):
     finally:
         a.close()
         b.close()
+
+
+@pytest.mark.parametrize("log2n,F", [(21, 320), (21, 160), (22, 160), (21, 60)])
+def test_handoff_plan_at_batch_sizes_that_leave_a_round_part_empty(log2n, F, monkeypatch):
+    """Batches below two frames per work-group take the hand-off plan when their uniform segments would not fill the
+    last round of work-groups (forward.hip: seg_plan_counts).  There a segment's predecessor is less than two segments
+    ahead: many first tiles fall back to a seam - every frame's pyramid and spectrum must still be bit-identical to
+    whole-frame segments."""
+    import ctypes as C
+    import hashlib
+    from phantomsdr_amd import Context, _lib
+    from test_real_fused_model import seg_plan
+    N = 1 << log2n
+    G = (N // 2 // 1024) // 16
+    assert seg_plan(G, F)[1]
+    rng = np.random.default_rng(log2n * 1000 + F)
+    raw = rng.integers(-2500, 2500, size=(2 * F + 1) * (N // 2), dtype=np.int16)
+
+    def run(seg_len):
+        if seg_len:
+            monkeypatch.setenv("PSDR_SEG_LEN", str(seg_len))
+        else:
+            monkeypatch.delenv("PSDR_SEG_LEN", raising=False)
+        ctx = Context(N, True, 12 if log2n == 22 else 11, input_format="s16", max_batch=F)
+        try:
+            d = ctx.dev_alloc(raw.nbytes)
+            ctx.h2d(d, raw)
+            ctx.process_batch(d, F)
+            ctx.process_batch(d, F, offset_bytes=F * ctx.half_frame_bytes())
+            if not seg_len:
+                fn = _lib.load().psdr_debug_seg_fallbacks
+                fn.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_void_p, C.c_uint]
+                ns, fb = C.c_uint(0), C.c_uint(0)
+                assert fn(ctx.h, C.byref(ns), C.byref(fb), None, 0) == 0
+                assert ns.value == F * (7 + log2n - 20), "the hand-off plan ran"
+            out = [(hashlib.blake2b(ctx.read_spectrum(f).tobytes(), digest_size=12).digest(),
+                    hashlib.blake2b(ctx.read_quantized(f).tobytes(), digest_size=12).digest()) for f in range(F)]
+            ctx.dev_free(d)
+            return out
+        finally:
+            ctx.close()
+    a, b = run(0), run(G)
+    bad = [f for f in range(F) if a[f] != b[f]]
+    assert not bad, bad[:8]

@@ -66,7 +66,23 @@ def untangle_pair(a, b, w, h):
 def seg_plan(G, nframes, num_cus=256, seg_len_env=0, static_tiles=False):
     """forward.hip: seg_plan_counts / seg_plan.  Returns (table, handoff, nseam): table[sg] = (frame, first tile, tiles,
     segment above, carry-in through memory)."""
-    handoff = seg_len_env <= 0 and not static_tiles and G >= 16 and nframes >= 2 * num_cus
+    def uniform_len():
+        if seg_len_env > 0:
+            sl = 1
+            while sl * 2 <= seg_len_env and sl * 2 <= G:
+                sl *= 2
+            return sl
+        want = G * nframes // (2 * max(num_cus, 1))
+        sl = 1
+        while sl * 2 <= want and sl * 2 <= G:
+            sl *= 2
+        return sl
+    want = nframes > num_cus
+    if not want and nframes * G >= 8 * num_cus:     # a batch whose uniform segments leave the last round part empty
+        ns = nframes * (G // uniform_len())
+        rounds = -(-ns // num_cus)
+        want = 100 * ns < 97 * rounds * num_cus
+    handoff = seg_len_env <= 0 and not static_tiles and G >= 16 and want
     tab = []
     if handoff:
         lens = [G // 4] * 3
@@ -81,15 +97,7 @@ def seg_plan(G, nframes, num_cus=256, seg_len_env=0, static_tiles=False):
                 tab.append((f, g, ln, ((lv - 1) if lv else len(lens) - 1) * nframes + f, lv > 0))
             g -= ln
         return tab, True, nframes
-    if seg_len_env > 0:
-        sl = 1
-        while sl * 2 <= seg_len_env and sl * 2 <= G:
-            sl *= 2
-    else:
-        want = G * nframes // (2 * max(num_cus, 1))
-        sl = 1
-        while sl * 2 <= want and sl * 2 <= G:
-            sl *= 2
+    sl = uniform_len()
     S = G // sl
     for f in range(nframes):
         for si in range(S):
@@ -187,14 +195,16 @@ def test_fused_real_pass2_model_matches_rfft(M1, M2, seg_len):
         assert np.allclose(rec[recmap2_pos(o, M1, M2)], P[8 * o: 8 * o + 8], rtol=1e-9, atol=0), o
 
 
-@pytest.mark.parametrize("G,nframes", [(64, 512), (128, 512), (64, 640), (16, 600), (64, 513), (64, 511), (64, 256), (64, 1), (128, 7)])
+@pytest.mark.parametrize("G,nframes", [(64, 512), (128, 512), (64, 640), (16, 600), (64, 513), (64, 511), (64, 256), (64, 1), (128, 7), (64, 320), (64, 160), (128, 160),
+                                      (64, 128), (64, 192), (64, 96), (64, 384), (64, 257)])
 def test_segment_plan_partitions_frames_and_orders_the_hand_offs(G, nframes):
     """the table k_fft_pass2_real walks (forward.hip, seg_plan): every tile of every frame in exactly one segment; the
     segments without a carry-in first (k_real_seam's grid); in hand-off mode a segment's predecessor is the segment of
     the SAME frame that ends one tile above it, handed out exactly nframes tickets earlier, and only a frame's top
     segment needs a seam (the ring closes through tile 0's row M1/2)"""
     tab, handoff, nseam = seg_plan(G, nframes)
-    assert handoff == (nframes >= 2 * 256)
+    assert handoff == {512: True, 640: True, 600: True, 513: True, 511: True, 256: False, 1: False, 7: False, 320: True,
+                       160: True, 128: False, 192: False, 96: False, 384: True, 257: True}[nframes]
     seen = np.zeros((nframes, G), int)
     for f, g0, ln, above, mem in tab:
         assert ln >= 1 and g0 - ln + 1 >= 0
