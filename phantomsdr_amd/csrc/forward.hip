@@ -43,16 +43,35 @@ int real_seg_len(const psdr_ctx *c, int nframes) {
         while (sl * 2 <= c->seg_len_env && sl * 2 <= G) sl *= 2;
         return sl;
     }
-    const long long want = (long long)G * nframes / (2LL * std::max(c->num_cus, 1));
-    int sl = 1;
-    while (sl * 2 <= want && sl * 2 <= G) sl *= 2;
-    return sl;
+    const int W = std::max(c->num_cus, 1);
+    const long long tiles = (long long)G * nframes;  // of the batch
+    auto pow2_floor = [&](long long v) {
+        int sl = 1;
+        while (sl * 2 <= v && sl * 2 <= G) sl *= 2;
+        return sl;
+    };
+    const long long want = tiles / (2LL * W);
+    if (psdr_tuning_env("PSDR_SEG_OLD")) return pow2_floor(want);
+    // What the measurements say (cfg3's stream, tools/ab_small_batches.sh, profiles/r04b_uniform_segments_small_batches.jsonl):
+    // up to 16 tiles per work-group ONE static segment each, rounded up to a power of two (32 frames: 256 segments of 8
+    // tiles 151 GS/s, 512 of 4 - the old choice - 140; 48 frames: 192 of 16 tiles 155, 768 of 4 141); two static segments per
+    // work-group when that comes out even (128, 256 frames of 2^21 points: nothing to balance, nothing drawn); else five
+    // to ten segments per work-group, so that the ticket counter has something to balance with - a work-group draws two
+    // tickets ahead, and with three or four segments each half the chip ends up with one more than the other half (192
+    // frames: 16-tile segments 158 GS/s, 8-tile segments 168; 384 frames: 162 / 182).
+    const long long per_wg = (tiles + W - 1) / W;
+    if (per_wg <= 16) {
+        int sl = 1;
+        while (sl < per_wg && sl * 2 <= G) sl *= 2;
+        return sl;
+    }
+    if (2LL * W * want == tiles && (want & (want - 1)) == 0 && want <= G) return (int)want;
+    return pow2_floor(tiles / (5LL * W));
 }
 // Chain segments of a batch (k_fft_pass2_real, fft_pass.h).  Two forms:
 //  * uniform segments of real_seg_len() tiles, frame-major, every segment's first tile WITHOUT a carry-in (it leaves its
 //    partial octets in seamP, k_real_seam completes them): small batches, PSDR_SEG_LEN, static tile hand-out;
-//  * hand-off (batches of more than one frame per work-group, and smaller ones that leave a round of work-groups
-//    part empty - seg_plan_counts): a frame is cut into segments of G/4, G/4, G/4, G/8, ... 2,
+//  * hand-off (batches of more than one frame per work-group - seg_plan_counts): a frame is cut into segments of G/4, G/4, G/4, G/8, ... 2,
 //    1, 1 tiles from the top, handed out LEVEL-major - all frames' top segments first, then all second segments, ... - by
 //    the ticket counter alone.  Only the top segment of a frame has no carry-in (the ring closes through tile 0's row
 //    M1/2: one seam per frame, as with whole-frame segments); every other segment reads the carried row its predecessor -
@@ -84,20 +103,14 @@ static std::vector<int> seg_plan_lens(const psdr_ctx *c) {
 void seg_plan_counts(const psdr_ctx *c, int nframes, unsigned *nsegs, unsigned *nseam, bool *handoff) {
     const int G = c->M1 / 16;
     // (PSDR_SEG_LEN=n is the way back to uniform segments; tuning builds: PSDR_SEG_HANDOFF=0)
-    // Which batches take the hand-off plan: all of more than one frame per work-group (384 frames of 2^21 points are three
-    // full rounds of uniform 32-tile segments and still 159 GS/s against 178); below that, those whose uniform
-    // segments do not fill the last round of work-groups (the tickets hand a round's leftovers to a part of the chip and
-    // the rest waits: 320 frames of 2^21 points = 640 segments of 32 tiles = 2.5 rounds - 148 GS/s against 186 with the
-    // hand-off plan; 288: 138 / 179; 160: 146 / 170; where the rounds are full - 96, 128, 192, 256 frames - the uniform
-    // plan is 1 ... 4 % ahead, the hand-offs of a batch that small mostly fall back to seams) and that are not tiny
-    // (a single frame's 64 tiles run side by side: nothing to hand over).  profiles/r04b_handoff_vs_uniform_by_batch.jsonl
+    // Which batches take the hand-off plan: those of more than one frame per work-group (cfg3's stream at 258 / 288 / 320 /
+    // 384 / 448 / 512 frames: +11 / +29 / +25 / +12 / +6 / +1.5 % over the uniform segments of round 3; against the uniform
+    // segments real_seg_len() picks now it is level at 320 and 384 frames and 1 - 5 % ahead at 512).  Up to one frame per
+    // work-group a segment's predecessor is less than a segment ahead, most hand-offs end as seams, and well-chosen uniform
+    // segments are 3 - 9 % faster (profiles/r04b_handoff_vs_uniform_by_batch.jsonl, r04b_uniform_segments_small_batches.jsonl).
     const char *off = psdr_tuning_env("PSDR_SEG_HANDOFF"), *mn = psdr_tuning_env("PSDR_SEG_HANDOFF_MIN");
     const int W = std::max(c->num_cus, 1);
-    bool want = nframes >= (mn ? atoi(mn) : W + 1);
-    if (!want && !mn && (long long)nframes * G >= 8LL * W) {
-        const long long ns = (long long)nframes * (G / real_seg_len(c, nframes)), rounds = (ns + W - 1) / W;
-        want = 100 * ns < 97 * rounds * W;
-    }
+    const bool want = nframes >= (mn ? atoi(mn) : W + 1);
     const bool ho = c->seg_len_env <= 0 && !c->static_tiles && G >= 16 && want && !(off && atoi(off) == 0);
     if (ho) {
         const int levels = (int)seg_plan_lens(c).size();

@@ -61,24 +61,17 @@ def test_fused_real_pass_long_chains_vs_oracle(wl_name, seg_len, splits, seg_len
     run_workload(wl, splits=splits, seed=1234 + seg_len)
 
 
-def _default_seg_len(M1, nframes, num_cus=256):
-    """real_seg_len() of psdr_api.hip"""
-    G = M1 // 16
-    want = G * nframes // (2 * num_cus)
-    sl = 1
-    while sl * 2 <= want and sl * 2 <= G:
-        sl *= 2
-    return sl
-
-
 def test_bench_seg_len_is_what_the_chain_tests_cover():
-    assert _default_seg_len(1024, 256) == 32 and _default_seg_len(2048, 256) == 64
-    assert _default_seg_len(1024, 512) == 64 and _default_seg_len(2048, 512) == 128  # whole frames: PSDR_SEG_LEN = G
-    # bench.DEFAULT_BATCH = 512 frames >= 1.5 per work-group: the hand-off plan (test_real_fused_model.py states it,
-    # test_handoff_plan_bit_identical_to_whole_frame_segments below runs it against the whole-frame segments)
+    """what the segment plan (forward.hip: real_seg_len / seg_plan, restated in test_real_fused_model.py) picks for the
+    batch sizes the bench has used: uniform 32- and 64-tile segments at 256 frames, the hand-off plan at 512"""
     import bench
     from test_real_fused_model import seg_plan
-    assert bench.DEFAULT_BATCH == 512 and seg_plan(64, 512)[1] and not seg_plan(64, 256)[1]
+    for G, sl in ((64, 32), (128, 64)):
+        tab, handoff, _ = seg_plan(G, 256)
+        assert not handoff and {t[2] for t in tab} == {sl}
+    # bench.DEFAULT_BATCH = 512 frames, more than one per work-group: the hand-off plan
+    # (test_handoff_plan_bit_identical_to_whole_frame_segments below runs it against whole-frame segments)
+    assert bench.DEFAULT_BATCH == 512 and seg_plan(64, 512)[1] and seg_plan(128, 512)[1]
 
 
 @pytest.mark.parametrize("log2n", [21, 22])
@@ -318,12 +311,11 @@ def test_handoff_two_contexts_interleaved_and_640_frames(monkeypatch):
         b.close()
 
 
-@pytest.mark.parametrize("log2n,F", [(21, 320), (21, 160), (22, 160), (21, 60)])
-def test_handoff_plan_at_batch_sizes_that_leave_a_round_part_empty(log2n, F, monkeypatch):
-    """Batches below two frames per work-group take the hand-off plan when their uniform segments would not fill the
-    last round of work-groups (forward.hip: seg_plan_counts).  There a segment's predecessor is less than two segments
-    ahead: many first tiles fall back to a seam - every frame's pyramid and spectrum must still be bit-identical to
-    whole-frame segments."""
+@pytest.mark.parametrize("log2n,F", [(21, 320), (21, 257), (22, 288)])
+def test_handoff_plan_between_one_and_two_frames_per_work_group(log2n, F, monkeypatch):
+    """Batches of more than one frame per work-group take the hand-off plan (forward.hip: seg_plan_counts).  Below two
+    frames per work-group a segment's predecessor is less than two segments ahead: many first tiles fall back to a seam -
+    every frame's pyramid and spectrum must still be bit-identical to whole-frame segments."""
     import ctypes as C
     import hashlib
     from phantomsdr_amd import Context, _lib

@@ -66,22 +66,28 @@ def untangle_pair(a, b, w, h):
 def seg_plan(G, nframes, num_cus=256, seg_len_env=0, static_tiles=False):
     """forward.hip: seg_plan_counts / seg_plan.  Returns (table, handoff, nseam): table[sg] = (frame, first tile, tiles,
     segment above, carry-in through memory)."""
-    def uniform_len():
-        if seg_len_env > 0:
-            sl = 1
-            while sl * 2 <= seg_len_env and sl * 2 <= G:
-                sl *= 2
-            return sl
-        want = G * nframes // (2 * max(num_cus, 1))
+    def pow2_floor(v):
         sl = 1
-        while sl * 2 <= want and sl * 2 <= G:
+        while sl * 2 <= v and sl * 2 <= G:
             sl *= 2
         return sl
-    want = nframes > num_cus
-    if not want and nframes * G >= 8 * num_cus:     # a batch whose uniform segments leave the last round part empty
-        ns = nframes * (G // uniform_len())
-        rounds = -(-ns // num_cus)
-        want = 100 * ns < 97 * rounds * num_cus
+
+    def uniform_len():   # forward.hip: real_seg_len
+        if seg_len_env > 0:
+            return pow2_floor(seg_len_env)
+        W = max(num_cus, 1)
+        tiles = G * nframes
+        want = tiles // (2 * W)
+        per_wg = -(-tiles // W)
+        if per_wg <= 16:                     # one static segment per work-group
+            sl = 1
+            while sl < per_wg and sl * 2 <= G:
+                sl *= 2
+            return sl
+        if 2 * W * want == tiles and want & (want - 1) == 0 and want <= G:
+            return want                      # two static segments per work-group
+        return pow2_floor(tiles // (5 * W))  # five to ten per work-group: the tickets have something to balance with
+    want = nframes > num_cus                 # the hand-off plan: more than one frame per work-group
     handoff = seg_len_env <= 0 and not static_tiles and G >= 16 and want
     tab = []
     if handoff:
@@ -204,7 +210,7 @@ def test_segment_plan_partitions_frames_and_orders_the_hand_offs(G, nframes):
     segment needs a seam (the ring closes through tile 0's row M1/2)"""
     tab, handoff, nseam = seg_plan(G, nframes)
     assert handoff == {512: True, 640: True, 600: True, 513: True, 511: True, 256: False, 1: False, 7: False, 320: True,
-                       160: True, 128: False, 192: False, 96: False, 384: True, 257: True}[nframes]
+                       160: False, 128: False, 192: False, 96: False, 384: True, 257: True}[nframes]
     seen = np.zeros((nframes, G), int)
     for f, g0, ln, above, mem in tab:
         assert ln >= 1 and g0 - ln + 1 >= 0
