@@ -227,6 +227,7 @@ int build(psdr_ctx *c) {
     c->stream = c->own_stream;
     c->side = c->own_side;
     c->static_tiles = psdr_tuning_env("PSDR_STATIC_TILES") != nullptr;
+    if (const char *e = psdr_tuning_env("PSDR_Y_PAD")) c->y_pad = (size_t)atoi(e) & ~(size_t)15;
     c->no_col_tail = psdr_tuning_env("PSDR_NO_COL_TAIL") != nullptr;
     // pass 1 on its own stream overlaps the two passes of consecutive batches; it pays only when
     // both batches' intermediates fit the 256 MiB MALL together (measured: F=16 2^20-point frames
@@ -290,7 +291,7 @@ int build(psdr_ctx *c) {
     }
     // the second Y buffer only exists when pass 1 runs on its own stream (PSDR_P1_STREAM)
     for (int i = 0; i < (c->no_p1_stream ? 1 : 2); i++)
-        HIPCHK(hipMalloc((void **)&c->y_pool[i], F * c->M * sizeof(cf)));
+        HIPCHK(hipMalloc((void **)&c->y_pool[i], F * (c->M + c->y_pad) * sizeof(cf)));
     if (c->is_real && !c->real_fused) HIPCHK(hipMalloc((void **)&c->d_Z, F * c->M * sizeof(cf)));
     if (!c->is_real && c->lay.mode) HIPCHK(hipMalloc((void **)&c->d_Z, (c->M + 2) * sizeof(cf)));  // k-order staging
     if (c->real_fused) {

@@ -178,6 +178,7 @@ struct psdr_ctx {
     // kernel overlap with the other kernel's steady state); Y is double-buffered for that
     hipStream_t p1 = nullptr;
     cf *y_pool[2] = {nullptr, nullptr};
+    size_t y_pad = 0;  // complex elements between the frames of Y beyond M (tuning: PSDR_Y_PAD)
     int cur_y = 0;
     bool y_pending[2] = {false, false};
     // TileQueue counters: a ring of TICKET_SLOTS launches x 8 counters per pass; half the ring is

@@ -204,7 +204,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     // inside the pass-1 tile's own linear block
     a1.ytile = c->y_blocked ? (size_t)16 * (c->T1 * cols) : (size_t)c->M2 * c->T2;
     a1.ytl = c->y_blocked ? a1.yblk : (size_t)16 * (c->T1 * cols);
-    a1.yframe = c->M;
+    a1.yframe = c->M + c->y_pad;
     a1.wdelta = c->wdelta;
     a1.M2 = c->M2;
     a1.log2M2 = c->log2M2;
