@@ -15,12 +15,14 @@
 #include "hip_fanout.h"
 #include "mock_reference.h"
 
+#include <atomic>
 #include <cassert>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <thread>
 
 extern "C" {
 typedef struct orc_dcblocker orc_dcblocker;
@@ -40,6 +42,7 @@ static int g_audio_rate = 12000;
 static std::map<const void *, orc_dcblocker *> g_dc;
 static std::map<const void *, orc_agc *> g_agc;
 static std::mutex g_state_mtx;
+static std::atomic<int> g_tasks_in_flight{0};  // posted send_audio / send_waterfall tasks that have not finished
 void dsp_float_to_int16(float *arr, int32_t *output, float mult, size_t len) { orc_float_to_int16(arr, output, mult, len); }
 template <typename T> void DCBlocker<T>::removeDC(T *buf, size_t len) {
     orc_dcblocker *d;
@@ -209,6 +212,12 @@ struct TestSetup {
             int read(void *arr, int num) {
                 const int frame = calls - 1;
                 calls++;
+                // The send tasks of the frame before run on pool threads and fft_task waits for them only AFTER this
+                // read (src/fft.cpp:82-88): a mode change applied here could reset the AGC under a task that is still
+                // converting that frame (seen once in ~100 runs: client 1's last LSB packet before its change to AM).
+                // The reference has the same window between its websocket and pool threads; the oracle this test
+                // compares with has not, so the script's events wait for the tasks.
+                while (g_tasks_in_flight.load() != 0) std::this_thread::yield();
                 for (auto &e : *ev) {
                     if (e.frame != frame) continue;
                     auto &c = (*acl)[e.client];
@@ -228,7 +237,14 @@ struct TestSetup {
             return false;
         };
         psdr_level2::Access::fft_task(
-            srv, raw, [](auto fn) { return std::async(std::launch::async, fn); },
+            srv, raw,
+            [](auto fn) {
+                g_tasks_in_flight++;
+                return std::async(std::launch::async, [fn] {
+                    fn();
+                    g_tasks_in_flight--;
+                });
+            },
             [&](connection_hdl h) -> size_t {
                 const int tag = *std::static_pointer_cast<int>(h.lock());
                 return (tag >= 100 ? slow(tag - 100, true) : slow(tag, false)) ? 50001 : 50000;  // > 50000 is slow (src/websocket.cpp:174)
