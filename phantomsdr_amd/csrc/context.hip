@@ -215,13 +215,21 @@ int build(psdr_ctx *c) {
         HIPCHK(hipGetDeviceProperties(&prop, c->device));
         c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    if (const char *e = psdr_tuning_env("PSDR_MAIN_PRIO")) {  // (tuning) 1: the passes' stream at the highest priority
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, atoi(e) > 0 ? hi : lo));
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    }
     {
         // the consumers are short kernels that must squeeze in next to the persistent FFT
         // work-groups: give their stream the highest priority
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIPCHK(hipStreamCreateWithPriority(&c->own_side, hipStreamNonBlocking, hi));
+        int pr = hi;
+        if (const char *e = psdr_tuning_env("PSDR_SIDE_PRIO")) pr = atoi(e) > 0 ? lo : (atoi(e) == 0 ? (lo + hi) / 2 : hi);  // 1: lowest, 0: middle
+        HIPCHK(hipStreamCreateWithPriority(&c->own_side, hipStreamNonBlocking, pr));
     }
     HIPCHK(hipStreamCreateWithFlags(&c->own_p1, hipStreamNonBlocking));
     c->stream = c->own_stream;
