@@ -44,6 +44,9 @@ WORKLOADS = {
                  desc="70 MSPS real s16, 2^22-pt R2C, 128 audio clients + 8 zoomed waterfalls per GPU"),
     # the target's own wording: 256 concurrent (mixed) audio clients on one MI355X, cfg2's stream (the `clients256`
     # sub-object of the default line is this workload; here it can be profiled on its own)
+    # (tuning only: 2^21-point IQ frames - the IQ twin of cfg5's 2^21-point packed transform, for A/Bs of the M1 x M2 split)
+    "iq21": dict(sps=70_000_000, fft_size=1 << 21, is_real=False, fmt="s16", audio=32, waterfall=4,
+                 modes=("USB", "LSB", "AM", "FM"), desc="70 MSPS IQ cs16, 2^21-pt C2C, 32 mixed audio + 4 waterfall clients (tuning)"),
     "clients256": dict(sps=35_000_000, fft_size=1 << 20, is_real=False, fmt="s16", audio=256, waterfall=4,
                        modes=("USB", "LSB", "AM", "FM"),
                        desc="35 MSPS IQ cs16, 2^20-pt C2C, 256 mixed USB/LSB/AM/FM audio + 4 waterfall clients"),
@@ -306,7 +309,7 @@ def cpu_threaded_pipeline(wl, params, threads, seconds=4.0):
             "what": "one pipeline, FFT::load + FFT::execute (window, transform, /N, power, int8 pyramid), no clients: BASELINE.md section 2's measurement"}
 
 
-def cpu_baseline_subprocess(wl_name, timeout_s=300):
+def cpu_baseline_subprocess(wl_name, timeout_s=300, nclients=None):
     """runs cpu_baseline() in a child process (a third-party FFT library is dlopen()ed there: keep it
     away from the process that owns the GPU context) and falls back to the built-in transform; then, in further
     children with the FFT library's threading on, ONE pipeline with 8 and with all usable threads
@@ -315,6 +318,8 @@ def cpu_baseline_subprocess(wl_name, timeout_s=300):
     out = None
     for lib in (None, ""):
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", wl_name]
+        if nclients is not None:
+            cmd += ["--cpu-clients", str(nclients)]
         if lib == "":
             cmd.append("--cpu-builtin-fft")
         try:
@@ -392,9 +397,25 @@ def emit(out):
         print(json.dumps(out), flush=True)
 
 
+TARGET_FRAC = 0.40  # BASELINE.json north_star: ">= 40 % of HBM roofline"
+
+
+def path_roofline(b_frame, frames_per_s):
+    """SURVEY 8(d) / BASELINE.md section 3, the graded figure: compulsory bytes of the WHOLE path per frame x frames/s
+    over the HBM spec peak.  Reproduces from `value` alone: frames/s = value * 1e6 / (N/2)."""
+    achieved = b_frame * frames_per_s
+    return {"bound": "hbm", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK, 4), "target_frac": TARGET_FRAC,
+            "definition": "B_frame x frames/s / 8.0e12 (SURVEY 8d: input read once + spectrum + int8 pyramid written once + per-client "
+                          "slices and audio; intermediates count zero); one step = one launch of every kernel of the path over "
+                          "frames_per_launch frames",
+            "algorithmic_bytes_per_frame": int(b_frame)}
+
+
 def kernel_roofline(ctx, step, first_step, nsteps, wl, wl_name, params, clients, waterfalls, frames_per_launch,
-                    clock_us=None, ms_per_step=None, ms_per_step_stamped=None):
-    """Per-kernel durations and the roofline block of the dominant kernel (DESIGN.md "Roofline accounting").
+                    clock_us=None, ms_per_step=None, ms_per_step_stamped=None, frames_per_s=None):
+    """Per-kernel durations and the roofline block (DESIGN.md "Roofline accounting"): `frac` is the whole path's
+    (path_roofline: SURVEY 8d's figure), the dominant kernel on its own algorithmic bytes sits beside it as `kernel_*`.
 
     clock_us: {"fft_pass1": [...], "fft_pass2": [...]} - per-launch durations of the two FFT passes stamped on
       the device clock in the INSTRUMENTED repetitions of the timed loop (psdr_set_profiling mode 2: first work-group
@@ -445,25 +466,34 @@ def kernel_roofline(ctx, step, first_step, nsteps, wl, wl_name, params, clients,
     if dom:
         avg_s = dur[dom] / 1e6
         achieved = per_kernel_bytes.get(dom, 0) / avg_s
-        traffic = None
+        traffic = step_traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile)).get(wl_name, {})
+                scale = Fl / tj.get("_frames_per_launch", Fl)  # measured at tj["_frames_per_launch"] frames per launch
                 traffic = tj.get(dom)
-                if traffic is not None:  # measured at tj["_frames_per_launch"] frames per launch
-                    traffic = int(traffic * Fl / tj.get("_frames_per_launch", Fl))
+                if traffic is not None:
+                    traffic = int(traffic * scale)
+                tot = sum(v for k, v in tj.items() if not k.startswith("_"))
+                step_traffic = int(tot * scale) if tot else None
             except Exception:
-                traffic = None
+                traffic = step_traffic = None
         ev = {k: float(np.median(per_chunk[k])) for k in ("fft_pass1", "fft_pass2", "untangle_real") if k in per_chunk}
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
-                    "traffic_source": "rocprofv3 --pmc passes of this workload (profiles/traffic.json), scaled to this batch size",
-                    "algorithmic_bytes_per_launch": int(per_kernel_bytes.get(dom, 0)),
-                    "avg_launch_us": round(avg_s * 1e6, 2),
-                    "method": ("median launch duration on the device clock, stamped by the kernel itself in the instrumented repetitions of the timed loop (path.instrumentation)"
-                               if dom in clock_med else "median of hipEvent brackets in a replay after the timed loop"),
-                    "hip_event_us": round(ev.get(dom, 0.0), 2) if dom in ev else None}
+        fps = frames_per_s if frames_per_s else (Fl / (ms_per_step * 1e-3) if ms_per_step else 0.0)
+        roofline = path_roofline(ab["total"], fps)
+        roofline.update({
+            "frames_per_launch": Fl, "traffic": step_traffic,
+            "traffic_source": "rocprofv3 --pmc passes of this workload (profiles/traffic.json: FETCH_SIZE + WRITE_SIZE of every kernel of one "
+                              "step), scaled to this batch size",
+            "algorithmic_bytes_per_step": int(ab["total"] * Fl),
+            # the dominant kernel on ITS OWN algorithmic bytes (pass 2: spectrum + pyramid written once)
+            "kernel": dom, "kernel_achieved": round(achieved / 1e9, 2), "kernel_frac": round(achieved / HBM_PEAK, 4),
+            "kernel_traffic": traffic, "kernel_algorithmic_bytes_per_launch": int(per_kernel_bytes.get(dom, 0)),
+            "kernel_avg_launch_us": round(avg_s * 1e6, 2),
+            "kernel_method": ("median launch duration on the device clock, stamped by the kernel itself in the instrumented repetitions of the timed loop (path.instrumentation)"
+                              if dom in clock_med else "median of hipEvent brackets in a replay after the timed loop"),
+            "kernel_hip_event_us": round(ev.get(dom, 0.0), 2) if dom in ev else None})
         if ms_per_step:
             # the passes of one step run back to back on one stream: their durations cannot add up to more
             # than the step unless the measurement itself lengthened them
@@ -524,8 +554,10 @@ def c_group_bench(ngpus, steps, warmup, F, ring_mib):
             out["by_shard"][shard] = {
                 "value": round(steps * F * (N // 2) / dt / 1e6, 2), "ms_per_step": round(dt / steps * 1e3, 4), "clients_placed": placed,
                 "link_bytes_per_step": int(link_bytes), "exchange_ms_last_step": round(ex_ms, 4),
-                "GB_per_s_per_link_during_exchange": round(link_bytes / (ex_ms * 1e-3) / 1e9, 2) if ex_ms > 0 else None,
-                "GB_per_s_per_link_over_the_step": round(link_bytes * steps / dt / 1e9, 2), "link_peak_GB_per_s": 153.0}
+                # (one device: the "exchange" is a copy onto itself - no link, no rate)
+                "GB_per_s_per_link_during_exchange": round(link_bytes / (ex_ms * 1e-3) / 1e9, 2) if ex_ms > 0 and ngpus > 1 else None,
+                "GB_per_s_per_link_over_the_step": round(link_bytes * steps / dt / 1e9, 2) if ngpus > 1 else None,
+                "link_peak_GB_per_s": 153.0}
             root.dev_free(d)
             g.close()
         except Exception as e:
@@ -534,8 +566,9 @@ def c_group_bench(ngpus, steps, warmup, F, ring_mib):
 
 
 def run_sharded_bench(args, torch, rank, world, local_rank):
-    """N > 1, one process per GPU over RCCL.  Three ways to shard the path are measured in the same run;
-    `value` is the one --shard names (default: BASELINE.json configs[3]):
+    """N > 1, one process per GPU over RCCL.  Five ways to shard the path are measured in the same run; `value` is the one
+    --shard names - default `clients`, BASELINE.json configs[3] verbatim (256 audio clients sharded over the GPUs with an RCCL
+    broadcast of the shared forward spectrum); the others sit beside it under `sharding`:
 
       clients  audio clients sharded over the ranks (client i -> rank i mod G); rank 0 FFTs and
                broadcasts each spectrum batch (8N bytes per frame) over RCCL/xGMI
@@ -677,8 +710,12 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
         # time mode: every rank ingests its own F new frames per step; client modes: one stream
         frames = steps * F * (world if time_mode else 1)
         msps = frames * (N // 2) / dt / 1e6
+        # (the root GPU's: rank 0 reads the ring, transforms, and serves its share of the clients; time sharding: every rank its own frames)
         roofline, kernels, _ = kernel_roofline(eng.ctx, step, warmup + steps, min(steps, 20), wl, wl_name, params,
-                                               clients, waterfalls, F + warm, ms_per_step=dt / steps * 1e3)
+                                               clients, waterfalls, F + warm, ms_per_step=dt / steps * 1e3,
+                                               frames_per_s=frames / dt / (world if time_mode else 1))
+        if roofline:
+            roofline["gpu"] = "rank 0 (root: raw ring, forward FFT, waterfalls, its share of the clients)"
         fence()
         ab = algorithmic_bytes_per_frame(wl, params, clients, waterfalls)
         res = {"value": round(msps, 2), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
@@ -698,10 +735,11 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
         torch.cuda.empty_cache()
         return res
 
-    # `value`: band sharding for IQ workloads (per link and frame 8N/G bytes, pack-free at 2^20 / 2^21 points: the one
-    # client sharding whose ceiling grows with G); the north star's spectrum broadcast (BASELINE.json configs[3], link-bound
-    # at ~9.5 GS/s by construction) is measured in the same run and reported as `north_star_sharding`
-    main_mode = args.shard or ("clients" if WORKLOADS[args.workload or "cfg4"]["is_real"] else "band")
+    # `value`: the north star's sharding - clients over the ranks, ONE RCCL broadcast of the spectrum batch per step
+    # (BASELINE.json configs[3]; link-bound at ~9.5 GS/s by construction: SURVEY 8e).  The cheaper exchanges of SURVEY 8e
+    # (raw half-frames, one band per rank - the one whose ceiling grows with G), the pipelined broadcast and time sharding
+    # are measured in the same run and reported under `sharding`.
+    main_mode = args.shard or "clients"
     results = {}
     for m in (main_mode,) + tuple(x for x in ("clients", "clients_pipelined", "raw", "band", "time") if x != main_mode):
         try:
@@ -742,6 +780,20 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
             store.wait(["psdr_c_group_done"])
     except Exception as e:
         c_group = {"error": repr(e)}
+    # the CPU baseline of THIS job (the oracle on rank 0's host cores over a bounded sample of the same workload with the
+    # whole job's clients; a child process, the other ranks wait on the rendezvous store with idle GPUs)
+    cpu = None
+    try:
+        store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            if not args.no_cpu_baseline:
+                r0 = results[main_mode]
+                cpu = cpu_baseline_subprocess((r0.get("workload") or "cfg4").split(":")[0], nclients=r0.get("audio_clients"))
+            store.set("psdr_cpu_baseline_done", "1")
+        else:
+            store.wait(["psdr_cpu_baseline_done"])
+    except Exception as e:
+        cpu = {"error": repr(e)}
     if rank == 0:
         r = results[main_mode]
         out = {
@@ -761,7 +813,7 @@ def run_sharded_bench(args, torch, rank, world, local_rank):
                          for m in results},
             "north_star_sharding": {k: v for k, v in results.get("clients", {}).items() if k in ("value", "ms_per_step", "xgmi", "error")},
             "c_group": c_group,
-            "cpu_baseline": None,
+            "cpu_baseline": cpu,
         }
     else:
         out = None
@@ -889,6 +941,8 @@ class SingleGpuRun:
             out["passes_device_clock_us"] = {"fft_pass1": round(p1, 2), "fft_pass2": round(p2, 2)}
             if fused:
                 out["pass2_frac_of_hbm_peak"] = round((ab["spectrum"] + ab["pyramid"]) * self.F / (p2 * 1e-6) / HBM_PEAK, 4)
+        # the same block as the headline's: `frac` = B_frame x frames/s / 8 TB/s, the second pass on its own bytes beside it
+        out["roofline"] = dict(path_roofline(ab["total"], frames / med), kernel="fft_pass2", kernel_frac=out.get("pass2_frac_of_hbm_peak"))
         return out
 
     def close(self):
@@ -913,8 +967,8 @@ def main():
                     help="skip the clients256 / cfg3 sub-objects (profiling runs of one workload)")
     ap.add_argument("--ring-mib", type=int, default=512)
     ap.add_argument("--shard", default=None, choices=["clients", "clients_pipelined", "time", "raw", "band"],
-                    help="N > 1 (default: band for IQ workloads - the client sharding whose link bytes shrink with N - and "
-                         "clients for real input; every other sharding is measured and reported beside it): "
+                    help="N > 1: which sharding `value` reports (default: clients = BASELINE.json configs[3], RCCL spectrum broadcast; "
+                         "every other sharding is measured and reported beside it): "
                          "shard the clients with a spectrum broadcast (BASELINE.json configs[3]), "
                          "the clients with a RAW half-frame broadcast + replicated FFT, the clients by frequency band "
                          "with a scatter of one band per rank, or the stream (no collective)")
@@ -926,6 +980,7 @@ def main():
     ap.add_argument("--cpu-threaded-only", default=None, metavar="WORKLOAD",
                     help="(internal) one CPU pipeline with the FFT library's own threads (--cpu-threads)")
     ap.add_argument("--cpu-threads", type=int, default=8)
+    ap.add_argument("--cpu-clients", type=int, default=None, help="(internal) audio clients of the CPU leg (N > 1: the whole job's)")
     ap.add_argument("--c-group-only", type=int, default=0, metavar="NGPUS",
                     help="(internal) ONE process over NGPUS devices through psdr_group_* (RCCL called by the library): prints its JSON")
     args = ap.parse_args()
@@ -934,9 +989,11 @@ def main():
         from phantomsdr_amd.core import derived_params
         wl = WORKLOADS[args.cpu_baseline_only]
         p = derived_params(wl["sps"], wl["fft_size"], wl["is_real"])
-        cl = make_clients(wl, p, seed=0x5D5D0002)
+        cl = make_clients(wl, p, seed=0x5D5D0002, count=args.cpu_clients)
         wf = make_waterfalls(wl, p, seed=0x5D5D0002)
-        print(json.dumps(cpu_baseline(wl, p, cl, wf, fft_library="" if args.cpu_builtin_fft else None)), flush=True)
+        # (PSDR_BENCH_CPU_BUDGET_S: the orchestration tests shorten the sample; the default is the ~20 s the contract asks for)
+        print(json.dumps(cpu_baseline(wl, p, cl, wf, budget_s=float(os.environ.get("PSDR_BENCH_CPU_BUDGET_S", "22")),
+                                      fft_library="" if args.cpu_builtin_fft else None)), flush=True)
         return
 
     if args.cpu_threaded_only:
@@ -992,7 +1049,8 @@ def main():
     # per-kernel durations: profiled replay of the same steps (the events do not perturb `value`)
     roofline, kernels, ab = kernel_roofline(eng.ctx, run.step, run.next_step, 50, wl, wl_name, params,
                                             clients, waterfalls, F, clock_us=run.clock_us, ms_per_step=head["ms_per_step"],
-                                            ms_per_step_stamped=(head.get("instrumentation") or {}).get("ms_per_step_with_device_clock_stamps"))
+                                            ms_per_step_stamped=(head.get("instrumentation") or {}).get("ms_per_step_with_device_clock_stamps"),
+                                            frames_per_s=head["frames_per_s"])
 
     # SURVEY 8f-2 (widened row): the optional post-demodulation chain (DC blocker + AGC + int16),
     # measured separately - it is NOT part of `value` (the metric's clients end at float audio)

@@ -116,7 +116,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < NCL; i++) {
         /* a tone of amplitude A on a Hann-windowed frame: slice power ~ A^2 * 1.5 / 4 ... the exact figure is the oracle's
          * business; here: every client sees its tone (power far above the empty slices' zero) */
-        printf("client %d on device %d: slice power %.6g\n", i, gid[i] >> 16, pw_last[i]);
+        printf("client %d on rank %d: slice power %.6g\n", i, psdr_group_client_rank(g, gid[i]), pw_last[i]);
         if (!(pw_last[i] > 1e-4)) return 5;
         if (fa[i]) fclose(fa[i]);
     }

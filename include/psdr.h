@@ -279,21 +279,37 @@ int psdr_read_quantized(psdr_ctx *ctx, int frame, int8_t *out);
  *   PSDR_SHARD_BAND     device b receives band b of the spectrum + a halo of one maximal window (ncclSend / ncclRecv of
  *                       1/n of the bytes; n a power of two); a client lives on the device of the band its window starts in
  * | PSDR_SHARD_FORCE_COMM: create the communicator and issue the collectives even for ONE device (testing the RCCL
- * plumbing on a single-GPU box).  Everything of a rank is ordered on one stream per device; psdr_group_step returns
- * without synchronising.  The process-per-GPU twin of this (torch.distributed over RCCL) is phantomsdr_amd/distributed.py.
- * Time sharding (batch g on device g mod n, no collective) needs no group: n independent contexts. */
+ * plumbing on a single-GPU box): CLIENTS / RAW broadcast to the one rank; BAND packs band 0 (the whole spectrum), sends it to
+ * and receives it from itself (ncclSend / ncclRecv in one group) and demodulates from the received buffer.
+ * | PSDR_SHARD_PEER_COPY: no RCCL at all - after the root's transform every peer pulls its share with hipMemcpyPeerAsync
+ * on its own stream (n - 1 independent copies, one per root-to-peer xGMI link, ordered by events).  With it a device may
+ * be listed more than once: n ranks on fewer GPUs, which is how a one-GPU box runs the multi-rank logic (placement, band
+ * regions and halos, migration, fetch) for real.
+ * Everything of a rank is ordered on one stream per device; psdr_group_step returns without synchronising.  The calls
+ * below may come from different threads (the server's websocket threads and its frame loop): the group serialises them.
+ * The process-per-GPU twin of this (torch.distributed over RCCL) is phantomsdr_amd/distributed.py.
+ * Time sharding (batch g on device g mod n, no collective) needs no group: n independent contexts.
+ * STATUS: no group of more than one physical device has run on hardware yet (every round's GPU box had one MI355X): the
+ * RCCL calls have executed with one rank only, the multi-rank logic through PSDR_SHARD_PEER_COPY on one device.  Treat
+ * ndevices > 1 - and PSDR_SHARD_BAND over RCCL in particular - as EXPERIMENTAL until a node run exists. */
 typedef struct psdr_group psdr_group;
-enum { PSDR_SHARD_CLIENTS = 0, PSDR_SHARD_RAW = 1, PSDR_SHARD_BAND = 2, PSDR_SHARD_FORCE_COMM = 0x100 };
+enum { PSDR_SHARD_CLIENTS = 0, PSDR_SHARD_RAW = 1, PSDR_SHARD_BAND = 2, PSDR_SHARD_FORCE_COMM = 0x100, PSDR_SHARD_PEER_COPY = 0x200 };
 int psdr_group_create(const psdr_config *cfg, const int *devices, int ndevices, int shard, psdr_group **out);
 void psdr_group_destroy(psdr_group *g);
 int psdr_group_size(const psdr_group *g);
 psdr_ctx *psdr_group_ctx(psdr_group *g, int rank);
-/* audio clients: the group picks the device; *gid_out names the client in every psdr_group_client_* / _fetched_* call.
+/* audio clients: the group picks the device; *gid_out names the client in every psdr_group_client_* / _fetched_* call and
+ * NEVER changes (an index into the group's own table of (device, slot)).
  * psdr_group_client_set_audio_range: band sharding moves a client whose window now starts in another band to that
- * band's device (*gid changes; the overlap-add tail does not travel: one frame starts from silence). */
+ * band's device behind its gid.  The demodulation state the reference keeps across a retune (src/signal.cpp:81-94) -
+ * overlap-add tails, FM's last sample - the mode and the paused flag travel with it; the post chain's history on the GPU
+ * (DC sums, AGC gain and look-ahead) does not: the client starts there like a fresh one (an AGC transient the reference
+ * does not have); and psdr_group_fetched_audio answers PSDR_ERR_NO_DATA until the new device has demodulated a batch.
+ * psdr_group_client_rank: the rank (index into `devices`) a client lives on now, -1 for an unknown gid. */
 int psdr_group_client_add(psdr_group *g, int l, double audio_mid, int r, int mode, int *gid_out);
 int psdr_group_client_remove(psdr_group *g, int gid);
-int psdr_group_client_set_audio_range(psdr_group *g, int *gid, int l, double audio_mid, int r);
+int psdr_group_client_set_audio_range(psdr_group *g, int gid, int l, double audio_mid, int r);
+int psdr_group_client_rank(psdr_group *g, int gid);
 int psdr_group_client_set_audio_demodulation(psdr_group *g, int gid, int mode);
 int psdr_group_client_set_paused(psdr_group *g, int gid, int paused);
 /* one batch: the root transforms nframes frames (d_halves_root: nframes + 1 raw half-frames on the ROOT device; _ring:
@@ -302,7 +318,8 @@ int psdr_group_client_set_paused(psdr_group *g, int gid, int paused);
 int psdr_group_step(psdr_group *g, const void *d_halves_root, int nframes, uint64_t first_frame_num);
 int psdr_group_step_ring(psdr_group *g, uint64_t first_half, int nframes, uint64_t first_frame_num);
 int psdr_group_synchronize(psdr_group *g);
-/* bytes that crossed ONE root-to-peer link in the last step, and the exchange's duration on the root's stream */
+/* bytes that crossed ONE root-to-peer link in the last step, and the exchange's duration (RCCL: on the root's stream;
+ * PSDR_SHARD_PEER_COPY: the slowest peer's own copy) */
 int psdr_group_link_stats(psdr_group *g, double *bytes_per_link, double *exchange_ms);
 /* psdr_fetch_batch on every device, then psdr_fetched_audio / psdr_fetched_window by gid */
 int psdr_group_fetch(psdr_group *g);

@@ -107,7 +107,8 @@ SYMBOLS = [
     ("psdr_group_ctx", _vp, [_vp, _i]),
     ("psdr_group_client_add", _i, [_vp, _i, C.c_double, _i, _i, C.POINTER(_i)]),
     ("psdr_group_client_remove", _i, [_vp, _i]),
-    ("psdr_group_client_set_audio_range", _i, [_vp, C.POINTER(_i), _i, C.c_double, _i]),
+    ("psdr_group_client_set_audio_range", _i, [_vp, _i, _i, C.c_double, _i]),
+    ("psdr_group_client_rank", _i, [_vp, _i]),
     ("psdr_group_client_set_audio_demodulation", _i, [_vp, _i, _i]),
     ("psdr_group_client_set_paused", _i, [_vp, _i, _i]),
     ("psdr_group_step", _i, [_vp, _vp, _i, _u64]),

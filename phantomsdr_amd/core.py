@@ -444,16 +444,17 @@ class WaterfallClient:
 
 class Group:
     """psdr_group (include/psdr.h): one process, n GPUs, the batch exchanged over xGMI through RCCL called from C.
-    shard: "clients" | "raw" | "band"; force_comm: issue the collectives even with one device (testing)."""
+    shard: "clients" | "raw" | "band"; force_comm: issue the collectives even with one device (testing); peer_copy: no
+    RCCL, the peers pull with hipMemcpyPeerAsync (a device may then be listed more than once)."""
     SHARDS = {"clients": 0, "raw": 1, "band": 2}
 
-    def __init__(self, devices, shard, fft_size, is_real, downsample_levels, force_comm=False, **ctx_kwargs):
+    def __init__(self, devices, shard, fft_size, is_real, downsample_levels, force_comm=False, peer_copy=False, **ctx_kwargs):
         # a throw-away Context object only to build the psdr_config the same way Context does
         self.lib = _lib.load()
         cfg = Context._config(fft_size, is_real, downsample_levels, **ctx_kwargs)
         devs = (C.c_int * len(devices))(*devices)
         self.h = C.c_void_p()
-        flag = self.SHARDS[shard] | (0x100 if force_comm else 0)
+        flag = self.SHARDS[shard] | (0x100 if force_comm else 0) | (0x200 if peer_copy else 0)
         check(self.lib.psdr_group_create(C.byref(cfg), devs, len(devices), flag, C.byref(self.h)))
         self.n = len(devices)
         self.cfg = cfg
@@ -467,9 +468,16 @@ class Group:
         return gid.value
 
     def client_set_audio_range(self, gid, l, mid, r):
-        g = C.c_int(gid)
-        check(self.lib.psdr_group_client_set_audio_range(self.h, C.byref(g), int(l), float(mid), int(r)))
-        return g.value
+        """(band sharding may move the client to another device behind its gid, which stays what it is)"""
+        check(self.lib.psdr_group_client_set_audio_range(self.h, int(gid), int(l), float(mid), int(r)))
+        return gid
+
+    def client_rank(self, gid):
+        return int(self.lib.psdr_group_client_rank(self.h, int(gid)))
+
+    def ctx_view(self, rank):
+        """the context of `rank` (psdr_group_ctx), owned by the group"""
+        return Context._view(self.lib, self.lib.psdr_group_ctx(self.h, int(rank)), self.cfg)
 
     def client_set_paused(self, gid, paused):
         check(self.lib.psdr_group_client_set_paused(self.h, gid, 1 if paused else 0))

@@ -9,8 +9,15 @@
 //                       R/n + halo bins per frame.  2^20- and 2^21-point IQ contexts: the root's second pass writes the
 //                       band regions itself (psdr_set_band_layout) and the regions ARE the send buffers; otherwise
 //                       psdr_pack_band fills them.
+// | PSDR_SHARD_PEER_COPY: no RCCL - the peers pull their share from the root with hipMemcpyPeerAsync on their own
+//                       streams (one copy per root->peer link, ordered by events).  A device may then be listed more than
+//                       once (n ranks on fewer GPUs): the whole multi-rank logic - placement, band regions and halos,
+//                       migration, fetch - runs on a one-GPU box, only the transport differs.
 // Everything of one rank - its kernels and its side of the collective - is enqueued in order on ONE stream per device
 // (psdr_set_stream), so a step needs no host synchronisation; psdr_group_synchronize() drains all devices.
+// Threads: client calls arrive on the server's websocket threads while the frame loop steps the group.  A client is named
+// by a STABLE gid (an index into the group's table of (rank, slot)); every psdr_group_* call that touches the table, a
+// stream or a client takes the group mutex, so a band migration can never interleave with a step's enqueue.
 // The Python twin for one PROCESS per GPU (torch.distributed, what bench.py --gpus N runs) is phantomsdr_amd/distributed.py.
 #include <dlfcn.h>
 
@@ -64,9 +71,19 @@ Rccl g_rccl;
 
 }  // namespace
 
+struct GroupClient {
+    int rank = -1, id = -1;  // device rank and the slot of that rank's context; rank < 0: free entry
+};
 struct psdr_group {
     int n = 0, shard = 0;
-    bool comm_on = false;           // collectives are issued (n > 1, or PSDR_SHARD_FORCE_COMM)
+    bool comm_on = false;           // RCCL collectives are issued (n > 1, or PSDR_SHARD_FORCE_COMM)
+    bool peer_copy = false;         // PSDR_SHARD_PEER_COPY: peers pull with hipMemcpyPeerAsync instead
+    std::mutex mtx;                 // the client table, next_rr, and every enqueue on the ranks' streams
+    std::vector<GroupClient> clients;  // gid -> (rank, slot): the gid a caller holds never changes
+    std::vector<hipEvent_t> ev_rank;   // per rank, on its device: migration hand-over / peer copy done
+    std::vector<hipEvent_t> ev_t0, ev_t1;  // peer copy: the copy's own duration on the peer's stream
+    hipEvent_t ev_x = nullptr;         // peer copy: the root's data of this step is ready
+    bool copies_pending = false;       // peer copy: ev_rank[r] of the last step not yet waited for by the root
     std::vector<int> dev;
     std::vector<psdr_ctx *> ctx;
     std::vector<hipStream_t> st;    // the one stream per device everything of that rank is ordered on
@@ -86,11 +103,21 @@ struct psdr_group {
     uint64_t steps = 0;
 };
 
+// (callers hold g->mtx)
 static int gid_split(psdr_group *g, int gid, int *rank, int *id) {
-    *rank = gid >> 16;
-    *id = gid & 0xFFFF;
-    if (gid < 0 || *rank >= g->n) return fail(PSDR_ERR_INVALID, "no client %d in this group", gid);
+    if (gid < 0 || gid >= (int)g->clients.size() || g->clients[gid].rank < 0) return fail(PSDR_ERR_INVALID, "no client %d in this group", gid);
+    *rank = g->clients[gid].rank;
+    *id = g->clients[gid].id;
     return PSDR_OK;
+}
+static int gid_new(psdr_group *g, int rank, int id) {
+    for (size_t i = 0; i < g->clients.size(); i++)
+        if (g->clients[i].rank < 0) {
+            g->clients[i] = GroupClient{rank, id};
+            return (int)i;
+        }
+    g->clients.push_back(GroupClient{rank, id});
+    return (int)g->clients.size() - 1;
 }
 static int band_of(const psdr_group *g, int l) {
     const size_t R = g->ctx[0]->R, per = R / (size_t)g->n;
@@ -112,6 +139,9 @@ extern "C" void psdr_group_destroy(psdr_group *g) {
             for (void *p : g->sbuf)
                 if (p) hipFree(p);
         if (r == 0 && g->ev0) hipEventDestroy(g->ev0), hipEventDestroy(g->ev1);
+        if (r == 0 && g->ev_x) hipEventDestroy(g->ev_x);
+        if (r < (int)g->ev_rank.size() && g->ev_rank[r]) hipEventDestroy(g->ev_rank[r]);
+        if (r < (int)g->ev_t0.size() && g->ev_t0[r]) hipEventDestroy(g->ev_t0[r]), hipEventDestroy(g->ev_t1[r]);
         if (g->ctx[r]) psdr_destroy(g->ctx[r]);
         if (r < (int)g->st.size() && g->st[r]) hipStreamDestroy(g->st[r]);
     }
@@ -120,24 +150,30 @@ extern "C" void psdr_group_destroy(psdr_group *g) {
 
 extern "C" int psdr_group_create(const psdr_config *cfg, const int *devices, int ndevices, int shard, psdr_group **out) {
     if (!cfg || !devices || !out) return fail(PSDR_ERR_INVALID, "null argument");
-    const bool force_comm = (shard & PSDR_SHARD_FORCE_COMM) != 0;
-    shard &= ~PSDR_SHARD_FORCE_COMM;
+    const bool force_comm = (shard & PSDR_SHARD_FORCE_COMM) != 0, peer_copy = (shard & PSDR_SHARD_PEER_COPY) != 0;
+    shard &= ~(PSDR_SHARD_FORCE_COMM | PSDR_SHARD_PEER_COPY);
     if (ndevices < 1 || ndevices > 16) return fail(PSDR_ERR_INVALID, "a group has 1..16 devices, not %d", ndevices);
     if (shard < PSDR_SHARD_CLIENTS || shard > PSDR_SHARD_BAND) return fail(PSDR_ERR_INVALID, "unknown sharding %d", shard);
-    for (int i = 0; i < ndevices; i++)
+    if (force_comm && peer_copy) return fail(PSDR_ERR_INVALID, "PSDR_SHARD_FORCE_COMM (RCCL) and PSDR_SHARD_PEER_COPY (no RCCL) exclude each other");
+    for (int i = 0; i < ndevices && !peer_copy; i++)
         for (int j = 0; j < i; j++)
-            if (devices[i] == devices[j]) return fail(PSDR_ERR_INVALID, "device %d listed twice (RCCL wants one rank per device)", devices[i]);
+            if (devices[i] == devices[j])
+                return fail(PSDR_ERR_INVALID, "device %d listed twice (RCCL wants one rank per device; PSDR_SHARD_PEER_COPY allows it)", devices[i]);
     if (shard == PSDR_SHARD_BAND && (ndevices & (ndevices - 1))) return fail(PSDR_ERR_INVALID, "band sharding: a power-of-two number of devices, not %d", ndevices);
     psdr_group *g = new (std::nothrow) psdr_group();
     if (!g) return fail(PSDR_ERR_NOMEM, "out of memory");
     g->n = ndevices;
     g->shard = shard;
-    g->comm_on = ndevices > 1 || force_comm;
+    g->peer_copy = peer_copy && ndevices > 1;
+    g->comm_on = !peer_copy && (ndevices > 1 || force_comm);
     g->dev.assign(devices, devices + ndevices);
     g->ctx.assign(ndevices, nullptr);
     g->st.assign(ndevices, nullptr);
     g->comm.assign(ndevices, nullptr);
     g->rbuf.assign(ndevices, nullptr);
+    g->ev_rank.assign(ndevices, nullptr);
+    g->ev_t0.assign(ndevices, nullptr);
+    g->ev_t1.assign(ndevices, nullptr);
     auto bail = [&](int rc) {
         const std::string msg = psdr_last_error();  // (the clean-up below must not overwrite it)
         psdr_group_destroy(g);
@@ -154,6 +190,16 @@ extern "C" int psdr_group_create(const psdr_config *cfg, const int *devices, int
         }
         rc = psdr_set_stream(g->ctx[r], g->st[r]);
         if (rc) return bail(rc);
+        // (events belong to the device that is current when they are created)
+        if (hipEventCreateWithFlags(&g->ev_rank[r], hipEventDisableTiming) != hipSuccess || hipEventCreate(&g->ev_t0[r]) != hipSuccess ||
+            hipEventCreate(&g->ev_t1[r]) != hipSuccess) {
+            fail(PSDR_ERR_HIP, "event creation on device %d failed", devices[r]);
+            return bail(PSDR_ERR_HIP);
+        }
+        if (g->peer_copy && r > 0 && devices[r] != devices[0]) {
+            (void)hipDeviceEnablePeerAccess(devices[0], 0);  // (direct xGMI reads; without it the copy is staged)
+            (void)hipGetLastError();
+        }
     }
     psdr_ctx *c0 = g->ctx[0];
     const size_t F = (size_t)c0->max_batch;
@@ -194,7 +240,10 @@ extern "C" int psdr_group_create(const psdr_config *cfg, const int *devices, int
             g->band_stride = cnt;
             for (int b = 0; b < ndevices; b++) g->band_first[b] = (uint32_t)((size_t)b * (R / (size_t)ndevices)), g->band_bins[b] = cnt;
             g->sbuf.assign(ndevices, nullptr);
-            for (int b = 1; b < ndevices; b++) {
+            // (one device with the collectives forced: band 0 - the whole spectrum - is packed, sent to and received from
+            // oneself and demodulated from the received buffer, so that the pack + ncclSend / ncclRecv + band demodulation
+            // path runs on a single-GPU box)
+            for (int b = (ndevices == 1 && g->comm_on) ? 0 : 1; b < ndevices; b++) {
                 if (hipSetDevice(devices[0]) != hipSuccess || hipMalloc(&g->sbuf[b], F * g->band_stride * sizeof(cf)) != hipSuccess) {
                     fail(PSDR_ERR_NOMEM, "band send buffer of %zu bytes", F * g->band_stride * sizeof(cf));
                     return bail(PSDR_ERR_NOMEM);
@@ -202,14 +251,15 @@ extern "C" int psdr_group_create(const psdr_config *cfg, const int *devices, int
             }
         }
         g->rbuf_bytes = F * g->band_stride * sizeof(cf);
-        for (int r = 1; r < ndevices; r++) {
+        for (int r = (ndevices == 1 && g->comm_on) ? 0 : 1; r < ndevices; r++) {
             if (hipSetDevice(devices[r]) != hipSuccess || hipMalloc(&g->rbuf[r], g->rbuf_bytes) != hipSuccess) {
                 fail(PSDR_ERR_NOMEM, "band receive buffer of %zu bytes on device %d", g->rbuf_bytes, devices[r]);
                 return bail(PSDR_ERR_NOMEM);
             }
         }
     }
-    if (hipSetDevice(devices[0]) != hipSuccess || hipEventCreate(&g->ev0) != hipSuccess || hipEventCreate(&g->ev1) != hipSuccess) {
+    if (hipSetDevice(devices[0]) != hipSuccess || hipEventCreate(&g->ev0) != hipSuccess || hipEventCreate(&g->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&g->ev_x, hipEventDisableTiming) != hipSuccess) {
         fail(PSDR_ERR_HIP, "event creation failed");
         return bail(PSDR_ERR_HIP);
     }
@@ -223,6 +273,7 @@ extern "C" psdr_ctx *psdr_group_ctx(psdr_group *g, int rank) { return (g && rank
 // ---- audio clients: the group picks the GPU ---------------------------------------------------------------------
 extern "C" int psdr_group_client_add(psdr_group *g, int l, double audio_mid, int r, int mode, int *gid_out) {
     if (!g || !gid_out) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->mtx);
     // clients / raw: round robin (client i on GPU i mod n, like assign_clients of distributed.py); band: the band the
     // window STARTS in (it may end in the halo)
     const int rank = g->shard == PSDR_SHARD_BAND ? band_of(g, l) : g->next_rr % g->n;
@@ -237,50 +288,93 @@ extern "C" int psdr_group_client_add(psdr_group *g, int l, double audio_mid, int
         return fail(rc, "%s", msg.c_str());
     }
     if (g->shard != PSDR_SHARD_BAND) g->next_rr++;
-    *gid_out = (rank << 16) | id;
+    *gid_out = gid_new(g, rank, id);
     return PSDR_OK;
 }
 extern "C" int psdr_group_client_remove(psdr_group *g, int gid) {
     if (!g) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->mtx);
     int rank, id, rc = gid_split(g, gid, &rank, &id);
-    return rc ? rc : psdr_client_remove(g->ctx[rank], id);
+    if (rc) return rc;
+    g->clients[gid].rank = -1;
+    return psdr_client_remove(g->ctx[rank], id);
 }
 extern "C" int psdr_group_client_set_audio_demodulation(psdr_group *g, int gid, int mode) {
     if (!g) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->mtx);
     int rank, id, rc = gid_split(g, gid, &rank, &id);
     return rc ? rc : psdr_client_set_audio_demodulation(g->ctx[rank], id, mode);
 }
 extern "C" int psdr_group_client_set_paused(psdr_group *g, int gid, int paused) {
     if (!g) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->mtx);
     int rank, id, rc = gid_split(g, gid, &rank, &id);
     return rc ? rc : psdr_client_set_paused(g->ctx[rank], id, paused);
 }
+extern "C" int psdr_group_client_rank(psdr_group *g, int gid) {
+    if (!g) return -1;
+    std::lock_guard<std::mutex> lk(g->mtx);
+    int rank, id;
+    return gid_split(g, gid, &rank, &id) ? -1 : rank;
+}
 // A retune inside the client's GPU is AudioClient::set_audio_range.  Band sharding only: a window that now starts in
-// another band moves the client to that band's GPU - a new slot there, *gid changes, and the overlap-add tail does not
-// travel (one frame of audio starts from silence; the reference keeps the tail across a retune, src/signal.cpp:81-94).
-extern "C" int psdr_group_client_set_audio_range(psdr_group *g, int *gid, int l, double audio_mid, int r) {
-    if (!g || !gid) return fail(PSDR_ERR_INVALID, "null argument");
-    int rank, id, rc = gid_split(g, *gid, &rank, &id);
+// another band moves the client to that band's GPU BEHIND its gid (the caller's handle does not change).  What travels:
+// the demodulation state the reference keeps across a retune (src/signal.cpp:81-94 touches none of it) - the SSB
+// overlap-add tail, the AM / FM baseband tail and FM's last sample (one peer copy of the current state rows, ordered
+// after the old device's last batch and before the new device's next one), the mode and the paused flag.  What does NOT
+// travel: the post chain's history on the GPU (DC-blocker sums, AGC gain and look-ahead: the client starts there like a
+// fresh one - an AGC transient of 0.2 s, where the reference has none), and the results of the batch demodulated before
+// the move (psdr_group_fetched_audio answers PSDR_ERR_NO_DATA until the new device has demodulated a batch: one frame
+// at F = 1).
+extern "C" int psdr_group_client_set_audio_range(psdr_group *g, int gid, int l, double audio_mid, int r) {
+    if (!g) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->mtx);
+    int rank, id, rc = gid_split(g, gid, &rank, &id);
     if (rc) return rc;
     const int want = g->shard == PSDR_SHARD_BAND ? band_of(g, l) : rank;
     if (want == rank) return psdr_client_set_audio_range(g->ctx[rank], id, l, audio_mid, r);
-    int mode, nid = -1;
+    psdr_ctx *src = g->ctx[rank], *dst = g->ctx[want];
+    int mode, nid = -1, src_par;
+    bool paused;
     {
-        std::lock_guard<std::mutex> lk(g->ctx[rank]->mtx);
-        if (id >= (int)g->ctx[rank]->aslots.size() || !g->ctx[rank]->aslots[id].active) return fail(PSDR_ERR_INVALID, "no client %d in this group", *gid);
-        mode = g->ctx[rank]->aslots[id].mode;
+        std::lock_guard<std::mutex> lk2(src->mtx);
+        if (id >= (int)src->aslots.size() || !src->aslots[id].active) return fail(PSDR_ERR_INVALID, "no client %d in this group", gid);
+        mode = src->aslots[id].mode;
+        paused = src->aslots[id].paused;
+        src_par = src->aslots[id].state_cur;  // the parity the NEXT batch would read: what the last one wrote
     }
-    rc = psdr_client_add(g->ctx[want], &nid);
+    rc = psdr_client_add(dst, &nid);
     if (rc) return rc;
-    rc = psdr_client_set_audio_demodulation(g->ctx[want], nid, mode);
-    if (!rc) rc = psdr_client_set_audio_range(g->ctx[want], nid, l, audio_mid, r);
+    rc = psdr_client_set_audio_demodulation(dst, nid, mode);
+    if (!rc) rc = psdr_client_set_audio_range(dst, nid, l, audio_mid, r);
+    if (!rc && paused) rc = psdr_client_set_paused(dst, nid, 1);
     if (rc) {
         const std::string msg = psdr_last_error();
-        psdr_client_remove(g->ctx[want], nid);
+        psdr_client_remove(dst, nid);
         return fail(rc, "%s", msg.c_str());
     }
-    psdr_client_remove(g->ctx[rank], id);
-    *gid = (want << 16) | nid;
+    // the state rows: [parity][slot][n/2] (ctx.h); the fresh slot reads parity 0 first.  Ordered on the two ranks' streams:
+    // after everything the old device has enqueued, before anything the new one enqueues from here on; the old slot may be
+    // handed out again only after the copy has read it.
+    {
+        const size_t h = (size_t)src->n / 2, Ss = src->aslots.size(), Sd = dst->aslots.size();
+        HIPCHK(hipSetDevice(g->dev[rank]));
+        HIPCHK(hipEventRecord(g->ev_rank[rank], g->st[rank]));
+        HIPCHK(hipSetDevice(g->dev[want]));
+        HIPCHK(hipStreamWaitEvent(g->st[want], g->ev_rank[rank], 0));
+        auto copy = [&](void *d, const void *sp, size_t bytes) -> hipError_t {
+            return g->dev[rank] == g->dev[want] ? hipMemcpyAsync(d, sp, bytes, hipMemcpyDeviceToDevice, g->st[want])
+                                                : hipMemcpyPeerAsync(d, g->dev[want], sp, g->dev[rank], bytes, g->st[want]);
+        };
+        HIPCHK(copy(dst->d_real_prev + ((size_t)0 * Sd + nid) * h, src->d_real_prev + ((size_t)src_par * Ss + id) * h, h * sizeof(float)));
+        HIPCHK(copy(dst->d_bb_tail + ((size_t)0 * Sd + nid) * h, src->d_bb_tail + ((size_t)src_par * Ss + id) * h, h * sizeof(cf)));
+        HIPCHK(copy(dst->d_bb_last + ((size_t)0 * Sd + nid), src->d_bb_last + ((size_t)src_par * Ss + id), sizeof(cf)));
+        HIPCHK(hipEventRecord(g->ev_rank[want], g->st[want]));
+        HIPCHK(hipSetDevice(g->dev[rank]));
+        HIPCHK(hipStreamWaitEvent(g->st[rank], g->ev_rank[want], 0));
+    }
+    psdr_client_remove(src, id);
+    g->clients[gid] = GroupClient{want, nid};
     return PSDR_OK;
 }
 
@@ -295,6 +389,38 @@ static int group_step(psdr_group *g, const void *raw_root, uint64_t first_half, 
     auto root_transform = [&]() -> int { return raw_root ? psdr_process_batch(c0, raw_root, nframes) : psdr_process_ring(c0, first_half, nframes); };
     g->timed = false;
     g->link_bytes = 0;
+    // PSDR_SHARD_PEER_COPY: what the root is about to overwrite (its spectrum / band regions / send buffers) was the source
+    // of the peers' copies of the previous step
+    auto root_waits_for_copies = [&]() -> int {
+        if (!g->copies_pending) return PSDR_OK;
+        HIPCHK(hipSetDevice(g->dev[0]));
+        for (int r = 1; r < g->n; r++) HIPCHK(hipStreamWaitEvent(g->st[0], g->ev_rank[r], 0));
+        g->copies_pending = false;
+        return PSDR_OK;
+    };
+    // ... and the pull itself: peer r copies `bytes` from the root's src[r] into dst[r] on ITS OWN stream, behind the
+    // root's "data ready" event - n - 1 independent copies, one per root -> peer link
+    auto peers_pull = [&](const std::vector<const void *> &src, const std::vector<void *> &dst, size_t bytes) -> int {
+        HIPCHK(hipSetDevice(g->dev[0]));
+        HIPCHK(hipEventRecord(g->ev_x, g->st[0]));
+        for (int r = 1; r < g->n; r++) {
+            HIPCHK(hipSetDevice(g->dev[r]));
+            HIPCHK(hipStreamWaitEvent(g->st[r], g->ev_x, 0));
+            HIPCHK(hipEventRecord(g->ev_t0[r], g->st[r]));
+            if (g->dev[r] == g->dev[0])
+                HIPCHK(hipMemcpyAsync(dst[r], src[r], bytes, hipMemcpyDeviceToDevice, g->st[r]));
+            else
+                HIPCHK(hipMemcpyPeerAsync(dst[r], g->dev[r], src[r], g->dev[0], bytes, g->st[r]));
+            HIPCHK(hipEventRecord(g->ev_t1[r], g->st[r]));
+            HIPCHK(hipEventRecord(g->ev_rank[r], g->st[r]));
+        }
+        g->copies_pending = true;
+        g->timed = true;
+        g->link_bytes = (double)bytes;
+        return PSDR_OK;
+    };
+    rc = root_waits_for_copies();
+    if (rc) return rc;
     if (g->shard == PSDR_SHARD_RAW) {
         // the raw half-frames cross the links, every GPU transforms them itself
         const unsigned char *src = (const unsigned char *)raw_root;
@@ -324,6 +450,13 @@ static int group_step(psdr_group *g, const void *raw_root, uint64_t first_half, 
             HIPCHK(hipEventRecord(g->ev1, g->st[0]));
             g->timed = true;
             g->link_bytes = (double)bytes;
+        } else if (g->peer_copy) {
+            rc = peers_pull(std::vector<const void *>(g->n, src), g->rbuf, bytes);
+            if (rc) return rc;
+            // the raw halves are the caller's (or the ingest ring's, whose slots are released by the root's first pass):
+            // the root's transform - and with it everything the caller orders behind it - comes after the pulls
+            rc = root_waits_for_copies();
+            if (rc) return rc;
         }
         rc = root_transform();
         if (rc) return rc;
@@ -354,6 +487,11 @@ static int group_step(psdr_group *g, const void *raw_root, uint64_t first_half, 
                 HIPCHK(hipEventRecord(g->ev1, g->st[0]));
                 g->timed = true;
                 g->link_bytes = (double)count * sizeof(float);
+            } else if (g->peer_copy) {
+                std::vector<void *> dst(g->n, nullptr);
+                for (int r = 1; r < g->n; r++) dst[r] = g->ctx[r]->d_spec;
+                rc = peers_pull(std::vector<const void *>(g->n, c0->d_spec), dst, count * sizeof(float));
+                if (rc) return rc;
             }
             rc = psdr_demod_batch(c0, first_frame_num);
             if (rc) return rc;
@@ -373,11 +511,17 @@ static int group_step(psdr_group *g, const void *raw_root, uint64_t first_half, 
                 }
                 if (rc) return rc;
             }
-            if (g->comm_on && g->n > 1) {
+            const bool self_loop = g->comm_on && g->n == 1;  // forced on one device: band 0 goes through RCCL to oneself
+            if (self_loop) {
+                rc = psdr_pack_band(c0, nframes, g->band_first[0], g->band_bins[0], (float *)g->sbuf[0], g->band_stride);
+                if (rc) return rc;
+                send[0] = (const float *)g->sbuf[0];
+            }
+            if (g->comm_on) {
                 HIPCHK(hipSetDevice(g->dev[0]));
                 HIPCHK(hipEventRecord(g->ev0, g->st[0]));
                 NCCLCHK(g_rccl.GroupStart());
-                for (int b = 1; b < g->n; b++) {
+                for (int b = self_loop ? 0 : 1; b < g->n; b++) {
                     HIPCHK(hipSetDevice(g->dev[0]));
                     NCCLCHK(g_rccl.Send(send[b], count, ncclFloat, b, g->comm[0], g->st[0]));
                     HIPCHK(hipSetDevice(g->dev[b]));
@@ -388,8 +532,15 @@ static int group_step(psdr_group *g, const void *raw_root, uint64_t first_half, 
                 HIPCHK(hipEventRecord(g->ev1, g->st[0]));
                 g->timed = true;
                 g->link_bytes = (double)count * sizeof(float);
+            } else if (g->peer_copy) {
+                std::vector<const void *> src(g->n, nullptr);
+                for (int b = 1; b < g->n; b++) src[b] = send[b];
+                rc = peers_pull(src, g->rbuf, count * sizeof(float));
+                if (rc) return rc;
             }
-            rc = psdr_demod_batch(c0, first_frame_num);  // the root's own clients read its spectrum through SpecLayout::pos
+            // the root's own clients read its spectrum through SpecLayout::pos (self_loop: the band buffer that came back)
+            rc = self_loop ? psdr_demod_batch_from_band(c0, (const float *)g->rbuf[0], g->band_stride, g->band_first[0], g->band_bins[0], nframes, first_frame_num)
+                           : psdr_demod_batch(c0, first_frame_num);
             if (rc) return rc;
             for (int b = 1; b < g->n; b++) {
                 rc = g->banded ? psdr_demod_batch_from_band_region(g->ctx[b], (const float *)g->rbuf[b], g->band_stride, g->band_first[b], g->band_bins[b], nframes, first_frame_num)
@@ -405,10 +556,12 @@ static int group_step(psdr_group *g, const void *raw_root, uint64_t first_half, 
 }
 extern "C" int psdr_group_step(psdr_group *g, const void *d_halves_root, int nframes, uint64_t first_frame_num) {
     if (!g || !d_halves_root) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->mtx);  // (enqueue only: a step never waits for the device)
     return group_step(g, d_halves_root, 0, nframes, first_frame_num);
 }
 extern "C" int psdr_group_step_ring(psdr_group *g, uint64_t first_half, int nframes, uint64_t first_frame_num) {
     if (!g) return fail(PSDR_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(g->mtx);
     return group_step(g, nullptr, first_half, nframes, first_frame_num);
 }
 extern "C" int psdr_group_synchronize(psdr_group *g) {
@@ -426,7 +579,15 @@ extern "C" int psdr_group_link_stats(psdr_group *g, double *bytes_per_link, doub
     if (bytes_per_link) *bytes_per_link = g->link_bytes;
     if (exchange_ms) {
         *exchange_ms = 0;
-        if (g->timed) {
+        if (g->timed && g->peer_copy) {  // the slowest peer's own copy
+            for (int r = 1; r < g->n; r++) {
+                HIPCHK(hipSetDevice(g->dev[r]));
+                HIPCHK(hipEventSynchronize(g->ev_t1[r]));
+                float ms = 0;
+                HIPCHK(hipEventElapsedTime(&ms, g->ev_t0[r], g->ev_t1[r]));
+                *exchange_ms = std::max(*exchange_ms, (double)ms);
+            }
+        } else if (g->timed) {
             HIPCHK(hipSetDevice(g->dev[0]));
             HIPCHK(hipEventSynchronize(g->ev1));
             float ms = 0;
@@ -441,7 +602,7 @@ extern "C" int psdr_group_link_stats(psdr_group *g, double *bytes_per_link, doub
 extern "C" int psdr_group_fetch(psdr_group *g) {
     if (!g) return fail(PSDR_ERR_INVALID, "null argument");
     bool any = false;
-    for (int r = 0; r < g->n; r++) {
+    for (int r = 0; r < g->n; r++) {  // (no group lock: this waits for the devices; a context's own mutex guards its slots)
         const int rc = psdr_fetch_batch(g->ctx[r]);
         if (rc == PSDR_OK)
             any = true;
@@ -452,11 +613,19 @@ extern "C" int psdr_group_fetch(psdr_group *g) {
 }
 extern "C" int psdr_group_fetched_audio(psdr_group *g, int gid, int frame, const float **audio, float *pwr, int32_t *nan_flag, const int32_t **pcm) {
     if (!g) return fail(PSDR_ERR_INVALID, "null argument");
-    int rank, id, rc = gid_split(g, gid, &rank, &id);
+    int rank, id, rc;
+    {
+        std::lock_guard<std::mutex> lk(g->mtx);
+        rc = gid_split(g, gid, &rank, &id);
+    }
     return rc ? rc : psdr_fetched_audio(g->ctx[rank], id, frame, audio, pwr, nan_flag, pcm);
 }
 extern "C" int psdr_group_fetched_window(psdr_group *g, int gid, int *l, double *audio_mid, int *r) {
     if (!g) return fail(PSDR_ERR_INVALID, "null argument");
-    int rank, id, rc = gid_split(g, gid, &rank, &id);
+    int rank, id, rc;
+    {
+        std::lock_guard<std::mutex> lk(g->mtx);
+        rc = gid_split(g, gid, &rank, &id);
+    }
     return rc ? rc : psdr_fetched_window(g->ctx[rank], id, l, audio_mid, r);
 }

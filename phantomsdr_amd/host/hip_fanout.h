@@ -131,17 +131,19 @@ class HipFanout {
         else
             psdr_client_remove(ctx, id);
     }
-    // (group: the id may CHANGE when band sharding moves the client to another GPU - the caller keeps the returned one)
-    bool set_audio_range(int &id, int l, double m, int r) {
+    // (group: band sharding may move the client to another GPU BEHIND its id - the id a client holds never changes, so
+    // the websocket thread that retunes, the frame loop that reads client->psdr_id under signal_slice_mtx and the asio
+    // send tasks that read it without a lock all see one constant; the group's own mutex orders the move against a step)
+    bool set_audio_range(int id, int l, double m, int r) {
         if (id < 0) return false;
-        return (grp ? psdr_group_client_set_audio_range(grp, &id, l, m, r) : psdr_client_set_audio_range(ctx, id, l, m, r)) == PSDR_OK;
+        return (grp ? psdr_group_client_set_audio_range(grp, id, l, m, r) : psdr_client_set_audio_range(ctx, id, l, m, r)) == PSDR_OK;
     }
-    bool on_audio_window_message(int &id, int l, double m, int r) {
+    bool on_audio_window_message(int id, int l, double m, int r) {
         if (id < 0) return false;
         if (!grp) return psdr_client_on_window_message(ctx, id, l, m, r) == PSDR_OK;  // false: the reference returns silently
         const int R = (int)(prm.is_real ? prm.fft_size / 2 : prm.fft_size);           // src/signal.cpp:305-311
         if (l < 0 || l >= R || r < 0 || r >= R || l > r || r - l > prm.audio_max_fft_size) return false;
-        return psdr_group_client_set_audio_range(grp, &id, l, m, r) == PSDR_OK;
+        return psdr_group_client_set_audio_range(grp, id, l, m, r) == PSDR_OK;
     }
     bool set_audio_demodulation(int id, psdr_mode mode) {
         if (id < 0) return false;

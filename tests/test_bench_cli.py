@@ -62,3 +62,38 @@ def test_self_launch_command_line():
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and cmd[-7].endswith("bench.py")
     assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_roofline_frac_is_the_surveys_path_figure_and_reproduces_from_value():
+    """`roofline.frac` = B_frame x frames/s / 8e12 - derivable from
+    `value` and the workload alone; the dominant kernel's own-bytes figure is `kernel_frac`, beside it."""
+    import bench
+    from phantomsdr_amd.core import derived_params
+    wl = bench.WORKLOADS["cfg2"]
+    p = derived_params(wl["sps"], wl["fft_size"], wl["is_real"])
+    cl = bench.make_clients(wl, p, seed=0x5D5D0002)
+    wf = bench.make_waterfalls(wl, p, seed=0x5D5D0002)
+    ab = bench.algorithmic_bytes_per_frame(wl, p, cl, wf)
+    value = 102_300.0  # MSamples/s (round 4's driver line)
+    fps = value * 1e6 / (wl["fft_size"] // 2)
+    rf = bench.path_roofline(ab["total"], fps)
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and rf["target_frac"] == 0.40
+    assert abs(rf["frac"] - ab["total"] * fps / 8.0e12) < 1e-4 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    assert 0.355 < rf["frac"] < 0.362  # 14.70 MB x 195 k frames/s = 2.87 TB/s (VERDICT r4's recomputation: 0.359)
+
+
+def test_recorded_driver_line_reproduces_its_path_fraction():
+    """a recorded round-4 line (profiles/r04c_cfg2_bench.json): path.frac_of_hbm_peak (now the headline `frac`) from `value` alone"""
+    import json
+    import bench
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r04c_cfg2_bench.json")).read().strip().splitlines()[-1])
+    fps = d["value"] * 1e6 / (d["config"]["fft_size"] // 2)
+    rf = bench.path_roofline(d["path"]["algorithmic_bytes_per_frame"], fps)
+    assert abs(rf["frac"] - d["path"]["frac_of_hbm_peak"]) < 2e-4
+
+
+def test_n_gt_1_defaults():
+    """the N > 1 line: `value` = the north star's sharding unless --shard says otherwise; the line carries cpu_baseline"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'main_mode = args.shard or "clients"' in src
+    assert '"cpu_baseline": cpu,' in src and '"cpu_baseline": None' not in src

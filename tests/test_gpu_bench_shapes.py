@@ -248,7 +248,7 @@ def test_bench_gpus_2_runs_every_sharding_as_two_processes():
     over gloo: an orchestration test (it found int16 tensors handed to a collective), not a measurement."""
     import json
     import subprocess
-    env = dict(os.environ, PSDR_BENCH_ONE_DEVICE="1")
+    env = dict(os.environ, PSDR_BENCH_ONE_DEVICE="1", PSDR_BENCH_CPU_BUDGET_S="4")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
@@ -261,13 +261,26 @@ def test_bench_gpus_2_runs_every_sharding_as_two_processes():
     assert set(d["sharding"]) == {"clients", "clients_pipelined", "raw", "band", "time"}
     for mode, v in d["sharding"].items():
         assert v.get("error") is None and v["value"] > 0, (mode, v)
-    # band sharding is `value` for IQ workloads, the north star's broadcast sits beside it, and the C-side group leg
-    # (one child process through psdr_group_*; here: the one device with forced collectives) reported its three shardings
-    assert d["shard"] == "band" and d["north_star_sharding"]["value"] > 0
+    # `value` is the north star's sharding (BASELINE.json configs[3]: clients over the GPUs, RCCL spectrum broadcast), band /
+    # raw / pipelined / time sit beside it, and the C-side group leg (one child process through psdr_group_*; here: the one
+    # device with forced collectives) reported its three shardings
+    assert d["shard"] == "clients" and d["value"] == d["sharding"]["clients"]["value"] and d["north_star_sharding"]["value"] > 0
+    assert "spectrum" in d["config"]["parallelism"] and "broadcast" in d["config"]["parallelism"]
     cg = d["c_group"]
     assert cg and "by_shard" in cg, cg
     for shard, v in cg["by_shard"].items():
         assert v.get("error") is None and v["value"] > 0, (shard, v)
+        # one device: the exchange is a copy onto itself - never reported as a link rate
+        assert v["GB_per_s_per_link_during_exchange"] is None and v["GB_per_s_per_link_over_the_step"] is None
+    # the N > 1 line is adjudicable on its own: CPU baseline of the job and the root GPU's roofline block
+    cpu = d["cpu_baseline"]
+    assert cpu and cpu.get("error") is None and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["kind"] == "port" and cpu["sample"]
+    rf = d["roofline"]
+    assert rf and rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["target_frac"] == 0.40
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 2e-4 and rf["kernel"] and rf["kernel_frac"] > 0
+    # `frac` reproduces from `value` alone: frames/s = value * 1e6 / (N/2)
+    fps = d["value"] * 1e6 / (d["config"]["fft_size"] // 2)
+    assert abs(rf["frac"] - rf["algorithmic_bytes_per_frame"] * fps / 8.0e12) < 2e-3 * max(rf["frac"], 1e-9) + 1e-4
 
 
 def test_handoff_two_contexts_interleaved_and_640_frames(monkeypatch):

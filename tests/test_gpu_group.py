@@ -3,8 +3,12 @@ directly (phantomsdr_amd/csrc/group.hip).  Whatever the sharding, every client's
 single plain context (the same kernels run on the same spectra; only where they run differs).
 
 * one device with PSDR_SHARD_FORCE_COMM: the whole group path including librccl.so's dlopen, ncclCommInitAll and the
-  collectives (a broadcast to oneself; the band path's pack) - what a single-GPU box can exercise;
-* two and more devices: skipped unless the box has them."""
+  collectives (a broadcast to oneself; band: pack + ncclSend / ncclRecv to oneself + demodulation from the received
+  band buffer) - what a single-GPU box can exercise of RCCL;
+* n RANKS ON ONE DEVICE with PSDR_SHARD_PEER_COPY (the peers pull with device copies instead of RCCL): the multi-rank
+  logic itself - round-robin / band placement, band regions and halos, raw replication, per-rank fetch, migration of a
+  client between bands with its state - runs for real on a one-GPU box;
+* two and more physical devices over RCCL: skipped unless the box has them."""
 import ctypes as C
 
 import numpy as np
@@ -63,16 +67,16 @@ def _run_plain(N, is_real, n, F, nb, raw, clients, levels):
         ctx.close()
 
 
-def _run_group(devices, shard, force, N, is_real, n, F, nb, raw, clients, levels):
+def _run_group(devices, shard, force, N, is_real, n, F, nb, raw, clients, levels, peer_copy=False):
     from phantomsdr_amd import Group
-    g = Group(devices, shard, N, is_real, levels, force_comm=force, additional_size=n, audio_fft_size=n, input_format="s16",
-              max_batch=F, max_clients=len(clients), max_waterfall_clients=2)
+    g = Group(devices, shard, N, is_real, levels, force_comm=force, peer_copy=peer_copy, additional_size=n, audio_fft_size=n,
+              input_format="s16", max_batch=F, max_clients=len(clients), max_waterfall_clients=2)
     try:
         root = g.root
         d = root.dev_alloc(raw.nbytes)
         root.h2d(d, raw)
         gids = [g.client_add(l, m, r, mode) for mode, l, m, r in clients]
-        ranks = sorted({gid >> 16 for gid in gids})
+        ranks = sorted({g.client_rank(gid) for gid in gids})
         hb = root.half_frame_bytes()
         out = []
         links = []
@@ -121,8 +125,104 @@ def test_single_device_group_with_forced_rccl_matches_a_plain_context(shard, N, 
     _same(ref, got, f"{shard} N=2^{N.bit_length() - 1}")
     assert np.array_equal(spec_r.view(np.uint32), spec_g.view(np.uint32)) and np.array_equal(q_r, q_g)
     assert ranks == [0]
-    if shard != "band":  # (a one-device band group has nothing to send)
-        assert links[-1][0] > 0 and links[-1][1] > 0, links  # bytes crossed the (self) link, the exchange took time: RCCL ran
+    # bytes crossed the (self) link, the exchange took time: RCCL ran (band: the packed band sent to and received from oneself)
+    assert links[-1][0] > 0 and links[-1][1] > 0, links
+
+
+@pytest.mark.parametrize("ndev", [2, 4, 8])
+@pytest.mark.parametrize("shard", ["clients", "raw", "band"])
+@pytest.mark.parametrize("N,is_real,n", CASES)
+def test_n_ranks_on_one_device_with_peer_copies_match_a_plain_context(shard, N, is_real, n, ndev):
+    """n contexts on device 0, the exchange by device copies (PSDR_SHARD_PEER_COPY): every rank serves clients, and every
+    client's audio is the bits of a plain context - band sharding through the root's band regions + halos (2^20 IQ) or
+    the pack (2^16 IQ, real input), raw through n forward transforms"""
+    F, nb = 4, 3
+    R = N // 2 if is_real else N
+    levels = levels_for(R)
+    x = synth_stream((nb * F + 1) * (N // 2), bool(is_real), seed=21, fft_size=N)
+    raw = quantize_raw(x, "s16", bool(is_real))
+    clients = _clients(N, R, n, 24)
+    ref, spec_r, q_r = _run_plain(N, is_real, n, F, nb, raw, clients, levels)
+    got, spec_g, q_g, ranks, links = _run_group([0] * ndev, shard, False, N, is_real, n, F, nb, raw, clients, levels, peer_copy=True)
+    _same(ref, got, f"{shard} x{ndev} ranks on one device N=2^{N.bit_length() - 1}")
+    assert np.array_equal(spec_r.view(np.uint32), spec_g.view(np.uint32)) and np.array_equal(q_r, q_g)
+    assert ranks == list(range(ndev)), "every rank serves clients"
+    assert links[-1][0] > 0 and links[-1][1] > 0
+
+
+@pytest.mark.parametrize("N,is_real,n", [(1 << 16, 0, 248), (1 << 20, 0, 360)])
+def test_band_migration_keeps_the_gid_and_the_demodulation_state(N, is_real, n):
+    """Band sharding, 4 ranks (on one device): clients retune across band edges between batches - the gid stays, the rank
+    changes, and because the overlap-add tails / FM's last sample travel with the client every sample after the move is
+    the plain context's (which retunes the same clients at the same batch boundaries).  The batch in flight when the move
+    happens reads as PSDR_ERR_NO_DATA through the group until the new rank has demodulated (documented in psdr.h)."""
+    from phantomsdr_amd import AudioClient, Context, Group, PsdrError
+    F, nb, ndev = 3, 5, 4
+    R = N
+    levels = levels_for(R)
+    x = synth_stream((nb * F + 1) * (N // 2), False, seed=33, fft_size=N)
+    raw = quantize_raw(x, "s16", False)
+    per = R // ndev
+    # (mode, window before, window after): across one edge, across two, back into band 0, and one that stays
+    def win(mode, m, w=60):
+        return (m, float(m), m + w) if mode == "USB" else (m - w, float(m) + 0.5, m) if mode == "LSB" else (m - w, float(m), m + w)
+    plan = [("USB", per - 500, per + 700), ("LSB", per // 2, 3 * per - 90), ("AM", 3 * per + 4000, 300), ("FM", 2 * per + 100, 2 * per + 9000),
+            ("FM", per + 50, 3 * per + 77)]
+    move_at = 2  # the retune lands between batch 1 and batch 2
+    ctx = Context(N, False, levels, additional_size=n, audio_fft_size=n, input_format="s16", max_batch=F, max_clients=len(plan), max_waterfall_clients=1)
+    try:
+        d = ctx.dev_alloc(raw.nbytes)
+        ctx.h2d(d, raw)
+        pcl = []
+        for mode, m0, _ in plan:
+            c = AudioClient(ctx)
+            c.set_audio_demodulation(mode)
+            c.set_audio_range(*win(mode, m0))
+            pcl.append(c)
+        hb = ctx.half_frame_bytes()
+        ref = []
+        for b in range(nb):
+            if b == move_at:
+                for c, (mode, _, m1) in zip(pcl, plan):
+                    c.set_audio_range(*win(mode, m1))
+            ctx.process_batch(d, F, offset_bytes=b * F * hb)
+            ctx.demod_batch(b * F)
+            ref.append([c.read_audio(F) for c in pcl])
+        ctx.dev_free(d)
+    finally:
+        ctx.close()
+    g = Group([0] * ndev, "band", N, False, levels, peer_copy=True, additional_size=n, audio_fft_size=n, input_format="s16", max_batch=F,
+              max_clients=len(plan), max_waterfall_clients=1)
+    try:
+        root = g.root
+        d = root.dev_alloc(raw.nbytes)
+        root.h2d(d, raw)
+        gids = [g.client_add(*win(mode, m0), mode) for mode, m0, _ in plan]
+        before = [g.client_rank(gid) for gid in gids]
+        hb = root.half_frame_bytes()
+        for b in range(nb):
+            if b == move_at:
+                for gid, (mode, _, m1) in zip(gids, plan):
+                    assert g.client_set_audio_range(gid, *win(mode, m1)) == gid
+                after = [g.client_rank(gid) for gid in gids]
+                assert [a != b_ for a, b_ in zip(after, before)] == [True, True, True, False, True], (before, after)
+                # the batch demodulated before the move is gone for the clients that moved
+                for gid, moved in zip(gids, [True, True, True, False, True]):
+                    if moved:
+                        with pytest.raises(PsdrError):
+                            g.fetched_audio(gid, 0)
+            g.step(d, F, b * F, offset_bytes=b * F * hb)
+            g.fetch()
+            for ci, gid in enumerate(gids):
+                for f in range(F):
+                    a, pw, nan = g.fetched_audio(gid, f)
+                    ra, rp, rn = ref[b][ci][0][f], ref[b][ci][1][f], ref[b][ci][2][f]
+                    assert np.array_equal(a.view(np.uint32), ra.view(np.uint32)), f"batch {b} client {ci} frame {f}: audio differs"
+                    assert np.float32(pw).view(np.uint32) == np.float32(rp).view(np.uint32) and nan == rn
+        g.synchronize()
+        root.dev_free(d)
+    finally:
+        g.close()
 
 
 @pytest.mark.skipif(_ndev() < 2, reason="needs two HIP devices")
@@ -151,6 +251,9 @@ def test_group_argument_errors():
     with pytest.raises(PsdrError) as e:
         Group([0, 0], "clients", 1 << 16, False, 7, audio_fft_size=248, additional_size=248)
     assert e.value.code == -1 and "twice" in str(e.value)
+    with pytest.raises(PsdrError) as e:  # RCCL forced and no RCCL at all exclude each other
+        Group([0], "clients", 1 << 16, False, 7, force_comm=True, peer_copy=True, audio_fft_size=248, additional_size=248)
+    assert e.value.code == -1
     if _ndev() >= 3:
         with pytest.raises(PsdrError) as e:
             Group([0, 1, 2], "band", 1 << 16, False, 7, audio_fft_size=248, additional_size=248)
@@ -158,8 +261,9 @@ def test_group_argument_errors():
     g = Group([0], "band", 1 << 16, False, 7, audio_fft_size=248, additional_size=248, max_clients=4)
     try:
         gid = g.client_add(100, 100.0, 160, "USB")
-        assert gid >> 16 == 0
+        assert g.client_rank(gid) == 0 and g.client_rank(gid + 1) == -1
         assert g.client_set_audio_range(gid, 60000, 60000.0, 60060) == gid  # one band: nothing to migrate to
+        assert g.client_rank(gid) == 0
     finally:
         g.close()
 
