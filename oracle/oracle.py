@@ -128,6 +128,39 @@ def ref():
     return _ref
 
 
+_ref_core = None
+
+
+def ref_core():
+    """More of the reference's own code - class FFTW (fft_impl.cpp), convert<T> (samplereader.cpp), DCBlocker (utils.h) -
+    when `make -C oracle ref_core` could build it (an image with a genuine fftw3.h + libfftw3f + boost); None otherwise."""
+    global _ref_core
+    if _ref_core is None:
+        p = os.path.join(_HERE, "_ref", "libref_core.so")
+        if not os.path.exists(p) and os.path.isdir("/root/reference/src/utils"):
+            subprocess.call(["make", "-C", _HERE, "ref_core"], stdout=subprocess.DEVNULL)  # (prints why when it cannot)
+        if not os.path.exists(p):
+            return None
+        R = C.CDLL(p)
+        vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+        R.refc_fft_create.argtypes = [sz, i32, i32, i32, i32, i32]
+        R.refc_fft_create.restype = vp
+        R.refc_fft_destroy.argtypes = [vp]
+        R.refc_fft_execute.argtypes = [vp, i32, vp, vp]
+        R.refc_fft_output.argtypes = [vp]
+        R.refc_fft_output.restype = vp
+        R.refc_fft_quantized.argtypes = [vp]
+        R.refc_fft_quantized.restype = vp
+        R.refc_convert.argtypes = [i32, vp, vp, i32]
+        R.refc_dc_create.argtypes = [i32]
+        R.refc_dc_create.restype = vp
+        R.refc_dc_destroy.argtypes = [vp]
+        R.refc_dc_process.argtypes = [vp, vp, i32]
+        R.refc_dc_reset.argtypes = [vp]
+        _ref_core = R
+    return _ref_core
+
+
 def aligned(n, dtype, align=64):
     """numpy array whose data pointer is `align`-byte aligned (the reference's dsp.cpp
     uses std::assume_aligned<64>)."""

@@ -19,6 +19,16 @@
  *     without fftw3.h / boost / websocketpp): vec_log2 + int8 quantiser + pyramid,
  *     index maps, AudioClient::send_audio control flow, sample conversion and the
  *     DC blocker are restated line by line from the cited source only.
+ *     `make -C oracle ref_core` builds class FFTW (fft_impl.cpp), convert<T>
+ *     (samplereader.cpp) and DCBlocker (utils.h) of the reference in place the day an
+ *     image carries a genuine fftw3.h + libfftw3f + boost (it probes the compiler and
+ *     shims nothing); tests/test_oracle_ref_core.py then pins the quantiser, pyramid,
+ *     rotation, conversion and DC blocker bit for bit.  In the round-5 image the
+ *     target builds nothing and those tests skip: still UNPINNED.
+ *   - measured against an independent truth on the GPU box: float64 numpy of the
+ *     f32-windowed input with the reference's own Hann table, spectra at 2^20 / 2^21 /
+ *     2^22 points and one AM / FM client's audio - the oracle AND the HIP path
+ *     (tests/test_gpu_truth_f64.py).
  */
 #ifndef PSDR_ORACLE_H
 #define PSDR_ORACLE_H

@@ -47,7 +47,7 @@ inline const char *psdr_tuning_env(const char *name) {
 
 namespace psdr {
 
-enum KernelId { K_PASS1, K_PASS2, K_UNTANGLE, K_TAIL, K_IDFT, K_OLA, K_WFALL, K_POST, K_SEAM, K_BAND, K_COUNT };
+enum KernelId { K_PASS1, K_PASS2, K_UNTANGLE, K_TAIL, K_IDFT, K_OLA, K_WFALL, K_POST, K_SEAM, K_BAND, K_FUSED, K_COUNT };
 extern const char *kKernelNames[K_COUNT];
 
 struct PendingEvent {
@@ -138,12 +138,20 @@ struct psdr_ctx {
     // and builds pyramid levels 0..3 itself (k_fft_pass2_real); smaller real transforms keep the
     // three-pass form (pass 1, pass 2, k_untangle_real)
     bool real_fused = false;
-    // 2^20-point IQ transforms of 8/16-bit samples: pass 1 with wave-owned column couples (fft_pass1w.h), Y
-    // couple-major.  Experimental, off unless PSDR_P1_WAVE=1: correct (parity tests run it), not yet faster
-    bool p1_wave = false;
     SpecLayout lay{};                // device layout of the spectrum (natural unless real_fused)
     int nbands = 0, band_H = 0;      // psdr_set_band_layout: band regions (SpecLayout mode 3), halo columns per band
     bool y_blocked = false;          // PSDR_REAL_YBLOCKED (tuning)
+    // Both passes in ONE launch with Y as a ring of a few frames that stays in the Infinity Cache (fft_pass.h: FlowArgs,
+    // k_fft_fused): 2^20- and 2^21-point IQ frames, batches of ring_min_batch frames and more (smaller ones fit the cache
+    // anyway and keep the two launches).  PSDR_RING=0 switches it off, PSDR_RING_FRAMES / PSDR_RING_P1_WGS size it.
+    bool ring_on = false;
+    int ring_frames = 16, ring_min_batch = 64;
+    unsigned ring_n1 = 0;            // work-groups of the pass-1 role (0: by shape)
+    unsigned *d_flow = nullptr;      // [16 + 2 * max_batch]: abort word, then done1[], done2[] (zeroed per launch)
+    unsigned *d_flow_sticky = nullptr, *h_flow_sticky = nullptr;  // flow-control timeouts since create (device word, pinned mirror)
+    unsigned flow_timeouts_seen = 0;
+    std::vector<char> kclk_fused;    // per stamped launch: the two roles ran in one launch
+    unsigned kclk_fused_done = 0;
     int seg_len_env = 0;             // PSDR_SEG_LEN: tiles per chain segment (uniform segments, every one with a seam)
     float *d_seamP = nullptr, *d_seamC = nullptr;  // of the current result set
     float *seam_pool[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
@@ -371,10 +379,13 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
 // pass1.hip / pass2.hip (Pass1Args / Pass2Args: fft_pass.h)
 struct Pass1Args;
 struct Pass2Args;
-int launch_pass1(psdr_ctx *c, int L, int T, int sb, const Pass1Args &a, unsigned blocks, bool pair, bool wave);
-int launch_pass2(psdr_ctx *c, int L, int T, bool fused, const Pass2Args &a, unsigned blocks, bool ycm);
+int launch_pass1(psdr_ctx *c, int L, int T, int sb, const Pass1Args &a, unsigned blocks, bool pair);
+int launch_pass2(psdr_ctx *c, int L, int T, bool fused, const Pass2Args &a, unsigned blocks);
 int launch_pass2_band(psdr_ctx *c, const Pass2Args &a, unsigned blocks);
 int launch_pass2_real(psdr_ctx *c, const Pass2Args &a);
+// fused.hip: both passes in one launch (IQ); false from fused_supported(): this shape keeps the two launches
+bool fused_supported(const psdr_ctx *c, int sb);
+int launch_fused(psdr_ctx *c, int sb, const Pass1Args &a1, const Pass2Args &a2);
 // postchain.hip: the chain's kernels for the batch demod_impl has just enqueued; *last_user = the last stream that reads
 // the client parameter block
 int post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, int nact, int npaused, int nframes, hipStream_t *last_user);

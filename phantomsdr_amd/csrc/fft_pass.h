@@ -372,20 +372,27 @@ struct TileQueue {
     unsigned ptx;          // ... and the XCD whose counter it came from
     unsigned owner;        // the thread that draws (0 unless the kernel has a loader wave)
     unsigned level;        // 0: drawing from the own XCD's queue, k: from the queue of XCD x ^ k
+    unsigned vb, vgrid;    // this work-group's index among the work-groups that share the queue, and their number
+                           // (blockIdx.x / gridDim.x unless the launch is split into roles: k_fft_fused)
     bool dynamic, global, own_done;
     // global_: ONE counter for the whole chip (perfect balance, no XCD affinity)
-    __device__ __forceinline__ void init(unsigned *t, unsigned total_, bool global_ = false, unsigned owner_ = 0) {
+    __device__ __forceinline__ void init(unsigned *t, unsigned total_, bool global_, unsigned owner_, unsigned vb_, unsigned vgrid_) {
         global = global_;
         owner = owner_;
         tickets = t;
         total = total_;
-        base = gridDim.x >> 2;  // 2*gridDim.x / 8
-        first_dyn = 2u * gridDim.x;
+        vb = vb_;
+        vgrid = vgrid_;
+        base = vgrid >> 2;  // 2*vgrid / 8
+        first_dyn = 2u * vgrid;
         pending = 0;
-        ptx = blockIdx.x & 7u;
+        ptx = vb & 7u;
         own_done = false;
         level = 0;
-        dynamic = t != nullptr && 2u * gridDim.x < total_;
+        dynamic = t != nullptr && 2u * vgrid < total_;
+    }
+    __device__ __forceinline__ void init(unsigned *t, unsigned total_, bool global_ = false, unsigned owner_ = 0) {
+        init(t, total_, global_, owner_, blockIdx.x, gridDim.x);
     }
     // thread 0: start drawing (no wait)
     __device__ __forceinline__ void draw_begin() {
@@ -399,7 +406,7 @@ struct TileQueue {
             // passes (pass 2 moves 4.9 GB per 256 frames at 5.6 TB/s - it waits for memory either way),
             // -3 % on the fused real-input pass 2 together with the scalar twiddle load there.
             typedef __attribute__((address_space(1))) unsigned gu32;  // global, not flat: flat returns out of order
-            ptx = (blockIdx.x & 7u) ^ level;
+            ptx = (vb & 7u) ^ level;
             gu32 *p = (gu32 *)(tickets + (global ? 0u : ptx));
             asm volatile("" : "+v"(p));
             pending = __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -415,11 +422,12 @@ struct TileQueue {
     }
     // thread 0: finish the draw begun one tile ago and publish the index (or 0xFFFFFFFF) to
     // *slot; `prev` is the index two positions earlier in this work-group's sequence
-    __device__ __forceinline__ void draw_end(unsigned *slot, unsigned prev2) {
+    // (returns the published index - meaningful in the owner thread only)
+    __device__ __forceinline__ unsigned draw_end(unsigned *slot, unsigned prev2) {
+        unsigned s = 0xFFFFFFFFu;
         if (threadIdx.x == owner) {
-            unsigned s = 0xFFFFFFFFu;
             if (!tickets) {  // static round-robin
-                if (prev2 < total) s = prev2 + 2u * gridDim.x;
+                if (prev2 < total) s = prev2 + 2u * vgrid;
             } else if (dynamic) {
                 s = global ? pending + first_dyn : (pending + base) * 8u + ptx;
 #ifndef PSDR_NO_PARTNER_STEAL
@@ -434,7 +442,7 @@ struct TileQueue {
                     // (Probing all seven other counters was tried in round 1: +27 us per launch.)
                     level++;
                     own_done = true;
-                    ptx = (blockIdx.x & 7u) ^ level;
+                    ptx = (vb & 7u) ^ level;
                     typedef __attribute__((address_space(1))) unsigned gu32;
                     gu32 *p = (gu32 *)(tickets + ptx);
                     asm volatile("" : "+v"(p));
@@ -446,8 +454,58 @@ struct TileQueue {
             }
             *slot = s;
         }
+        return s;
     }
 };
+
+// ---- both passes in ONE persistent launch, Y a ring of a few frames that never leaves the Infinity Cache (k_fft_fused) ----
+// A launch's work-groups are split into a pass-1 role and a pass-2 role that run SIDE BY SIDE, a few frames apart: pass 2
+// starts a tile of frame f once every pass-1 tile of f has its rows of Y in memory (done1[f] == tiles1), pass 1 overwrites
+// the ring slot of frame f - ring only after every pass-2 tile of that frame has read it (done2[f - ring] == tiles2).
+// With the two launches of DESIGN.md 3.1 a batch's Y (8 MB per 2^20-point frame, 4 GB per 512 frames) goes out to HBM and
+// comes back; here a row of Y is read ~5 frames after it was written and re-written `ring` frames later, both while it is
+// still in the 256 MiB memory-side cache: per frame 16.8 MB of the 31.5 MB of HBM traffic go away (measured bound with all
+// frames aliased onto 4 / 16 frames of Y: +14 % / +5 % on cfg2's step, profiles/r05_*).
+// Visibility (cdna_hip_programming.md G16, sc1 form): Y is stored write-through (buffer_store ... sc1 - an XCD's L2 keeps no
+// dirty copy), every storing wave drains its stores with a COUNTED wait a tile later, a barrier, ONE lane adds to done1[f]
+// (relaxed, agent scope); the consumer's lane 0 polls the counter relaxed, a barrier, then sc1 loads (past the CU's L1; the
+// L2s are kept coherent for device memory by the memory-side probes).  Waits are bounded: a wait that outlasts
+// `timeout` ticks of the 100 MHz clock raises *abort, every later wait returns at once, and the host reports the launch
+// as failed instead of hanging (a work-group waits only for work that was handed out BEFORE its own tile - tiles are
+// drawn in frame order - so with the launch's work-groups resident nothing can wait in a circle).
+struct FlowArgs {
+    unsigned *done1;  // [nframes] (zeroed per launch); nullptr: two launches, no flow control
+    unsigned *done2;  // [nframes]
+    unsigned *abort;  // [1] (zeroed per launch): a wait timed out - nobody waits any longer
+    unsigned *sticky; // [1] (never zeroed): timeouts since the context was created, read by the host at its synchronisations
+    unsigned ring;    // frames of Y (a power of two; Pass*Args::ymask == ring - 1)
+    unsigned tiles1, tiles2;  // tiles per frame of the two passes
+    unsigned n1;              // work-groups of the pass-1 role (a multiple of 8; the rest are pass 2)
+    unsigned long long timeout;
+};
+typedef __attribute__((address_space(1))) unsigned flow_gu32;
+__device__ __forceinline__ unsigned flow_peek(const unsigned *p) {
+    return __hip_atomic_load((const flow_gu32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// ONE lane: until *ctr >= want (true), or the launch was aborted / the wait timed out (false)
+__device__ __forceinline__ bool flow_wait(const unsigned *ctr, unsigned want, const FlowArgs &fl) {
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        if (flow_peek(ctr) >= want) return true;
+        if (flow_peek(fl.abort)) return false;
+        if (wall_clock64() - t0 > fl.timeout) {
+            __hip_atomic_store((flow_gu32 *)fl.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add((flow_gu32 *)fl.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+__device__ __forceinline__ void flow_add(unsigned *ctr) {  // fire and forget
+    (void)__hip_atomic_fetch_add((flow_gu32 *)ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+typedef unsigned ring_u32x4 __attribute__((ext_vector_type(4)));
+enum { PSDR_AUX_SC1 = 16 };  // raw_buffer_load / _store aux: sc1 (loads: past L1; stores: write-through)
 
 struct Pass1Args {
     const void *raw;  // nframes+1 raw half-frames, contiguous
@@ -472,6 +530,7 @@ struct Pass1Args {
     unsigned long long *trace;
     unsigned long long *kclk;  // device-clock stamps of this launch (kclk_begin / kclk_end) or nullptr
     unsigned ymask;            // frame index mask of Y (~0u; a timing-only experiment aliases frames: PSDR_Y_ALIAS)
+    FlowArgs flow;             // k_fft_fused (RING): flow control of the one-launch form; flow.done1 == nullptr otherwise
     float yscale;              // a power of two carried by the window weights, so that Y - and with it the second pass's
                                // outputs - arrive scaled: 1/N for IQ input, 0.5/N for the fused real path (the untangle's
                                // 1/2 with it), 1 for the three-pass real path.  Scaling by a power of two commutes with every
@@ -568,8 +627,12 @@ __device__ __forceinline__ constexpr float image_scale() {
 //   * mirror rows (c1 > M1/2) are stored as conj(Y[c1][n2]) * W_M2^{n2}: the plain forward row
 //     transform of that sequence is G[c2] = conj(Z[c1][M2-1-c2]), exactly the partner of the
 //     couple's other half at the same output index c2.
-template <int L, int T, int SB, bool PAIR = false>
-__device__ __forceinline__ void pass1_body(const Pass1Args &a) {
+// RING (k_fft_fused): this work-group is number vb of the vgrid work-groups of the launch that run pass 1; tiles are drawn
+// in frame order from ONE counter, Y is a ring of flow.ring frames stored write-through, and the FlowArgs counters order
+// the tiles against pass 2's (see FlowArgs)
+template <int L, int T, int SB, bool PAIR = false, bool RING = false>
+__device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsigned vgrid) {
+    static_assert(!RING || (!PAIR && Plan<L>::NS == 3), "one-launch form: IQ first passes with three stages");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *tile = reinterpret_cast<float4 *>(smem);
     cf *Wl = reinterpret_cast<cf *>(smem) + L * T;
@@ -616,7 +679,7 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
     unsigned rq[NCHK][WPL];
     const unsigned char *nxt = nullptr;
     auto point_at = [&](unsigned sidx) {
-        const unsigned slot = xcd_slot(sidx, total);
+        const unsigned slot = RING ? sidx : xcd_slot(sidx, total);  // (RING: frame order; XCD affinity is moot with one queue)
         const unsigned f = slot / a.tiles_per_frame;
         const unsigned tl = slot - f * a.tiles_per_frame;
         nxt = reinterpret_cast<const unsigned char *>(a.raw) + ((size_t)f * (M / 2) + (size_t)tl * T) * gsb + g_lane;
@@ -645,12 +708,18 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
     };
     __shared__ unsigned s_next[2];
     TileQueue tq;
-    tq.init(a.tickets, total);
-    unsigned s = blockIdx.x, snext = blockIdx.x + gridDim.x;
+    tq.init(a.tickets, total, RING, 0, vb, vgrid);
+    unsigned s = vb, snext = vb + vgrid;
     if (s < total) {
         point_at(s);
         static_for<0, NCHK>(issue);
     }
+    // RING: Y through a buffer descriptor (write-through stores carry the sc1 bit in their aux field); the frame whose
+    // tile's rows are stored but not yet counted in done1; this tile's sample of the counter that frees its ring slot
+    __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)a.Y, 0, RING ? (int)(((size_t)a.flow.ring * a.yframe) * sizeof(cf)) : 0, 0x00020000);
+    constexpr unsigned NOFRAME = 0xFFFFFFFFu;
+    unsigned post_f = NOFRAME, slot_seen = 0;
+    (void)yrs, (void)post_f, (void)slot_seen;
     // table staging after the first tile's loads are in flight (one latency, not two)
     for (int i = tid; i < L; i += NT) Wl[i] = a.Wl[i];
     for (int i = tid; i < M2; i += NT) ldsTB[i] = a.TB[i];
@@ -681,11 +750,15 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
     int it = 0;
     for (; s < total; it++) {
         PSDR_TRACE(a.trace, it, 0);
-        const unsigned slot = xcd_slot(s, total);
+        const unsigned slot = RING ? s : xcd_slot(s, total);
         const unsigned f = slot / a.tiles_per_frame;
         const unsigned tl = slot - f * a.tiles_per_frame;
+        // RING: the ring slot of this frame was last read by pass 2 for frame f - ring: sampled now, looked at two stages on
+        if (RING && tid == 0 && f >= a.flow.ring) slot_seen = flow_peek(a.flow.done2 + (f - a.flow.ring));
         // this tile's block (plain) / its chunk of pass-2 tile 0 (PAIR: pass-2 tiles have 16 rows)
         cf *Yb = a.Y + (size_t)(f & a.ymask) * a.yframe + (PAIR ? (size_t)tl * a.ytl : (size_t)tl * a.yblk);
+        const unsigned yb_bytes = (unsigned)(((size_t)(f & a.ymask) * a.yframe + (size_t)tl * a.yblk) * sizeof(cf));  // RING: inside the ring
+        (void)yb_bytes;
         // PAIR: where the lane's part of a row index puts it (see the store below)
         cf *Ylo = Yb + (size_t)(i0_ >> 3) * a.ytile + (i0_ & 7) * T + 2 * p_;
         cf *Yhi = Yb - (size_t)((i0_ + 7) >> 3) * a.ytile + (8 + ((-i0_) & 7)) * T + 2 * p_;
@@ -854,7 +927,15 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
 #ifdef PSDR_ABL_P1_NOSTORE
                 if (yA.x == 1.2345678e-33f)  // timing-only: (almost) never true, keeps the arithmetic alive
 #endif
-                *reinterpret_cast<float4 *>(dst) = make_float4(yA.x, yA.y, yB.x, yB.y);
+                if constexpr (RING) {
+                    // write-through (sc1): the reader is a work-group of the same launch on another XCD.  (No SGPR offset:
+                    // a 128-bit buffer store with one, followed closely by inline-asm VALU that overwrites its data
+                    // registers, stores corrupted data on gfx950 - DESIGN.md 3.1.)
+                    const ring_u32x4 v = {__float_as_uint(yA.x), __float_as_uint(yA.y), __float_as_uint(yB.x), __float_as_uint(yB.y)};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, yrs, (int)(yb_bytes + (unsigned)((c1 * T + 2 * p) * (int)sizeof(cf))), 0, PSDR_AUX_SC1);
+                } else {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(yA.x, yA.y, yB.x, yB.y);
+                }
             },
             // ---- trickle the rest of the next tile's loads through the stages
             [&](int k) {
@@ -865,8 +946,30 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
                         constexpr int hi = lo + LPT < NCHK ? lo + LPT : NCHK;
                         static_for<lo, hi>(issue);
                     });
+                if constexpr (RING) {
+                    if (k == 2) {
+                        // (a) the previous tile's rows of Y: every wave drains ITS stores - they are older than the loads of
+                        // the next tile issued since (EARLY + 3 LPT of them when there is a next tile: a counted wait, the
+                        // stores are a whole stage and a half old; a wave that issued more - wave 0's ticket and samples -
+                        // only waits longer), the stage's barrier follows, thread 0 counts the tile at tick 3
+                        if (post_f != NOFRAME) {
+                            if (more)
+                                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EARLY + 3 * LPT) : "memory");
+                            else
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        }
+                        // (b) this tile's ring slot: free once pass 2 has read all of frame f - ring (the barriers of this
+                        // stage stand between thread 0's wait and everybody's stores in the last stage)
+                        if (tid == 0 && f >= a.flow.ring && slot_seen < a.flow.tiles2) (void)flow_wait(a.flow.done2 + (f - a.flow.ring), a.flow.tiles2, a.flow);
+                    }
+                    if (k == 3 && post_f != NOFRAME) {
+                        if (tid == 0) flow_add(a.flow.done1 + post_f);
+                        post_f = NOFRAME;
+                    }
+                }
             },
             [&](int k) { PSDR_TRACE(a.trace, it, k); }, stw_front, stw_last);
+        if constexpr (RING) post_f = f;
         PSDR_TRACE(a.trace, it, 10);
         PSDR_WGTRACE(a.trace, 2 + it);
         // (published by thread 0 before the stages' barriers)
@@ -874,12 +977,19 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a) {
         s = snext;
         snext = s2;
     }
+    if constexpr (RING) {
+        if (post_f != NOFRAME) {  // the work-group's last tile
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) flow_add(a.flow.done1 + post_f);
+        }
+    }
     PSDR_WGTRACE(a.trace, 7);
     kclk_end(a.kclk);
 }
 template <int L, int T, int SB, bool PAIR = false>
 __global__ __launch_bounds__(L *T / 32) void k_fft_pass1(Pass1Args a) {
-    pass1_body<L, T, SB, PAIR>(a);
+    pass1_body<L, T, SB, PAIR>(a, blockIdx.x, gridDim.x);
 }
 
 struct Pass2Args {
@@ -908,6 +1018,7 @@ struct Pass2Args {
     unsigned long long *trace;
     unsigned long long *kclk;  // device-clock stamps of this launch (kclk_begin / kclk_end) or nullptr
     unsigned ymask;            // as Pass1Args::ymask
+    FlowArgs flow;             // as Pass1Args::flow
     // BAND kernels: the spectrum goes out in band regions (SpecLayout mode 3, quantize.h): column c2 of tile tl is the
     // line ((c2 >> l2Lb) * band_stride) + (tl * Lw + (c2 & lbmask)) * 16 of the frame's slot in its band's region
     int l2Lb, lbmask, Lw;
@@ -932,14 +1043,15 @@ enum { PSDR_SEG_CARRY_MEM = 1 };  // segtab flags: the first tile's carry-in com
 // pass 2: row FFT (length L = M2) of T adjacent rows c1 (T/2 couples); FUSED adds /N,
 // |X|^2, int8 level 0..LT of the pyramid.  L*T/32 threads.
 // TWC: pass-1 tile width when known at compile time (all fill addresses fold), 0: a.TW
-// YCM: Y is couple-major, [frame][pass-1 tile][couple][c1][2] (written by k_fft_pass1_w, fft_pass1w.h): the 16
-// rows of this tile are one 256-byte piece of every (pass-1 tile, couple) block
 // BAND: banded spectrum layout (band sharding without a pack pass: every band's lines of a whole batch form one
 // contiguous region, which is what is sent over the link)
-template <int L, int T, bool FUSED, int TWC, bool YCM = false, bool BAND = false>
-__device__ __forceinline__ void pass2_body(const Pass2Args &a) {
+// RING (k_fft_fused): as in pass1_body - work-group vb of the vgrid that run pass 2 in a launch that runs both passes; Y is
+// read with sc1 loads (past the CU's L1: a ring slot was read here `ring` frames ago), a tile's loads wait for its
+// frame's done1 count, and done2 counts the tiles whose rows of Y have landed in registers
+template <int L, int T, bool FUSED, int TWC, bool BAND = false, bool RING = false>
+__device__ __forceinline__ void pass2_body(const Pass2Args &a, unsigned vb, unsigned vgrid) {
     static_assert(!BAND || (FUSED && L == 1024 && T == 16), "banded layout: the tile-major IQ spectrum only");
-    static_assert(!YCM || (T == 16 && TWC == 16), "couple-major Y: 16-row tiles of 16-column pass-1 tiles");
+    static_assert(!RING || FUSED, "one-launch form: the fused IQ second pass");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *tile = reinterpret_cast<float4 *>(smem);
     cf *tile_cf = reinterpret_cast<cf *>(smem);
@@ -975,15 +1087,21 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
     const size_t blk = a.yblk;
     float4 r[NLD];
     const cf *nxt = nullptr;
+    unsigned nxt_b = 0;  // RING: byte offset of the next tile's first piece inside the ring
+    (void)nxt_b;
     const unsigned lane_off = (unsigned)((size_t)((2 * tid) >> lc) * blk + ((2 * tid) & (chunk - 1)));
+    __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)a.Y, 0, RING ? (int)(((size_t)a.flow.ring * a.yframe) * sizeof(cf)) : 0, 0x00020000);
+    (void)yrs;
+    auto frame_of = [&](unsigned sidx) { return xcd_slot(sidx, total) / a.tiles_per_frame; };
     auto point_at = [&](unsigned sidx) {
         const unsigned slot = xcd_slot(sidx, total);
         const unsigned f = slot / a.tiles_per_frame;
         const unsigned tl = slot - f * a.tiles_per_frame;
-        nxt = a.Y + (size_t)(f & a.ymask) * a.yframe + (size_t)(tl * T) * (YCM ? 2 : TW);
+        if constexpr (RING)
+            nxt_b = (unsigned)(((size_t)(f & a.ymask) * a.yframe + (size_t)(tl * T) * TW) * sizeof(cf));
+        else
+            nxt = a.Y + (size_t)(f & a.ymask) * a.yframe + (size_t)(tl * T) * TW;
     };
-    // couple-major Y: load q = i*NT + tid is (row rr = q & 15, couple pc = (q >> 4) & 7, pass-1 tile j = q >> 7)
-    const unsigned ycm_lane = (unsigned)((size_t)(tid >> 7) * blk + ((size_t)((tid >> 4) & 7) * a.M1 + (tid & 15)) * 2);
     // SPLIT (fused kernels): register i holds the tile's load number i ^ 8, so that the loads issued FIRST (i < 8) are
     // the upper half of the LDS tile (n2 >= L/2).  The powers the record loop reads (Pst) live in the lower half only,
     // so a wave that has finished its records fills the upper half of the NEXT tile at once; the "tile is free again"
@@ -996,20 +1114,37 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
     auto issue = [&](auto qc) {
         constexpr int i = decltype(qc)::value;
         constexpr int ip = SPLIT ? (i ^ (NLD / 2)) : i;  // which sixteenth of the tile
-        const cf *q;
-        if constexpr (YCM)
-            q = nxt + (size_t)((ip * NT) >> 7) * blk + ycm_lane;
-        else  // uniform part of idx = 2*ip*NT: block (2*ip*NT)>>lc, offset (2*ip*NT)&(chunk-1)
-            q = nxt + (size_t)((2 * ip * NT) >> lc) * blk + ((2 * ip * NT) & (chunk - 1)) + lane_off;
-        r[i] = *reinterpret_cast<const float4 *>(q);
+        // uniform part of idx = 2*ip*NT: block (2*ip*NT)>>lc, offset (2*ip*NT)&(chunk-1)
+        if constexpr (RING) {
+            // scalar part in the instruction's SGPR offset, the lane's part (loop-invariant) in its VGPR offset; sc1: past L1
+            const unsigned ub = nxt_b + (unsigned)(((size_t)((2 * ip * NT) >> lc) * blk + ((2 * ip * NT) & (chunk - 1))) * sizeof(cf));
+            const ring_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(lane_off * (unsigned)sizeof(cf)), (int)ub, PSDR_AUX_SC1);
+            r[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        } else {
+            const cf *q = nxt + (size_t)((2 * ip * NT) >> lc) * blk + ((2 * ip * NT) & (chunk - 1)) + lane_off;
+            r[i] = *reinterpret_cast<const float4 *>(q);
+        }
     };
     __shared__ unsigned s_next[2];
     TileQueue tq;
     // pass 2 has no use for XCD affinity (full-line stores, tile-major records) and the XCDs
     // differ by ~10 % in speed: one chip-wide counter (pass 1 keeps the per-XCD queues: adjacent
     // tiles share the 128-byte lines of the raw rows)
-    tq.init(a.tickets, total, true);
-    unsigned s = blockIdx.x, snext = blockIdx.x + gridDim.x;
+    tq.init(a.tickets, total, true, 0, vb, vgrid);
+    unsigned s = vb, snext = vb + vgrid;
+    // RING: thread 0's sample of done1[frame of the tile after next], taken when that index is published and looked at a
+    // tile later, right before the tile's loads begin
+    unsigned rdy_seen = 0;
+    (void)rdy_seen;
+    if constexpr (RING) {
+        if (s < total) {
+            if (tid == 0) {
+                (void)flow_wait(a.flow.done1 + frame_of(s), a.flow.tiles1, a.flow);
+                if (snext < total) rdy_seen = flow_peek(a.flow.done1 + frame_of(snext));
+            }
+            __syncthreads();
+        }
+    }
     if (s < total) {
         point_at(s);
         static_for<0, NLD>(issue);
@@ -1036,8 +1171,16 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
         const bool has_next = snext < total;
         if (has_next) point_at(snext);
         const bool more = PSDR_UNCOND_PREFETCH ? true : has_next;  // (the loads below; nxt stays on this tile without a next one)
+        if constexpr (RING) {
+            // the next tile's loads start below, behind the fill's barrier: its frame's rows of Y must be in memory
+            if (tid == 0 && has_next && rdy_seen < a.flow.tiles1) (void)flow_wait(a.flow.done1 + frame_of(snext), a.flow.tiles1, a.flow);
+        }
         // the index after `snext`: drawn one tile ago, published now, read after the barrier
-        tq.draw_end(&s_next[it & 1], s);
+        const unsigned s2o = tq.draw_end(&s_next[it & 1], s);
+        if constexpr (RING) {
+            if (tid == 0 && s2o < total) rdy_seen = flow_peek(a.flow.done1 + frame_of(s2o));
+        }
+        (void)s2o;
         tq.draw_begin();
         int i0 = i0_, p = p_, tidx = tid;  // opaque copies (see pass 1)
         asm volatile("" : "+v"(i0), "+v"(p), "+v"(tidx));
@@ -1046,9 +1189,8 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
         for (int i = 0; i < NLD; i++) {
             const int ip = SPLIT ? (i ^ (NLD / 2)) : i;
             const int w = ((2 * ip * NT) & (chunk - 1)) + ((2 * tidx) & (chunk - 1));
-            const int rr = YCM ? (tidx & 15) : w >> log2TW, cc = w & (TW - 1);
-            const int n2 = YCM ? (((ip * NT) >> 7) + (tidx >> 7)) * 16 + 2 * ((tidx >> 4) & 7)
-                               : (((2 * ip * NT) >> lc) + ((2 * tidx) >> lc)) * TW + cc;  // even
+            const int rr = w >> log2TW, cc = w & (TW - 1);
+            const int n2 = (((2 * ip * NT) >> lc) + ((2 * tidx) >> lc)) * TW + cc;  // even
             const int slot0 = lds_slot<H, true>(n2, rr >> 1);  // rows n2, n2+1 share the swizzle
             tile_cf[2 * slot0 + (rr & 1)] = make_float2(r[i].x, r[i].y);
             tile_cf[2 * (slot0 + H) + (rr & 1)] = make_float2(r[i].z, r[i].w);
@@ -1064,6 +1206,9 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
         PSDR_TRACE(a.trace, it, 1);
         __syncthreads();
         PSDR_TRACE(a.trace, it, 2);
+        if constexpr (RING) {
+            if (tid == 0) flow_add(a.flow.done2 + f);  // every thread's rows of this tile have left the ring (they are in LDS)
+        }
         // stage-0 input comes from the tile itself: all reads, then a barrier, before any
         // in-place write
         c2 u[16];
@@ -1175,9 +1320,24 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a) {
     kclk_end(a.kclk);
 }
 
-template <int L, int T, bool FUSED, int TWC, bool YCM = false, bool BAND = false>
+template <int L, int T, bool FUSED, int TWC, bool BAND = false>
 __global__ __launch_bounds__(L *T / 32) void k_fft_pass2(Pass2Args a) {
-    pass2_body<L, T, FUSED, TWC, YCM, BAND>(a);
+    pass2_body<L, T, FUSED, TWC, BAND>(a, blockIdx.x, gridDim.x);
+}
+
+// ---- both passes of an IQ transform in ONE persistent launch (see FlowArgs) ----
+// The launch's work-groups are split by their index INSIDE their XCD (work-group b runs on XCD b % 8: every XCD gets both
+// roles, so whichever part of the grid is resident first holds producers and consumers alike): of every XCD's gridDim.x / 8
+// work-groups flow.n1 / 8 run pass 1, spread evenly (Bresenham), the rest pass 2.
+template <int L1, int T1, int SB, int L2, int T2, int TWC>
+__global__ __launch_bounds__(512) void k_fft_fused(Pass1Args a1, Pass2Args a2) {
+    static_assert(L1 * T1 / 32 == 512 && L2 * T2 / 32 == 512, "512-thread work-groups in both roles");
+    const unsigned x = blockIdx.x & 7u, y = blockIdx.x >> 3, ny = gridDim.x >> 3, n1x = a1.flow.n1 >> 3;
+    const unsigned lo = (y * n1x) / ny, hi = ((y + 1) * n1x) / ny;  // pass-1 work-groups of this XCD below y, up to and including y
+    if (hi > lo)
+        pass1_body<L1, T1, SB, false, true>(a1, lo * 8u + x, n1x * 8u);
+    else
+        pass2_body<L2, T2, true, TWC, false, true>(a2, (y - lo) * 8u + x, (ny - n1x) * 8u);
 }
 
 // ---- pass 2 for REAL input, fused with the Hermitian untangle, /N, |X|^2 and pyramid levels 0..3 ----

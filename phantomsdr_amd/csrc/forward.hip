@@ -219,16 +219,42 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     a1.yscale = !c->is_real ? 1.0f / (float)c->N : (c->real_fused ? 0.5f / (float)c->N : 1.0f);
     // (tuning builds only: a timing-only experiment with WRONG results - all frames of a launch share a few frames of Y)
     if (const char *e = psdr_tuning_env("PSDR_Y_ALIAS")) a1.ymask = (unsigned)atoi(e) - 1u;
+    // Both passes in ONE launch, Y a ring of ring_frames frames (fft_pass.h: FlowArgs): IQ batches of ring_min_batch frames
+    // and more on the context's own stream pair; everything else - small batches, band regions, a caller's pipelined
+    // first-pass stream - keeps the two launches
+    const bool ring = c->ring_on && !c->nbands && !piped && !c->static_tiles && nframes >= c->ring_min_batch && a1.ymask == ~0u &&
+                      fused_supported(c, sb);
+    FlowArgs fl{};
+    if (ring) {
+        const size_t F = (size_t)c->max_batch;
+        fl.abort = c->d_flow;
+        fl.done1 = c->d_flow + 16;
+        fl.done2 = c->d_flow + 16 + F;
+        fl.ring = (unsigned)c->ring_frames;
+        fl.tiles1 = tiles1;
+        fl.tiles2 = tiles2;
+        const unsigned grid = ((unsigned)c->num_cus) & ~7u;
+        // the roles' shares follow the two passes' costs (1000 : 1620 us per 512 frames of 2^20 points, 2500 : 3200 at 2^21)
+        const unsigned dflt = (unsigned)((c->M1 == 1024 ? 0.375 : 0.4375) * (double)(grid / 8) + 0.5) * 8u;
+        fl.n1 = std::min(std::max(c->ring_n1 ? c->ring_n1 : dflt, 8u), grid - 8u);
+        fl.timeout = (unsigned long long)(c->wall_clock_khz * 2000.0);  // 2 s
+        fl.sticky = c->d_flow_sticky;
+        a1.ymask = fl.ring - 1u;
+        a1.flow = fl;
+        HIPCHK(hipMemsetAsync(c->d_flow, 0, (16 + 2 * (size_t)nframes) * sizeof(unsigned), c->stream));
+    }
     {
         int rc = next_tickets(c, 0, c->p1, &a1.tickets);
         if (rc) return rc;
     }
     a1.tiles_per_frame = tiles1;
     a1.total_slots = tiles1 * (unsigned)nframes;
-    const bool wave1 = c->p1_wave && sb <= 4;  // (f32 / f64 samples: the image does not fit, classic kernel)
-    int rc = launch_pass1(c, c->M1, c->T1, sb, a1, a1.total_slots, c->real_fused, wave1);
-    if (rc) return rc;
-    if (ev_raw_consumed) HIPCHK(hipEventRecord(ev_raw_consumed, c->p1));  // pass 1 is the only reader of the raw halves
+    int rc = PSDR_OK;
+    if (!ring) {
+        rc = launch_pass1(c, c->M1, c->T1, sb, a1, a1.total_slots, c->real_fused);
+        if (rc) return rc;
+        if (ev_raw_consumed) HIPCHK(hipEventRecord(ev_raw_consumed, c->p1));  // pass 1 is the only reader of the raw halves
+    }
     if (piped) {
         HIPCHK(hipEventRecord(c->ev_p1[c->cur_y], c->p1));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_p1[c->cur_y], 0));
@@ -264,7 +290,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     // pass 2 overwrites this result set: its previous consumers (two batches ago) must be done
     if (c->set_pending[c->cur_set] && c->side != c->stream)
         HIPCHK(hipStreamWaitEvent(c->stream, c->ev_set_done[c->cur_set], 0));
-    auto run_pass2 = [&](bool fused) -> int { return launch_pass2(c, c->M2, c->T2, fused, a2, a2.total_slots, wave1 /* couple-major Y */); };
+    auto run_pass2 = [&](bool fused) -> int { return launch_pass2(c, c->M2, c->T2, fused, a2, a2.total_slots); };
     const psdr_ctx::SegPlan *plan = nullptr;  // fused real path: the seam kernel runs with the consumers
     if (!c->is_real) {
         a2.X = c->d_spec;
@@ -282,6 +308,13 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
                                    c->spec_stride, c->lay, c->nbands, nframes, c->M1 / 16, c->band_H);
                 HIPCHK(hipGetLastError());
             }
+        } else if (ring) {
+            a2.flow = fl;
+            if (c->kclock && c->kclk_pos[1] >= 1 && c->kclk_pos[1] - 1 < c->kclk_fused.size()) c->kclk_fused[c->kclk_pos[1] - 1] = 1;
+            rc = launch_fused(c, sb, a1, a2);
+            if (rc) return rc;
+            if (ev_raw_consumed) HIPCHK(hipEventRecord(ev_raw_consumed, c->stream));
+            HIPCHK(hipMemcpyAsync(c->h_flow_sticky, c->d_flow_sticky, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         } else {
             rc = run_pass2(true);
             if (rc) return rc;
@@ -525,7 +558,7 @@ extern "C" int psdr_pack_band(psdr_ctx *c, int nframes, uint32_t first_bin, uint
 // ---- band sharding without the pack: pass 2 writes band regions ------------------------------------------------
 extern "C" int psdr_set_band_layout(psdr_ctx *c, int nbands, uint32_t halo_bins) {
     if (!c) return fail(PSDR_ERR_INVALID, "null argument");
-    if (c->is_real || c->lay.mode == 0 || c->lay.mode == 2 || (c->M1 != 1024 && c->M1 != 2048) || c->M2 != 1024 || c->p1_wave)
+    if (c->is_real || c->lay.mode == 0 || c->lay.mode == 2 || (c->M1 != 1024 && c->M1 != 2048) || c->M2 != 1024)
         return fail(PSDR_ERR_UNSUPPORTED, "banded spectrum: 2^20- and 2^21-point IQ frames only (use psdr_pack_band)");
     if (nbands < 1 || nbands > 16 || (nbands & (nbands - 1))) return fail(PSDR_ERR_INVALID, "nbands %d: a power of two <= 16", nbands);
     if (halo_bins > (uint32_t)c->M) return fail(PSDR_ERR_INVALID, "halo of %u bins", halo_bins);

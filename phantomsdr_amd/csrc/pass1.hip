@@ -1,9 +1,6 @@
 // pass1.hip - launchers of the first FFT pass (fft_pass.h: convert + Hann + column transform + inter-pass twiddle)
 #include "ctx.h"
 #include "fft_pass.h"
-#ifdef PSDR_TUNING_BUILD
-#include "fft_pass1w.h"  // the barrier-free first pass of round 3 (measured slower: DESIGN.md 5.2) lives in tuning builds only
-#endif
 
 namespace psdr {
 
@@ -22,21 +19,6 @@ static int launch_pass1_t(psdr_ctx *c, const Pass1Args &a, unsigned blocks) {
     HIPCHK(hipGetLastError());
     return PSDR_OK;
 }
-#ifdef PSDR_TUNING_BUILD
-// pass 1 with wave-owned column couples (fft_pass1w.h): 2^20-point IQ frames of 8/16-bit samples
-template <int SB>
-static int launch_pass1_w(psdr_ctx *c, const Pass1Args &a, unsigned blocks) {
-    constexpr size_t lds = pass1w_lds_bytes<SB>();
-    if (c->lds_attr_done.insert((const void *)k_fft_pass1_w<SB>).second)
-        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass1_w<SB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ProfScope ps(c, K_PASS1, c->p1);
-    unsigned grid = persistent_grid(c, blocks, lds);
-    if (c->p1_grid && c->p1_grid < grid) grid = c->p1_grid;
-    hipLaunchKernelGGL((k_fft_pass1_w<SB>), dim3(grid), dim3(kPass1wThreads), lds, c->p1, a);
-    HIPCHK(hipGetLastError());
-    return PSDR_OK;
-}
-#endif
 
 #define P1CASE(L_, T_)                                                   \
     if (L == L_ && T == T_) {                                            \
@@ -50,16 +32,8 @@ static int launch_pass1_w(psdr_ctx *c, const Pass1Args &a, unsigned blocks) {
         if (sb == 4) return launch_pass1_t<L_, T_, 4, true>(c, a, blocks);     \
         return launch_pass1_t<L_, T_, 8, true>(c, a, blocks);                  \
     }
-// sb: bytes per complex sample slot of the raw image (2, 4, 8); pair: the real-input form feeding k_fft_pass2_real;
-// wave: the wave-owned kernel (tuning builds)
-int launch_pass1(psdr_ctx *c, int L, int T, int sb, const Pass1Args &a, unsigned blocks, bool pair, bool wave) {
-    if (wave) {
-#ifdef PSDR_TUNING_BUILD
-        return sb == 2 ? launch_pass1_w<2>(c, a, blocks) : launch_pass1_w<4>(c, a, blocks);
-#else
-        return fail(PSDR_ERR_UNSUPPORTED, "the wave-owned first pass exists in tuning builds only");
-#endif
-    }
+// sb: bytes per complex sample slot of the raw image (2, 4, 8); pair: the real-input form feeding k_fft_pass2_real
+int launch_pass1(psdr_ctx *c, int L, int T, int sb, const Pass1Args &a, unsigned blocks, bool pair) {
     if (pair) {
         P1PAIR(1024, 16)
         P1PAIR(2048, 8)

@@ -5,16 +5,16 @@
 
 namespace psdr {
 
-template <int L, int T, bool FUSED, int TWC, bool YCM = false, bool BAND = false>
+template <int L, int T, bool FUSED, int TWC, bool BAND = false>
 static int launch_pass2_t(psdr_ctx *c, const Pass2Args &a, unsigned blocks) {
     constexpr size_t lds = (size_t)L * T * sizeof(cf) + (size_t)L * sizeof(cf);
     // (per context = per device: the attribute is a property of the function ON a device)
-    if (c->lds_attr_done.insert((const void *)k_fft_pass2<L, T, FUSED, TWC, YCM, BAND>).second)
-        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass2<L, T, FUSED, TWC, YCM, BAND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (c->lds_attr_done.insert((const void *)k_fft_pass2<L, T, FUSED, TWC, BAND>).second)
+        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass2<L, T, FUSED, TWC, BAND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope ps(c, K_PASS2);
     unsigned grid = persistent_grid(c, blocks, lds);
     if (c->p2_grid && c->p2_grid < grid) grid = c->p2_grid;
-    hipLaunchKernelGGL((k_fft_pass2<L, T, FUSED, TWC, YCM, BAND>), dim3(grid), dim3(L * T / 32), lds, c->stream, a);
+    hipLaunchKernelGGL((k_fft_pass2<L, T, FUSED, TWC, BAND>), dim3(grid), dim3(L * T / 32), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return PSDR_OK;
 }
@@ -22,15 +22,7 @@ static int launch_pass2_t(psdr_ctx *c, const Pass2Args &a, unsigned blocks) {
     if (L == L_ && T == T_)                                                    \
         return fused ? launch_pass2_t<L_, T_, true, 0>(c, a, blocks)           \
                      : launch_pass2_t<L_, T_, false, 0>(c, a, blocks);
-// ycm: Y is couple-major (written by the wave-owned first pass: tuning builds)
-int launch_pass2(psdr_ctx *c, int L, int T, bool fused, const Pass2Args &a, unsigned blocks, bool ycm) {
-    if (ycm) {
-#ifdef PSDR_TUNING_BUILD
-        return launch_pass2_t<1024, 16, true, 16, true>(c, a, blocks);
-#else
-        return fail(PSDR_ERR_UNSUPPORTED, "couple-major Y exists in tuning builds only");
-#endif
-    }
+int launch_pass2(psdr_ctx *c, int L, int T, bool fused, const Pass2Args &a, unsigned blocks) {
     P2CASE(64, 64)
     P2CASE(64, 128)
     P2CASE(128, 128)
@@ -48,8 +40,8 @@ int launch_pass2(psdr_ctx *c, int L, int T, bool fused, const Pass2Args &a, unsi
 }
 // banded spectrum layout (psdr_set_band_layout): 2^20- and 2^21-point IQ frames
 int launch_pass2_band(psdr_ctx *c, const Pass2Args &a, unsigned blocks) {
-    return a.TW == 16 ? launch_pass2_t<1024, 16, true, 16, false, true>(c, a, blocks)
-                      : launch_pass2_t<1024, 16, true, 8, false, true>(c, a, blocks);
+    return a.TW == 16 ? launch_pass2_t<1024, 16, true, 16, true>(c, a, blocks)
+                      : launch_pass2_t<1024, 16, true, 8, true>(c, a, blocks);
 }
 
 // fused real-input pass 2 (TWC = pass-1 tile width: 16 for 1024 x 1024, 8 for 2048 x 1024)

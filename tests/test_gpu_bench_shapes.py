@@ -189,59 +189,6 @@ def test_bench_launch_256_frames_vs_oracle(wl_name):
         run.close()
 
 
-def _tuning_build():
-    from phantomsdr_amd import _lib
-    return b"tuning build" in _lib.load().psdr_version()
-
-
-# The barrier-free first pass of round 3 (measured slower: DESIGN.md 5.2) is not part of the library that ships: it is
-# compiled into -DPSDR_TUNING_BUILD variants only (tools/build_variants.py tuning=PSDR_TUNING_BUILD), and these two
-# tests run when the suite is pointed at one:  PSDR_LIB=build/variants/libpsdr_tuning.so pytest -m gpu -k wave_owned
-needs_tuning = pytest.mark.skipif(not _tuning_build(), reason="the wave-owned first pass exists in tuning builds only (PSDR_LIB=...libpsdr_tuning.so)")
-
-
-@needs_tuning
-def test_wave_owned_pass1_bench_launch_vs_oracle(monkeypatch):
-    """the experimental barrier-free first pass (PSDR_P1_WAVE=1, fft_pass1w.h: wave-owned column couples, image hand-over
-    through LDS flags, couple-major Y) on the bench's own 256-frame launch: every work-group walks 64 tiles, so the
-    hand-over counters, the ticket sequence and the rotated loop all run in steady state"""
-    monkeypatch.setenv("PSDR_P1_WAVE", "1")
-    test_bench_launch_256_frames_vs_oracle("cfg2")
-
-
-@needs_tuning
-@pytest.mark.parametrize("fmt", ["u8", "s16", "u16"])
-def test_wave_owned_pass1_formats_vs_classic(monkeypatch, fmt):
-    """the same samples through both first passes: spectra within float rounding of each other (the two kernels order
-    their arithmetic identically except for the twiddle recurrences), pyramids equal up to the quantiser's boundaries"""
-    from phantomsdr_amd import Context
-    from helpers import quantize_raw, synth_stream
-    N, F = 1 << 20, 24  # 1536 tiles: six per work-group
-    x = synth_stream((F + 1) * (N // 2), False, seed=3, sigma=2.0 ** -5 if fmt == "u8" else 2.0 ** -9, fft_size=N)
-    raw = quantize_raw(x, fmt, False)
-
-    def run(wave):
-        if wave:
-            monkeypatch.setenv("PSDR_P1_WAVE", "1")
-        else:
-            monkeypatch.delenv("PSDR_P1_WAVE", raising=False)
-        ctx = Context(N, False, 11, input_format=fmt, max_batch=F)
-        try:
-            d = ctx.dev_alloc(raw.nbytes)
-            ctx.h2d(d, raw)
-            ctx.process_batch(d, F)
-            out = [(ctx.read_spectrum(f).copy(), ctx.read_quantized(f).copy()) for f in range(F)]
-            ctx.dev_free(d)
-            return out
-        finally:
-            ctx.close()
-    a, b = run(True), run(False)
-    for f in range(F):
-        assert rel_err(a[f][0], b[f][0]) < 2e-6, f"frame {f}"
-        dq = np.abs(a[f][1].astype(np.int16) - b[f][1].astype(np.int16))
-        assert dq.max() <= 1 and (dq != 0).mean() < 1e-3
-
-
 def test_bench_gpus_2_runs_every_sharding_as_two_processes():
     """`python bench.py --gpus 2` with no launcher around it: the self-launch, two ranks, all five shardings with the
     HIP back-ends.  A one-GPU box cannot run RCCL with two ranks, so PSDR_BENCH_ONE_DEVICE=1 puts both ranks on cuda:0
