@@ -7,7 +7,7 @@
  * dlopen or call it; only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg do.
  *
- * PINNING STATUS (see DESIGN.md "Oracle"):
+ * PINNING STATUS:
  *   - pinned against the reference's own compiled code (oracle/_ref, built from
  *     /root/reference/src/utils/{dsp,audioprocessing}.cpp): Hann window, AM
  *     envelope, FM polar discriminator, negate/add helpers, float->int16, AGC.

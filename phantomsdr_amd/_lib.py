@@ -96,6 +96,7 @@ SYMBOLS = [
                                 C.POINTER(C.POINTER(C.c_int32))]),
     ("psdr_fetched_window", _i, [_vp, _i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     ("psdr_get_kernel_samples", _i, [_vp, C.c_char_p, C.POINTER(C.c_double), _i, C.POINTER(_i)]),
+    ("psdr_get_flow_stats", _i, [_vp, C.POINTER(C.c_uint64)]),
     ("psdr_reset_kernel_stats", _i, [_vp]),
     ("psdr_timer_start", _i, [_vp]),
     ("psdr_timer_stop_ms", _i, [_vp, C.POINTER(C.c_double)]),

@@ -300,7 +300,7 @@ int build(psdr_ctx *c) {
             rc = upload(&c->d_UB, make_twiddles(UB, 1, c->N, -1));
             if (rc) return rc;
             if (c->real_fused) {
-                rc = upload(&c->d_UG, make_twiddles((size_t)(c->M1 / 16), 8, c->N, -1));
+                rc = upload(&c->d_UG, make_twiddles((size_t)(c->M1 / c->T2), (size_t)(c->T2 / 2), c->N, -1));  // W_N^{CP g}: the tile's factor
                 if (rc) return rc;
             }
         }
@@ -336,7 +336,7 @@ int build(psdr_ctx *c) {
         c->seam_cap = cap;
         c->seg_cap = capc;
         for (int st = 0; st < 2; st++) {  // part of the double-buffered result sets: k_real_seam is a consumer
-            HIPCHK(hipMalloc((void **)&c->seam_pool[st][0], cap * (size_t)c->M2 * 8 * sizeof(float)));
+            HIPCHK(hipMalloc((void **)&c->seam_pool[st][0], cap * (size_t)c->M2 * (size_t)(c->T2 / 2) * sizeof(float)));  // [segment][M2][couples per tile]
             HIPCHK(hipMalloc((void **)&c->seam_pool[st][1], capc * (size_t)c->M2 * sizeof(float)));
         }
         // flags (inside a launch only), then the fallback marks - ONE ARRAY PER RESULT SET: k_real_seam is a consumer, it may
@@ -351,8 +351,8 @@ int build(psdr_ctx *c) {
         }
     }
     if (c->ring_on) {
-        HIPCHK(hipMalloc((void **)&c->d_flow, (16 + 2 * F) * sizeof(unsigned)));
-        HIPCHK(hipMemset(c->d_flow, 0, (16 + 2 * F) * sizeof(unsigned)));
+        HIPCHK(hipMalloc((void **)&c->d_flow, (16 + 4 * F) * sizeof(unsigned)));
+        HIPCHK(hipMemset(c->d_flow, 0, (16 + 4 * F) * sizeof(unsigned)));
         HIPCHK(hipMalloc((void **)&c->d_flow_sticky, 16 * sizeof(unsigned)));
         HIPCHK(hipMemset(c->d_flow_sticky, 0, 16 * sizeof(unsigned)));
         HIPCHK(hipHostMalloc((void **)&c->h_flow_sticky, 16 * sizeof(unsigned), hipHostMallocDefault));
@@ -514,6 +514,14 @@ extern "C" int psdr_create(const psdr_config *cfg, psdr_ctx **out) {
     c->is_real = is_real;
     c->R = M;  // fft_result_size: N (IQ) or N/2 (real), src/spectrumserver.cpp:99-105
     c->log2M2 = m / 2;
+    // 2^22-point real frames (a 2^21-point packed transform): 1024 x 2048 - the first pass is then the 16-column kernel
+    // of the 2^20 / 2^21-point shapes (128-byte raw rows and Y rows: 5.3 TB/s against the 8-column 2048-point kernel's
+    // 4.1), the second pass walks tiles of FOUR (row, mirror row) couples of 2048-point rows (k_fft_pass2_real<2048, 8, 16>).
+    // PSDR_REAL_SPLIT=2048x1024 selects round 4's split.
+    if (is_real && m == 21) {
+        const char *e = getenv("PSDR_REAL_SPLIT");
+        if (!(e && strcmp(e, "2048x1024") == 0)) c->log2M2 = 11;
+    }
     if (const char *e = psdr_tuning_env("PSDR_LOG2M2")) c->log2M2 = atoi(e);  // tuning: split M = M1 * M2
     c->log2M1 = m - c->log2M2;
     c->M1 = 1 << c->log2M1;
@@ -528,13 +536,14 @@ extern "C" int psdr_create(const psdr_config *cfg, psdr_ctx **out) {
     c->q_len = 0;
     for (int i = 0; i < c->levels; i++) c->q_len += c->R >> i;
     c->q_stride = (c->q_len + 127) & ~(size_t)127;
-    c->real_fused = is_real && c->M2 == 1024 && c->T2 == 16 && (c->M1 == 1024 || c->M1 == 2048) &&
+    c->real_fused = is_real && ((c->M2 == 1024 && c->T2 == 16 && (c->M1 == 1024 || c->M1 == 2048)) || (c->M2 == 2048 && c->T2 == 8 && c->M1 == 1024 && c->T1 == 16)) &&
                     getenv("PSDR_REAL_3PASS") == nullptr;
     if (c->real_fused) {
-        c->tile_ch = 8;  // octet records, levels 0..3 (quantize.h, RecMap mode 2)
-        c->LT = 3;
-        c->tiled_lt = 3;
-        c->recmap.l2tpr = ilog2((size_t)(c->M1 / 8));
+        const int cp = c->T2 / 2;  // (row, mirror row) couples per tile: 8 (octet records, levels 0..3) or 4 (quartets, levels 0..2)
+        c->tile_ch = cp;           // quantize.h, RecMap mode 2
+        c->LT = ilog2((size_t)cp);
+        c->tiled_lt = c->LT;
+        c->recmap.l2tpr = ilog2((size_t)(c->M1 / cp));
         c->recmap.l2gpt = 0;
         c->recmap.l2rows = c->log2M2;
         c->recmap.mapped = 2;
@@ -544,6 +553,7 @@ extern "C" int psdr_create(const psdr_config *cfg, psdr_ctx **out) {
         c->lay.l2m1 = c->log2M1;
         c->lay.L = c->M2;
         c->lay.l2L = c->log2M2;
+        c->lay.l2cp = c->LT;
     } else if (is_real) {
         c->LT = 8;  // the untangle kernel finishes levels 0..8 (4 bins per lane, 64 lanes)
         c->tiled_lt = -1;
@@ -809,6 +819,19 @@ extern "C" int psdr_set_profiling(psdr_ctx *c, int mode) {
         if (rc) return rc;
     }
     c->kclock = mode == 2;
+    return PSDR_OK;
+}
+extern "C" int psdr_get_flow_stats(psdr_ctx *c, uint64_t out[5]) {
+    if (!c || !out) return fail(PSDR_ERR_INVALID, "null argument");
+    for (int i = 0; i < 5; i++) out[i] = 0;
+    if (!c->d_flow_sticky) return PSDR_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    unsigned h[16];
+    HIPCHK(hipMemcpy(h, c->d_flow_sticky, sizeof h, hipMemcpyDeviceToHost));
+    const unsigned long long *st = (const unsigned long long *)(h + 4);
+    for (int i = 0; i < 4; i++) out[i] = st[i];
+    out[4] = h[0];
     return PSDR_OK;
 }
 extern "C" int psdr_get_kernel_samples(psdr_ctx *c, const char *name, double *us_out, int cap, int *n_out) {

@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256, N <= 512 ? PSDR_IDFT_WPE : PSDR_IDFT_WPE - 1) 
     // chain frame by frame has one frame's loads in flight at a time).  Measured on the round-4 build, same box, three
     // interleaved repetitions: 256 clients on cfg2's stream 94.75-94.79 GS/s with it, 94.65-95.06 without; cfg3 and the
     // cfg5 share inside their spread; n = 720 with it (=2: 128 VGPRs + 48 bytes of scratch) -1 %.  The chain kernel's time
-    // beside the passes is not its own latency: off.
+    // beside the passes is not its own latency (docs/history.md 5.4): off.
 #ifndef PSDR_DEMOD_PREFETCH
 #define PSDR_DEMOD_PREFETCH 0
 #endif

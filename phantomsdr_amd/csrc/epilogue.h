@@ -351,6 +351,7 @@ struct SeamArgs {
     const unsigned *segmark;  // hand-off plans: == epoch for a segment whose carry-in was not in memory in time (else nullptr)
     unsigned epoch;
     int L;               // row length (M2)
+    int cp;              // couples per tile: 8 (octets, records of 16 bytes) or 4 (quartets, 8 bytes)
     int size_log2;
     int8_t *Qt;
     size_t qt_stride;
@@ -362,10 +363,22 @@ __global__ __launch_bounds__(256) void k_real_seam(SeamArgs a) {
     if ((se.w & 1u) && a.segmark[blockIdx.x] != a.epoch) return;  // (PSDR_SEG_CARRY_MEM) the carried row arrived inside the launch
     const int f = (int)se.x;
     const int g = (int)(se.y & 0xFFFFu);  // the segment's first tile
-    const float *P = a.seamP + (size_t)blockIdx.x * a.L * 8;
+    const float *P = a.seamP + (size_t)blockIdx.x * a.L * a.cp;
     const float *Cc = a.seamC + (size_t)se.z * a.L;  // carry-out of the segment above (the top segment: row M1/2 from tile 0)
     int8_t *Qf = a.Qt + (size_t)f * a.qt_stride;
     float *Pf = a.Pscr + (size_t)f * a.p_stride;
+    if (a.cp == 4) {  // quartets (2048-point rows)
+        for (int c = threadIdx.x; c < a.L; c += blockDim.x) {
+            const float4 v = reinterpret_cast<const float4 *>(P)[c];
+            float pw[4] = {Cc[c], v.x, v.y, v.z};  // elements 1..3 at [0..3)
+            const size_t rp = ((size_t)g * 2 + 1) * a.L + c;
+            uint2 rec;
+            pyr_record4(pw, a.size_log2, rec);
+            *reinterpret_cast<uint2 *>(Qf + rp * 8) = rec;
+            Pf[rp] = pw[0];
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < a.L; c += blockDim.x) {
         const float4 v0 = reinterpret_cast<const float4 *>(P)[2 * c], v1 = reinterpret_cast<const float4 *>(P)[2 * c + 1];
         float pw[8] = {Cc[c], v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z};  // elements 1..7 at [0..7)

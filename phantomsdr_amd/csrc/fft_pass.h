@@ -462,7 +462,7 @@ struct TileQueue {
 // A launch's work-groups are split into a pass-1 role and a pass-2 role that run SIDE BY SIDE, a few frames apart: pass 2
 // starts a tile of frame f once every pass-1 tile of f has its rows of Y in memory (done1[f] == tiles1), pass 1 overwrites
 // the ring slot of frame f - ring only after every pass-2 tile of that frame has read it (done2[f - ring] == tiles2).
-// With the two launches of DESIGN.md 3.1 a batch's Y (8 MB per 2^20-point frame, 4 GB per 512 frames) goes out to HBM and
+// With the two launches a batch's Y (8 MB per 2^20-point frame, 4 GB per 512 frames) goes out to HBM and
 // comes back; here a row of Y is read ~5 frames after it was written and re-written `ring` frames later, both while it is
 // still in the 256 MiB memory-side cache: per frame 16.8 MB of the 31.5 MB of HBM traffic go away (measured bound with all
 // frames aliased onto 4 / 16 frames of Y: +14 % / +5 % on cfg2's step, profiles/r05_*).
@@ -474,8 +474,15 @@ struct TileQueue {
 // as failed instead of hanging (a work-group waits only for work that was handed out BEFORE its own tile - tiles are
 // drawn in frame order - so with the launch's work-groups resident nothing can wait in a circle).
 struct FlowArgs {
+    // done1[f] / done2[f] are FLAGS (0, or the tile count once the frame is complete): written ONCE, by the work-group whose
+    // increment of cnt1[f] / cnt2[f] was the last one; the other role samples and polls the flags only.  (First form: the
+    // other role polled the counters themselves - a word that ~100 work-groups read while 64 atomics per frame change it
+    // keeps bouncing between the XCDs' L2s, every increment waits for the probes, and an increment that takes
+    // microseconds holds up wave 0's in-order vmcnt queue: the whole launch ran 1.5 x slower than without flow control.)
     unsigned *done1;  // [nframes] (zeroed per launch); nullptr: two launches, no flow control
     unsigned *done2;  // [nframes]
+    unsigned *cnt1;   // [nframes] pass-1 tiles of frame f whose rows of Y are in memory (atomic increments only)
+    unsigned *cnt2;   // [nframes] pass-2 tiles of frame f that have read their rows
     unsigned *abort;  // [1] (zeroed per launch): a wait timed out - nobody waits any longer
     unsigned *sticky; // [1] (never zeroed): timeouts since the context was created, read by the host at its synchronisations
     unsigned ring;    // frames of Y (a power of two; Pass*Args::ymask == ring - 1)
@@ -488,21 +495,51 @@ __device__ __forceinline__ unsigned flow_peek(const unsigned *p) {
     return __hip_atomic_load((const flow_gu32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // ONE lane: until *ctr >= want (true), or the launch was aborted / the wait timed out (false)
-__device__ __forceinline__ bool flow_wait(const unsigned *ctr, unsigned want, const FlowArgs &fl) {
+// role: 0 = a pass-1 work-group waiting for a ring slot, 1 = a pass-2 work-group waiting for a frame.  The waits are
+// counted (how many, how many clock ticks) behind fl.sticky: psdr_get_flow_stats.
+__device__ __forceinline__ bool flow_wait(const unsigned *ctr, unsigned want, const FlowArgs &fl, int role) {
+#ifdef PSDR_ABL_RING_NOFLOW
+    return true;  // timing-only (tuning builds): nobody waits for anybody - results are wrong
+#endif
+    typedef __attribute__((address_space(1))) unsigned long long flow_gu64;
+    flow_gu64 *st = (flow_gu64 *)(fl.sticky + 4) + 2 * role;
     const unsigned long long t0 = wall_clock64();
+    bool ok = false;
     for (;;) {
-        if (flow_peek(ctr) >= want) return true;
-        if (flow_peek(fl.abort)) return false;
+        if (flow_peek(ctr) >= want) {
+            ok = true;
+            break;
+        }
+        if (flow_peek(fl.abort)) break;
         if (wall_clock64() - t0 > fl.timeout) {
             __hip_atomic_store((flow_gu32 *)fl.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             (void)__hip_atomic_fetch_add((flow_gu32 *)fl.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
+            break;
         }
-        __builtin_amdgcn_s_sleep(16);
+        __builtin_amdgcn_s_sleep(40);
     }
+    (void)__hip_atomic_fetch_add(st, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)__hip_atomic_fetch_add(st + 1, wall_clock64() - t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ok;
 }
-__device__ __forceinline__ void flow_add(unsigned *ctr) {  // fire and forget
-    (void)__hip_atomic_fetch_add((flow_gu32 *)ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// ONE lane: count a tile; the increment that completes the frame raises the flag the other role looks at.  _begin / _end:
+// the same with the atomic's result used later (its round trip hides behind whatever lies in between)
+__device__ __forceinline__ unsigned flow_count_begin(unsigned *cnt) {
+    // (the address through a vector register the compiler cannot see through: with a uniform address its atomic optimiser
+    // makes this "one lane adds, v_readfirstlane broadcasts", and the broadcast wants the result at once - s_waitcnt
+    // vmcnt(0) on the spot, every tile; see TileQueue::draw_begin)
+    flow_gu32 *p = (flow_gu32 *)cnt;
+    asm volatile("" : "+v"(p));
+    return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (called under `if (tid == 0)`: the empty asm pins the comparison - and the wait for the atomic's result in front of it -
+// inside that branch; hoisted out of it, every wave of the work-group waits, with vmcnt(0))
+__device__ __forceinline__ void flow_count_end(unsigned old, unsigned *flag, unsigned tiles) {
+    asm volatile("" : "+v"(old));
+    if (old + 1u == tiles) __hip_atomic_store((flow_gu32 *)flag, tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void flow_count(unsigned *cnt, unsigned *flag, unsigned tiles) {
+    flow_count_end(flow_count_begin(cnt), flag, tiles);
 }
 typedef unsigned ring_u32x4 __attribute__((ext_vector_type(4)));
 enum { PSDR_AUX_SC1 = 16 };  // raw_buffer_load / _store aux: sc1 (loads: past L1; stores: write-through)
@@ -630,9 +667,13 @@ __device__ __forceinline__ constexpr float image_scale() {
 // RING (k_fft_fused): this work-group is number vb of the vgrid work-groups of the launch that run pass 1; tiles are drawn
 // in frame order from ONE counter, Y is a ring of flow.ring frames stored write-through, and the FlowArgs counters order
 // the tiles against pass 2's (see FlowArgs)
-template <int L, int T, int SB, bool PAIR = false, bool RING = false>
+// CP (PAIR): (row, mirror row) couples per pass-2 tile - 8 for 1024-point rows (tiles of 16 rows), 4 for 2048-point rows
+// (tiles of 8 rows: 2^22-point real frames split 1024 x 2048)
+template <int L, int T, int SB, bool PAIR = false, bool RING = false, int CP = 8>
 __device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsigned vgrid) {
     static_assert(!RING || (!PAIR && Plan<L>::NS == 3), "one-launch form: IQ first passes with three stages");
+    static_assert(CP == 8 || CP == 4, "couples per pass-2 tile");
+    constexpr int L2CP = CP == 8 ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *tile = reinterpret_cast<float4 *>(smem);
     cf *Wl = reinterpret_cast<cf *>(smem) + L * T;
@@ -706,7 +747,7 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsi
             rq[i][0] = *reinterpret_cast<const unsigned *>(q);
         }
     };
-    __shared__ unsigned s_next[2];
+    __shared__ unsigned s_next[4];  // [0..1]: TileQueue; RING: [2] = this tile's ring slot is not free yet (thread 0's view)
     TileQueue tq;
     tq.init(a.tickets, total, RING, 0, vb, vgrid);
     unsigned s = vb, snext = vb + vgrid;
@@ -718,11 +759,16 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsi
     // tile's rows are stored but not yet counted in done1; this tile's sample of the counter that frees its ring slot
     __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)a.Y, 0, RING ? (int)(((size_t)a.flow.ring * a.yframe) * sizeof(cf)) : 0, 0x00020000);
     constexpr unsigned NOFRAME = 0xFFFFFFFFu;
-    unsigned post_f = NOFRAME, slot_seen = 0;
-    (void)yrs, (void)post_f, (void)slot_seen;
+    unsigned post_f = NOFRAME, post_f2 = NOFRAME, slot_seen = 0;  // frames of the previous tile and of the one before it
+    unsigned pub_f = NOFRAME, pub_old = 0;  // the frame whose count thread 0 incremented at tick 3, and what the atomic returned
+    (void)yrs, (void)post_f, (void)post_f2, (void)slot_seen, (void)pub_f, (void)pub_old;
     // table staging after the first tile's loads are in flight (one latency, not two)
     for (int i = tid; i < L; i += NT) Wl[i] = a.Wl[i];
     for (int i = tid; i < M2; i += NT) ldsTB[i] = a.TB[i];
+    if constexpr (RING) {
+        const unsigned f0 = (s < total ? s : 0u) / a.tiles_per_frame;
+        slot_seen = flow_peek(a.flow.done2 + (f0 >= a.flow.ring ? f0 - a.flow.ring : 0u));
+    }
     tq.draw_first();
     __syncthreads();  // Wl and the twiddle table are visible
     PSDR_WGTRACE(a.trace, 1);
@@ -753,20 +799,33 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsi
         const unsigned slot = RING ? s : xcd_slot(s, total);
         const unsigned f = slot / a.tiles_per_frame;
         const unsigned tl = slot - f * a.tiles_per_frame;
-        // RING: the ring slot of this frame was last read by pass 2 for frame f - ring: sampled now, looked at two stages on
-        if (RING && tid == 0 && f >= a.flow.ring) slot_seen = flow_peek(a.flow.done2 + (f - a.flow.ring));
+        // RING: the ring slot of this frame was last read by pass 2 for frame f - ring.  slot_seen is a sample of that frame's
+        // done2 count taken at tick 3 of the PREVIOUS tile (before the loop for the first): by EVERY lane and behind the
+        // last conditional load of that tile, so that the wait the compiler puts in front of its use here is a counted one
+        // (the last stage's sixteen stores are younger).  A load under `if (tid == 0)`, or one with `if (more)` loads
+        // between it and its use, is waited for with vmcnt(0) in every wave: a drain of the next tile's loads per tile.
+        // Thread 0's view decides for the work-group (s_next[2], read behind the first stage's barriers: tick 1).  A
+        // work-group that has to wait first PUBLISHES what it still holds (drain, barrier, done1 of its last two tiles):
+        // pass 2 may be waiting for exactly those tiles' frame before it can free the slot - waiting while holding
+        // unpublished work closes a circle (first form of this kernel: a flow-control timeout with every ring <= 16).
+        if constexpr (RING) {
+            if (tid == 0) s_next[2] = (f >= a.flow.ring && slot_seen < a.flow.tiles2) ? 1u : 0u;
+        }
         // this tile's block (plain) / its chunk of pass-2 tile 0 (PAIR: pass-2 tiles have 16 rows)
         cf *Yb = a.Y + (size_t)(f & a.ymask) * a.yframe + (PAIR ? (size_t)tl * a.ytl : (size_t)tl * a.yblk);
         const unsigned yb_bytes = (unsigned)(((size_t)(f & a.ymask) * a.yframe + (size_t)tl * a.yblk) * sizeof(cf));  // RING: inside the ring
         (void)yb_bytes;
         // PAIR: where the lane's part of a row index puts it (see the store below)
-        cf *Ylo = Yb + (size_t)(i0_ >> 3) * a.ytile + (i0_ & 7) * T + 2 * p_;
-        cf *Yhi = Yb - (size_t)((i0_ + 7) >> 3) * a.ytile + (8 + ((-i0_) & 7)) * T + 2 * p_;
+        cf *Ylo = Yb + (size_t)(i0_ >> L2CP) * a.ytile + (i0_ & (CP - 1)) * T + 2 * p_;
+        cf *Yhi = Yb - (size_t)((i0_ + CP - 1) >> L2CP) * a.ytile + (CP + ((-i0_) & (CP - 1))) * T + 2 * p_;
         (void)Ylo;
         (void)Yhi;
         const bool has_next = snext < total;
         if (has_next) point_at(snext);
-        const bool more = PSDR_UNCOND_PREFETCH ? true : has_next;  // (the loads below; nxt stays on this tile without a next one)
+        // (the loads below; nxt stays on this tile without a next one.  RING: unconditional - a work-group's last tile fetches
+        // its own rows once more - so that every wait behind them is a counted one: the drain of the write-through stores and
+        // the atomic's result below)
+        const bool more = (PSDR_UNCOND_PREFETCH || RING) ? true : has_next;
         // the index after `snext`: drawn one tile ago, published now, read after the barrier
         tq.draw_end(&s_next[it & 1], s);
         tq.draw_begin();
@@ -912,14 +971,14 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsi
                 }
                 cf *dst;
                 if constexpr (PAIR) {
-                    // row k1 < L/2 is row k1 & 7 of pass-2 tile k1 >> 3, its mirror L-k1 row 8 + (k1 & 7) of the
+                    // row k1 < L/2 is row k1 & (CP-1) of pass-2 tile k1 / CP, its mirror L-k1 row CP + (k1 & (CP-1)) of the
                     // same tile.  k1 = i0 + (a multiple of L/16 known at compile time): the lane part lives
                     // in Ylo / Yhi, the rest is a compile-time multiple of the (uniform) tile stride
                     if (sidx < RL / 2) {
-                        dst = Ylo + (size_t)((b * L16 + sidx * PL) >> 3) * a.ytile;
+                        dst = Ylo + (size_t)((b * L16 + sidx * PL) >> L2CP) * a.ytile;
                     } else {
-                        dst = Yhi + (size_t)((L - sidx * PL - b * L16) >> 3) * a.ytile;
-                        if (sidx == RL / 2 && b == 0) dst = i0 == 0 ? Yb + 8 * T + 2 * p : dst;  // row L/2: beside row 0
+                        dst = Yhi + (size_t)((L - sidx * PL - b * L16) >> L2CP) * a.ytile;
+                        if (sidx == RL / 2 && b == 0) dst = i0 == 0 ? Yb + CP * T + 2 * p : dst;  // row L/2: beside row 0
                     }
                 } else {
                     dst = Yb + (size_t)c1 * T + 2 * p;
@@ -927,10 +986,15 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsi
 #ifdef PSDR_ABL_P1_NOSTORE
                 if (yA.x == 1.2345678e-33f)  // timing-only: (almost) never true, keeps the arithmetic alive
 #endif
-                if constexpr (RING) {
+#ifdef PSDR_ABL_RING_PLAIN_ST
+                constexpr bool kRingStore = false;  // timing-only (tuning builds): plain stores - pass 2 may read stale rows
+#else
+                constexpr bool kRingStore = RING;
+#endif
+                if constexpr (kRingStore) {
                     // write-through (sc1): the reader is a work-group of the same launch on another XCD.  (No SGPR offset:
                     // a 128-bit buffer store with one, followed closely by inline-asm VALU that overwrites its data
-                    // registers, stores corrupted data on gfx950 - DESIGN.md 3.1.)
+                    // registers, stores corrupted data on gfx950 - docs/history.md 3.1.)
                     const ring_u32x4 v = {__float_as_uint(yA.x), __float_as_uint(yA.y), __float_as_uint(yB.x), __float_as_uint(yB.y)};
                     __builtin_amdgcn_raw_buffer_store_b128(v, yrs, (int)(yb_bytes + (unsigned)((c1 * T + 2 * p) * (int)sizeof(cf))), 0, PSDR_AUX_SC1);
                 } else {
@@ -947,29 +1011,55 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsi
                         static_for<lo, hi>(issue);
                     });
                 if constexpr (RING) {
-                    if (k == 2) {
-                        // (a) the previous tile's rows of Y: every wave drains ITS stores - they are older than the loads of
-                        // the next tile issued since (EARLY + 3 LPT of them when there is a next tile: a counted wait, the
-                        // stores are a whole stage and a half old; a wave that issued more - wave 0's ticket and samples -
-                        // only waits longer), the stage's barrier follows, thread 0 counts the tile at tick 3
-                        if (post_f != NOFRAME) {
-                            if (more)
-                                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EARLY + 3 * LPT) : "memory");
-                            else
-                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (k == 1 && s_next[2]) {  // (uniform; rare: pass 2 has fallen a whole ring behind)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __syncthreads();
+                        if (tid == 0) {
+                            if (post_f2 != NOFRAME) flow_count(a.flow.cnt1 + post_f2, a.flow.done1 + post_f2, a.flow.tiles1);
+                            if (post_f != NOFRAME) flow_count(a.flow.cnt1 + post_f, a.flow.done1 + post_f, a.flow.tiles1);
+                            (void)flow_wait(a.flow.done2 + (f - a.flow.ring), a.flow.tiles2, a.flow, 0);
                         }
-                        // (b) this tile's ring slot: free once pass 2 has read all of frame f - ring (the barriers of this
-                        // stage stand between thread 0's wait and everybody's stores in the last stage)
-                        if (tid == 0 && f >= a.flow.ring && slot_seen < a.flow.tiles2) (void)flow_wait(a.flow.done2 + (f - a.flow.ring), a.flow.tiles2, a.flow);
+                        post_f = post_f2 = NOFRAME;
+                        __syncthreads();  // (the last stage's stores come behind this)
                     }
-                    if (k == 3 && post_f != NOFRAME) {
-                        if (tid == 0) flow_add(a.flow.done1 + post_f);
+                    if (k == 2) {
+                        // (a) the rows of Y of the tile BEFORE THE PREVIOUS one: every wave drains ITS stores of that tile with
+                        // a counted wait - younger than them are the previous tile's NCHK loads (issued during the tile
+                        // before) and NCHK stores and, when there is a next tile, the EARLY + 3 LPT loads issued in this one;
+                        // a wave that issued more (wave 0's ticket and samples) only waits longer.  Write-through stores are
+                        // acknowledged from the memory side, later than a tile lasts: counted a tile earlier (the previous
+                        // tile's stores, a stage and a half old) every tile of the pass stalled here (first form of this
+                        // kernel: 12.4 us per tile instead of 7.8).  The stage's barrier follows, thread 0 counts at tick 3.
+                        static_assert(2 * NCHK + EARLY + 3 * LPT <= 63, "vmcnt is a 6-bit field");
+                        if (post_f2 != NOFRAME) {
+                            if (more)
+                                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCHK + EARLY + 3 * LPT) : "memory");
+                            else
+                                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCHK) : "memory");  // (the previous tile's stores may stay out)
+                        }
+                    }
+                    if (k == 3) {
+                        // (the atomic's result is looked at behind the last stage's stores: pub_old / pub_f)
+                        pub_f = post_f2;
+                        if (post_f2 != NOFRAME) {
+                            if (tid == 0) pub_old = flow_count_begin(a.flow.cnt1 + post_f2);
+                        }
+                        post_f2 = post_f;
                         post_f = NOFRAME;
+                        // (b) the NEXT tile's ring slot is free once pass 2 has read all of the frame `ring` before its own
+                        const unsigned fn = (has_next ? snext : s) / a.tiles_per_frame;
+                        slot_seen = flow_peek(a.flow.done2 + (fn >= a.flow.ring ? fn - a.flow.ring : 0u));
                     }
                 }
             },
             [&](int k) { PSDR_TRACE(a.trace, it, k); }, stw_front, stw_last);
-        if constexpr (RING) post_f = f;
+        if constexpr (RING) {
+            post_f = f;
+            if (pub_f != NOFRAME) {
+                if (tid == 0) flow_count_end(pub_old, a.flow.done1 + pub_f, a.flow.tiles1);
+                pub_f = NOFRAME;
+            }
+        }
         PSDR_TRACE(a.trace, it, 10);
         PSDR_WGTRACE(a.trace, 2 + it);
         // (published by thread 0 before the stages' barriers)
@@ -978,18 +1068,19 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsi
         snext = s2;
     }
     if constexpr (RING) {
-        if (post_f != NOFRAME) {  // the work-group's last tile
+        if (post_f != NOFRAME || post_f2 != NOFRAME) {  // the work-group's last two tiles
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) flow_add(a.flow.done1 + post_f);
+            if (tid == 0 && post_f2 != NOFRAME) flow_count(a.flow.cnt1 + post_f2, a.flow.done1 + post_f2, a.flow.tiles1);
+            if (tid == 0 && post_f != NOFRAME) flow_count(a.flow.cnt1 + post_f, a.flow.done1 + post_f, a.flow.tiles1);
         }
     }
     PSDR_WGTRACE(a.trace, 7);
     kclk_end(a.kclk);
 }
-template <int L, int T, int SB, bool PAIR = false>
+template <int L, int T, int SB, bool PAIR = false, int CP = 8>
 __global__ __launch_bounds__(L *T / 32) void k_fft_pass1(Pass1Args a) {
-    pass1_body<L, T, SB, PAIR>(a, blockIdx.x, gridDim.x);
+    pass1_body<L, T, SB, PAIR, false, CP>(a, blockIdx.x, gridDim.x);
 }
 
 struct Pass2Args {
@@ -1115,17 +1206,22 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, unsigned vb, unsi
         constexpr int i = decltype(qc)::value;
         constexpr int ip = SPLIT ? (i ^ (NLD / 2)) : i;  // which sixteenth of the tile
         // uniform part of idx = 2*ip*NT: block (2*ip*NT)>>lc, offset (2*ip*NT)&(chunk-1)
+#ifdef PSDR_ABL_RING_PLAIN_LD
+        constexpr int kAux = 0;  // timing-only (tuning builds): through L1
+#else
+        constexpr int kAux = PSDR_AUX_SC1;
+#endif
         if constexpr (RING) {
             // scalar part in the instruction's SGPR offset, the lane's part (loop-invariant) in its VGPR offset; sc1: past L1
             const unsigned ub = nxt_b + (unsigned)(((size_t)((2 * ip * NT) >> lc) * blk + ((2 * ip * NT) & (chunk - 1))) * sizeof(cf));
-            const ring_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(lane_off * (unsigned)sizeof(cf)), (int)ub, PSDR_AUX_SC1);
+            const ring_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(lane_off * (unsigned)sizeof(cf)), (int)ub, kAux);
             r[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         } else {
             const cf *q = nxt + (size_t)((2 * ip * NT) >> lc) * blk + ((2 * ip * NT) & (chunk - 1)) + lane_off;
             r[i] = *reinterpret_cast<const float4 *>(q);
         }
     };
-    __shared__ unsigned s_next[2];
+    __shared__ unsigned s_next[4];  // [0..1]: TileQueue; RING: [2] = the next tile's frame is not complete yet (thread 0's view)
     TileQueue tq;
     // pass 2 has no use for XCD affinity (full-line stores, tile-major records) and the XCDs
     // differ by ~10 % in speed: one chip-wide counter (pass 1 keeps the per-XCD queues: adjacent
@@ -1135,14 +1231,14 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, unsigned vb, unsi
     // RING: thread 0's sample of done1[frame of the tile after next], taken when that index is published and looked at a
     // tile later, right before the tile's loads begin
     unsigned rdy_seen = 0;
-    (void)rdy_seen;
+    constexpr unsigned NOFRAME2 = 0xFFFFFFFFu;
+    unsigned cnt_f = NOFRAME2, cnt_old = 0;  // the frame whose count thread 0 incremented at the end of the previous tile; the atomic's result
+    (void)rdy_seen, (void)cnt_f, (void)cnt_old;
     if constexpr (RING) {
         if (s < total) {
-            if (tid == 0) {
-                (void)flow_wait(a.flow.done1 + frame_of(s), a.flow.tiles1, a.flow);
-                if (snext < total) rdy_seen = flow_peek(a.flow.done1 + frame_of(snext));
-            }
+            if (tid == 0) (void)flow_wait(a.flow.done1 + frame_of(s), a.flow.tiles1, a.flow, 1);
             __syncthreads();
+            rdy_seen = flow_peek(a.flow.done1 + frame_of(snext < total ? snext : s));  // (every lane: see pass 1)
         }
     }
     if (s < total) {
@@ -1171,16 +1267,14 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, unsigned vb, unsi
         const bool has_next = snext < total;
         if (has_next) point_at(snext);
         const bool more = PSDR_UNCOND_PREFETCH ? true : has_next;  // (the loads below; nxt stays on this tile without a next one)
+        // RING: the next tile's loads start behind the fill: its frame's rows of Y must be in memory by then.  Thread 0's
+        // sample (a tile old) decides for the work-group; a work-group that has to wait first COUNTS the tile it holds
+        // (done2, behind the fill) - pass 1 may need exactly that slot before it can complete the frame waited for.
         if constexpr (RING) {
-            // the next tile's loads start below, behind the fill's barrier: its frame's rows of Y must be in memory
-            if (tid == 0 && has_next && rdy_seen < a.flow.tiles1) (void)flow_wait(a.flow.done1 + frame_of(snext), a.flow.tiles1, a.flow);
+            if (tid == 0) s_next[2] = (has_next && rdy_seen < a.flow.tiles1) ? 1u : 0u;
         }
         // the index after `snext`: drawn one tile ago, published now, read after the barrier
-        const unsigned s2o = tq.draw_end(&s_next[it & 1], s);
-        if constexpr (RING) {
-            if (tid == 0 && s2o < total) rdy_seen = flow_peek(a.flow.done1 + frame_of(s2o));
-        }
-        (void)s2o;
+        tq.draw_end(&s_next[it & 1], s);
         tq.draw_begin();
         int i0 = i0_, p = p_, tidx = tid;  // opaque copies (see pass 1)
         asm volatile("" : "+v"(i0), "+v"(p), "+v"(tidx));
@@ -1201,21 +1295,40 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, unsigned vb, unsi
             }
         }
         PSDR_SCHED_FENCE();
-        if (more) static_for<0, EARLY>(issue);
+        bool late_early = false;  // RING: the next tile's first loads wait until its frame is complete (uniform)
+        if constexpr (RING) {
+            late_early = s_next[2] != 0;  // (written before the fill's barrier)
+            if (cnt_f != NOFRAME2) {      // the previous tile's count: was it the frame's last?  (the atomic is a tile old)
+                if (tid == 0) flow_count_end(cnt_old, a.flow.done2 + cnt_f, a.flow.tiles2);
+                cnt_f = NOFRAME2;
+            }
+        }
+        if (more && !late_early) static_for<0, EARLY>(issue);
         PSDR_SCHED_FENCE();
         PSDR_TRACE(a.trace, it, 1);
         __syncthreads();
         PSDR_TRACE(a.trace, it, 2);
-        if constexpr (RING) {
-            if (tid == 0) flow_add(a.flow.done2 + f);  // every thread's rows of this tile have left the ring (they are in LDS)
-        }
+        // (RING: every thread's rows of this tile have left the ring - they are in LDS; the tile is counted at the end of
+        // the loop body, or right now if the work-group is about to wait)
         // stage-0 input comes from the tile itself: all reads, then a barrier, before any
         // in-place write
         c2 u[16];
         tile_read<L, H, true>(u, tile, i0, p);
+        if constexpr (RING) {
+            if (late_early) {  // (rare: pass 2 has caught up with pass 1)
+                if (tid == 0) {
+                    flow_count(a.flow.cnt2 + f, a.flow.done2 + f, a.flow.tiles2);  // never wait while holding an uncounted tile
+                    (void)flow_wait(a.flow.done1 + frame_of(snext), a.flow.tiles1, a.flow, 1);
+                }
+            }
+        }
         __syncthreads();
+        if (late_early && more) static_for<0, EARLY>(issue);
         PSDR_TRACE(a.trace, it, 3);
         const unsigned s2 = s_next[it & 1];
+        // RING: the tile after next is known to every thread now - every lane samples its frame's count (one word, no
+        // condition: the wait for it, a tile from here, is a counted one)
+        if constexpr (RING) rdy_seen = flow_peek(a.flow.done1 + frame_of(s2 < total ? s2 : s));
 
         cf *Xf = a.X + (size_t)f * a.spec_stride;
         cf *Xt = Xf + (size_t)tl * (L * T);  // the tile's block of a tile-major frame
@@ -1310,11 +1423,22 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, unsigned vb, unsi
             }
         }
         PSDR_TRACE(a.trace, it, 12);
+        if constexpr (RING) {
+            if (!late_early) {  // count the tile; the result is looked at behind the next tile's fill
+                if (tid == 0) cnt_old = flow_count_begin(a.flow.cnt2 + f);
+                cnt_f = f;
+            }
+        }
         if (!SPLIT) __syncthreads();  // the tile is free again (SPLIT: between the next tile's two half-fills)
         PSDR_TRACE(a.trace, it, 13);
         PSDR_WGTRACE(a.trace, 2 + it);
         s = snext;
         snext = s2;
+    }
+    if constexpr (RING) {
+        if (cnt_f != NOFRAME2) {
+            if (tid == 0) flow_count_end(cnt_old, a.flow.done2 + cnt_f, a.flow.tiles2);
+        }
     }
     PSDR_WGTRACE(a.trace, 7);
     kclk_end(a.kclk);
@@ -1418,7 +1542,11 @@ __device__ __forceinline__ float bin_power(cf x) {
 // Octet staging Pst[c2][16] floats (one 64-byte row per column: low octet, then elements 1..7 of the high octet and the
 // tile's carry-out).  Side-major records: the octet loop reads ONE 16-byte quarter per lane with lanes = adjacent
 // rows, 64 bytes apart - a four-way bank conflict in the plain order - so quarter j of row c sits at j ^ ((c >> 2) & 3).
+// (CP = 4 couples per tile - 2048-point rows: a row is 8 floats, [low quartet | elements 1..3 of the high quartet, carry-out],
+// one 16-byte quarter per side; lanes = adjacent rows read the SAME quarter 32 bytes apart: two-way, left as it is)
+template <int CP = 8>
 __device__ __forceinline__ int pst_at(int row, int e) {
+    if constexpr (CP == 4) return row * 8 + e;
 #if PSDR_REC_SIDE_MAJOR
     return row * 16 + ((((e >> 2) ^ (row >> 2)) & 3) << 2) + (e & 3);
 #else
@@ -1428,12 +1556,18 @@ __device__ __forceinline__ int pst_at(int row, int e) {
 
 template <int L, int T, int TWC>
 __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
-    static_assert(T == 16, "eight (row, mirror) couples per tile");
+    static_assert((T == 16 && L == 1024) || (T == 8 && L == 2048), "eight (row, mirror) couples per tile of 1024-point rows, four of 2048-point rows");
+    constexpr int CP = T / 2, L2CP = CP == 8 ? 3 : 2, LINE = 2 * CP;  // couples per tile; bins per spectrum line = floats per staging row
+    static_assert(CP == 8 || PSDR_REC_SIDE_MAJOR, "quartet tiles: side-major records only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *tile = reinterpret_cast<float4 *>(smem);
     cf *tile_cf = reinterpret_cast<cf *>(smem);
     cf *Wl = tile_cf + L * T;
-    float *carry = reinterpret_cast<float *>(Wl + L);  // [2][L]
+    // the carried row: double-buffered where LDS has room; 2048-point rows (tile 128 KiB + table 16 KiB) keep ONE buffer - the
+    // thread that reads entry c in the group loop is the thread that then writes entry c, and the row that arrives through
+    // memory is written before the last stage, behind the barriers that follow the previous tile's group loop
+    constexpr int NCARRY = L == 2048 ? 1 : 2;
+    float *carry = reinterpret_cast<float *>(Wl + L);  // [NCARRY][L]
     constexpr int H = T / 2;
     constexpr int NT = (L / 16) * H;
     constexpr int L16 = L / 16;
@@ -1454,7 +1588,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
     constexpr int log2TW = TWC == 16 ? 4 : 3;
     static_assert(TWC == 16 || TWC == 8, "pass-1 tile width");
     const int chunk = T * TW;
-    const int lc = log2TW + 4;  // log2(chunk)
+    const int lc = log2TW + (T == 16 ? 4 : 3);  // log2(chunk)
     float4 r[NLD];
     const cf *nxt = nullptr;
     // element idx of the tile = (pass-1 tile j, row rr, column cc), idx = j*chunk + rr*TW + cc: chunk j of
@@ -1526,7 +1660,9 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
     // registers of their own for the whole loop instead (never re-initialised, a dummy use at the loop's end, where
     // thirty younger operations make any such wait a formality).
     unsigned fl = 0;                 // thread 0: flag of the segment above the NEXT segment to start
-    unsigned long long cin_mem = 0;  // carry-in row, floats 2 tid and 2 tid + 1
+    constexpr int NCIN = L / (2 * NT);   // 8-byte pieces of the carried row per thread (1; 2048-point rows: 2)
+    static_assert(NCIN == 1 || NCIN == 2, "carried row: L floats over NT threads");
+    unsigned long long cin_mem = 0, cin_mem2 = 0;  // carry-in row, floats 2 tid and 2 tid + 1 (and 2 (tid + NT), + 1)
     if (a.segflag && tid == 0 && s < total && (se.w & PSDR_SEG_CARRY_MEM))
         fl = __hip_atomic_load(a.segflag + se.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
@@ -1551,7 +1687,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         if (!ev_) wc = make_float2(-wc.x, -wc.y);
     }
     const unsigned sgn_mine = ev_ ? 0u : 0x80000000u, sgn_send = ev_ ? 0x80000000u : 0u;
-    const int off_ = ev_ ? (p_ & ~1) : 14 - (p_ & ~1);  // bin of the lane's pair inside the 16-bin line
+    const int off_ = ev_ ? (p_ & ~1) : (LINE - 2) - (p_ & ~1);  // bin of the lane's pair inside the line of LINE bins
     const int xflip_ = ev_ ? 0 : L - 1;                 // mirror-side values of column c belong to column L-1-c
     int j = 0, segit = 0;
     for (int it = 0; s < total; it++) {
@@ -1587,9 +1723,9 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             const int w = ((2 * ip * NT) & (chunk - 1)) + ((2 * tidx) & (chunk - 1));
             const int rr = w >> log2TW, cc = w & (TW - 1);
             const int n2 = (((2 * ip * NT) >> lc) + ((2 * tidx) >> lc)) * TW + cc;  // even
-            const int slot0 = lds_slot<H, true>(n2, rr & 7);  // couple p = (row p, row 8 + p of the tile)
-            tile_cf[2 * slot0 + (rr >> 3)] = make_float2(r[i].x, r[i].y);
-            tile_cf[2 * (slot0 + H) + (rr >> 3)] = make_float2(r[i].z, r[i].w);
+            const int slot0 = lds_slot<H, true>(n2, rr & (CP - 1));  // couple p = (row p, row CP + p of the tile)
+            tile_cf[2 * slot0 + (rr >> L2CP)] = make_float2(r[i].x, r[i].y);
+            tile_cf[2 * (slot0 + H) + (rr >> L2CP)] = make_float2(r[i].z, r[i].w);
             if (SPLIT && i == NLD / 2 - 1) {
                 PSDR_SCHED_FENCE();
                 __syncthreads();  // every wave has finished the previous tile's octet loop: the lower half is free
@@ -1597,7 +1733,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             }
         }
         PSDR_SCHED_FENCE();
-        asm volatile("" ::"v"(fl), "v"(cin_mem));  // (see their declaration; behind the fill's own waits)
+        asm volatile("" ::"v"(fl), "v"(cin_mem), "v"(cin_mem2));  // (see their declaration; behind the fill's own waits)
         static_for<0, EARLY>(issue);
         PSDR_SCHED_FENCE();
         PSDR_TRACE(a.trace, it, 1);
@@ -1609,12 +1745,20 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         PSDR_TRACE(a.trace, it, 3);
 
         cf *Xf = a.X + (size_t)f * a.spec_stride;
-        float *Pst = reinterpret_cast<float *>(smem);             // [L][16]: low octet, high octet
-        cf *exA = tile_cf + (size_t)L * 8, *exB = exA + L;        // tile 0: rows 0 and M1/2 (beyond Pst)
-        float *carry_w = carry + (it & 1) * L, *carry_r = carry + ((it & 1) ^ 1) * L;
+        float *Pst = reinterpret_cast<float *>(smem);             // [L][LINE]: low octet, high octet
+        cf *exA = tile_cf + (size_t)L * CP, *exB = exA + L;       // tile 0: rows 0 and M1/2 (beyond Pst)
+        float *carry_w = carry + (NCARRY == 2 ? (it & 1) * L : 0), *carry_r = carry + (NCARRY == 2 ? ((it & 1) ^ 1) * L : 0);
         float *seamC = a.seamC + (size_t)s * L;
         bool cin_ok = false;  // the carried row is in memory and was fetched at tick 1 (uniform: thread 0 looked at the flag)
+        // The counted drain at tick 2 (hand-off of the carried row) is correct ONLY IF every wave has issued exactly
+        // EARLY + 3 * LPT vector-memory loads since its carry-out stores and nothing else in between: `issue` must stay
+        // UNCONDITIONAL in this kernel (a load under a condition, or one the compiler can drop, makes the wait too weak and
+        // the flag could be published before the row is acknowledged), the ticks must carry LPT loads each, and loads and
+        // stores retire in order (one vmcnt counter).  PSDR_HANDOFF_FULL_DRAIN=1 (tuning builds) waits with vmcnt(0)
+        // instead: the A/B that the bit-identity tests run against.
         static_assert(NTICK == 4 && LPT == 1, "the counted drain below knows what the ticks issue");
+        static_assert(NFRONT - EARLY == NTICK * LPT && EARLY + 3 * LPT == EARLY + 3, "tick k issues load EARLY + k: three of them by tick 2");
+        static_assert(EARLY + 3 * LPT <= 63, "vmcnt is a 6-bit field");
         run_front_stages<L, T, true>(
             tile, Wl, i0, p, u,
             [&](int k) {
@@ -1627,7 +1771,11 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                 if (k == 2 && post_seg != NOSEG) {
                     // this wave's carry-out stores of the previous tile: older than the EARLY + 3 loads of the next tile
                     // issued since (and than the flag load and wave 0's ticket, if any: then the wait is only stricter)
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EARLY + 3) : "memory");
+#ifdef PSDR_HANDOFF_FULL_DRAIN
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EARLY + 3 * LPT) : "memory");
+#endif
                 }
                 if (k == 0 && tid == 0) {
                     if (carry_mem) {
@@ -1648,9 +1796,13 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                 }
                 if (k == 1 && carry_mem) {  // behind stage 0's barriers
                     cin_ok = s_next[2] != 0;
-                    if (cin_ok)  // sc1: from memory, not from this XCD's L2; a stage and a half before it is needed
+                    if (cin_ok) {  // sc1: from memory, not from this XCD's L2; a stage and a half before it is needed
                         cin_mem = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(a.seamC + (size_t)se.z * L) + tid,
                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if constexpr (NCIN == 2)
+                            cin_mem2 = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(a.seamC + (size_t)se.z * L) + NT + tid,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
                 if (k == 3 && post_seg != NOSEG) {  // behind stage 1's barriers: every wave has drained
                     if (tid == 0) __hip_atomic_store(a.segflag + post_seg, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1665,12 +1817,15 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         if (cin_ok) {
             reinterpret_cast<float2 *>(carry_r)[tid] =
                 make_float2(__uint_as_float((unsigned)cin_mem), __uint_as_float((unsigned)(cin_mem >> 32)));
+            if constexpr (NCIN == 2)
+                reinterpret_cast<float2 *>(carry_r)[NT + tid] =
+                    make_float2(__uint_as_float((unsigned)cin_mem2), __uint_as_float((unsigned)(cin_mem2 >> 32)));
         }
         // no carry-in (the table says so, or the segment above was not published in time): k_real_seam completes the octets
         const bool seam_in = seg_first && !cin_ok;
         if (seam_in && carry_mem && tid == 0) a.segmark[s] = a.epoch;
         const cf w0 = cmul(wc, wg);
-        cf *Xt = Xf + (size_t)g * (16 * L);  // line (g, c) of the frame starts at Xt + 16 * c
+        cf *Xt = Xf + (size_t)g * (LINE * L);  // line (g, c) of the frame starts at Xt + LINE * c
         // Octet staging Pst[c2][16]: [0..8) the low octet of column c2; [8..15) elements 1..7 of the
         // high octet of column c2 (its element 0 is the carried row).
         // Tile 0 only (couple 0 is special there): 8 bytes per lane.
@@ -1679,10 +1834,10 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             const cf w0p = (p & 1) ? make_float2(-w0.x, -w0.y) : w0;  // (w0 carries the lane's sigma)
             untangle_pair(x.a, x.b, cmul(w0p, w32(t)), xk, xm);
             const int cm = L - 1 - c2i;
-            Xt[16 * c2i + p] = xk;
-            Xt[16 * c2i + 15 - p] = xm;  // mirror row M1-p: element 7-p of the mirror octet
-            Pst[pst_at(c2i, p)] = bin_power(xk);
-            Pst[pst_at(cm, 15 - p)] = bin_power(xm);  // (p >= 1 here: element 8-p at [7+8-p])
+            Xt[LINE * c2i + p] = xk;
+            Xt[LINE * c2i + LINE - 1 - p] = xm;  // mirror row M1-p: element CP-1-p of the mirror octet
+            Pst[pst_at<CP>(c2i, p)] = bin_power(xk);
+            Pst[pst_at<CP>(cm, LINE - 1 - p)] = bin_power(xm);  // (p >= 1 here: element CP-p at [CP-1+CP-p])
         };
         // Every other tile: two outputs (A, B) per call.  Lane pair (2q, 2q+1): the even lane ends up
         // with rows 8g+2q, 8g+2q+1 of both outputs, the odd lane with the mirror rows M1-8g-2q-1,
@@ -1694,10 +1849,10 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         // (scalar) + t * 8 KiB (scalar) + one per-thread byte offset.  Staging: the even lane writes
         // row c, the odd lane row L-1-c = (L/16-1-i0) + (L/16)*(15-t): per-thread base and +-4 KiB
         // stride.  (Opaque copies: see the loop-invariant-address note in pass 1.)
-        unsigned gofs = (unsigned)((i0_ * 16 + off_) * (int)sizeof(cf));
+        unsigned gofs = (unsigned)((i0_ * LINE + off_) * (int)sizeof(cf));
         // (the row moves by +-L/16 = 64 per output: the quarter swizzle of pst_at is the same for all sixteen)
-        int lbase = pst_at(ev_ ? i0_ : (L16 - 1 - i0_) + 15 * L16, off_) * (int)sizeof(float);
-        int lstride = (ev_ ? L16 : -L16) * 16 * (int)sizeof(float);
+        int lbase = pst_at<CP>(ev_ ? i0_ : (L16 - 1 - i0_) + 15 * L16, off_) * (int)sizeof(float);
+        int lstride = (ev_ ? L16 : -L16) * LINE * (int)sizeof(float);
         asm volatile("" : "+v"(gofs), "+v"(lbase), "+v"(lstride));
         char *Xtb = reinterpret_cast<char *>(Xt);
         char *Pstb = reinterpret_cast<char *>(Pst);
@@ -1709,7 +1864,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             // scalar base + 32-bit lane offset: the store's own address mode, no vector address math
             typedef __attribute__((address_space(1))) char gchar;
             typedef float gf4 __attribute__((ext_vector_type(4)));
-            gchar *bA = (gchar *)(Xtb + (size_t)tA * (L16 * 16 * sizeof(cf))), *bB = (gchar *)(Xtb + (size_t)tB * (L16 * 16 * sizeof(cf)));
+            gchar *bA = (gchar *)(Xtb + (size_t)tA * (L16 * LINE * sizeof(cf))), *bB = (gchar *)(Xtb + (size_t)tB * (L16 * LINE * sizeof(cf)));
             asm volatile("" : "+s"(bA), "+s"(bB));
             *(__attribute__((address_space(1))) gf4 *)(bA + gofs) = gf4{mineA.x, mineA.y, recvA.x, recvA.y};
             *(__attribute__((address_space(1))) gf4 *)(bB + gofs) = gf4{mineB.x, mineB.y, recvB.x, recvB.y};
@@ -1718,13 +1873,14 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         };
         int tA = 0;
         if (g != 0) {
-            static_assert(LastStage<L>::R == 4 && NBL == 4, "outputs t and t + 8 of a thread are two last-stage outputs apart");
-            cf wsv[2];  // sigma * W_N^k of outputs t = b, b + 4
+            constexpr int RL = LastStage<L>::R;
+            static_assert((RL == 4 || RL == 8) && NBL * RL == 16, "outputs t and t + 8 of a thread are RL / 2 last-stage outputs apart");
+            cf wsv[RL / 2];  // sigma * W_N^k of outputs t = b + NBL * sidx, sidx < RL / 2
             run_last_stage<L>(Wl, i0, u, [&](int b, int sidx, int c2i, c2 x) {
                 const cf sm = cadd(x.a, x.b), d = csub(x.a, x.b);
                 const cf e = make_float2(d.y, -d.x);  // (-i)(a-b)
                 v2f mine, send;
-                if (sidx < 2) {
+                if (sidx < RL / 2) {
                     wsv[sidx] = cmul(w0, w32(b + NBL * sidx));
                     const cf wo = cmul(wsv[sidx], e);  // sigma * W_N^k * (-i)(a-b)
                     mine = to_v2f(sm) + to_v2f(wo), send = to_v2f(sm) - to_v2f(wo);
@@ -1733,7 +1889,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                     // a product with -i is a swap and a sign: the twiddle of output t + 8 is not multiplied out, the -i
                     // rides in the addition's operand selectors.  (The product with (-i)(a-b) rounds its two partial
                     // products in the other order than before: an ulp of the bin, inside every bound the tests state.)
-                    const cf wb = cmul(wsv[sidx - 2], e);
+                    const cf wb = cmul(wsv[sidx - RL / 2], e);
                     mine = to_v2f(add_mi(sm, wb)), send = to_v2f(sub_mi(sm, wb));
                 }
                 mine.y = __uint_as_float(__float_as_uint(mine.y) ^ sgn_mine);
@@ -1769,14 +1925,14 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                     cf xk, xm;
                     const cf pz = exA[(L - c2i) & (L - 1)];
                     untangle_pair(exA[c2i], make_float2(pz.x, -pz.y), cmul(w0z, w32(t)), xk, xm);
-                    Xf[16 * c2i] = xk;  // line (0, c2), bin 0
-                    Pst[pst_at(c2i, 0)] = bin_power(xk);
+                    Xf[LINE * c2i] = xk;  // line (0, c2), bin 0
+                    Pst[pst_at<CP>(c2i, 0)] = bin_power(xk);
                     // bin N/2 is never normalised by the reference (src/fft_impl.cpp:156-160 visits
                     // k < N/2 only): X[N/2] = Re Z[0] - Im Z[0]
                     if (c2i == 0) Xf[(size_t)L << a.log2M1] = make_float2((exA[0].x - exA[0].y) * unscale, 0.f);  // after the M bins
                     const cf ph = exB[L - 1 - c2i];
                     untangle_pair(exB[c2i], make_float2(ph.x, -ph.y), cmul(w0h, w32(t)), xk, xm);
-                    Xf[16 * (L - 1 - c2i) + 15] = xk;  // row M1/2 closes tile 0's mirror octet, line (0, L-1-c2)
+                    Xf[LINE * (L - 1 - c2i) + LINE - 1] = xk;  // row M1/2 closes tile 0's mirror octet, line (0, L-1-c2)
                     seamC[c2i] = bin_power(xk);  // element 0 of the octet [M1/2, M1/2+8) at column c2
                 }
             }
@@ -1788,7 +1944,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
         {
             int8_t *Qf = a.Qt + (size_t)f * a.qt_stride;
             float *Pf = a.Pscr + (size_t)f * a.p_stride;
-            float *seamP = a.seamP + (size_t)s * L * 8;  // (seam_in only: those segments come first in the table)
+            float *seamP = a.seamP + (size_t)s * L * CP;  // (seam_in only: those segments come first in the table)
             constexpr int NG = 2 * L / NT;  // octets per thread: chunk q = 2*c2 + side
             // GRP octets at a time: their LDS reads (staging + carried row) are issued together, then the records
 #ifndef PSDR_OCT_GROUP
@@ -1797,6 +1953,45 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             constexpr int GRP = PSDR_OCT_GROUP;
             static_assert(NG % GRP == 0, "octet groups");
 #if PSDR_REC_SIDE_MAJOR
+            if constexpr (CP == 4) {
+                // Quartets (2048-point rows, four couples per tile): group kk of the thread is side kk & 1 of column
+                // (kk >> 1) * NT + tidx; a staging row is [low quartet | elements 1..3 of the high quartet, carry-out]: one
+                // 16-byte quarter per side.  Records of 8 bytes [q0 x4 | q1 x2 | q2 | pad], levels 0..2; the level-2 sum
+                // goes to Pf for the column tail.
+                const float4 *P4 = reinterpret_cast<const float4 *>(Pst);
+#pragma unroll
+                for (int k0 = 0; k0 < NG; k0 += GRP) {
+                    float4 v[GRP];
+                    float cin[GRP];
+#pragma unroll
+                    for (int j = 0; j < GRP; j++) {
+                        const int kk = k0 + j, sd = kk & 1, c2i = (kk >> 1) * NT + tidx;
+                        v[j] = P4[2 * c2i + sd];
+                        cin[j] = sd ? carry_r[c2i] : 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < GRP; j++) {
+                        const int kk = k0 + j, sd = kk & 1, c2i = (kk >> 1) * NT + tidx;
+                        float pw[4];
+                        if (sd) {  // high quartet: element 0 is the carried row, 1..3 sit at [0..3), slot 3 holds this tile's carry-out
+                            carry_w[c2i] = v[j].w;
+                            if (seg_last && g != 0)
+                                __hip_atomic_store(reinterpret_cast<unsigned *>(seamC) + c2i, __float_as_uint(v[j].w), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                            pw[0] = cin[j], pw[1] = v[j].x, pw[2] = v[j].y, pw[3] = v[j].z;
+                            if (seam_in) reinterpret_cast<float4 *>(seamP)[c2i] = v[j];  // no carry-in: k_real_seam completes the quartet
+                        } else {
+                            pw[0] = v[j].x, pw[1] = v[j].y, pw[2] = v[j].z, pw[3] = v[j].w;
+                        }
+                        const size_t rp = (size_t)g * (2 * L) + (size_t)sd * L + c2i;  // RecMap mode 2
+                        uint2 rec;
+                        pyr_record4(pw, a.size_log2, rec);
+                        *reinterpret_cast<uint2 *>(Qf + rp * 8) = rec;
+                        Pf[rp] = pw[0];
+                    }
+                    PSDR_SCHED_FENCE();
+                }
+            } else {
             // Octet kk of the thread: side = kk & 1 (known after unrolling: no per-lane selects), column c2 = (kk >> 1) * NT +
             // tidx - a wave's 64 records of one side are 1 KiB of adjacent records (RecMap mode 2: [tile][side][column]).
             static_assert(L16 % 4 == 0 && NT % 16 == 0, "quarter swizzle: constant per thread");
@@ -1848,6 +2043,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                 }
                 PSDR_SCHED_FENCE();
             }
+            }  // (CP == 8)
 #else
             const int side = tidx & 1;  // (NT is even: q = k * NT + tidx keeps its parity)
 #pragma unroll

@@ -37,7 +37,7 @@ static int next_tickets(psdr_ctx *c, int which, hipStream_t st, unsigned **out) 
 // every segment costs one seam (k_real_seam: 177 / 89 / 52 / 31 us at 4 / 8 / 16 / 32 tiles per segment,
 // run beside the next batch's pass 1, which it slows).
 int real_seg_len(const psdr_ctx *c, int nframes) {
-    const int G = c->M1 / 16;
+    const int G = c->M1 / c->T2;  // tiles of a frame
     if (c->seg_len_env > 0) {
         int sl = 1;
         while (sl * 2 <= c->seg_len_env && sl * 2 <= G) sl *= 2;
@@ -82,7 +82,7 @@ int real_seg_len(const psdr_ctx *c, int nframes) {
 //    a cost of 8 KiB of traffic per hand-off (a seam: 92 KiB and a record written twice).
 // tiles per segment from the top of a frame: G/4, G/4, G/4, G/8, ... 2, 1, 1 (tuning builds: PSDR_SEG_PLAN="32,16,8,8")
 static std::vector<int> seg_plan_lens(const psdr_ctx *c) {
-    const int G = c->M1 / 16;
+    const int G = c->M1 / c->T2;  // tiles of a frame
     std::vector<int> lens;
     if (const char *e = psdr_tuning_env("PSDR_SEG_PLAN")) {
         int sum = 0;
@@ -101,7 +101,7 @@ static std::vector<int> seg_plan_lens(const psdr_ctx *c) {
     return lens;
 }
 void seg_plan_counts(const psdr_ctx *c, int nframes, unsigned *nsegs, unsigned *nseam, bool *handoff) {
-    const int G = c->M1 / 16;
+    const int G = c->M1 / c->T2;  // tiles of a frame
     // (PSDR_SEG_LEN=n is the way back to uniform segments; tuning builds: PSDR_SEG_HANDOFF=0)
     // Which batches take the hand-off plan: those of more than one frame per work-group (cfg3's stream at 258 / 288 / 320 /
     // 384 / 448 / 512 frames: +11 / +29 / +25 / +12 / +6 / +1.5 % over the uniform segments of round 3; against the uniform
@@ -130,7 +130,7 @@ int seg_plan(psdr_ctx *c, int nframes, const psdr_ctx::SegPlan **out) {
     psdr_ctx::SegPlan sp;
     sp.nframes = nframes;
     seg_plan_counts(c, nframes, &sp.nsegs, &sp.nseam, &sp.handoff);
-    const int G = c->M1 / 16;
+    const int G = c->M1 / c->T2;  // tiles of a frame
     std::vector<uint4> tab(sp.nsegs);
     if (sp.handoff) {
         const std::vector<int> lens = seg_plan_lens(c);
@@ -202,8 +202,8 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     a1.l2t2 = ilog2((size_t)c->T2);
     // fused real: pass-2-tile-major by default (fft_pass.h, "Y layout"); PSDR_REAL_YBLOCKED=1: rows regrouped
     // inside the pass-1 tile's own linear block
-    a1.ytile = c->y_blocked ? (size_t)16 * (c->T1 * cols) : (size_t)c->M2 * c->T2;
-    a1.ytl = c->y_blocked ? a1.yblk : (size_t)16 * (c->T1 * cols);
+    a1.ytile = c->y_blocked ? (size_t)c->T2 * (c->T1 * cols) : (size_t)c->M2 * c->T2;
+    a1.ytl = c->y_blocked ? a1.yblk : (size_t)c->T2 * (c->T1 * cols);
     a1.yframe = c->M + c->y_pad;
     a1.wdelta = c->wdelta;
     a1.M2 = c->M2;
@@ -230,6 +230,8 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
         fl.abort = c->d_flow;
         fl.done1 = c->d_flow + 16;
         fl.done2 = c->d_flow + 16 + F;
+        fl.cnt1 = c->d_flow + 16 + 2 * F;
+        fl.cnt2 = c->d_flow + 16 + 3 * F;
         fl.ring = (unsigned)c->ring_frames;
         fl.tiles1 = tiles1;
         fl.tiles2 = tiles2;
@@ -241,7 +243,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
         fl.sticky = c->d_flow_sticky;
         a1.ymask = fl.ring - 1u;
         a1.flow = fl;
-        HIPCHK(hipMemsetAsync(c->d_flow, 0, (16 + 2 * (size_t)nframes) * sizeof(unsigned), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_flow, 0, (16 + 4 * F) * sizeof(unsigned), c->stream));
     }
     {
         int rc = next_tickets(c, 0, c->p1, &a1.tickets);
@@ -267,8 +269,8 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     a2.log2M1 = c->log2M1;
     a2.TW = c->T1 * cols;
     a2.yblk = a1.yblk;
-    a2.ytile = c->y_blocked ? (size_t)16 * (c->T1 * cols) : a1.ytile;
-    a2.yjs = c->y_blocked ? a1.yblk : (size_t)16 * (c->T1 * cols);
+    a2.ytile = c->y_blocked ? (size_t)c->T2 * (c->T1 * cols) : a1.ytile;
+    a2.yjs = c->y_blocked ? a1.yblk : (size_t)c->T2 * (c->T1 * cols);
     a2.yframe = a1.yframe;
     a2.log2TW = ilog2((size_t)(c->T1 * cols));
     a2.inv_n = 1.0f / (float)c->N;
@@ -385,6 +387,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
         sa.segmark = c->d_segflag + (size_t)(1 + c->cur_set) * c->seg_cap;
         sa.epoch = c->seg_epoch;
         sa.L = c->M2;
+        sa.cp = c->T2 / 2;
         sa.size_log2 = c->size_log2;
         sa.Qt = c->d_qt;
         sa.qt_stride = c->qt_stride;
@@ -401,8 +404,8 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     // tile-major sums of a fused pass 2 (rows of 1024 outputs): one thread per output row takes the
     // levels inside a row (k_col_tail), the generic kernel the few above
     const int ng = (int)(len >> c->log2M2);  // groups per output row
-    const bool col_tail = c->recmap.mapped && c->M2 == 1024 && c->recmap.l2gpt == 0 && (ng == 64 || ng == 128 || ng == 256) &&
-                          !c->no_col_tail;
+    const bool col_tail = c->recmap.mapped && (c->M2 == 1024 || (c->M2 == 2048 && c->real_fused)) && c->recmap.l2gpt == 0 &&
+                          (ng == 64 || ng == 128 || ng == 256) && !c->no_col_tail;
     if (col_tail && lvl + 1 < c->levels) {
         ColTailArgs t{};
         t.Pin = c->d_pscr[0];

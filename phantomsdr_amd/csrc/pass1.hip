@@ -4,18 +4,18 @@
 
 namespace psdr {
 
-template <int L, int T, int SB, bool PAIR = false>
+template <int L, int T, int SB, bool PAIR = false, int CP = 8>
 static int launch_pass1_t(psdr_ctx *c, const Pass1Args &a, unsigned blocks) {
     // tile + W_L (= first twiddle factor) + second twiddle factor (M2 entries)
     const size_t lds = (size_t)L * T * sizeof(cf) + (size_t)L * sizeof(cf) + (size_t)a.M2 * sizeof(cf);
     // (per context = per device: the attribute is a property of the function ON a device)
-    if (c->lds_attr_done.insert((const void *)k_fft_pass1<L, T, SB, PAIR>).second)
-        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass1<L, T, SB, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    if (c->lds_attr_done.insert((const void *)k_fft_pass1<L, T, SB, PAIR, CP>).second)
+        HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass1<L, T, SB, PAIR, CP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     ProfScope ps(c, K_PASS1, c->p1);
     // persistent: as many work-groups per CU as their LDS admits (a 128 KiB tile: one)
     unsigned grid = persistent_grid(c, blocks, lds);
     if (c->p1_grid && c->p1_grid < grid) grid = c->p1_grid;
-    hipLaunchKernelGGL((k_fft_pass1<L, T, SB, PAIR>), dim3(grid), dim3(L * T / 32), lds, c->p1, a);
+    hipLaunchKernelGGL((k_fft_pass1<L, T, SB, PAIR, CP>), dim3(grid), dim3(L * T / 32), lds, c->p1, a);
     HIPCHK(hipGetLastError());
     return PSDR_OK;
 }
@@ -35,6 +35,11 @@ static int launch_pass1_t(psdr_ctx *c, const Pass1Args &a, unsigned blocks) {
 // sb: bytes per complex sample slot of the raw image (2, 4, 8); pair: the real-input form feeding k_fft_pass2_real
 int launch_pass1(psdr_ctx *c, int L, int T, int sb, const Pass1Args &a, unsigned blocks, bool pair) {
     if (pair) {
+        if (L == 1024 && T == 16 && a.l2t2 == 3) {  // pass-2 tiles of 8 rows = four (row, mirror row) couples: 2048-point rows (1024 x 2048)
+            if (sb == 2) return launch_pass1_t<1024, 16, 2, true, 4>(c, a, blocks);
+            if (sb == 4) return launch_pass1_t<1024, 16, 4, true, 4>(c, a, blocks);
+            return launch_pass1_t<1024, 16, 8, true, 4>(c, a, blocks);
+        }
         P1PAIR(1024, 16)
         P1PAIR(2048, 8)
         return fail(PSDR_ERR_UNSUPPORTED, "no paired pass-1 kernel for L=%d T=%d", L, T);

@@ -44,11 +44,11 @@ int launch_pass2_band(psdr_ctx *c, const Pass2Args &a, unsigned blocks) {
                       : launch_pass2_t<1024, 16, true, 8, true>(c, a, blocks);
 }
 
-// fused real-input pass 2 (TWC = pass-1 tile width: 16 for 1024 x 1024, 8 for 2048 x 1024)
-template <int TWC>
+// fused real-input pass 2 (TWC = pass-1 tile width: 16 for 1024 x 1024, 8 for 2048 x 1024; rows of 2048 points: 1024 x 2048,
+// tiles of four couples, ONE carried-row buffer)
+template <int L, int T, int TWC>
 static int launch_pass2_real_t(psdr_ctx *c, const Pass2Args &a) {
-    constexpr int L = 1024, T = 16;
-    constexpr size_t lds = (size_t)L * T * sizeof(cf) + (size_t)L * sizeof(cf) + 2 * (size_t)L * sizeof(float);
+    constexpr size_t lds = (size_t)L * T * sizeof(cf) + (size_t)L * sizeof(cf) + (L == 2048 ? 1 : 2) * (size_t)L * sizeof(float);
     // (per context = per device: the attribute is a property of the function ON a device)
     if (c->lds_attr_done.insert((const void *)k_fft_pass2_real<L, T, TWC>).second)
         HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass2_real<L, T, TWC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -60,7 +60,8 @@ static int launch_pass2_real_t(psdr_ctx *c, const Pass2Args &a) {
     return PSDR_OK;
 }
 int launch_pass2_real(psdr_ctx *c, const Pass2Args &a) {
-    return a.TW == 16 ? launch_pass2_real_t<16>(c, a) : launch_pass2_real_t<8>(c, a);
+    if (c->M2 == 2048) return launch_pass2_real_t<2048, 8, 16>(c, a);
+    return a.TW == 16 ? launch_pass2_real_t<1024, 16, 16>(c, a) : launch_pass2_real_t<1024, 16, 8>(c, a);
 }
 
 }  // namespace psdr

@@ -171,6 +171,7 @@ __device__ __forceinline__ void pyr_levels(float (&p)[CH], int8_t *Qf, size_t qo
 // Instead the device keeps levels 0..LT of group g = c / CH in ONE record of 2*CH bytes:
 //   CH = 16: [q0 x16 | q1 x8 | q2 x4 | q3 x2 | q4 | pad]     (offsets 0,16,24,28,30)
 //   CH =  8: [q0 x8 | q1 x4 | q2 x2 | q3 | pad]              (offsets 0, 8,12,14)
+//   CH =  4: [q0 x4 | q1 x2 | q2 | pad]                      (offsets 0, 4, 6; the fused real pass with 2048-point rows)
 // Consumers on the GPU (waterfall gather) index the records directly; the reference's
 // level-major layout (src/fft_impl.cpp:162-172) is produced on demand by k_untile_q.
 // Record ORDER: tile-major.  The pass-2 work-group that owns rows c1base..c1base+T-1 writes
@@ -186,8 +187,8 @@ struct RecMap {
     int l2tpr, l2gpt, l2rows;
     int mapped;  // 0: identity (level-major producers: the three-pass real-input path)
                  // 1: IQ tile-major (above)
-                 // 2: fused real-input pass 2 (k_fft_pass2_real): octet o = k / 8 of bin k lives in
-                 //    row c2 = o / tpr (tpr = M1/8 octets per row); the lower half of a row's octets
+                 // 2: fused real-input pass 2 (k_fft_pass2_real): octet (or quartet: CH = the couples of a tile) o = k / CH
+                 //    of bin k lives in row c2 = o / tpr (tpr = M1/CH groups per row); the lower half of a row's octets
                  //    belongs to tile g = o % tpr as its LOW octet, the upper half to tile
                  //    g = tpr - 1 - o % tpr as its HIGH octet: pos = (g * 2 + side) * rows + c2 (a tile's low octets,
                  //    then its high octets: a wave of the octet loop stores 64 adjacent records of ONE side)
@@ -222,7 +223,9 @@ struct RecMap {
 //           [ rows 8g..8g+7 of column c | the mirror octet of tile g of column L-1-c ]; the mirror
 //           octet of tile g is rows M1-8g-7..M1-8g ascending (g = 0: its last element is row M1/2
 //           instead of "row M1").  The halves of a line are the two real-signal bins a
-//           (row, mirror row) couple produces together.
+//           (row, mirror row) couple produces together.  With 2048-point rows (2^22-point real frames
+//           split 1024 x 2048) a tile holds CP = 4 couples: lines of 8 bins, [ rows 4g..4g+3 | mirror
+//           quartet ] (l2cp = 2; 3 for the octets above).
 //   mode 3  IQ, BANDED (band sharding, psdr_set_band_layout): the columns are split into 2^(l2L - l2Lb) bands of
 //           Lb = 2^l2Lb columns; band b owns one region of the buffer (band_stride bins apart) that holds ALL frames of
 //           the batch, each frame as tiles of Lw = Lb + halo lines: line (tl, c2) of mode 1 is line tl * Lw + (c2 & (Lb-1))
@@ -236,6 +239,7 @@ struct SpecLayout {
     int k0;  // mode 0 only: the buffer starts at bin k0 (a band of the spectrum, psdr_demod_batch_from_band)
     int l2Lb, Lw, c2_0;  // modes 3, 4
     size_t band_stride;  // mode 3
+    int l2cp;            // mode 2: log2 of the couples per tile (3: lines of 16 bins; 2: lines of 8)
     __host__ __device__ __forceinline__ size_t pos(int k) const {
         if (!mode) return (size_t)(k - k0);
         const int c1 = k & (m1 - 1), c2 = k >> l2m1;
@@ -247,10 +251,11 @@ struct SpecLayout {
             if (cl < 0) cl += L;  // the last band's halo is the spectrum's first column
             return ((((size_t)(c1 >> 4) * Lw) + cl) << 4) + (c1 & 15);
         }
-        if (c1 < (m1 >> 1)) return ((((size_t)(c1 >> 3) << l2L) + c2) << 4) + (c1 & 7);
+        const int cp = 1 << l2cp;
+        if (c1 < (m1 >> 1)) return ((((size_t)(c1 >> l2cp) << l2L) + c2) << (l2cp + 1)) + (c1 & (cp - 1));
         const int hp = c1 == (m1 >> 1) ? m1 - 1 : c1 - 1;  // rows above M1/2 shift down, M1/2 goes last
-        const int g = (m1 - 1 - hp) >> 3;
-        return ((((size_t)g << l2L) + (L - 1 - c2)) << 4) + 8 + (hp & 7);
+        const int g = (m1 - 1 - hp) >> l2cp;
+        return ((((size_t)g << l2L) + (L - 1 - c2)) << (l2cp + 1)) + cp + (hp & (cp - 1));
     }
 };
 
@@ -288,6 +293,15 @@ __device__ __forceinline__ void pyr_record8(float (&p)[8], int size_log2, uint4 
     rec.w = pack2(p[0], p[1], size_log2 - 2);
     p[0] = __fadd_rn(p[0], p[1]);
     rec.w |= quantize_u8(p[0], size_log2 - 3) << 16;
+}
+
+__device__ __forceinline__ void pyr_record4(float (&p)[4], int size_log2, uint2 &rec) {
+    rec.x = pack4(p[0], p[1], p[2], p[3], size_log2);
+    p[0] = __fadd_rn(p[0], p[1]);
+    p[1] = __fadd_rn(p[2], p[3]);
+    rec.y = pack2(p[0], p[1], size_log2 - 1);
+    p[0] = __fadd_rn(p[0], p[1]);
+    rec.y |= quantize_u8(p[0], size_log2 - 2) << 16;
 }
 
 }  // namespace psdr

@@ -97,6 +97,9 @@ class HipFanout {
     // copy of all clients' results into pinned host memory (psdr_fetch_batch) - the per-client tasks the server posts
     // afterwards only read that block.  frame_num is the server's counter before its increment.  Returns false when
     // there is nothing to send yet (fewer than two half-frames).
+    // ONE frame per call: a window / mode / pause change made between two calls lands on exactly the frame the reference's
+    // next send_audio would have used it for (INTEGRATION.md "Command timing"; with larger batches - psdr_process_batch
+    // with F > 1 - a change lands on the next batch boundary instead).
     bool process_frame(uint64_t frame_num) {
         if (next_half < 2) return false;
         const uint64_t first = next_half - 2;

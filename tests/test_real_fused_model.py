@@ -18,26 +18,26 @@ import numpy as np
 import pytest
 
 
-def spec_layout_pos(k, M1, M2):
-    """SpecLayout::pos (quantize.h): 128-byte lines [low octet of column c | mirror octet of column L-1-c],
-    tile-major (line (g, c) = g*L + c)"""
+def spec_layout_pos(k, M1, M2, CP=8):
+    """SpecLayout::pos (quantize.h): lines of 2 CP bins [low octet of column c | mirror octet of column L-1-c],
+    tile-major (line (g, c) = g*L + c); CP = couples per tile: 8 (128-byte lines), or 4 with 2048-point rows"""
     c1, c2 = k % M1, k // M1
     if c1 < M1 // 2:
-        return ((c1 // 8) * M2 + c2) * 16 + c1 % 8
+        return ((c1 // CP) * M2 + c2) * (2 * CP) + c1 % CP
     hp = M1 - 1 if c1 == M1 // 2 else c1 - 1
-    g = (M1 - 1 - hp) // 8
-    return (g * M2 + (M2 - 1 - c2)) * 16 + 8 + hp % 8
+    g = (M1 - 1 - hp) // CP
+    return (g * M2 + (M2 - 1 - c2)) * (2 * CP) + CP + hp % CP
 
 
-def recmap2_pos(o, M1, M2):
-    tpr = M1 // 8
+def recmap2_pos(o, M1, M2, CP=8):
+    tpr = M1 // CP
     row, gc = o // tpr, o % tpr
     side = 1 if gc >= tpr // 2 else 0
     tl = tpr - 1 - gc if side else gc
     return ((tl * M2) + row) * 2 + side
 
 
-def pass1_pair(z, M1, M2):
+def pass1_pair(z, M1, M2, CP=8):
     """Y slots [M1][M2] as pass 1 stores them in PAIR mode"""
     M = M1 * M2
     zz = z.reshape(M1, M2)                       # z[M2*n1 + n2]
@@ -48,12 +48,12 @@ def pass1_pair(z, M1, M2):
     cW = np.exp(-2j * np.pi * n2 / M2)
     for c1 in range(M1):
         if c1 < M1 // 2:
-            slots[16 * (c1 // 8) + c1 % 8] = Y[c1]
+            slots[2 * CP * (c1 // CP) + c1 % CP] = Y[c1]
         elif c1 == M1 // 2:
-            slots[8] = Y[c1]                     # natural form, beside row 0 (couple 0 of tile 0)
+            slots[CP] = Y[c1]                    # natural form, beside row 0 (couple 0 of tile 0)
         else:
             m = M1 - c1
-            slots[16 * (m // 8) + 8 + m % 8] = np.conj(Y[c1]) * cW
+            slots[2 * CP * (m // CP) + CP + m % CP] = np.conj(Y[c1]) * cW
     return slots
 
 
@@ -111,14 +111,14 @@ def seg_plan(G, nframes, num_cus=256, seg_len_env=0, static_tiles=False):
     return tab, False, len(tab)
 
 
-def fused_pass2(slots, M1, M2, seg_len):
+def fused_pass2(slots, M1, M2, seg_len, CP=8):
     """uniform segments of seg_len tiles, every one with a seam (small batches, PSDR_SEG_LEN)"""
-    G = M1 // 16
+    G = M1 // (2 * CP)
     S = G // seg_len
-    return fused_pass2_segments(slots, M1, M2, [((si + 1) * seg_len - 1, seg_len, (si + 1) % S, False) for si in range(S)])
+    return fused_pass2_segments(slots, M1, M2, [((si + 1) * seg_len - 1, seg_len, (si + 1) % S, False) for si in range(S)], CP)
 
 
-def fused_pass2_segments(slots, M1, M2, segs):
+def fused_pass2_segments(slots, M1, M2, segs, CP=8):
     """One frame.  segs[i] = (first tile, tiles, index of the segment above, carry-in through memory); processed in the
     order given (a segment with a carry-in through memory needs its predecessor's carry-out: the order must provide it,
     as the ticket order of the kernel does).  Returns (permuted spectrum [M+1], records dict pos -> 8 powers)."""
@@ -131,33 +131,34 @@ def fused_pass2_segments(slots, M1, M2, segs):
         carry = seamC[above].copy() if carry_mem else None   # (KeyError: the plan handed the segments out in a wrong order)
         for j in range(seg_len):
             g = g_first - j
-            low = np.zeros((M2, 8))
-            high = np.zeros((M2, 8))
+            LN = 2 * CP
+            low = np.zeros((M2, CP))
+            high = np.zeros((M2, CP))
             carry_w = np.zeros(M2)
-            for p in range(8):
-                a = np.fft.fft(slots[16 * g + p])
-                b = np.fft.fft(slots[16 * g + 8 + p])
-                c1 = 8 * g + p
+            for p in range(CP):
+                a = np.fft.fft(slots[LN * g + p])
+                b = np.fft.fft(slots[LN * g + CP + p])
+                c1 = CP * g + p
                 if g == 0 and p == 0:
                     # row 0 <-> itself at column (M2-c2) % M2; row M1/2 <-> itself at column M2-1-c2
                     w = np.exp(-2j * np.pi * (M1 * c2) / N)
                     xk, _ = untangle_pair(a, np.conj(a[(M2 - c2) % M2]), w, h)
-                    X[16 * c2] = xk                       # line (0, c2), bin 0
+                    X[LN * c2] = xk                       # line (0, c2), bin 0
                     low[:, 0] = np.abs(xk) ** 2
                     X[M] = a[0].real - a[0].imag
                     w = np.exp(-2j * np.pi * (M1 // 2 + M1 * c2) / N)
                     xk, _ = untangle_pair(b, np.conj(b[M2 - 1 - c2]), w, h)
-                    X[16 * (M2 - 1 - c2) + 15] = xk       # row M1/2 closes tile 0's mirror octet
+                    X[LN * (M2 - 1 - c2) + LN - 1] = xk   # row M1/2 closes tile 0's mirror octet
                     seamC[si] = np.abs(xk) ** 2
                     continue
                 w = np.exp(-2j * np.pi * (c1 + M1 * c2) / N)
                 xk, xm = untangle_pair(a, b, w, h)
                 cm = M2 - 1 - c2
-                X[(g * M2 + c2) * 16 + p] = xk            # both halves of line (g, c2)
-                X[(g * M2 + c2) * 16 + 15 - p] = xm
+                X[(g * M2 + c2) * LN + p] = xk            # both halves of line (g, c2)
+                X[(g * M2 + c2) * LN + LN - 1 - p] = xm
                 low[:, p] = np.abs(xk) ** 2
                 if p:
-                    high[cm, 8 - p] = np.abs(xm) ** 2
+                    high[cm, CP - p] = np.abs(xm) ** 2
                 else:
                     carry_w[cm] = np.abs(xm) ** 2
                     if j == seg_len - 1:
@@ -181,24 +182,27 @@ def fused_pass2_segments(slots, M1, M2, segs):
     return X, rec
 
 
-@pytest.mark.parametrize("M1,M2,seg_len", [(32, 16, 1), (32, 16, 2), (64, 8, 2), (64, 8, 4), (16, 16, 1)])
-def test_fused_real_pass2_model_matches_rfft(M1, M2, seg_len):
+@pytest.mark.parametrize("M1,M2,seg_len,CP", [(32, 16, 1, 8), (32, 16, 2, 8), (64, 8, 2, 8), (64, 8, 4, 8), (16, 16, 1, 8),
+                                              (32, 16, 1, 4), (32, 16, 2, 4), (32, 64, 4, 4), (16, 32, 2, 4), (8, 16, 1, 4)])
+def test_fused_real_pass2_model_matches_rfft(M1, M2, seg_len, CP):
+    """CP = 8: tiles of eight (row, mirror row) couples, octet records (1024-point rows); CP = 4: four couples, quartet
+    records, lines of 8 bins (2048-point rows: 2^22-point real frames split 1024 x 2048)"""
     M, N = M1 * M2, 2 * M1 * M2
     rng = np.random.default_rng(M1 + seg_len)
     x = rng.standard_normal(N)
     z = x[0::2] + 1j * x[1::2]
-    Xp, rec = fused_pass2(pass1_pair(z, M1, M2), M1, M2, seg_len)
+    Xp, rec = fused_pass2(pass1_pair(z, M1, M2, CP), M1, M2, seg_len, CP)
     ref = np.fft.rfft(x) / N
     ref[M] *= N                                   # bin N/2 stays un-normalised
-    pos = np.array([spec_layout_pos(int(k), M1, M2) for k in range(M)])
+    pos = np.array([spec_layout_pos(int(k), M1, M2, CP) for k in range(M)])
     assert sorted(pos) == list(range(M))          # a permutation: every line written exactly once
     got = np.concatenate([Xp[pos], Xp[M:]])
     assert np.abs(got - ref).max() < 1e-12 * np.abs(ref).max() * N
-    # octet records in true k order through RecMap mode 2
+    # octet (quartet) records in true k order through RecMap mode 2
     P = np.abs(ref[:M]) ** 2
-    assert len(rec) == M // 8
-    for o in range(M // 8):
-        assert np.allclose(rec[recmap2_pos(o, M1, M2)], P[8 * o: 8 * o + 8], rtol=1e-9, atol=0), o
+    assert len(rec) == M // CP
+    for o in range(M // CP):
+        assert np.allclose(rec[recmap2_pos(o, M1, M2, CP)], P[CP * o: CP * o + CP], rtol=1e-9, atol=0), o
 
 
 @pytest.mark.parametrize("G,nframes", [(64, 512), (128, 512), (64, 640), (16, 600), (64, 513), (64, 511), (64, 256), (64, 1), (128, 7), (64, 320), (64, 160), (128, 160),
@@ -231,24 +235,24 @@ def test_segment_plan_partitions_frames_and_orders_the_hand_offs(G, nframes):
         assert len(tab) == nframes * (4 + int(np.log2(G // 8)) + 1)
 
 
-@pytest.mark.parametrize("M1,M2", [(256, 8), (512, 4)])
-def test_fused_real_pass2_model_with_the_hand_off_plan(M1, M2):
+@pytest.mark.parametrize("M1,M2,CP", [(256, 8, 8), (512, 4, 8), (128, 8, 4), (256, 16, 4)])
+def test_fused_real_pass2_model_with_the_hand_off_plan(M1, M2, CP):
     """the hand-off plan's segments of one frame (G/4, G/4, G/4, G/8 ... 1, 1 tiles from the top, carry-in through
     memory for all but the first) through the model: same spectrum and records as numpy.fft.rfft"""
-    M, N, G = M1 * M2, 2 * M1 * M2, M1 // 16
+    M, N, G = M1 * M2, 2 * M1 * M2, M1 // (2 * CP)
     tab, handoff, _ = seg_plan(G, 512)
     assert handoff
     segs = [(g0, ln, above // 512, mem) for (f, g0, ln, above, mem) in tab if f == 0]
     rng = np.random.default_rng(M1)
     x = rng.standard_normal(N)
     z = x[0::2] + 1j * x[1::2]
-    Xp, rec = fused_pass2_segments(pass1_pair(z, M1, M2), M1, M2, segs)
+    Xp, rec = fused_pass2_segments(pass1_pair(z, M1, M2, CP), M1, M2, segs, CP)
     ref = np.fft.rfft(x) / N
     ref[M] *= N
-    pos = np.array([spec_layout_pos(int(k), M1, M2) for k in range(M)])
+    pos = np.array([spec_layout_pos(int(k), M1, M2, CP) for k in range(M)])
     got = np.concatenate([Xp[pos], Xp[M:]])
     assert np.abs(got - ref).max() < 1e-12 * np.abs(ref).max() * N
     P = np.abs(ref[:M]) ** 2
-    assert len(rec) == M // 8
-    for o in range(M // 8):
-        assert np.allclose(rec[recmap2_pos(o, M1, M2)], P[8 * o: 8 * o + 8], rtol=1e-9, atol=0), o
+    assert len(rec) == M // CP
+    for o in range(M // CP):
+        assert np.allclose(rec[recmap2_pos(o, M1, M2, CP)], P[CP * o: CP * o + CP], rtol=1e-9, atol=0), o

@@ -15,8 +15,8 @@ import csv
 import json
 import sys
 
-WIDE_READ = ("k_fft_pass1", "k_fft_pass2", "k_untangle_real")
-SHORT = {"k_fft_pass1": "fft_pass1", "k_fft_pass2": "fft_pass2", "k_untangle_real": "untangle_real",
+WIDE_READ = ("k_fft_pass1", "k_fft_pass2", "k_fft_fused", "k_untangle_real")
+SHORT = {"k_fft_fused": "fft_fused", "k_fft_pass1": "fft_pass1", "k_fft_pass2": "fft_pass2", "k_untangle_real": "untangle_real",
          "k_pyramid_tail": "pyramid_tail", "k_col_tail": "col_tail", "k_real_seam": "real_seam", "k_demod_idft": "demod_idft", "k_demod_chain": "demod_chain", "k_demod_ola": "demod_ola",
          "k_waterfall_gather": "waterfall_gather", "k_untile_q": "untile_q"}
 
