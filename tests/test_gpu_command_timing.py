@@ -33,7 +33,7 @@ def test_a_command_between_two_batches_lands_on_the_next_batchs_first_frame(n, i
     from phantomsdr_amd import AudioClient, Context
     N = 1 << 15
     R = N // 2 if is_real else N
-    nframes = 12
+    nframes = 16  # (F = 4: the commands before frames 5, 7 and 9 land on the batches that start at frames 8 and 12)
     levels = levels_for(R)
     x = synth_stream((nframes + 1) * (N // 2), bool(is_real), seed=5, fft_size=N)
     raw = quantize_raw(x, "s16", bool(is_real))
