@@ -161,8 +161,7 @@ void free_all(psdr_ctx *c) {
     for (auto &sp : c->seg_plans) F(sp.d_tab);
     F(c->d_tickets[0]);
     F(c->d_tickets[1]);
-    F(c->y_pool[0]);
-    F(c->y_pool[1]);
+    F(c->d_Y);
     F(c->d_Z);
     for (int s = 0; s < 2; s++) {
         F(c->spec_pool[s]);
@@ -206,11 +205,8 @@ void free_all(psdr_ctx *c) {
     if (c->ev_fft_done) hipEventDestroy(c->ev_fft_done);
     if (c->ev_side_done) hipEventDestroy(c->ev_side_done);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
-    if (c->own_p1) hipStreamDestroy(c->own_p1);
     if (c->ev_in) hipEventDestroy(c->ev_in);
     for (int i = 0; i < 2; i++) {
-        if (c->ev_p1[i]) hipEventDestroy(c->ev_p1[i]);
-        if (c->ev_p2[i]) hipEventDestroy(c->ev_p2[i]);
     }
     if (c->own_side) hipStreamDestroy(c->own_side);
     if (c->side2) hipStreamDestroy(c->side2);
@@ -233,40 +229,21 @@ int build(psdr_ctx *c) {
         HIPCHK(hipGetDeviceProperties(&prop, c->device));
         c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    if (const char *e = psdr_tuning_env("PSDR_MAIN_PRIO")) {  // (tuning) 1: the passes' stream at the highest priority
-        int lo = 0, hi = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIPCHK(hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, atoi(e) > 0 ? hi : lo));
-    } else {
-        HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    }
+    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     {
         // the consumers are short kernels that must squeeze in next to the persistent FFT
-        // work-groups: give their stream the highest priority
+        // work-groups: give their stream the highest priority (the other way round, and the passes' stream at the
+        // highest, measured within +-1 %: docs/history.md section 5)
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        int pr = hi;
-        if (const char *e = psdr_tuning_env("PSDR_SIDE_PRIO")) pr = atoi(e) > 0 ? lo : (atoi(e) == 0 ? (lo + hi) / 2 : hi);  // 1: lowest, 0: middle
-        HIPCHK(hipStreamCreateWithPriority(&c->own_side, hipStreamNonBlocking, pr));
+        HIPCHK(hipStreamCreateWithPriority(&c->own_side, hipStreamNonBlocking, hi));
     }
-    HIPCHK(hipStreamCreateWithFlags(&c->own_p1, hipStreamNonBlocking));
     c->stream = c->own_stream;
     c->side = c->own_side;
-    c->static_tiles = psdr_tuning_env("PSDR_STATIC_TILES") != nullptr;
-    if (const char *e = psdr_tuning_env("PSDR_Y_PAD")) c->y_pad = (size_t)atoi(e) & ~(size_t)15;
-    c->no_col_tail = psdr_tuning_env("PSDR_NO_COL_TAIL") != nullptr;
-    // pass 1 on its own stream overlaps the two passes of consecutive batches; it pays only when
-    // both batches' intermediates fit the 256 MiB MALL together (measured: F=16 2^20-point frames
-    // lose 12 %, F>=32 gain nothing), so it is opt-in
-    c->no_p1_stream = psdr_tuning_env("PSDR_P1_STREAM") == nullptr;
-    if (const char *e = psdr_tuning_env("PSDR_P1_GRID")) c->p1_grid = (unsigned)atoi(e) & ~7u;
-    if (const char *e = psdr_tuning_env("PSDR_P2_GRID")) c->p2_grid = (unsigned)atoi(e) & ~7u;
-    c->p1 = c->no_p1_stream ? c->own_stream : c->own_p1;
+    // (both passes run on `stream`; the first pass of batch b+1 on a stream of its own beside the second pass of batch b
+    // was measured in rounds 1-3 - -12 % at F = 16, nothing from F = 32 on - and taken out in round 5)
+    c->p1 = c->own_stream;
     HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
-    for (int i = 0; i < 2; i++) {
-        HIPCHK(hipEventCreateWithFlags(&c->ev_p1[i], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_p2[i], hipEventDisableTiming));
-    }
     HIPCHK(hipEventCreateWithFlags(&c->ev_fft_done, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&c->t0));
@@ -315,16 +292,13 @@ int build(psdr_ctx *c) {
         HIPCHK(hipMalloc((void **)&c->d_tickets[i], TICKET_SLOTS * 8 * sizeof(unsigned)));
         HIPCHK(hipMemset(c->d_tickets[i], 0, TICKET_SLOTS * 8 * sizeof(unsigned)));
     }
-    // the second Y buffer only exists when pass 1 runs on its own stream (PSDR_P1_STREAM)
-    for (int i = 0; i < (c->no_p1_stream ? 1 : 2); i++)
-        HIPCHK(hipMalloc((void **)&c->y_pool[i], F * (c->M + c->y_pad) * sizeof(cf)));
+    HIPCHK(hipMalloc((void **)&c->d_Y, F * c->M * sizeof(cf)));
     if (c->is_real && !c->real_fused) HIPCHK(hipMalloc((void **)&c->d_Z, F * c->M * sizeof(cf)));
     if (!c->is_real && c->lay.mode) HIPCHK(hipMalloc((void **)&c->d_Z, (c->M + 2) * sizeof(cf)));  // k-order staging
     if (c->real_fused) {
         // one frame of k-order staging for psdr_read_spectrum / psdr_get_output_buffer
         HIPCHK(hipMalloc((void **)&c->d_Z, (c->M + 2) * sizeof(cf)));
         if (const char *e = getenv("PSDR_SEG_LEN")) c->seg_len_env = atoi(e);
-        c->y_blocked = psdr_tuning_env("PSDR_REAL_YBLOCKED") != nullptr;
         size_t cap = 0, capc = 0;
         for (int nf = 1; nf <= c->max_batch; nf++) {
             unsigned ns, nm;
@@ -439,8 +413,6 @@ int build(psdr_ctx *c) {
             rc = upload(&c->d_stage_tab, tab);
             if (rc) return rc;
             c->idft_threads = n <= 512 ? 128 : 256;
-            c->idft_block = psdr_tuning_env("PSDR_IDFT_BLOCK") != nullptr;
-            c->idft_generic = psdr_tuning_env("PSDR_IDFT_GENERIC") != nullptr;
             if (const char *e = getenv("PSDR_DEMOD_CHAIN")) c->demod_chain = atoi(e) != 0;
             if (const char *e = getenv("PSDR_DEMOD_K")) c->demod_chain_k = std::max(1, atoi(e));
         }
@@ -527,7 +499,6 @@ extern "C" int psdr_create(const psdr_config *cfg, psdr_ctx **out) {
     c->M1 = 1 << c->log2M1;
     c->M2 = 1 << c->log2M2;
     c->T1 = pick_T(c->M1, c->M2);
-    if (const char *e = psdr_tuning_env("PSDR_T1")) c->T1 = std::min(c->T1, std::max(8, atoi(e)));  // tuning: narrower pass-1 tiles, several work-groups per CU
     c->T2 = pick_T(c->M2, c->M1);
     c->size_log2 = (int)std::lround(std::log2((double)N)) + cfg->brightness_offset;
     c->levels = cfg->downsample_levels;
@@ -944,8 +915,7 @@ extern "C" int psdr_set_stream(psdr_ctx *c, void *hip_stream) {
     } else {
         c->stream = c->own_stream;
         c->side = c->own_side;
-        c->p1 = c->no_p1_stream ? c->own_stream : c->own_p1;
+        c->p1 = c->own_stream;
     }
-    c->y_pending[0] = c->y_pending[1] = false;
     return PSDR_OK;
 }

@@ -140,7 +140,6 @@ struct psdr_ctx {
     bool real_fused = false;
     SpecLayout lay{};                // device layout of the spectrum (natural unless real_fused)
     int nbands = 0, band_H = 0;      // psdr_set_band_layout: band regions (SpecLayout mode 3), halo columns per band
-    bool y_blocked = false;          // PSDR_REAL_YBLOCKED (tuning)
     // Both passes in ONE launch with Y as a ring of a few frames that stays in the Infinity Cache (fft_pass.h: FlowArgs,
     // k_fft_fused): 2^20- and 2^21-point IQ frames, batches of ring_min_batch frames and more (smaller ones fit the cache
     // anyway and keep the two launches).  PSDR_RING=0 switches it off, PSDR_RING_FRAMES / PSDR_RING_P1_WGS size it.
@@ -180,24 +179,18 @@ struct psdr_ctx {
     // batch (pyramid tail, demodulation, waterfall gather) runs on `side`, so it overlaps
     // the next batch's pass 1 (its work-groups fit next to the persistent FFT work-groups).
     hipStream_t stream = nullptr, side = nullptr;
-    hipStream_t own_stream = nullptr, own_side = nullptr, own_p1 = nullptr;
+    hipStream_t own_stream = nullptr, own_side = nullptr;
     // pass 1 runs on its own stream so that pass 1 of batch i+1 fills the CUs that pass 2 of
     // batch i leaves one by one (persistent work-groups: launch ramp, prologue and tail of one
     // kernel overlap with the other kernel's steady state); Y is double-buffered for that
     hipStream_t p1 = nullptr;
-    cf *y_pool[2] = {nullptr, nullptr};
-    size_t y_pad = 0;  // complex elements between the frames of Y beyond M (tuning: PSDR_Y_PAD)
-    int cur_y = 0;
-    bool y_pending[2] = {false, false};
+    cf *d_Y = nullptr;  // the inter-pass array, max_batch frames of M complex values
     // TileQueue counters: a ring of TICKET_SLOTS launches x 8 counters per pass; half the ring is
     // re-zeroed (in stream order) whenever the other half starts being used
     unsigned *d_tickets[2] = {nullptr, nullptr};
     unsigned ticket_pos[2] = {0, 0};
-    bool no_col_tail = false;  // tuning (PSDR_NO_COL_TAIL=1)
-    bool static_tiles = false, no_p1_stream = true;  // tuning knobs (PSDR_STATIC_TILES, PSDR_P1_STREAM)
-    unsigned p1_grid = 0, p2_grid = 0;  // PSDR_P1_GRID / PSDR_P2_GRID: work-groups of each pass (0: all CUs)
     bool input_on_main = false;  // level-1 H2D staging was enqueued on the main stream
-    hipEvent_t ev_in = nullptr, ev_p1[2] = {nullptr, nullptr}, ev_p2[2] = {nullptr, nullptr};
+    hipEvent_t ev_in = nullptr;
     hipEvent_t ev_fft_done = nullptr, ev_side_done = nullptr;
     bool side_pending = false;
     // Result buffers (spectrum, pyramid, level powers) exist twice: batch b+1 is produced
@@ -244,8 +237,6 @@ struct psdr_ctx {
     size_t idft_lds = 0;
     int4 *d_stage_tab = nullptr;
     int idft_threads = 256;
-    bool idft_generic = false;  // tuning (PSDR_IDFT_GENERIC=1): never the compile-time plans
-    bool idft_block = false;  // tuning (PSDR_IDFT_BLOCK=1): force the one-work-group-per-item kernel
     cf *d_Wn = nullptr, *d_ypost = nullptr, *d_gscratch = nullptr, *d_bb_tail = nullptr,
        *d_bb_last = nullptr;
     // post-demodulation chain (postchain.h), allocated by psdr_set_post_chain

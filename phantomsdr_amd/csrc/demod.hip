@@ -197,7 +197,7 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     bool ola_done = false;
     {
         ProfScope ps(c, K_IDFT, c->side);
-        const bool fixed_plan = (c->n == 360 || c->n == 720) && !c->idft_block && !c->idft_generic;
+        const bool fixed_plan = c->n == 360 || c->n == 720;
         if (fixed_plan && c->demod_chain) {
             // transform + overlap-add + demodulation in one kernel, one wave per chain of K consecutive frames of a
             // client (demod.h): long chains repeat fewer transforms (1 or 2 per chain), short ones give few clients
@@ -231,7 +231,7 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
             else
                 hipLaunchKernelGGL((k_demod_idft_fixed<720, 8, 9, 10>), dim3((items + W - 1) / W), dim3(64 * W), lds,
                                    c->side, a, nact);
-        } else if (c->n <= 512 && !c->idft_block) {
+        } else if (c->n <= 512) {
             // one wave per (client, frame), no work-group barriers (demod.h)
             const unsigned items = (unsigned)nact * (unsigned)nframes;
             const size_t lds = (size_t)(2 * PSDR_IDFT_WAVES + 1) * c->n * sizeof(cf);

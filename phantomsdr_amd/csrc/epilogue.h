@@ -170,14 +170,8 @@ __global__ __launch_bounds__(64, PSDR_CT_WPE) void k_col_tail(ColTailArgs a) {
             float lo[16], hi[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-#if PSDR_REC_SIDE_MAJOR
                 lo[i] = Pf[((size_t)(2 * (16 * ch + i)) << a.l2L) + c];
                 hi[15 - i] = Pf[((size_t)(2 * (16 * ch + i) + 1) << a.l2L) + c];
-#else
-                const float2 t = reinterpret_cast<const float2 *>(Pf)[((size_t)(16 * ch + i) << a.l2L) + c];
-                lo[i] = t.x;
-                hi[15 - i] = t.y;
-#endif
             }
             cs[ch] = col_chunk16<NG>(lo, ch, cl, a, sq, soff);
             cs[NC - 1 - ch] = col_chunk16<NG>(hi, NC - 1 - ch, cl, a, sq, soff);
@@ -382,11 +376,7 @@ __global__ __launch_bounds__(256) void k_real_seam(SeamArgs a) {
     for (int c = threadIdx.x; c < a.L; c += blockDim.x) {
         const float4 v0 = reinterpret_cast<const float4 *>(P)[2 * c], v1 = reinterpret_cast<const float4 *>(P)[2 * c + 1];
         float pw[8] = {Cc[c], v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z};  // elements 1..7 at [0..7)
-#if PSDR_REC_SIDE_MAJOR
         const size_t rp = ((size_t)g * 2 + 1) * a.L + c;
-#else
-        const size_t rp = ((size_t)g * a.L + c) * 2 + 1;
-#endif
         uint4 rec;
         pyr_record8(pw, a.size_log2, rec);
         *reinterpret_cast<uint4 *>(Qf + rp * 16) = rec;

@@ -76,12 +76,9 @@
 #endif
 
 // The passes fetch the NEXT tile while they work on the current one, under `if (there is a next tile)`.  The fused real
-// second pass issues those loads unconditionally (its hand-off needs counted waits behind them: see there).  For the first
-// pass and the IQ second pass the same change (PSDR_UNCOND_PREFETCH=1) measures -1.2 ... -1.4 % on cfg2 (same box, three
-// interleaved repetitions: the IQ second pass goes from 212 to 247 VGPRs and +1.4 %): off.
-#ifndef PSDR_UNCOND_PREFETCH
-#define PSDR_UNCOND_PREFETCH 0
-#endif
+// second pass - and the first pass's role in the one-launch form - issue those loads unconditionally (counted waits behind
+// them: see there).  For the plain first pass and the IQ second pass the same change measured -1.2 ... -1.4 % on cfg2 (same
+// box, three interleaved repetitions: the IQ second pass goes from 212 to 247 VGPRs and +1.4 %): conditional there.
 
 namespace psdr {
 
@@ -159,7 +156,7 @@ struct LastStage {
 // The stage twiddles of a thread do not depend on the tile (k is a function of i0 and b only): StageTw keeps
 // them in registers for the whole persistent loop instead of reading the LDS table once per tile (27 of the 43
 // table reads per thread and tile of a 1024-point pass; under the package power cap of DESIGN.md 5.2 an LDS byte
-// is time).  PSDR_TW_P1_MASK / PSDR_TW_P2_MASK (bit 0: second stage, bit 1: last stage) select it per pass.
+// is time).  Pass 1 keeps the second stage's (TWM); in pass 2 the same hoist measures nothing.
 template <int L>
 struct StageTw {
     using P = Plan<L>;
@@ -246,34 +243,8 @@ __device__ __forceinline__ void run_front_stages(float4 *tile, const cf *Wl, int
                                                  Mark mark, const StageTw<L> *stw = nullptr) {
     using P = Plan<L>;
     constexpr int H = T / 2;
-    // timing-only ablations of pass 1 (SWZ == false), tools/ab_p1.sh: results are WRONG with any of them
-#if defined(PSDR_ABL_P1_NOX1)
-    constexpr bool kX1 = SWZ;
-#else
-    constexpr bool kX1 = true;
-#endif
-#if defined(PSDR_ABL_P1_NOX2) || defined(PSDR_ABL_P1_NOX1)
-    constexpr bool kX2 = SWZ;
-#else
-    constexpr bool kX2 = true;
-#endif
-    // PSDR_ABL_P1_KEEPBAR=n with PSDR_ABL_P1_NOBAR: the first n of the four barriers stay
-#ifndef PSDR_ABL_P1_KEEPBAR
-#define PSDR_ABL_P1_KEEPBAR 0
-#endif
-    int nbar_ = 0;
-    (void)nbar_;
-#if defined(PSDR_ABL_P1_NOBAR)
-#define PSDR_P1_BARRIER()                                    \
-    do {                                                     \
-        if (SWZ || nbar_++ < PSDR_ABL_P1_KEEPBAR)            \
-            __syncthreads();                                 \
-        else                                                 \
-            __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */ \
-    } while (0)
-#else
+    constexpr bool kX1 = true, kX2 = true;  // (round 3's timing-only ablations - a stage without its LDS exchange - are in docs/history.md 5.2)
 #define PSDR_P1_BARRIER() __syncthreads()
-#endif
     if constexpr (kX1) {
         stage_compute<L, P::R0, 1>(u, i0, Wl,
                                    [&](int, int, int pos, c2 x) { tile[lds_slot<H, SWZ>(pos, p)] = pack_c2(x); });
@@ -362,8 +333,7 @@ __device__ __forceinline__ unsigned xcd_slot(unsigned bid, unsigned total) {
 // CUs with the previous batch's consumer kernels and with the other pass): with tickets a
 // late starter simply takes fewer tiles.  A ticket is drawn a whole tile ahead of its use
 // (the atomic goes to memory through the same queues as the passes' HBM streams).
-//   tickets[8] must be zero at launch; gridDim.x is a multiple of 8 or >= `total`;
-//   tickets == nullptr: static round-robin.
+//   tickets[8] must be zero at launch; gridDim.x is a multiple of 8 or >= `total`.
 struct TileQueue {
     unsigned *tickets;
     unsigned total, base;  // indices below 2*gridDim.x are the static first tiles
@@ -426,15 +396,12 @@ struct TileQueue {
     __device__ __forceinline__ unsigned draw_end(unsigned *slot, unsigned prev2) {
         unsigned s = 0xFFFFFFFFu;
         if (threadIdx.x == owner) {
-            if (!tickets) {  // static round-robin
-                if (prev2 < total) s = prev2 + 2u * vgrid;
-            } else if (dynamic) {
+            (void)prev2;
+            if (dynamic) {
                 s = global ? pending + first_dyn : (pending + base) * 8u + ptx;
-#ifndef PSDR_NO_PARTNER_STEAL
-#ifndef PSDR_STEAL_LEVELS
-#define PSDR_STEAL_LEVELS 1  // queues of other XCDs a work-group goes on with after its own: x^1 (, x^2, x^3 ...)
-#endif
-                while (!global && s >= total && level < PSDR_STEAL_LEVELS) {
+                constexpr unsigned kStealLevels = 1;  // queues of other XCDs a work-group goes on with after its own: x ^ 1 (three or all
+                                                      // seven measured -3 ... -4 %: docs/history.md section 5)
+                while (!global && s >= total && level < kStealLevels) {
                     // The own queue is empty: go on with the queue of the neighbouring XCD (x ^ 1).  Pass 1's
                     // even XCDs are consistently ~2 % slower than the odd ones (tools/trace_phases.py, every
                     // box seen), which left the chip half idle for the last 12-17 us of every launch.  One
@@ -449,7 +416,6 @@ struct TileQueue {
                     const unsigned t2 = __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s = (t2 + base) * 8u + ptx;
                 }
-#endif
                 if (s >= total) s = 0xFFFFFFFFu;
             }
             *slot = s;
@@ -498,9 +464,6 @@ __device__ __forceinline__ unsigned flow_peek(const unsigned *p) {
 // role: 0 = a pass-1 work-group waiting for a ring slot, 1 = a pass-2 work-group waiting for a frame.  The waits are
 // counted (how many, how many clock ticks) behind fl.sticky: psdr_get_flow_stats.
 __device__ __forceinline__ bool flow_wait(const unsigned *ctr, unsigned want, const FlowArgs &fl, int role) {
-#ifdef PSDR_ABL_RING_NOFLOW
-    return true;  // timing-only (tuning builds): nobody waits for anybody - results are wrong
-#endif
     typedef __attribute__((address_space(1))) unsigned long long flow_gu64;
     flow_gu64 *st = (flow_gu64 *)(fl.sticky + 4) + 2 * role;
     const unsigned long long t0 = wall_clock64();
@@ -776,16 +739,7 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsi
     // same box, interleaved, cfg2, per 256 frames - pass 1 577 -> 552 us and the whole step -1.5 ... -2 %.  Keeping the
     // last stage's twelve as well (PSDR_TW_P1_MASK=3) makes pass 1 itself faster still (525 us) but the step no faster:
     // at 238 VGPRs the previous batch's consumer kernels no longer fit beside a pass-1 work-group and run later instead.
-#ifndef PSDR_TW_P1_MASK
-#define PSDR_TW_P1_MASK 1
-#endif
-    // ... and the PAIR kernels (real input) have their own setting: they carry 13 more VGPRs than the IQ kernels
-    // (210 / 220 against 197), and with the twiddles on top the consumers of the previous batch (88 - 127 VGPRs) do not
-    // fit beside a pass-1 work-group's two waves per SIMD at all
-#ifndef PSDR_TW_P1_MASK_PAIR
-#define PSDR_TW_P1_MASK_PAIR PSDR_TW_P1_MASK
-#endif
-    constexpr int TWM = PAIR ? PSDR_TW_P1_MASK_PAIR : PSDR_TW_P1_MASK;
+    constexpr int TWM = 1;  // bit 0: second stage, bit 1: last stage
     StageTw<L> stw;
     if (TWM) stw.load(Wl, i0_);
     const StageTw<L> *stw_front = (Plan<L>::NS == 3 && (TWM & 1)) ? &stw : nullptr, *stw_last = (TWM & 2) ? &stw : nullptr;
@@ -825,7 +779,7 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsi
         // (the loads below; nxt stays on this tile without a next one.  RING: unconditional - a work-group's last tile fetches
         // its own rows once more - so that every wait behind them is a counted one: the drain of the write-through stores and
         // the atomic's result below)
-        const bool more = (PSDR_UNCOND_PREFETCH || RING) ? true : has_next;
+        const bool more = RING ? true : has_next;
         // the index after `snext`: drawn one tile ago, published now, read after the barrier
         tq.draw_end(&s_next[it & 1], s);
         tq.draw_begin();
@@ -983,15 +937,7 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsi
                 } else {
                     dst = Yb + (size_t)c1 * T + 2 * p;
                 }
-#ifdef PSDR_ABL_P1_NOSTORE
-                if (yA.x == 1.2345678e-33f)  // timing-only: (almost) never true, keeps the arithmetic alive
-#endif
-#ifdef PSDR_ABL_RING_PLAIN_ST
-                constexpr bool kRingStore = false;  // timing-only (tuning builds): plain stores - pass 2 may read stale rows
-#else
-                constexpr bool kRingStore = RING;
-#endif
-                if constexpr (kRingStore) {
+                if constexpr (RING) {
                     // write-through (sc1): the reader is a work-group of the same launch on another XCD.  (No SGPR offset:
                     // a 128-bit buffer store with one, followed closely by inline-asm VALU that overwrites its data
                     // registers, stores corrupted data on gfx950 - docs/history.md 3.1.)
@@ -1197,20 +1143,12 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, unsigned vb, unsi
     // the upper half of the LDS tile (n2 >= L/2).  The powers the record loop reads (Pst) live in the lower half only,
     // so a wave that has finished its records fills the upper half of the NEXT tile at once; the "tile is free again"
     // barrier moves between the two half-fills, where the late loads (i >= 8: the lower half) have had longer to land.
-#ifdef PSDR_P2_NO_SPLITFILL
-    constexpr bool SPLIT = false;
-#else
     constexpr bool SPLIT = FUSED;
-#endif
     auto issue = [&](auto qc) {
         constexpr int i = decltype(qc)::value;
         constexpr int ip = SPLIT ? (i ^ (NLD / 2)) : i;  // which sixteenth of the tile
         // uniform part of idx = 2*ip*NT: block (2*ip*NT)>>lc, offset (2*ip*NT)&(chunk-1)
-#ifdef PSDR_ABL_RING_PLAIN_LD
-        constexpr int kAux = 0;  // timing-only (tuning builds): through L1
-#else
         constexpr int kAux = PSDR_AUX_SC1;
-#endif
         if constexpr (RING) {
             // scalar part in the instruction's SGPR offset, the lane's part (loop-invariant) in its VGPR offset; sc1: past L1
             const unsigned ub = nxt_b + (unsigned)(((size_t)((2 * ip * NT) >> lc) * blk + ((2 * ip * NT) & (chunk - 1))) * sizeof(cf));
@@ -1246,14 +1184,9 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, unsigned vb, unsi
         static_for<0, NLD>(issue);
     }
     for (int i = tid; i < L; i += NT) Wl[i] = a.Wl[i];  // visible after the loop's first barrier
-    // (register-resident stage twiddles, as in pass 1: measured without effect here - 866 vs 865 us with the second
-    // stage's fifteen at 240 VGPRs, spills with the last stage's twelve on top - so off unless PSDR_TW_P2_MASK says so)
-#ifndef PSDR_TW_P2_MASK
-#define PSDR_TW_P2_MASK 0
-#endif
-    StageTw<L> stw;
-    if (PSDR_TW_P2_MASK) stw.load(a.Wl, i0_);  // (from the global table: the LDS copy is not visible yet)
-    const StageTw<L> *stw_front = (Plan<L>::NS == 3 && (PSDR_TW_P2_MASK & 1)) ? &stw : nullptr, *stw_last = (PSDR_TW_P2_MASK & 2) ? &stw : nullptr;
+    // (register-resident stage twiddles, as in pass 1, measure nothing here - 866 vs 865 us with the second stage's fifteen
+    // at 240 VGPRs, spills with the last stage's twelve on top: the stage table stays in LDS)
+    const StageTw<L> *stw_front = nullptr, *stw_last = nullptr;
     tq.draw_first();
     PSDR_WGTRACE(a.trace, 1);
 
@@ -1266,7 +1199,7 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, unsigned vb, unsi
         const int c1base = tl * T;
         const bool has_next = snext < total;
         if (has_next) point_at(snext);
-        const bool more = PSDR_UNCOND_PREFETCH ? true : has_next;  // (the loads below; nxt stays on this tile without a next one)
+        const bool more = has_next;  // (the loads below; nxt stays on this tile without a next one)
         // RING: the next tile's loads start behind the fill: its frame's rows of Y must be in memory by then.  Thread 0's
         // sample (a tile old) decides for the work-group; a work-group that has to wait first COUNTS the tile it holds
         // (done2, behind the fill) - pass 1 may need exactly that slot before it can complete the frame waited for.
@@ -1380,10 +1313,7 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, unsigned vb, unsi
             static_assert(CH == 16 || CH == 8, "tile width");
             int8_t *Qf = a.Qt + (size_t)f * a.qt_stride;
             float *Pf = a.Pscr + (size_t)f * a.p_stride;
-#ifndef PSDR_REC_GROUP
-#define PSDR_REC_GROUP 1
-#endif
-            constexpr int RGRP = PSDR_REC_GROUP <= NG ? PSDR_REC_GROUP : NG;  // chunks whose LDS reads are issued together
+            constexpr int RGRP = 1;  // chunks whose LDS reads are issued together (2 measured nothing here; the real pass's octet loop gains from it)
 #pragma unroll
             for (int k0 = 0; k0 < NG; k0 += RGRP) {
                 float4 q4[RGRP][CH / 4];
@@ -1547,18 +1477,13 @@ __device__ __forceinline__ float bin_power(cf x) {
 template <int CP = 8>
 __device__ __forceinline__ int pst_at(int row, int e) {
     if constexpr (CP == 4) return row * 8 + e;
-#if PSDR_REC_SIDE_MAJOR
     return row * 16 + ((((e >> 2) ^ (row >> 2)) & 3) << 2) + (e & 3);
-#else
-    return row * 16 + e;
-#endif
 }
 
 template <int L, int T, int TWC>
 __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
     static_assert((T == 16 && L == 1024) || (T == 8 && L == 2048), "eight (row, mirror) couples per tile of 1024-point rows, four of 2048-point rows");
     constexpr int CP = T / 2, L2CP = CP == 8 ? 3 : 2, LINE = 2 * CP;  // couples per tile; bins per spectrum line = floats per staging row
-    static_assert(CP == 8 || PSDR_REC_SIDE_MAJOR, "quartet tiles: side-major records only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *tile = reinterpret_cast<float4 *>(smem);
     cf *tile_cf = reinterpret_cast<cf *>(smem);
@@ -1610,11 +1535,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
     // arrived up to 2200 cycles apart (tools/trace_real.py, round 4: 9 % of a tile).
     // Same box, interleaved, F = 512: cfg3 (TWC = 16) 180.3 -> 183.4 GS/s; cfg5's share (TWC = 8: 1 KiB chunks of Y) 167.7 ->
     // 165.5 - there the end barrier costs less than the permuted load order, so it keeps the plain order.
-#ifdef PSDR_P2R_SPLITFILL
-    constexpr bool SPLIT = PSDR_P2R_SPLITFILL != 0;
-#else
     constexpr bool SPLIT = TWC == 16;
-#endif
     auto issue = [&](auto qc) {
         constexpr int i = decltype(qc)::value;
         constexpr int ip = SPLIT ? (i ^ (NLD / 2)) : i;  // which sixteenth of the tile
@@ -1947,12 +1868,8 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             float *seamP = a.seamP + (size_t)s * L * CP;  // (seam_in only: those segments come first in the table)
             constexpr int NG = 2 * L / NT;  // octets per thread: chunk q = 2*c2 + side
             // GRP octets at a time: their LDS reads (staging + carried row) are issued together, then the records
-#ifndef PSDR_OCT_GROUP
-#define PSDR_OCT_GROUP 2  // same box, interleaved, cfg3: step 6.57 -> 6.52 us per frame, pass 2 1045 -> 1025 us (4: the same)
-#endif
-            constexpr int GRP = PSDR_OCT_GROUP;
+            constexpr int GRP = 2;  // same box, interleaved, cfg3: step 6.57 -> 6.52 us per frame, pass 2 1045 -> 1025 us (4: the same)
             static_assert(NG % GRP == 0, "octet groups");
-#if PSDR_REC_SIDE_MAJOR
             if constexpr (CP == 4) {
                 // Quartets (2048-point rows, four couples per tile): group kk of the thread is side kk & 1 of column
                 // (kk >> 1) * NT + tidx; a staging row is [low quartet | elements 1..3 of the high quartet, carry-out]: one
@@ -2044,53 +1961,6 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                 PSDR_SCHED_FENCE();
             }
             }  // (CP == 8)
-#else
-            const int side = tidx & 1;  // (NT is even: q = k * NT + tidx keeps its parity)
-#pragma unroll
-            for (int k0 = 0; k0 < NG; k0 += GRP) {
-                float4 v0[GRP], v1[GRP];
-                float cin[GRP];
-#pragma unroll
-                for (int j = 0; j < GRP; j++) {
-                    const int q = (k0 + j) * NT + tidx;
-                    v0[j] = reinterpret_cast<const float4 *>(Pst)[2 * q];
-                    v1[j] = reinterpret_cast<const float4 *>(Pst)[2 * q + 1];
-                    cin[j] = side ? carry_r[q >> 1] : 0.f;
-                }
-#pragma unroll
-                for (int j = 0; j < GRP; j++) {
-                    const int q = (k0 + j) * NT + tidx;
-                    const int c2i = q >> 1;
-                    float pw[8] = {v0[j].x, v0[j].y, v0[j].z, v0[j].w, v1[j].x, v1[j].y, v1[j].z, v1[j].w};
-                    if (side) {  // high octet: element 0 is the carried row, 1..7 sit at [0..7), and slot 7
-                                 // holds this tile's own carry-out (row M1-8g of column c2i)
-                        carry_w[c2i] = v1[j].w;
-                        if (seg_last && g != 0)
-                            __hip_atomic_store(reinterpret_cast<unsigned *>(seamC) + c2i, __float_as_uint(v1[j].w), __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                        pw[0] = cin[j];
-                        pw[1] = v0[j].x, pw[2] = v0[j].y, pw[3] = v0[j].z, pw[4] = v0[j].w, pw[5] = v1[j].x, pw[6] = v1[j].y, pw[7] = v1[j].z;
-                    }
-                    if (side && seam_in) {  // no carry-in: the octet is completed by k_real_seam
-                        reinterpret_cast<float4 *>(seamP)[2 * c2i] = v0[j];
-                        reinterpret_cast<float4 *>(seamP)[2 * c2i + 1] = v1[j];
-                    }
-                    // The record is written by EVERY lane (a segment's first tile: with a stale carried row in the
-                    // high octets - k_real_seam, which runs before any consumer, writes those records again).  With
-                    // the stores under `else` the whole store could be skipped (s_cbranch_execz) as far as the
-                    // compiler knew, so it could not count them and waited for the next tile's loads with
-                    // s_waitcnt vmcnt(0) - i.e. for the acknowledgement of these stores, at the top of every tile.
-                    {
-                        const size_t rp = (size_t)g * (2 * L) + q;  // RecMap mode 2
-                        uint4 rec;
-                        pyr_record8(pw, a.size_log2, rec);
-                        *reinterpret_cast<uint4 *>(Qf + rp * 16) = rec;
-                        Pf[rp] = pw[0];
-                    }
-                }
-                PSDR_SCHED_FENCE();
-            }
-#endif
         }
         PSDR_TRACE(a.trace, it, 12);
         if (!SPLIT) __syncthreads();  // the tile is free again (SPLIT: between the next tile's two half-fills)

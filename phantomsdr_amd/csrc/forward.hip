@@ -15,10 +15,6 @@ static unsigned long long *next_kclk(psdr_ctx *c, int which) {
 }
 // counters for the next launch of pass `which` on stream st
 static int next_tickets(psdr_ctx *c, int which, hipStream_t st, unsigned **out) {
-    if (c->static_tiles) {
-        *out = nullptr;
-        return PSDR_OK;
-    }
     unsigned &pos = c->ticket_pos[which];
     const unsigned slot = pos % TICKET_SLOTS;
     if (slot % (TICKET_SLOTS / 2) == 0 && pos >= TICKET_SLOTS / 2) {
@@ -51,7 +47,6 @@ int real_seg_len(const psdr_ctx *c, int nframes) {
         return sl;
     };
     const long long want = tiles / (2LL * W);
-    if (psdr_tuning_env("PSDR_SEG_OLD")) return pow2_floor(want);
     // What the measurements say (cfg3's stream, tools/ab_small_batches.sh, profiles/r04b_uniform_segments_small_batches.jsonl):
     // up to 16 tiles per work-group ONE static segment each, rounded up to a power of two (32 frames: 256 segments of 8
     // tiles 151 GS/s, 512 of 4 - the old choice - 140; 48 frames: 192 of 16 tiles 155, 768 of 4 141); two static segments per
@@ -80,38 +75,25 @@ int real_seg_len(const psdr_ctx *c, int nframes) {
 //    and with two whole-frame segments each nothing balanced that - the launch ended with its slowest work-group, 3.4 %
 //    after the median one.  With tickets and segments that shrink to single tiles the spread at the end is one tile, at
 //    a cost of 8 KiB of traffic per hand-off (a seam: 92 KiB and a record written twice).
-// tiles per segment from the top of a frame: G/4, G/4, G/4, G/8, ... 2, 1, 1 (tuning builds: PSDR_SEG_PLAN="32,16,8,8")
+// tiles per segment from the top of a frame: G/4, G/4, G/4, G/8, ... 2, 1, 1
 static std::vector<int> seg_plan_lens(const psdr_ctx *c) {
     const int G = c->M1 / c->T2;  // tiles of a frame
-    std::vector<int> lens;
-    if (const char *e = psdr_tuning_env("PSDR_SEG_PLAN")) {
-        int sum = 0;
-        for (const char *q = e; *q;) {
-            const int v = atoi(q);
-            if (v > 0) lens.push_back(v), sum += v;
-            while (*q && *q != ',') q++;
-            if (*q == ',') q++;
-        }
-        if (sum == G) return lens;
-        lens.clear();
-    }
-    lens = {G / 4, G / 4, G / 4};
+    std::vector<int> lens = {G / 4, G / 4, G / 4};
     for (int l = G / 8; l >= 1; l >>= 1) lens.push_back(l);
     lens.push_back(1);
     return lens;
 }
 void seg_plan_counts(const psdr_ctx *c, int nframes, unsigned *nsegs, unsigned *nseam, bool *handoff) {
     const int G = c->M1 / c->T2;  // tiles of a frame
-    // (PSDR_SEG_LEN=n is the way back to uniform segments; tuning builds: PSDR_SEG_HANDOFF=0)
+    // (PSDR_SEG_LEN=n is the way back to uniform segments)
     // Which batches take the hand-off plan: those of more than one frame per work-group (cfg3's stream at 258 / 288 / 320 /
     // 384 / 448 / 512 frames: +11 / +29 / +25 / +12 / +6 / +1.5 % over the uniform segments of round 3; against the uniform
     // segments real_seg_len() picks now it is level at 320 and 384 frames and 1 - 5 % ahead at 512).  Up to one frame per
     // work-group a segment's predecessor is less than a segment ahead, most hand-offs end as seams, and well-chosen uniform
     // segments are 3 - 9 % faster (profiles/r04b_handoff_vs_uniform_by_batch.jsonl, r04b_uniform_segments_small_batches.jsonl).
-    const char *off = psdr_tuning_env("PSDR_SEG_HANDOFF"), *mn = psdr_tuning_env("PSDR_SEG_HANDOFF_MIN");
     const int W = std::max(c->num_cus, 1);
-    const bool want = nframes >= (mn ? atoi(mn) : W + 1);
-    const bool ho = c->seg_len_env <= 0 && !c->static_tiles && G >= 16 && want && !(off && atoi(off) == 0);
+    const bool want = nframes >= W + 1;
+    const bool ho = c->seg_len_env <= 0 && G >= 16 && want;
     if (ho) {
         const int levels = (int)seg_plan_lens(c).size();
         *nsegs = (unsigned)(levels * nframes);
@@ -181,18 +163,8 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     const int cols = 1;
     const int sb = fmt <= PSDR_FMT_S8 ? 2 : (fmt <= PSDR_FMT_S16 ? 4 : 8);  // image bytes per sample
     const unsigned tiles1 = (unsigned)(c->M2 / (c->T1 * cols)), tiles2 = (unsigned)(c->M1 / c->T2);
-    const bool piped = c->p1 != c->stream;
-    if (piped) {
-        c->cur_y ^= 1;
-        if (c->input_on_main) {  // the staged input was copied on the main stream
-            HIPCHK(hipEventRecord(c->ev_in, c->stream));
-            HIPCHK(hipStreamWaitEvent(c->p1, c->ev_in, 0));
-        }
-        // this Y buffer's previous reader (pass 2, two batches ago) must be done
-        if (c->y_pending[c->cur_y]) HIPCHK(hipStreamWaitEvent(c->p1, c->ev_p2[c->cur_y], 0));
-    }
     c->input_on_main = false;
-    cf *Y = c->y_pool[c->cur_y];
+    cf *Y = c->d_Y;
     Pass1Args a1{};
     a1.raw = d_halves;
     a1.Y = Y;
@@ -200,11 +172,10 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     a1.TB = c->d_TB;
     a1.yblk = (size_t)c->M1 * (c->T1 * cols);  // plain: one linear block per pass-1 tile
     a1.l2t2 = ilog2((size_t)c->T2);
-    // fused real: pass-2-tile-major by default (fft_pass.h, "Y layout"); PSDR_REAL_YBLOCKED=1: rows regrouped
-    // inside the pass-1 tile's own linear block
-    a1.ytile = c->y_blocked ? (size_t)c->T2 * (c->T1 * cols) : (size_t)c->M2 * c->T2;
-    a1.ytl = c->y_blocked ? a1.yblk : (size_t)c->T2 * (c->T1 * cols);
-    a1.yframe = c->M + c->y_pad;
+    // fused real: pass-2-tile-major (fft_pass.h, "Y layout")
+    a1.ytile = (size_t)c->M2 * c->T2;
+    a1.ytl = (size_t)c->T2 * (c->T1 * cols);
+    a1.yframe = c->M;
     a1.wdelta = c->wdelta;
     a1.M2 = c->M2;
     a1.log2M2 = c->log2M2;
@@ -222,7 +193,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     // Both passes in ONE launch, Y a ring of ring_frames frames (fft_pass.h: FlowArgs): IQ batches of ring_min_batch frames
     // and more on the context's own stream pair; everything else - small batches, band regions, a caller's pipelined
     // first-pass stream - keeps the two launches
-    const bool ring = c->ring_on && !c->nbands && !piped && !c->static_tiles && nframes >= c->ring_min_batch && a1.ymask == ~0u &&
+    const bool ring = c->ring_on && !c->nbands && c->p1 == c->stream && nframes >= c->ring_min_batch && a1.ymask == ~0u &&
                       fused_supported(c, sb);
     FlowArgs fl{};
     if (ring) {
@@ -257,10 +228,6 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
         if (rc) return rc;
         if (ev_raw_consumed) HIPCHK(hipEventRecord(ev_raw_consumed, c->p1));  // pass 1 is the only reader of the raw halves
     }
-    if (piped) {
-        HIPCHK(hipEventRecord(c->ev_p1[c->cur_y], c->p1));
-        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_p1[c->cur_y], 0));
-    }
 
     Pass2Args a2{};
     a2.Y = Y;
@@ -269,8 +236,8 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     a2.log2M1 = c->log2M1;
     a2.TW = c->T1 * cols;
     a2.yblk = a1.yblk;
-    a2.ytile = c->y_blocked ? (size_t)c->T2 * (c->T1 * cols) : a1.ytile;
-    a2.yjs = c->y_blocked ? a1.yblk : (size_t)c->T2 * (c->T1 * cols);
+    a2.ytile = a1.ytile;
+    a2.yjs = (size_t)c->T2 * (c->T1 * cols);
     a2.yframe = a1.yframe;
     a2.log2TW = ilog2((size_t)(c->T1 * cols));
     a2.inv_n = 1.0f / (float)c->N;
@@ -370,10 +337,6 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
         hipLaunchKernelGGL(k_untangle_real, dim3(nb, nframes), dim3(256), 0, c->stream, u);
         HIPCHK(hipGetLastError());
     }
-    if (piped) {
-        HIPCHK(hipEventRecord(c->ev_p2[c->cur_y], c->stream));
-        c->y_pending[c->cur_y] = true;
-    }
     // consumers of the finished batch go to the side stream
     if (c->side != c->stream) {
         HIPCHK(hipEventRecord(c->ev_fft_done, c->stream));
@@ -405,7 +368,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     // levels inside a row (k_col_tail), the generic kernel the few above
     const int ng = (int)(len >> c->log2M2);  // groups per output row
     const bool col_tail = c->recmap.mapped && (c->M2 == 1024 || (c->M2 == 2048 && c->real_fused)) && c->recmap.l2gpt == 0 &&
-                          (ng == 64 || ng == 128 || ng == 256) && !c->no_col_tail;
+                          (ng == 64 || ng == 128 || ng == 256);
     if (col_tail && lvl + 1 < c->levels) {
         ColTailArgs t{};
         t.Pin = c->d_pscr[0];

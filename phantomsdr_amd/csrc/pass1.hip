@@ -13,8 +13,7 @@ static int launch_pass1_t(psdr_ctx *c, const Pass1Args &a, unsigned blocks) {
         HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass1<L, T, SB, PAIR, CP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
     ProfScope ps(c, K_PASS1, c->p1);
     // persistent: as many work-groups per CU as their LDS admits (a 128 KiB tile: one)
-    unsigned grid = persistent_grid(c, blocks, lds);
-    if (c->p1_grid && c->p1_grid < grid) grid = c->p1_grid;
+    const unsigned grid = persistent_grid(c, blocks, lds);
     hipLaunchKernelGGL((k_fft_pass1<L, T, SB, PAIR, CP>), dim3(grid), dim3(L * T / 32), lds, c->p1, a);
     HIPCHK(hipGetLastError());
     return PSDR_OK;

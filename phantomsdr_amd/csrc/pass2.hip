@@ -12,8 +12,7 @@ static int launch_pass2_t(psdr_ctx *c, const Pass2Args &a, unsigned blocks) {
     if (c->lds_attr_done.insert((const void *)k_fft_pass2<L, T, FUSED, TWC, BAND>).second)
         HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass2<L, T, FUSED, TWC, BAND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope ps(c, K_PASS2);
-    unsigned grid = persistent_grid(c, blocks, lds);
-    if (c->p2_grid && c->p2_grid < grid) grid = c->p2_grid;
+    const unsigned grid = persistent_grid(c, blocks, lds);
     hipLaunchKernelGGL((k_fft_pass2<L, T, FUSED, TWC, BAND>), dim3(grid), dim3(L * T / 32), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return PSDR_OK;
@@ -53,8 +52,7 @@ static int launch_pass2_real_t(psdr_ctx *c, const Pass2Args &a) {
     if (c->lds_attr_done.insert((const void *)k_fft_pass2_real<L, T, TWC>).second)
         HIPCHK(hipFuncSetAttribute((const void *)k_fft_pass2_real<L, T, TWC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ProfScope ps(c, K_PASS2);
-    unsigned grid = persistent_grid(c, a.total_slots, lds);
-    if (c->p2_grid && c->p2_grid < grid) grid = c->p2_grid;
+    const unsigned grid = persistent_grid(c, a.total_slots, lds);
     hipLaunchKernelGGL((k_fft_pass2_real<L, T, TWC>), dim3(grid), dim3(L * T / 32), lds, c->stream, a);
     HIPCHK(hipGetLastError());
     return PSDR_OK;

@@ -59,19 +59,8 @@ __device__ __forceinline__ QConst qconst() {
 __device__ __forceinline__ q_v2f quantize2(float a, float b, float koff, const QConst &k) {
     const unsigned ba = __float_as_uint(a), bb = __float_as_uint(b);
     // exponent: (float)((bits >> 23) & 255) + (power_offset - 128), exact in either order
-#ifdef PSDR_Q_ALIGNBIT
-    // ONE instruction per value instead of bfe + cvt: (0x4B000000 | bits >> 23) is the float 2^23 + exponent (a
-    // power is never negative: bit 31 is clear, so bits >> 23 IS the exponent field), and 2^23 leaves again in the
-    // packed add below - sums of small integers, exact in any order
-    unsigned ea, eb;
-    asm("v_alignbit_b32 %0, %1, %2, 23" : "=v"(ea) : "v"(k.magic), "v"(ba));
-    asm("v_alignbit_b32 %0, %1, %2, 23" : "=v"(eb) : "v"(k.magic), "v"(bb));
-    q_v2f lf = {__uint_as_float(ea), __uint_as_float(eb)};
-    const q_v2f kk = {koff - 8388608.f, koff - 8388608.f};
-#else
     q_v2f lf = {(float)((ba >> 23) & 0xFFu), (float)((bb >> 23) & 0xFFu)};
     const q_v2f kk = {koff, koff};
-#endif
     unsigned ma, mb;
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ma) : "v"(ba), "v"(k.mmask), "v"(k.mone));
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(mb) : "v"(bb), "v"(k.mmask), "v"(k.mone));
@@ -180,9 +169,6 @@ __device__ __forceinline__ void pyr_levels(float (&p)[CH], int8_t *Qf, size_t qo
 // g = c / CH of client-order bin c sits in record
 //   pos(g) = tl * (rows * gpt) + row * gpt + k,  row = g / tpr, tl = (g % tpr) / gpt, k = g % gpt
 // (tpr = M1/CH groups per output row, gpt = T/CH groups per tile and row, rows = M2).
-#ifndef PSDR_REC_SIDE_MAJOR
-#define PSDR_REC_SIDE_MAJOR 1  // 0: round 1-3 order (g * rows + c2) * 2 + side, lanes alternate between the sides
-#endif
 struct RecMap {
     int l2tpr, l2gpt, l2rows;
     int mapped;  // 0: identity (level-major producers: the three-pass real-input path)
@@ -199,11 +185,7 @@ struct RecMap {
             const size_t tpr = (size_t)1 << l2tpr;
             const size_t side = gc >= (tpr >> 1) ? 1 : 0;
             const size_t tl = side ? tpr - 1 - gc : gc;
-#if PSDR_REC_SIDE_MAJOR
             return (((tl << 1) + side) << l2rows) + row;
-#else
-            return (((tl << l2rows) + row) << 1) + side;
-#endif
         }
         const size_t tl = gc >> l2gpt, k = gc & (((size_t)1 << l2gpt) - 1);
         return (((tl << l2rows) + row) << l2gpt) + k;

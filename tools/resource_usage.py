@@ -13,7 +13,7 @@ if len(sys.argv) > 1:
 else:
     from concurrent.futures import ThreadPoolExecutor
     d = tempfile.mkdtemp()
-    extra = os.environ.get("PSDR_DEFINES", "").split()  # e.g. PSDR_DEFINES="-DPSDR_TW_P1_MASK_PAIR=0"
+    extra = os.environ.get("PSDR_DEFINES", "").split()  # e.g. PSDR_DEFINES="-DPSDR_HANDOFF_FULL_DRAIN"
 
     def one(u):
         r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-fPIC", "-c",
