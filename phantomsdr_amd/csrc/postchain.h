@@ -44,6 +44,9 @@ namespace psdr {
 
 
 typedef float pc_f4 __attribute__((ext_vector_type(4)));
+#ifndef PSDR_PC_SETPRIO
+#define PSDR_PC_SETPRIO 3
+#endif
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void pc_static_for(F &&f) {
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(64) void k_pc_ma2(PostArgs a) {
     constexpr int KB = 16, D = 32, RING = PSDR_PC_RING, AHEAD = RING - 3;
     static_assert(RING % 2 == 0 && RING >= 6, "ring of x blocks");
     // one wave next to the FFT passes' eight issue-bound waves: let it issue first
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(PSDR_PC_SETPRIO);
     const bool fresh = cp.agc_reset == 2;  // zero sums (k_pc_index zeroed the history rows)
     const int T = a.len[slot];
     if (T == 0) return;
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(64) void k_pc_gain(PostArgs a) {
         n0 = 0;
     }
     constexpr int KB = 16, GR = PSDR_PC_RING, AHEAD = GR - 1;  // blocks of loads in flight: see k_pc_ma2
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(PSDR_PC_SETPRIO);
     const float *__restrict__ W = a.S + (size_t)slot * a.pv;
     float *__restrict__ G = a.P + (size_t)slot * a.pv;
     const float att = a.attack, rel = a.release;

@@ -60,6 +60,8 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
         if (!c->side2) {
             int lo = 0, hi = 0;
             HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            if (const char *e = psdr_tuning_env("PSDR_PC_ABL"))
+                if (atoi(e) & 16) hi = 0;  // (tuning build: the chain's two streams at normal priority)
             HIPCHK(hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, hi));
             HIPCHK(hipStreamCreateWithPriority(&c->side3, hipStreamNonBlocking, hi));
             HIPCHK(hipEventCreateWithFlags(&c->ev_demod, hipEventDisableTiming));
@@ -85,7 +87,9 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
 // block, the nact active clients first, then npaused paused ones with an empty stream)
 int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, int nact, int npaused, int nframes, hipStream_t *last_user) {
     const int par = (int)(c->chain_seq & 1);
-    const bool piped = c->side != c->stream && c->side2 != nullptr;
+    int abl = 0;  // (tuning build only: which part of the chain costs the step what)
+    if (const char *e = psdr_tuning_env("PSDR_PC_ABL")) abl = atoi(e);
+    const bool piped = c->side != c->stream && c->side2 != nullptr && !(abl & 8);
     hipStream_t s2 = piped ? c->side2 : c->side, s1 = piped ? c->side3 : c->side;
     PostArgs pa = c->post;
     pa.clients = d_clients;
@@ -115,7 +119,8 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, int nac
             c->gather_pending = true;
         }
         pa.ma_fused = pa.D == 32 ? 1 : 0;  // both averages in one loop (postchain.h)
-        if (pa.ma_fused) {
+        if (abl & 1) {
+        } else if (pa.ma_fused) {
             hipLaunchKernelGGL(k_pc_ma2, dim3(cb), dim3(64), 0, s1, pa);
         } else if ((pa.D & (pa.D - 1)) == 0) {
             hipLaunchKernelGGL((k_pc_ma<false, true>), dim3(cb), dim3(64), 0, s1, pa);
@@ -129,8 +134,10 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, int nac
         // the look-ahead maxima and w_t are parallel work: they ride in this stage (P and S exist per parity), so
         // that stage 2 is nothing but the gain recurrence and the output - the two sequential kernels (k_pc_ma2
         // here, k_pc_gain there: ~1.1 ms each beside the FFT passes) sit in different stages
-        hipLaunchKernelGGL(k_pc_scan, dim3(nall, nblk, 2), dim3(64), 0, s1, pa);
-        hipLaunchKernelGGL(k_pc_want, dim3(nall, (unsigned)((Tb + 255) / 256)), dim3(256), 0, s1, pa);
+        if (!(abl & 4)) {
+            hipLaunchKernelGGL(k_pc_scan, dim3(nall, nblk, 2), dim3(64), 0, s1, pa);
+            hipLaunchKernelGGL(k_pc_want, dim3(nall, (unsigned)((Tb + 255) / 256)), dim3(256), 0, s1, pa);
+        }
         // w_t is all the gain recurrence needs: it must not wait for the history copy below, which in turn waits
         // for the previous batch's output kernel (gain -> out -> history -> gain would be one serial chain per batch)
         if (piped) HIPCHK(hipEventRecord(c->ev_want[par], s1));
@@ -147,7 +154,8 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, int nac
     }
     {  // ---- stage 2
         ProfScope ps(c, K_POST, s2);
-        if (pa.attack >= pa.release)
+        if (abl & 2) {
+        } else if (pa.attack >= pa.release)
             hipLaunchKernelGGL(k_pc_gain<true>, dim3(cb), dim3(64), 0, s2, pa);
         else
             hipLaunchKernelGGL(k_pc_gain<false>, dim3(cb), dim3(64), 0, s2, pa);
