@@ -412,6 +412,33 @@ def path_roofline(b_frame, frames_per_s):
             "algorithmic_bytes_per_frame": int(b_frame)}
 
 
+def post_chain_measure(run, eng, params, wl, F, N, nclients, plain_ms):
+    """SURVEY 8f-2 (widened row): the step with the optional post-demodulation chain on (DC blocker + AGC + int16).  NOT part
+    of `value` (the metric's clients end at float audio).  The chain is a pipeline over three side streams and three
+    rotating buffer sets: a batch's PCM is ready about two steps after its passes, so a repetition of K steps carries
+    about two steps of drain - 200 steps per repetition (a server never drains), 50-step repetitions beside it."""
+    try:
+        eng.ctx.set_post_chain(True)
+        pk = 200
+        pt = run.timed(pk, 5, min_reps=3, min_total_s=0.1)
+        pt50 = run.timed(50, 3, min_reps=3, min_total_s=0.05)
+        eng.ctx.set_post_chain(False)
+        pdt = float(np.median(pt)) / pk
+        h = params["audio_fft_size"] // 2
+        return {"ms_per_step": round(pdt * 1e3, 3), "plain_ms_per_step": plain_ms,
+                "over_plain": round(pdt * 1e3 / plain_ms, 4) if plain_ms else None,
+                "MSamples_per_s_ingest": round(F * (N // 2) / pdt / 1e6, 1),
+                "audio_clients": nclients,
+                "audio_samples_per_s": round(nclients * F * h / pdt, 1),
+                "realtime_factor": round(F * (N // 2) / pdt / wl["sps"], 1),
+                "steps_per_repetition": pk,
+                "ms_per_step_50_step_repetitions": round(float(np.median(pt50)) / 50 * 1e3, 3),
+                "note": "whole step with psdr_set_post_chain(1): three f32 recurrences, sequential per client (one lane each); "
+                        "repetitions of 200 steps between full synchronisations (50-step repetitions, as in round 4, beside it)"}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def kernel_roofline(ctx, step, first_step, nsteps, wl, wl_name, params, clients, waterfalls, frames_per_launch,
                     clock_us=None, ms_per_step=None, ms_per_step_stamped=None, frames_per_s=None):
     """Per-kernel durations and the roofline block: `frac` is the whole path's
@@ -1072,25 +1099,7 @@ def main():
     # measured separately - it is NOT part of `value` (the metric's clients end at float audio)
     post = None
     if clients and not args.no_post_chain:
-        try:
-            eng.ctx.set_post_chain(True)
-            # the chain is a four-stage pipeline over three side streams (a batch's PCM is ready ~2.5 ms after its
-            # passes): repetitions of 10 steps measured mostly its fill and drain, not its rate
-            pk = 50
-            pt = run.timed(pk, 5, min_reps=3, min_total_s=0.1)
-            pt10 = run.timed(10, 3, min_reps=3, min_total_s=0.05)
-            eng.ctx.set_post_chain(False)
-            pdt = float(np.median(pt)) / pk
-            h = params["audio_fft_size"] // 2
-            post = {"ms_per_step": round(pdt * 1e3, 3), "MSamples_per_s_ingest": round(F * (N // 2) / pdt / 1e6, 1),
-                    "audio_samples_per_s": round(len(clients) * F * h / pdt, 1),
-                    "realtime_factor": round(F * (N // 2) / pdt / wl["sps"], 1),
-                    "steps_per_repetition": pk,
-                    "ms_per_step_10_step_bursts": round(float(np.median(pt10)) / 10 * 1e3, 3),
-                    "note": "whole step with psdr_set_post_chain(1): f32 recurrences, sequential per client; "
-                            "repetitions of 50 steps between full synchronisations (10-step bursts, as up to round 2, beside it)"}
-        except Exception as e:
-            post = {"error": repr(e)}
+        post = post_chain_measure(run, eng, params, wl, F, N, len(clients), head["ms_per_step"])
     nhalves, hb = run.nhalves, run.hb
     run.close()
     del run
@@ -1110,6 +1119,8 @@ def main():
                            f"cfg2 shape with {nc} mixed USB/LSB/AM/FM audio clients + {w2['waterfall']} waterfall clients on one GPU",
                            "audio_clients": len(r2.clients), "steps": st,
                            "realtime_factor": round(sm["value"] * 1e6 / w2["sps"], 1)})
+                if nc is not None and not args.no_post_chain:  # the chain with all 64 lanes of four waves in use
+                    sm["post_chain"] = post_chain_measure(r2, r2.eng, r2.eng.params, w2, F, w2["fft_size"], len(r2.clients), sm["ms_per_step"])
                 extra[key] = sm
                 r2.close()
                 del r2

@@ -31,8 +31,8 @@ void resolve_pending(psdr_ctx *c) {
     hipStreamSynchronize(c->p1);
     hipStreamSynchronize(c->stream);
     hipStreamSynchronize(c->side);
-    if (c->side2) hipStreamSynchronize(c->side2);
-    if (c->side3) hipStreamSynchronize(c->side3);
+    for (hipStream_t st : c->pc_s)
+        if (st) hipStreamSynchronize(st);
     for (auto &p : c->pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
@@ -206,19 +206,12 @@ void free_all(psdr_ctx *c) {
     if (c->ev_side_done) hipEventDestroy(c->ev_side_done);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     if (c->ev_in) hipEventDestroy(c->ev_in);
-    for (int i = 0; i < 2; i++) {
-    }
     if (c->own_side) hipStreamDestroy(c->own_side);
-    if (c->side2) hipStreamDestroy(c->side2);
-    if (c->side3) hipStreamDestroy(c->side3);
-    if (c->ev_demod) hipEventDestroy(c->ev_demod);
-    if (c->ev_gather) hipEventDestroy(c->ev_gather);
-    for (int i = 0; i < 2; i++)
-        if (c->ev_want[i]) hipEventDestroy(c->ev_want[i]);
-    for (int i = 0; i < 2; i++) {
-        if (c->ev_s1[i]) hipEventDestroy(c->ev_s1[i]);
-        if (c->ev_s2[i]) hipEventDestroy(c->ev_s2[i]);
-    }
+    for (hipStream_t st : c->pc_s)
+        if (st) hipStreamDestroy(st);
+    for (auto &stage : c->ev_pc)
+        for (hipEvent_t e : stage)
+            if (e) hipEventDestroy(e);
 }
 
 int build(psdr_ctx *c) {
@@ -432,7 +425,7 @@ int build(psdr_ctx *c) {
         HIPCHK(hipMemset(c->d_pwr, 0, S * F * sizeof(float)));
         HIPCHK(hipMemset(c->d_nan, 0, S * F * sizeof(int)));
         if (c->lds_mode == 2) HIPCHK(hipMalloc((void **)&c->d_gscratch, S * F * 2 * n * sizeof(cf)));
-        if (c->client_ring.init(S * sizeof(ClientParams)))
+        if (c->client_ring.init(S * (sizeof(ClientParams) + sizeof(int))))  // the batch's client list + the slot -> list index table
             return fail(PSDR_ERR_HIP, "client parameter ring allocation failed");
     }
     // ---- waterfall clients
@@ -760,8 +753,8 @@ int psdr::drain(psdr_ctx *c) {
     if (c->p1 != c->stream) HIPCHK(hipStreamSynchronize(c->p1));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->side != c->stream) HIPCHK(hipStreamSynchronize(c->side));
-    if (c->side2) HIPCHK(hipStreamSynchronize(c->side2));
-    if (c->side3) HIPCHK(hipStreamSynchronize(c->side3));
+    for (hipStream_t st : c->pc_s)
+        if (st) HIPCHK(hipStreamSynchronize(st));
     // one-launch transforms (k_fft_fused): a flow-control wait that timed out left wrong results behind - say so, once
     if (c->h_flow_sticky && *c->h_flow_sticky != c->flow_timeouts_seen) {
         const unsigned n = *c->h_flow_sticky - c->flow_timeouts_seen;
@@ -858,7 +851,7 @@ extern "C" int psdr_timer_start(psdr_ctx *c) {
 extern "C" int psdr_timer_stop_ms(psdr_ctx *c, double *ms_out) {
     if (!c || !ms_out) return fail(PSDR_ERR_INVALID, "null argument");
     if (c->side_pending && c->side != c->stream) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_side_done, 0));
-    if (c->side2_pending && c->chain_seq > 0) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_s2[(c->chain_seq - 1) & 1], 0));
+    if (c->chain_pending && c->chain_seq > 0) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_pc[3][(c->chain_seq - 1) % psdr_ctx::PC_SETS], 0));
     HIPCHK(hipEventRecord(c->t1, c->stream));
     HIPCHK(hipEventSynchronize(c->t1));
     float ms = 0;

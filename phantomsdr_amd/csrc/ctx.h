@@ -242,23 +242,23 @@ struct psdr_ctx {
     // post-demodulation chain (postchain.h), allocated by psdr_set_post_chain
     bool post_on = false;
     PostArgs post{};
-    // The chain is a two-stage pipeline across batches: stage 1 (index, gather, moving averages) of
-    // batch b+1 runs on `side` while stage 2 (look-ahead peak, gain, int16) of batch b runs on
-    // `side2`; what the stages share is double-buffered (V1, frame offsets, stream lengths)
-    hipStream_t side2 = nullptr;
-    // ... and stage 1 has a stream of its own too (round 3): on `side` its sequential kernel (k_pc_ma2, ~0.9 ms beside
-    // the passes) sat between this batch's demodulation and the NEXT batch's tails and demodulation - the side
-    // stream, not the GPU, set the step (1.88 ms of serial work per 1.4 ms of passes)
-    hipStream_t side3 = nullptr;
-    hipEvent_t ev_want[2] = {nullptr, nullptr};  // w_t of this parity is ready (the gain recurrence may start)
-    hipEvent_t ev_demod = nullptr, ev_gather = nullptr;  // demodulation done (stage 1 may read); audio rows read (the next demodulation may write)
-    bool gather_pending = false;
-    float *post_v1[2] = {nullptr, nullptr};
-    float *post_p[2] = {nullptr, nullptr}, *post_s[2] = {nullptr, nullptr};  // prefix / suffix maxima, then w_t / g_t
-    int *post_fstart[2] = {nullptr, nullptr}, *post_len[2] = {nullptr, nullptr};
-    hipEvent_t ev_s1[2] = {nullptr, nullptr}, ev_s2[2] = {nullptr, nullptr};
+    // The chain is a pipeline across batches on three streams of its own (round 5), in the order of a batch's data:
+    //   side     index, gather (behind the demodulation)
+    //   pc_s[0]  moving averages (sequential), history
+    //   pc_s[1]  look-ahead peak, w_t    pc_s[2]  gain recurrence (sequential), int16 output
+    // The two sequential kernels (~2 ms per 512 frames each, whatever the client count) are what a stream must not
+    // share: rounds 3-4 had two streams, and the one with k_pc_ma2 AND the six short kernels of its stage was longer
+    // than the step it hid behind (3.2 ms against 2.6).  What the stages hand on rotates over PC_SETS sets, so a
+    // batch's chain may take up to two steps longer than a step.
+    static constexpr int PC_SETS = 3;
+    hipStream_t pc_s[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_pc[4][PC_SETS] = {};  // [stage][set]: the stage's kernels of the batch that used the set are done
+    float *post_x[PC_SETS] = {}, *post_m1[PC_SETS] = {}, *post_v1[PC_SETS] = {};
+    float *post_p[PC_SETS] = {}, *post_s[PC_SETS] = {}, *post_sm[PC_SETS] = {};  // prefix maxima then g_t / w_t / sub-block maxima
+    int *post_fstart[PC_SETS] = {}, *post_len[PC_SETS] = {};
     uint64_t chain_seq = 0;
-    bool side2_pending = false;
+    bool chain_pending = false;
+    int post_reserve = 8;  // CUs the FFT passes leave free while the chain is on (a multiple of 8: one per XCD); 0: none
     std::vector<void *> post_allocs;
     float *d_pwr = nullptr, *d_audio = nullptr, *d_real_prev = nullptr;
     int *d_nan = nullptr;
@@ -352,7 +352,13 @@ inline int pick_T(int L, int other) { return std::min(16384 / L, other); }
 // persistent launch: as many work-groups as the CUs hold (LDS-limited), a multiple of 8 (XCD
 // round-robin of the TileQueue), or one per tile when there are fewer tiles than that
 inline unsigned persistent_grid(psdr_ctx *c, unsigned blocks, size_t lds) {
-    const unsigned cap = ((unsigned)c->num_cus * (unsigned)std::max<size_t>(1, 160 * 1024 / lds)) & ~7u;
+    unsigned cap = ((unsigned)c->num_cus * (unsigned)std::max<size_t>(1, 160 * 1024 / lds)) & ~7u;
+    // post chain on: one CU per XCD stays free of the passes' work-groups - the home of the chain's recurrence waves
+    // (postchain.hip: they ask for more LDS than a pass leaves, so they land THERE and nowhere else; beside a pass's eight
+    // waves a recurrence runs 1.9 - 2.8 ms per 512 frames, longer than the step).  0.5 % of the plain step.
+    unsigned reserve = c->post_on ? (unsigned)c->post_reserve : 0u;
+    if (const char *e = psdr_tuning_env("PSDR_GRID_RESERVE")) reserve = (unsigned)atoi(e) & ~7u;  // (tuning build)
+    if (lds * 2 > 160 * 1024 && cap >= reserve + 8u) cap -= reserve;
     return blocks <= cap ? blocks : std::max(cap, 8u);
 }
 
@@ -379,6 +385,7 @@ bool fused_supported(const psdr_ctx *c, int sb);
 int launch_fused(psdr_ctx *c, int sb, const Pass1Args &a1, const Pass2Args &a2);
 // postchain.hip: the chain's kernels for the batch demod_impl has just enqueued; *last_user = the last stream that reads
 // the client parameter block
-int post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, int nact, int npaused, int nframes, hipStream_t *last_user);
+int post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const int *d_slot_ci, int nact, int npaused, int nframes,
+                       hipStream_t *last_user);
 
 }  // namespace psdr

@@ -102,6 +102,9 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     if (ring < 0) return fail(PSDR_ERR_HIP, "client parameter ring: event wait failed");
     ClientParams *h_clients = (ClientParams *)c->client_ring.host(ring);
     ClientParams *d_clients = (ClientParams *)c->client_ring.dev(ring);
+    // behind the list, for the post chain: the list index of every slot's client (its kernels walk the SLOTS, lane = slot & 63)
+    const size_t S = c->aslots.size();
+    int *h_slot_ci = (int *)(h_clients + S), *d_slot_ci = (int *)(d_clients + S);
     {
         std::lock_guard<std::mutex> lk(c->mtx);
         if (band) {  // checked under the same lock that fixes the windows this batch is demodulated with
@@ -133,6 +136,10 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
             p.paused = 0;
             if (c->post_on) s.agc_reset = 0;
         }
+        if (c->post_on) {
+            for (size_t i = 0; i < S; i++) h_slot_ci[i] = -1;
+            for (int i = 0; i < nact; i++) h_slot_ci[h_clients[i].slot] = i;
+        }
         // Paused clients (psdr_client_set_paused) are not demodulated: signal_loop never calls send_audio for a client
         // whose socket is backed up (src/websocket.cpp:170-176), so its overlap-add tails, FM sample, DC blocker and
         // AGC stand still (src/signal.cpp:273-284).  The post chain lists them BEHIND the active ones with an empty
@@ -147,11 +154,12 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
                 p.slot = (int)i;
                 p.state_cur = s.state_cur;
                 p.paused = 1;
+                h_slot_ci[i] = nact + npaused - 1;
             }
     }
     c->last_demod_frames = nframes;
     if (nact == 0) return PSDR_OK;
-    HIPCHK(hipMemcpyAsync(d_clients, h_clients, (size_t)(nact + npaused) * sizeof(ClientParams),
+    HIPCHK(hipMemcpyAsync(d_clients, h_clients, c->post_on ? S * (sizeof(ClientParams) + sizeof(int)) : (size_t)nact * sizeof(ClientParams),
                           hipMemcpyHostToDevice, c->side));
     DemodArgs a{};
     a.spec = spec;
@@ -190,10 +198,6 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     a.bb_tail = c->d_bb_tail;
     a.bb_last = c->d_bb_last;
     a.slots = (int)c->aslots.size();
-    if (c->gather_pending && c->side3) {  // post chain: the previous batch's audio rows are still being gathered
-        HIPCHK(hipStreamWaitEvent(c->side, c->ev_gather, 0));
-        c->gather_pending = false;
-    }
     bool ola_done = false;
     {
         ProfScope ps(c, K_IDFT, c->side);
@@ -253,7 +257,7 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     }
     hipStream_t last_user = c->side;
     if (c->post_on && nact > 0) {
-        int rc = post_chain_enqueue(c, d_clients, nact, npaused, nframes, &last_user);
+        int rc = post_chain_enqueue(c, d_clients, d_slot_ci, nact, npaused, nframes, &last_user);
         if (rc) return rc;
     }
     HIPCHK(c->client_ring.release(ring, last_user));

@@ -10,27 +10,31 @@
 //   s1_t = (s1_{t-1} - x_{t-D}) + x_t            first moving average  (m1 = s1 / D)
 //   s2_t = (s2_{t-1} - m1_{t-D}) + m1_t          second moving average (out = x_{t-D+1} - s2 / D)
 //   g_t  = g + (w_t < g ? attack : release) * (w_t - g)           AGC attack / release
-// Everything else is a pure function of the streams and runs fully parallel.
+// Nothing else in the chain is sequential, but the recurrences decide the shape of everything: they cannot be split
+// along time, so their parallelism is the CLIENTS - one lane per client, one wave per 64 clients, ~25 cycles per sample
+// (the latency of three dependent f32 operations), 2 ms per 512-frame batch whatever the client count.
 //
-// Layout (round 2): every stream is CLIENT-MAJOR, [slot][row], with the history it needs kept IN
-// FRONT of the new samples (D rows for the averages, L-1 rows for the AGC look-ahead) - no rings.
-// A lane of a sequential kernel owns a client and walks its stream with 16-byte loads and stores
-// (four samples per memory instruction, a whole 16-step block = four loads, prefetched three
-// blocks ahead); the parallel kernels put their lanes along time.  Round 1 kept the streams
-// time-major with one 4-byte access per sample and one block of prefetch: with a single wave per 64
-// clients the two recurrence loops were bound by memory latency (43 and 32 ns per sample, 2.0 and
-// 1.5 ms per 256-frame batch) rather than by their 7 and 3 arithmetic operations per sample.
+// Layout (round 5): every stream is LANE-INTERLEAVED per group of 64 slots - sample t of slot s at float
+//   ((s >> 6) * pitch + (t >> 2) * 4) * 64 + (s & 63) * 4 + (t & 3)
+// i.e. [group][t / 4][lane][4].  Lane l of a wave owns slot 64 g + l: its four next samples are ONE 16-byte access,
+// and the wave's 64 of them one contiguous KiB.  (Rounds 2-4 kept the streams client-major, [slot][t]: a wave's load
+// touched 64 different lines, and with all 64 lanes in use - 256 clients - the two recurrence kernels were bound by the
+// texture addresser, 4.5 ms instead of 2 ms; the parallel kernels ran lanes-along-time through LDS and starved beside
+// the FFT passes, which own all but 32 KiB of every CU's LDS.)  The history a kernel needs sits IN FRONT of the new
+// samples (D rows for the averages, L-1 rows for the AGC look-ahead); the sets rotate per batch (three of them: a
+// batch's chain may still be running when the next two start), the tails are copied into the next set's history rows.
+// EVERY kernel is lane = client now; the ones that are not recurrences split time into independent pieces:
 //   k_pc_index    stream offset of every frame of every client (NaN-flagged frames dropped)
 //   k_pc_gather   audio[slot][frame][j] -> X[slot][D + t]
 //   k_pc_ma2      both running sums in one loop (D = 32)          (sequential)
 //   k_pc_ma<0|1>  the two running sums, any D                      (sequential, fallback)
-//   k_pc_scan     AGC look-ahead peak: sliding maximum of |x| over L samples (the reference's
-//                 monotonic deque) as van Herk prefix / suffix maxima of blocks of L (sequential,
-//                 but over (client, block) pairs)
-//   k_pc_want     w_t = desired / (peak_t + 1e-10)                 (parallel)
+//   k_pc_history  the last D / L-1 rows become the next set's history
+//   k_pc_submax / k_pc_prefix / k_pc_want
+//                 AGC look-ahead peak: the sliding maximum of |x| over L samples (the reference's monotonic deque) as
+//                 van Herk prefix / suffix maxima of blocks of L rows, a wave per (group, sub-block of a block), then
+//                 w_t = desired / (peak_t + 1e-10)
 //   k_pc_gain     the gain recurrence                              (sequential)
 //   k_pc_out      delayed sample * gain, int16 conversion, straight into pcm[slot][frame][j]
-//   k_pc_history  the last D / L-1 rows become the next batch's history
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -47,6 +51,13 @@ typedef float pc_f4 __attribute__((ext_vector_type(4)));
 #ifndef PSDR_PC_SETPRIO
 #define PSDR_PC_SETPRIO 3
 #endif
+
+// the lane-interleaved stream layout (see above): a slot's lane base, and the offset of its row t from there
+__device__ __forceinline__ size_t pc_base(int slot, size_t pitch) { return (size_t)(slot >> 6) * pitch * 64 + (size_t)(slot & 63) * 4; }
+__device__ __forceinline__ size_t pc_el(int t) { return ((size_t)(t >> 2) << 8) + (size_t)(t & 3); }
+// the 16-byte row group q (rows 4q .. 4q+3) of a lane
+__device__ __forceinline__ pc_f4 *pc_row4(float *lane_base, int q) { return reinterpret_cast<pc_f4 *>(lane_base) + (size_t)q * 64; }
+__device__ __forceinline__ const pc_f4 *pc_row4(const float *lane_base, int q) { return reinterpret_cast<const pc_f4 *>(lane_base) + (size_t)q * 64; }
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void pc_static_for(F &&f) {
@@ -74,10 +85,8 @@ __global__ __launch_bounds__(64) void k_pc_index(PostArgs a) {
         cnt += __popcll(m);
     }
     if (lane == 0) a.len[slot] = cnt * a.h;
-    if (cp.agc_reset == 2) {  // a new client in this slot starts from zero history (sums: see k_pc_ma*)
-        float *x = a.X + (size_t)slot * a.px, *m1 = a.M1 + (size_t)slot * a.px;
-        for (int r = lane; r < a.D; r += 64) x[r] = m1[r] = 0.f;
-    }
+    // (a new client in this slot - agc_reset 2 - starts from zero history: the moving-average kernels zero their own
+    // history rows, k_pc_ma*)
 }
 
 // grid (client, frame): one frame of audio to its place in the stream (contiguous both sides)
@@ -86,8 +95,23 @@ __global__ __launch_bounds__(256) void k_pc_gather(PostArgs a) {
     const int pos = a.fstart[(size_t)slot * a.max_batch + f];
     if (pos < 0) return;
     const float *src = a.audio + ((size_t)slot * a.max_batch + f) * a.h;
-    float *dst = a.X + (size_t)slot * a.px + a.D + pos;
-    for (int j = threadIdx.x; j < a.h; j += blockDim.x) dst[j] = src[j];
+    float *dst = a.X + pc_base(slot, a.px);
+    for (int j = threadIdx.x; j < a.h; j += blockDim.x) dst[pc_el(a.D + pos + j)] = src[j];
+}
+
+// the same with lane = slot (h and D multiples of 4: every frame starts on a row group): grid (groups of 64 slots, frame),
+// thread (lane, j / 4) - 16 bytes from the client's audio row (64 rows per wave, each line used up over eight turns),
+// one contiguous KiB into X per wave
+typedef int pc_i4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_pc_gather4(PostArgs a) {
+    const int slot = blockIdx.x * 64 + (threadIdx.x & 63), f = blockIdx.y;
+    if (slot >= a.slots || a.slot_ci[slot] < 0) return;
+    const int pos = a.fstart[(size_t)slot * a.max_batch + f];
+    if (pos < 0) return;
+    const pc_f4 *src = reinterpret_cast<const pc_f4 *>(a.audio + ((size_t)slot * a.max_batch + f) * a.h);
+    float *X = a.X + pc_base(slot, a.px);
+    const int q0 = (a.D + pos) >> 2;
+    for (int j4 = threadIdx.x >> 6; j4 < (a.h >> 2); j4 += 4) *pc_row4(X, q0 + j4) = src[j4];
 }
 
 // One moving average (MovingAverage::insert, src/utils.h:84-93: sum -= oldest; push; sum += val),
@@ -99,204 +123,309 @@ __global__ __launch_bounds__(256) void k_pc_gather(PostArgs a) {
 // POW2: D is a power of two (x / 2^k == x * 2^-k exactly: no division in the loop)
 template <bool SECOND, bool POW2>
 __global__ __launch_bounds__(64) void k_pc_ma(PostArgs a) {
-    const int lane = threadIdx.x, ci = blockIdx.x * 64 + lane;
-    if (ci >= a.nact) return;
+    const int slot = blockIdx.x * 64 + threadIdx.x;  // lane = slot & 63: the wave's accesses are contiguous
+    if (slot >= a.slots) return;
+    const int ci = a.slot_ci[slot];
+    if (ci < 0) return;
     const ClientParams cp = a.clients[ci];
-    const int slot = cp.slot, D = a.D;
-    const bool fresh = cp.agc_reset == 2;  // a new client in this slot: zero sums (k_pc_index zeroed the history)
+    const int D = a.D;
+    const bool fresh = cp.agc_reset == 2;  // a new client in this slot: zero sums and zero history
     const int T = a.len[slot];
-    const float *__restrict__ in = (SECOND ? a.M1 : a.X) + (size_t)slot * a.px;
-    const float *__restrict__ X = a.X + (size_t)slot * a.px;
-    float *__restrict__ out = SECOND ? a.V1 + (size_t)slot * a.pv + a.vo + (a.L - 1) : a.M1 + (size_t)slot * a.px + D;
+    float *inw = (SECOND ? a.M1 : a.X) + pc_base(slot, a.px);
+    if (fresh)
+        for (int r = 0; r < D; r++) inw[pc_el(r)] = 0.f;
+    const float *in = inw;
+    const float *X = a.X + pc_base(slot, a.px);
+    float *out = SECOND ? a.V1 + pc_base(slot, a.pv) : a.M1 + pc_base(slot, a.px);
+    const int o0 = SECOND ? a.vo + a.L - 1 : D;
     float s = fresh ? 0.f : (SECOND ? a.dc_s2 : a.dc_s1)[slot];
     const float fD = (float)D, rD = 1.0f / fD;
     for (int t = 0; t < T; t++) {
-        s = __fadd_rn(s, -in[t]);
-        s = __fadd_rn(s, in[D + t]);
+        s = __fadd_rn(s, -in[pc_el(t)]);
+        s = __fadd_rn(s, in[pc_el(D + t)]);
         const float m = POW2 ? __fmul_rn(s, rD) : __fdiv_rn(s, fD);
-        out[t] = SECOND ? __fsub_rn(X[t + 1], m) : m;
+        out[pc_el(o0 + t)] = SECOND ? __fsub_rn(X[pc_el(t + 1)], m) : m;
     }
     (SECOND ? a.dc_s2 : a.dc_s1)[slot] = s;
 }
 
-// Both moving averages in one loop for D = 32.  The x values the first average evicts were
-// inserted two 16-step blocks earlier and the m1 values the second average evicts were produced two
-// blocks earlier: both stay in two alternating register sets, so a 16-step block costs four 16-byte
-// loads (the new x), four 16-byte stores and 16 x 7 arithmetic operations.  M1 only holds the 32
-// carried values between batches (time order, oldest first).  A stream that is not a whole number
-// of blocks ends with a short scalar loop on the in-memory history.
-__global__ __launch_bounds__(64) void k_pc_ma2(PostArgs a) {
-    const int lane = threadIdx.x, ci = blockIdx.x * 64 + lane;
-    if (ci >= a.nact) return;
-    const ClientParams cp = a.clients[ci];
-    const int slot = cp.slot;
-    // RING register sets of one 16-step block each: blocks b-2, b-1 (evicted values), b, and AHEAD = RING - 3 blocks of
-    // loads in flight.  Round 3: 13 blocks ahead instead of 3 - vmcnt is ONE in-order counter for loads and stores,
-    // so waiting for a load also waits for every store issued before it, and beside the FFT passes a store is
-    // acknowledged thousands of cycles after issue: the distance has to cover THAT, not the load latency.  A single-wave
-    // kernel has the registers (RING must be even: the two m1 sets alternate).
-    constexpr int KB = 16, D = 32, RING = PSDR_PC_RING, AHEAD = RING - 3;
-    static_assert(RING % 2 == 0 && RING >= 6, "ring of x blocks");
-    // one wave next to the FFT passes' eight issue-bound waves: let it issue first
-    __builtin_amdgcn_s_setprio(PSDR_PC_SETPRIO);
-    const bool fresh = cp.agc_reset == 2;  // zero sums (k_pc_index zeroed the history rows)
-    const int T = a.len[slot];
-    if (T == 0) return;
+// Both moving averages for D = 32, as TWO waves of one work-group (round 5).  One wave doing both sums issues six
+// instructions per sample - 25 cycles, 1.9 - 2.8 ms per 512 frames at the capped clock beside the FFT passes: longer than
+// the step it is meant to hide behind, and no pipeline helps a stage that is sequential across batches.  Split:
+//   wave 0  loads x (a ring of register sets, the loads nine blocks ahead), runs s1 and leaves each 16-step block of x
+//           and s1 in LDS;  no global stores - its s_waitcnt vmcnt never waits for a store's acknowledgement
+//   wave 1  takes the block from LDS one barrier later, runs s2 and the output, stores V1;  no global loads in its loop -
+//           its stores are fire and forget
+// two instructions on the critical path of either (sub, add / fma, fma): ~17 cycles per sample with the barrier.
+// The x values the first average evicts were inserted two blocks earlier and the m1 values the second average evicts were
+// produced two blocks earlier: both stay in alternating register sets.  M1 only holds the 32 carried values between
+// batches (time order, oldest first).  A stream that is not a whole number of blocks ends with a short scalar loop on
+// the in-memory history (wave 1).  Lanes of a group may have streams of different lengths (dropped frames, paused
+// clients): the trip count is the group's maximum, a lane past its own end keeps its state.
+constexpr int PC_MA_RING = 12;  // wave 0's register sets of x: blocks b-2 .. b (in use), b+1 .. b+9 in flight
+__global__ __launch_bounds__(128) void k_pc_ma2(PostArgs a) {
+    __shared__ pc_f4 hand[2][8][64];  // [buffer][0-3: x of the block, 4-7: s1 of the block][lane]: 16 KiB
+    __shared__ float fin[64];         // wave 0's s1 after its last block
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 64 + lane;  // lane = slot & 63 (the streams of a group are allocated whole)
+    const int ci = slot < a.slots ? a.slot_ci[slot] : -1;
+    const bool listed = ci >= 0;
+    const bool fresh = listed && a.clients[ci].agc_reset == 2;  // a new client in this slot: zero sums, zero history rows
+    constexpr int KB = 16, D = 32;
+    __builtin_amdgcn_s_setprio(PSDR_PC_SETPRIO);  // a few waves next to the FFT passes' issue-bound ones: let them issue first
+    const int T = listed ? a.len[slot] : 0;
     const int nfull = T / KB;
-    float *__restrict__ X = a.X + (size_t)slot * a.px;
-    float *__restrict__ M1 = a.M1 + (size_t)slot * a.px;
-    float *__restrict__ V1 = a.V1 + (size_t)slot * a.pv + a.vo + (a.L - 1);  // 16-byte aligned (vo)
-    float s1 = fresh ? 0.f : a.dc_s1[slot], s2 = fresh ? 0.f : a.dc_s2[slot];
-    const float rD = 1.0f / 32.0f;
-    // x lives in a ring of SIX register sets of one 16-step block each: at block b the sets hold the blocks
-    // b-2 and b-1 (the values the first sum evicts; the first of b-1 is x_{t-D+1} of the block's last step,
-    // getLatest(delay - 1), src/utils.h:160-166), b (inserted now) and b+1..b+3 (loads in flight).  Nothing is
-    // ever copied from set to set - the ring is indexed at compile time, six blocks per trip.  ms: the first
-    // running SUM of the steps whose average the second sum evicts, two alternating sets (s1 = 32 * m1 exactly,
-    // so the eviction and the insertion are one fma each).
-    pc_f4 xr[RING][4];
+    int nmax = nfull;
+#pragma unroll
+    for (int d = 32; d; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d, 64));
+    float *__restrict__ X = a.X + pc_base(slot, a.px);
+    float *__restrict__ M1 = a.M1 + pc_base(slot, a.px);
+    float *__restrict__ M1n = a.M1n + pc_base(slot, a.px);
+    float *__restrict__ V1 = a.V1 + pc_base(slot, a.pv);
+    const float rD = 1.0f / 32.0f, nrD = -rD;
+    if (wid == 0) {
+        // ---- wave 0: s1_t = (s1 - x_{t-32}) + x_t
+        constexpr int RING = PC_MA_RING, AHEAD = RING - 3;
+        if (fresh)
+            for (int r = 0; r < D; r++) X[pc_el(r)] = 0.f;
+        float s1 = (fresh || !listed) ? 0.f : a.dc_s1[slot];
+        pc_f4 xr[RING][4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            xr[RING - 2][q] = *pc_row4(X, q);      // block -2
+            xr[RING - 1][q] = *pc_row4(X, 4 + q);  // block -1
+        }
+        auto fetch = [&](auto kc, int blk) {
+            constexpr int k = decltype(kc)::value;
+            // UNCONDITIONAL: a load under an exec mask makes the compiler wait with vmcnt(0) at the top of every block.
+            // Blocks up to nmax + AHEAD are read: inside the pitch's PC_PAD floats of padding, values never used.
+            const pc_f4 *src = pc_row4(X, (D + blk * KB) >> 2);
+#pragma unroll
+            for (int q = 0; q < 4; q++) xr[k][q] = src[q * 64];
+        };
+        pc_f4 sv[4] = {};
+        auto block = [&](auto jc, int b) {
+            constexpr int J = decltype(jc)::value, E = (J + RING - 2) % RING;
+            if (b < nfull) {
+#pragma unroll
+                for (int i = 0; i < KB; i++) {
+                    s1 = __fadd_rn(__fsub_rn(s1, xr[E][i >> 2][i & 3]), xr[J][i >> 2][i & 3]);
+                    sv[i >> 2][i & 3] = s1;
+                }
+            }
+            // the barrier comes BEFORE this block's LDS writes: it publishes the previous block, whose writes have had a
+            // whole block's time to land (waiting for one's own writes in front of every barrier cost a third of the loop)
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                hand[b & 1][q][lane] = xr[J][q];
+                hand[b & 1][4 + q][lane] = sv[q];
+            }
+            if (b + 1 == nmax) fin[lane] = s1;
+        };
+        pc_static_for<0, AHEAD>([&](auto kc) { fetch(kc, decltype(kc)::value); });
+        int b = 0;
+        for (; b + RING <= nmax; b += RING)
+            pc_static_for<0, RING>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                fetch(std::integral_constant<int, (J + AHEAD) % RING>{}, b + J + AHEAD);
+                block(jc, b + J);
+            });
+        {
+            const int b0 = b;
+            pc_static_for<0, RING - 1>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                if (b0 + J < nmax) {
+                    fetch(std::integral_constant<int, (J + AHEAD) % RING>{}, b0 + J + AHEAD);
+                    block(jc, b0 + J);
+                }
+            });
+        }
+        if (nmax == 0) fin[lane] = s1;
+        __syncthreads();  // (wave 1 runs three blocks behind)
+        __syncthreads();
+        __syncthreads();
+        return;
+    }
+    // ---- wave 1: s2_t = (s2 - m1_{t-32}) + m1_t, out_t = x_{t-31} - s2_t / 32, one block behind wave 0
+    // m1 = s1 / 32 is exact (a power of two), so rounding (s2 - m1_old) + m1 and x - s2 / 32 after the exact products is the
+    // reference's arithmetic with three fused operations instead of five:
+    //   t = s2 - s1_old / 32      s2 = t + s1 / 32      out = x_{t-D+1} - s2 / 32
+    if (fresh)
+        for (int r = 0; r < D; r++) M1[pc_el(r)] = 0.f;
+    float s2 = (fresh || !listed) ? 0.f : a.dc_s2[slot];
+    const int vq = (a.vo + a.L - 1) >> 2;  // sample 0's row group (vo makes row L-1 a multiple of 4)
+    // x in four register sets (blocks b-2, b-1, b and the block being read: x_{t-31} of the block's last step is the first
+    // of b-1, getLatest(delay - 1), src/utils.h:160-166), the first running SUM of the steps whose average the second sum
+    // evicts in two (s1 = 32 m1 exactly), the incoming s1 in two: all indexed at compile time, four blocks per trip.  The
+    // LDS reads of block b+1 are issued BEFORE block b is computed (and waited for at the barrier): three blocks behind wave 0.
+    pc_f4 xb[4][4], svs[2][4];
     float ms[2][KB];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        xr[RING - 2][q] = reinterpret_cast<const pc_f4 *>(X)[q];          // block -2
-        xr[RING - 1][q] = reinterpret_cast<const pc_f4 *>(X + KB)[q];     // block -1
+        xb[2][q] = *pc_row4(X, q);      // block -2 (b mod 4)
+        xb[3][q] = *pc_row4(X, 4 + q);  // block -1
+        if (fresh) xb[2][q] = xb[3][q] = pc_f4{0.f, 0.f, 0.f, 0.f};  // (wave 0 is zeroing those rows)
     }
 #pragma unroll
     for (int i = 0; i < KB; i++) {
-        ms[0][i] = __fmul_rn(M1[i], 32.0f);
-        ms[1][i] = __fmul_rn(M1[KB + i], 32.0f);
+        ms[0][i] = __fmul_rn(M1[pc_el(i)], 32.0f);
+        ms[1][i] = __fmul_rn(M1[pc_el(KB + i)], 32.0f);
     }
-    auto fetch = [&](auto kc, int blk) {
-        constexpr int k = decltype(kc)::value;
-        // UNCONDITIONAL (round 3): a load under `if (blk < nfull)` is a load under an exec mask, and behind those the
-        // compiler waits with s_waitcnt vmcnt(0) at the top of every block.  Blocks up to nfull + AHEAD are read:
-        // inside the row's PC_PAD floats of padding (psdr_set_post_chain: px, pv), values never used.
-        const pc_f4 *src = reinterpret_cast<const pc_f4 *>(X + D + blk * KB);  // D, KB, px: multiples of 4
+    auto take = [&](auto jc, int r) {  // block r (r mod 4 == J) from LDS into its register sets
+        constexpr int J = decltype(jc)::value;
 #pragma unroll
-        for (int q = 0; q < 4; q++) xr[k][q] = src[q];
-    };
-    // m1 = s1 / 32 is exact (a power of two), so rounding (s2 - m1_old) + m1 and x - s2 / 32 after the exact
-    // products is the reference's arithmetic with three fused operations instead of five:
-    //   t = s2 - s1_old / 32      s2 = t + s1 / 32      out = x_{t-D+1} - s2 / 32
-    // (the loop is bound by its own instruction stream: 7 -> 5 operations per sample, and no moves)
-    const float nrD = -rD;
-    auto block = [&](auto jc, int t0) {
-        constexpr int J = decltype(jc)::value, E = (J + RING - 2) % RING, N1 = (J + RING - 1) % RING, P = J & 1;
-        pc_f4 o[4];
-#pragma unroll
-        for (int i = 0; i < KB; i++) {
-            s1 = __fadd_rn(__fsub_rn(s1, xr[E][i >> 2][i & 3]), xr[J][i >> 2][i & 3]);
-            const float t2 = __fmaf_rn(ms[P][i], nrD, s2);
-            s2 = __fmaf_rn(s1, rD, t2);
-            ms[P][i] = s1;
-            const float xd = i + 1 < KB ? xr[E][(i + 1) >> 2][(i + 1) & 3] : xr[N1][0][0];
-            o[i >> 2][i & 3] = __fmaf_rn(s2, nrD, xd);
+        for (int q = 0; q < 4; q++) {
+            xb[J][q] = hand[r & 1][q][lane];
+            svs[J & 1][q] = hand[r & 1][4 + q][lane];
         }
-#pragma unroll
-        for (int q = 0; q < 4; q++) reinterpret_cast<pc_f4 *>(V1 + t0)[q] = o[q];
     };
-    pc_static_for<0, AHEAD>([&](auto kc) { fetch(kc, decltype(kc)::value); });
+    auto block = [&](auto jc, int b) {
+        constexpr int J = decltype(jc)::value, E = (J + 2) % 4, N1 = (J + 3) % 4, P = J & 1;
+        if (b + 1 < nmax) take(std::integral_constant<int, (J + 1) % 4>{}, b + 1);
+        if (b < nfull) {
+            pc_f4 o[4];
+#pragma unroll
+            for (int i = 0; i < KB; i++) {
+                const float s1 = svs[P][i >> 2][i & 3];
+                const float t2 = __fmaf_rn(ms[P][i], nrD, s2);
+                s2 = __fmaf_rn(s1, rD, t2);
+                ms[P][i] = s1;
+                const float xd = i + 1 < KB ? xb[E][(i + 1) >> 2][(i + 1) & 3] : xb[N1][0][0];
+                o[i >> 2][i & 3] = __fmaf_rn(s2, nrD, xd);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) *pc_row4(V1, vq + b * (KB / 4) + q) = o[q];
+        }
+        __syncthreads();
+    };
+    __syncthreads();
+    __syncthreads();  // block 0 is in LDS
+    if (nmax > 0) take(std::integral_constant<int, 0>{}, 0);
+    __syncthreads();
     int b = 0;
-    for (; b + RING <= nfull; b += RING)
-        pc_static_for<0, RING>([&](auto jc) {
-            constexpr int J = decltype(jc)::value;
-            fetch(std::integral_constant<int, (J + AHEAD) % RING>{}, b + J + AHEAD);
-            block(jc, (b + J) * KB);
-        });
-    // up to RING - 1 more whole blocks (b is a multiple of RING: block b + j lives in set j)
+    for (; b + 4 <= nmax; b += 4) pc_static_for<0, 4>([&](auto jc) { block(jc, b + decltype(jc)::value); });
     {
         const int b0 = b;
-        pc_static_for<0, RING - 1>([&](auto jc) {
-            constexpr int J = decltype(jc)::value;
-            if (b0 + J < nfull) {
-                fetch(std::integral_constant<int, (J + AHEAD) % RING>{}, b0 + J + AHEAD);
-                block(jc, (b0 + J) * KB);
-                b = b0 + J + 1;
-            }
+        pc_static_for<0, 3>([&](auto jc) {
+            if (b0 + decltype(jc)::value < nmax) block(jc, b0 + decltype(jc)::value);
         });
     }
-    // now (b even) ms[0] is the older set of m1 values, else ms[1]: the window of m1 values in time
-    // order goes to rows t1.. of M1 for the remaining T - nfull*KB (< KB) steps, one by one
+    if (!listed) return;
+    float s1 = fin[lane];  // (a lane whose stream is shorter than the group's longest kept its state from its own last block on)
+    // now (nfull even) ms[0] is the older set of m1 values, else ms[1]: the window of m1 values in time order goes to rows
+    // t1.. of M1 for the remaining T - nfull * KB (< KB) steps, one by one
     const int t1 = nfull * KB;
 #pragma unroll
     for (int i = 0; i < KB; i++) {
-        M1[t1 + i] = __fmul_rn((b & 1) ? ms[1][i] : ms[0][i], rD);
-        M1[t1 + KB + i] = __fmul_rn((b & 1) ? ms[0][i] : ms[1][i], rD);
+        M1[pc_el(t1 + i)] = __fmul_rn((nfull & 1) ? ms[1][i] : ms[0][i], rD);
+        M1[pc_el(t1 + KB + i)] = __fmul_rn((nfull & 1) ? ms[0][i] : ms[1][i], rD);
     }
+    const int v0 = a.vo + a.L - 1;
     for (int t = t1; t < T; t++) {
-        s1 = __fadd_rn(__fadd_rn(s1, -X[t]), X[D + t]);
+        s1 = __fadd_rn(__fadd_rn(s1, -X[pc_el(t)]), X[pc_el(D + t)]);
         const float m1 = __fmul_rn(s1, rD);
-        s2 = __fadd_rn(__fadd_rn(s2, -M1[t]), m1);
-        M1[D + t] = m1;
-        V1[t] = __fsub_rn(X[t + 1], __fmul_rn(s2, rD));
+        s2 = __fadd_rn(__fadd_rn(s2, -M1[pc_el(t)]), m1);
+        M1[pc_el(D + t)] = m1;
+        V1[pc_el(v0 + t)] = __fsub_rn(X[pc_el(t + 1)], __fmul_rn(s2, rD));
     }
-    // the last 32 m1 values in time order become rows 0..31 (X's own history is moved by k_pc_history)
-    float keep[D];
+    // the last 32 m1 values in time order become rows 0..31 of the NEXT set (X's own history is moved by k_pc_history)
 #pragma unroll
-    for (int i = 0; i < D; i++) keep[i] = M1[T + i];
-#pragma unroll
-    for (int i = 0; i < D; i++) M1[i] = keep[i];
+    for (int i = 0; i < D; i++) M1n[pc_el(i)] = M1[pc_el(T + i)];
     a.dc_s1[slot] = s1;
     a.dc_s2[slot] = s2;
 }
 
-// grid (client, block k of L rows of V1, 2): z = 0: prefix maxima of |v| inside the block, 1: suffix
-// maxima.  max is associative and exact, so this one IS parallel: the block's rows go through LDS
-// (coalesced both ways), each lane scans a contiguous piece, the piece totals are combined by a wave
-// scan.  The block is walked in chunks of PC_SCAN_CHUNK rows with the running maximum carried from chunk
-// to chunk, so the LDS need does not grow with the look-ahead L (200 ms: 2400 rows at 12 kHz, 38400 at
-// the 192 kHz of the reference's shipped config.toml - 150 KB if the block had to fit at once).
-constexpr int PC_SCAN_CHUNK = 4096;
-__global__ __launch_bounds__(64) void k_pc_scan(PostArgs a) {
-    __shared__ float pc_blk[PC_SCAN_CHUNK];
-    const int lane = threadIdx.x;
-    const int slot = a.clients[blockIdx.x].slot;
-    const int rows = a.L - 1 + a.len[slot];
-    const int r0 = blockIdx.y * a.L, r1 = min(r0 + a.L, rows);
-    if (r0 >= rows) return;
-    const int n = r1 - r0;
-    const float *__restrict__ v1 = a.V1 + (size_t)slot * a.pv + a.vo + r0;
-    const bool suffix = blockIdx.z != 0;
-    float *__restrict__ out = (suffix ? a.S : a.P) + (size_t)slot * a.pv + r0;
-    float carry = 0.f;  // maximum of everything before this chunk (scan order)
-    // scan position q = distance from the scan's start (suffix scans run backwards): row q, or n - 1 - q
-    for (int q0 = 0; q0 < n; q0 += PC_SCAN_CHUNK) {
-        const int m = min(PC_SCAN_CHUNK, n - q0);
-        for (int i = lane; i < m; i += 64) pc_blk[i] = fabsf(v1[suffix ? n - 1 - (q0 + i) : q0 + i]);
-        __syncthreads();
-        const int C = (m + 63) / 64, i0 = min(lane * C, m), i1 = min(i0 + C, m);
-        float mx = 0.f;
-        for (int i = i0; i < i1; i++) mx = fmaxf(mx, pc_blk[i]);
-        float incl = mx;  // inclusive wave scan of the piece maxima
+// ---- the AGC look-ahead peak: peak_t = max |V1| over rows [t, t + L - 1] (the reference's monotonic deque) ----------
+// van Herk: with the rows cut into blocks of L, a window is a suffix of one block and a prefix of the next, so
+//   peak_t = max(S[t], P[t + L - 1]),  P[r] = max over [block start, r],  S[r] = max over [r, block end].
+// max is associative and exact: this IS parallel along time.  Lane = slot like everything else here; a wave owns one
+// SUB-BLOCK (a.sb rows) of one block of 64 slots and walks it row by row - forwards for P, backwards for S, the loads
+// 16 rows ahead - and starts from the maximum of the block's other sub-blocks on its side (k_pc_submax: only when the
+// look-ahead is longer than a sub-block - 38400 rows at the 192 kHz of the reference's shipped config.toml).
+// grid (groups of 64 slots, blocks x sub-blocks); sub-block j of block k: rows [kL + j sb, min(kL + (j + 1) sb, (k + 1) L, rows))
+struct PcPiece {
+    int slot, k, j, r0, r1;  // r1 <= r0: nothing to do
+    bool listed;
+};
+__device__ __forceinline__ PcPiece pc_piece(const PostArgs &a) {
+    PcPiece p;
+    p.slot = blockIdx.x * 64 + threadIdx.x;
+    p.listed = p.slot < a.slots && a.slot_ci[p.slot] >= 0;
+    p.k = blockIdx.y / a.nsub;
+    p.j = blockIdx.y - p.k * a.nsub;
+    const int rows = p.listed ? a.L - 1 + a.len[p.slot] : 0;
+    p.r0 = p.k * a.L + p.j * a.sb;
+    p.r1 = min(min(p.r0 + a.sb, (p.k + 1) * a.L), rows);
+    return p;
+}
+constexpr int PC_PEAK_U = 16;  // rows of loads in flight
+
+// SM[group][block * nsub + j][lane] = max |V1| over the sub-block (0 where it is empty)
+__global__ __launch_bounds__(64) void k_pc_submax(PostArgs a) {
+    const PcPiece p = pc_piece(a);
+    float mx = 0.f;
+    if (p.listed) {
+        const float *v1 = a.V1 + pc_base(p.slot, a.pv);
+        for (int r = p.r0; r < p.r1; r += PC_PEAK_U) {
+            float v[PC_PEAK_U];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const float o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl = fmaxf(incl, o);
+            for (int i = 0; i < PC_PEAK_U; i++) v[i] = v1[pc_el(a.vo + min(r + i, p.r1 - 1))];
+#pragma unroll
+            for (int i = 0; i < PC_PEAK_U; i++) mx = fmaxf(mx, fabsf(v[i]));
         }
-        float run = __shfl_up(incl, 1, 64);  // maximum of all earlier pieces of this chunk ...
-        if (lane == 0) run = 0.f;
-        run = fmaxf(run, carry);             // ... and of all earlier chunks
-        for (int i = i0; i < i1; i++) {
-            run = fmaxf(run, pc_blk[i]);
-            pc_blk[i] = run;
-        }
-        carry = fmaxf(carry, __shfl(incl, 63, 64));
-        __syncthreads();
-        for (int i = lane; i < m; i += 64) out[suffix ? n - 1 - (q0 + i) : q0 + i] = pc_blk[i];
-        __syncthreads();
+    }
+    a.SM[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 64 + threadIdx.x] = mx;
+}
+
+// P[r] = max |V1| over [block start, r]
+__global__ __launch_bounds__(64) void k_pc_prefix(PostArgs a) {
+    const PcPiece p = pc_piece(a);
+    if (!p.listed || p.r1 <= p.r0) return;
+    const float *v1 = a.V1 + pc_base(p.slot, a.pv);
+    float *P = a.P + pc_base(p.slot, a.pv);
+    float run = 0.f;
+    for (int j = 0; j < p.j; j++) run = fmaxf(run, a.SM[((size_t)blockIdx.x * gridDim.y + (blockIdx.y - p.j + j)) * 64 + threadIdx.x]);
+    for (int r = p.r0; r < p.r1; r += PC_PEAK_U) {
+        float v[PC_PEAK_U];
+#pragma unroll
+        for (int i = 0; i < PC_PEAK_U; i++) v[i] = v1[pc_el(a.vo + min(r + i, p.r1 - 1))];
+#pragma unroll
+        for (int i = 0; i < PC_PEAK_U; i++)
+            if (r + i < p.r1) {
+                run = fmaxf(run, fabsf(v[i]));
+                P[pc_el(a.vo + r + i)] = run;
+            }
     }
 }
 
-// w_t = desired / (peak_t + 1e-10), peak_t = max |V1| over rows [t, t+L-1] = max(S[t], P[t+L-1]);
-// in place into S[t] (only this thread reads S[t]).  grid (client, blocks of 256 samples)
-__global__ __launch_bounds__(256) void k_pc_want(PostArgs a) {
-    const int slot = a.clients[blockIdx.x].slot;
-    const int t = blockIdx.y * 256 + threadIdx.x;
-    if (t >= a.len[slot]) return;
-    float *S = a.S + (size_t)slot * a.pv;
-    const float *P = a.P + (size_t)slot * a.pv;
-    const float peak = fmaxf(S[t], P[t + a.L - 1]);
-    S[t] = __fdiv_rn(a.desired, __fadd_rn(peak, 1e-10f));
+// w_t = desired / (peak_t + 1e-10) for the samples t = r of the sub-block (r < T), peak_t = max(S[t], P[t + L - 1]); w_t goes
+// to sample t's row (vo + L - 1 + t, where V1 keeps sample t and k_pc_gain will put g_t) of S.  (t + L - 1 is the
+// last row of the same block when t is the block's first row: S[t] is the whole block then, and so is that P.)
+__global__ __launch_bounds__(64) void k_pc_want(PostArgs a) {
+    const PcPiece p = pc_piece(a);
+    if (!p.listed || p.r1 <= p.r0) return;
+    const int T = a.len[p.slot], v0 = a.vo + a.L - 1;
+    const float *v1 = a.V1 + pc_base(p.slot, a.pv);
+    const float *P = a.P + pc_base(p.slot, a.pv);
+    float *W = a.S + pc_base(p.slot, a.pv);
+    float run = 0.f;
+    for (int j = p.j + 1; j < a.nsub; j++) run = fmaxf(run, a.SM[((size_t)blockIdx.x * gridDim.y + (blockIdx.y - p.j + j)) * 64 + threadIdx.x]);
+    for (int r = p.r1 - 1; r >= p.r0; r -= PC_PEAK_U) {
+        float v[PC_PEAK_U], q[PC_PEAK_U];
+#pragma unroll
+        for (int i = 0; i < PC_PEAK_U; i++) {
+            const int rr = max(r - i, p.r0);
+            v[i] = v1[pc_el(a.vo + rr)];
+            q[i] = P[pc_el(v0 + min(rr, T - 1 + (T == 0)))];  // (rows r >= T have no sample: clamped, unused)
+        }
+#pragma unroll
+        for (int i = 0; i < PC_PEAK_U; i++)
+            if (r - i >= p.r0) {
+                run = fmaxf(run, fabsf(v[i]));
+                if (r - i < T) W[pc_el(v0 + r - i)] = __fdiv_rn(a.desired, __fadd_rn(fmaxf(run, q[i]), 1e-10f));
+            }
+    }
 }
 
 // the gain recurrence (src/utils/audioprocessing.cpp:55-66); g_t -> P[t] (0 while the
@@ -304,10 +433,12 @@ __global__ __launch_bounds__(256) void k_pc_want(PostArgs a) {
 // an active gain is never 0: w_t > 0)
 template <bool ATT_FASTER>
 __global__ __launch_bounds__(64) void k_pc_gain(PostArgs a) {
-    const int lane = threadIdx.x, ci = blockIdx.x * 64 + lane;
-    if (ci >= a.nact) return;
+    const int slot = blockIdx.x * 64 + threadIdx.x;  // lane = slot & 63
+    if (slot >= a.slots) return;
+    const int ci = a.slot_ci[slot];
+    if (ci < 0) return;
     const ClientParams cp = a.clients[ci];
-    const int slot = cp.slot, L = a.L;
+    const int L = a.L;
     const int T = a.len[slot];
     float gain = a.agc_gain[slot];
     int n0 = a.agc_n0[slot];
@@ -317,8 +448,9 @@ __global__ __launch_bounds__(64) void k_pc_gain(PostArgs a) {
     }
     constexpr int KB = 16, GR = PSDR_PC_RING, AHEAD = GR - 1;  // blocks of loads in flight: see k_pc_ma2
     __builtin_amdgcn_s_setprio(PSDR_PC_SETPRIO);
-    const float *__restrict__ W = a.S + (size_t)slot * a.pv;
-    float *__restrict__ G = a.P + (size_t)slot * a.pv;
+    // sample t's row in S (w_t) and P (g_t): vo + L - 1 + t, a multiple of 4 at t = 0
+    const float *__restrict__ W = a.S + pc_base(slot, a.pv) + (size_t)((a.vo + L - 1) >> 2) * 256;
+    float *__restrict__ G = a.P + pc_base(slot, a.pv) + (size_t)((a.vo + L - 1) >> 2) * 256;
     const float att = a.attack, rel = a.release;
     // gain <- gain + (w < gain ? attack : release) * (w - gain): three operations per sample
     // (fma(-a, g - w, g) and fma(a, w - g, g) are the same value: negating both factors is exact)
@@ -343,23 +475,23 @@ __global__ __launch_bounds__(64) void k_pc_gain(PostArgs a) {
     // reference outputs 0 and leaves the gain alone: those steps, then (once 16-byte aligned) whole
     // blocks with the loads three blocks ahead, then the rest
     int t = 0;
-    for (; t < T && n0 + t + 1 < L; t++) G[t] = 0.f;
-    for (; t < T && (t & 3); t++) G[t] = step(W[t]);
+    for (; t < T && n0 + t + 1 < L; t++) G[pc_el(t)] = 0.f;
+    for (; t < T && (t & 3); t++) G[pc_el(t)] = step(W[pc_el(t)]);
     const int nblk = (T - t) / KB;
     pc_f4 w[GR][4];
     auto fetch = [&](auto kc, int blk) {
         constexpr int k = decltype(kc)::value;
         // (unconditional, like k_pc_ma2's: blocks up to nblk + AHEAD stay inside the row's padding)
-        const pc_f4 *src = reinterpret_cast<const pc_f4 *>(W + t + blk * KB);
+        const pc_f4 *src = pc_row4(W, (t + blk * KB) >> 2);
 #pragma unroll
-        for (int q = 0; q < 4; q++) w[k][q] = src[q];
+        for (int q = 0; q < 4; q++) w[k][q] = src[q * 64];
     };
     auto block = [&](const pc_f4 (&wv)[4], int blk) {
         pc_f4 g[4];
 #pragma unroll
         for (int i = 0; i < KB; i++) g[i >> 2][i & 3] = step(wv[i >> 2][i & 3]);
 #pragma unroll
-        for (int q = 0; q < 4; q++) reinterpret_cast<pc_f4 *>(G + t + blk * KB)[q] = g[q];
+        for (int q = 0; q < 4; q++) *pc_row4(G, ((t + blk * KB) >> 2) + q) = g[q];
     };
     pc_static_for<0, AHEAD>([&](auto kc) { fetch(kc, decltype(kc)::value); });
     int b = 0;
@@ -379,7 +511,7 @@ __global__ __launch_bounds__(64) void k_pc_gain(PostArgs a) {
             }
         });
     }
-    for (t += nblk * KB; t < T; t++) G[t] = step(W[t]);
+    for (t += nblk * KB; t < T; t++) G[pc_el(t)] = step(W[pc_el(t)]);
     a.agc_gain[slot] = gain;
     a.agc_n0[slot] = min(n0 + T, L);
 }
@@ -391,12 +523,13 @@ __global__ __launch_bounds__(256) void k_pc_out(PostArgs a) {
     const int slot = a.clients[blockIdx.x].slot, f = blockIdx.y;
     const int pos = a.fstart[(size_t)slot * a.max_batch + f];
     int32_t *dst = a.pcm + ((size_t)slot * a.max_batch + f) * a.h;
-    const float *G = a.P + (size_t)slot * a.pv + pos, *V = a.V1 + (size_t)slot * a.pv + a.vo + pos;
+    const float *G = a.P + pc_base(slot, a.pv), *V = a.V1 + pc_base(slot, a.pv);
+    const int g0 = a.vo + a.L - 1 + pos, v0 = a.vo + pos;  // sample pos + j: g in its own row, the delayed sample L - 1 rows earlier
     for (int j = threadIdx.x; j < a.h; j += blockDim.x) {
         int v = 0;
         if (pos >= 0) {
-            const float g = G[j];
-            const float y = g == 0.f ? 0.f : __fmul_rn(V[j], g);
+            const float g = G[pc_el(g0 + j)];
+            const float y = g == 0.f ? 0.f : __fmul_rn(V[pc_el(v0 + j)], g);
             v = (int)__fmaf_rn(y, 16384.f, 32768.5f) - 32768;
             v = v > 32767 ? 32767 : (v < -32768 ? -32768 : v);
         }
@@ -404,33 +537,42 @@ __global__ __launch_bounds__(256) void k_pc_out(PostArgs a) {
     }
 }
 
-// the last D rows of X / M1 and the last L-1 rows of V1 become the history rows of the next
-// batch.  grid (client); hist_sel = 0: X and M1, 1: V1 -> V1n.  One work-group per stream: all reads, a
-// barrier, all writes (source and destination overlap when the batch is shorter than the history).
-// dynamic LDS: max(D, L - 1) floats
+// the same with lane = slot (h a multiple of 4): grid (groups of 64 slots, frame), thread (lane, j / 4)
+__global__ __launch_bounds__(256) void k_pc_out4(PostArgs a) {
+    const int slot = blockIdx.x * 64 + (threadIdx.x & 63), f = blockIdx.y;
+    if (slot >= a.slots || a.slot_ci[slot] < 0) return;
+    const int pos = a.fstart[(size_t)slot * a.max_batch + f];
+    pc_i4 *dst = reinterpret_cast<pc_i4 *>(a.pcm + ((size_t)slot * a.max_batch + f) * a.h);
+    const float *G = a.P + pc_base(slot, a.pv), *V = a.V1 + pc_base(slot, a.pv);
+    const int gq = (a.vo + a.L - 1 + max(pos, 0)) >> 2, v0 = a.vo + max(pos, 0);
+    for (int j4 = threadIdx.x >> 6; j4 < (a.h >> 2); j4 += 4) {
+        pc_i4 o = {0, 0, 0, 0};
+        if (pos >= 0) {
+            const pc_f4 g = *pc_row4(G, gq + j4);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float y = g[i] == 0.f ? 0.f : __fmul_rn(V[pc_el(v0 + 4 * j4 + i)], g[i]);
+                int v = (int)__fmaf_rn(y, 16384.f, 32768.5f) - 32768;
+                o[i] = v > 32767 ? 32767 : (v < -32768 ? -32768 : v);
+            }
+        }
+        dst[j4] = o;
+    }
+}
+
+// the last D rows of X / M1 and the last L-1 rows of V1 become the history rows of the NEXT set (the sets rotate per
+// batch: source and destination never overlap, however short the batch).  grid (listed client); an empty stream (T = 0)
+// copies its history as it is.  M1: only on the two-kernel path (k_pc_ma2 moves its own 32 values).
 __global__ __launch_bounds__(256) void k_pc_history(PostArgs a) {
-    extern __shared__ float pc_hist[];
     const int slot = a.clients[blockIdx.x].slot;
     const int T = a.len[slot];
-    if (T == 0 && a.hist_sel == 0) return;
-    if (a.hist_sel == 0) {
-        float *x = a.X + (size_t)slot * a.px, *m = a.M1 + (size_t)slot * a.px;
-        for (int r = threadIdx.x; r < a.D; r += blockDim.x) pc_hist[r] = x[r + T];
-        __syncthreads();
-        for (int r = threadIdx.x; r < a.D; r += blockDim.x) x[r] = pc_hist[r];
-        if (!a.ma_fused) {
-            __syncthreads();
-            for (int r = threadIdx.x; r < a.D; r += blockDim.x) pc_hist[r] = m[r + T];
-            __syncthreads();
-            for (int r = threadIdx.x; r < a.D; r += blockDim.x) m[r] = pc_hist[r];
-        }
-        return;
+    const float *x = a.X + pc_base(slot, a.px), *m = a.M1 + pc_base(slot, a.px), *v = a.V1 + pc_base(slot, a.pv);
+    float *xn = a.Xn + pc_base(slot, a.px), *mn = a.M1n + pc_base(slot, a.px), *vn = a.V1n + pc_base(slot, a.pv);
+    for (int r = threadIdx.x; r < a.D; r += blockDim.x) {
+        xn[pc_el(r)] = x[pc_el(r + T)];
+        if (!a.ma_fused) mn[pc_el(r)] = m[pc_el(r + T)];
     }
-    // V1 and V1n are the two buffers of the double-buffered stream: source and destination never overlap, a plain
-    // copy (no LDS: at 192 kHz the L - 1 rows would be 150 KB of it)
-    const float *v = a.V1 + (size_t)slot * a.pv + a.vo;
-    float *vn = a.V1n + (size_t)slot * a.pv + a.vo;
-    for (int r = threadIdx.x; r < a.L - 1; r += blockDim.x) vn[r] = v[r + T];
+    for (int r = threadIdx.x; r < a.L - 1; r += blockDim.x) vn[pc_el(a.vo + r)] = v[pc_el(a.vo + r + T)];
 }
 
 }  // namespace psdr

@@ -42,34 +42,35 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
             c->post_allocs.push_back(*ptr);
             return PSDR_OK;
         };
-        // client-major streams (postchain.h): pitches are multiples of 4 floats, + padding for the
-        // blocked kernels' look-ahead
+        // lane-interleaved streams (postchain.h): pitches are multiples of 4 floats per slot, + padding for the
+        // blocked kernels' look-ahead; a block of 64 slots is allocated whole
+        const size_t S64 = (S + 63) / 64 * 64;
         a.px = ((size_t)a.D + Tm + PSDR_PC_PAD + 3) & ~(size_t)3;
         a.vo = (4 - ((a.L - 1) & 3)) & 3;
         a.pv = ((size_t)a.vo + (size_t)a.L - 1 + Tm + PSDR_PC_PAD + 3) & ~(size_t)3;
+        // look-ahead peak: sub-blocks of at most 256 rows of a block of L rows (postchain.h: a wave per sub-block and 64 slots,
+        // 16 rows per round trip to memory - beside the FFT passes a round trip is microseconds)
+        a.nsub = (a.L + 255) / 256;
+        a.sb = (a.L + a.nsub - 1) / a.nsub;
+        const size_t nblk = (((size_t)a.L - 1 + Tm) + a.L - 1) / a.L;
         int rc = 0;
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < psdr_ctx::PC_SETS; i++) {
             rc |= alloc((void **)&c->post_fstart[i], S * c->max_batch * sizeof(int));
             rc |= alloc((void **)&c->post_len[i], S * sizeof(int));
-            rc |= alloc((void **)&c->post_v1[i], a.pv * S * sizeof(float));
-            rc |= alloc((void **)&c->post_p[i], a.pv * S * sizeof(float));
-            rc |= alloc((void **)&c->post_s[i], a.pv * S * sizeof(float));
-            if (!c->ev_s1[i]) HIPCHK(hipEventCreateWithFlags(&c->ev_s1[i], hipEventDisableTiming));
-            if (!c->ev_s2[i]) HIPCHK(hipEventCreateWithFlags(&c->ev_s2[i], hipEventDisableTiming));
+            rc |= alloc((void **)&c->post_x[i], a.px * S64 * sizeof(float));
+            rc |= alloc((void **)&c->post_m1[i], a.px * S64 * sizeof(float));
+            rc |= alloc((void **)&c->post_v1[i], a.pv * S64 * sizeof(float));
+            rc |= alloc((void **)&c->post_p[i], a.pv * S64 * sizeof(float));
+            rc |= alloc((void **)&c->post_s[i], a.pv * S64 * sizeof(float));
+            rc |= alloc((void **)&c->post_sm[i], S64 * nblk * a.nsub * sizeof(float));
+            for (auto &stage : c->ev_pc)
+                if (!stage[i]) HIPCHK(hipEventCreateWithFlags(&stage[i], hipEventDisableTiming));
         }
-        if (!c->side2) {
+        if (!c->pc_s[0]) {
             int lo = 0, hi = 0;
             HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            if (const char *e = psdr_tuning_env("PSDR_PC_ABL"))
-                if (atoi(e) & 16) hi = 0;  // (tuning build: the chain's two streams at normal priority)
-            HIPCHK(hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, hi));
-            HIPCHK(hipStreamCreateWithPriority(&c->side3, hipStreamNonBlocking, hi));
-            HIPCHK(hipEventCreateWithFlags(&c->ev_demod, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&c->ev_gather, hipEventDisableTiming));
-            for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_want[i], hipEventDisableTiming));
+            for (hipStream_t &st : c->pc_s) HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
         }
-        rc |= alloc((void **)&a.X, a.px * S * sizeof(float));
-        rc |= alloc((void **)&a.M1, a.px * S * sizeof(float));
         rc |= alloc((void **)&a.pcm, S * Tm * sizeof(int32_t));
         rc |= alloc((void **)&a.dc_s1, S * sizeof(float));
         rc |= alloc((void **)&a.dc_s2, S * sizeof(float));
@@ -79,95 +80,122 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
         a.audio = c->d_audio;
         a.nan_flags = c->d_nan;
     }
+    c->post_reserve = 8;
+    if (const char *e = psdr_tuning_env("PSDR_PC_RESERVE")) c->post_reserve = atoi(e) & ~7;  // (tuning build)
     c->post_on = true;
     return PSDR_OK;
 }
 
 // the chain's kernels for the batch whose demodulation has just been enqueued on c->side (d_clients: its parameter
-// block, the nact active clients first, then npaused paused ones with an empty stream)
-int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, int nact, int npaused, int nframes, hipStream_t *last_user) {
-    const int par = (int)(c->chain_seq & 1);
+// block - the nact active clients first, then npaused paused ones with an empty stream - and d_slot_ci: the list index of
+// every slot's client, -1 = not listed)
+int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const int *d_slot_ci, int nact, int npaused, int nframes,
+                             hipStream_t *last_user) {
+    constexpr int NS = psdr_ctx::PC_SETS;
+    const int set = (int)(c->chain_seq % NS), nxt = (set + 1) % NS;
+    const uint64_t seq = c->chain_seq;
     int abl = 0;  // (tuning build only: which part of the chain costs the step what)
     if (const char *e = psdr_tuning_env("PSDR_PC_ABL")) abl = atoi(e);
-    const bool piped = c->side != c->stream && c->side2 != nullptr && !(abl & 8);
-    hipStream_t s2 = piped ? c->side2 : c->side, s1 = piped ? c->side3 : c->side;
+    const bool piped = c->side != c->stream && c->pc_s[0] != nullptr && !(abl & 8);
+    // (stage 0 rides behind the demodulation on `side`: two short kernels, and a process gets few hardware queues - with
+    // four chain streams the fourth shared a queue with the third, the gain recurrence in front of the next batch's peak)
+    hipStream_t sg = c->side, sm = piped ? c->pc_s[0] : c->side, sp = piped ? c->pc_s[1] : c->side, sc = piped ? c->pc_s[2] : c->side;
+    // the recurrence kernels go to the CUs the passes leave free (ctx.h persistent_grid): with this much LDS they do not fit
+    // beside a pass's work-group (128 KiB of 160)
+    const size_t home_lds = c->post_reserve > 0 ? 40 * 1024 : 0;
+    const bool rows4 = (c->post.h & 3) == 0 && (c->post.D & 3) == 0;  // every frame starts on a row group: the lane = slot gather / output
     PostArgs pa = c->post;
     pa.clients = d_clients;
+    pa.slot_ci = d_slot_ci;
     pa.nact = nact + npaused;
     pa.nframes = nframes;
-    pa.V1 = c->post_v1[par];
-    pa.V1n = c->post_v1[par ^ 1];
-    pa.fstart = c->post_fstart[par];
-    pa.len = c->post_len[par];
-    pa.P = c->post_p[par];
-    pa.S = c->post_s[par];
+    pa.X = c->post_x[set], pa.Xn = c->post_x[nxt];
+    pa.M1 = c->post_m1[set], pa.M1n = c->post_m1[nxt];
+    pa.V1 = c->post_v1[set], pa.V1n = c->post_v1[nxt];
+    pa.P = c->post_p[set];
+    pa.S = c->post_s[set];
+    pa.SM = c->post_sm[set];
+    pa.fstart = c->post_fstart[set];
+    pa.len = c->post_len[set];
+    pa.ma_fused = pa.D == 32 ? 1 : 0;  // both averages in one loop (postchain.h)
     const int nall = nact + npaused;
-    const unsigned cb = (unsigned)((nall + 63) / 64);
+    const unsigned groups = (unsigned)((pa.slots + 63) / 64);
     const size_t Tb = (size_t)nframes * pa.h;  // longest possible stream of this batch
     const unsigned nblk = (unsigned)((pa.L - 1 + Tb + pa.L - 1) / pa.L);
-    {  // ---- stage 1 (its own stream when the consumers have theirs)
-        if (piped) {
-            HIPCHK(hipEventRecord(c->ev_demod, c->side));
-            HIPCHK(hipStreamWaitEvent(s1, c->ev_demod, 0));
-            if (c->chain_seq >= 2) HIPCHK(hipStreamWaitEvent(s1, c->ev_s2[par], 0));  // stage 2 of batch b-2 read this set
-        }
-        ProfScope ps(c, K_POST, s1);
-        hipLaunchKernelGGL(k_pc_index, dim3(nall), dim3(64), 0, s1, pa);
-        hipLaunchKernelGGL(k_pc_gather, dim3(nall, nframes), dim3(256), 0, s1, pa);
-        if (piped) {  // the audio rows and NaN flags are read: the next batch's demodulation may overwrite them
-            HIPCHK(hipEventRecord(c->ev_gather, s1));
-            c->gather_pending = true;
-        }
-        pa.ma_fused = pa.D == 32 ? 1 : 0;  // both averages in one loop (postchain.h)
+    // Who touched what last (sets rotate: batch b uses set b mod 3 and writes the history rows of set b + 1):
+    //   X[set] rows >= D, fstart / len[set]   gather(b)      <- moving averages, history, output of batch b - 3
+    //   V1[set] rows >= L-1                   averages(b)    <- peak / output of batch b - 3
+    //   X / M1 / V1[nxt] history rows         history(b)     <- averages(b - 2) (same stream), peak / output of batch b - 2
+    //   P / S / SM[set]                       peak(b)        <- gain / output of batch b - 3
+    // i.e. a stage waits for its predecessor of THIS batch and for the output stage of the batch that had the set.
+    auto wait = [&](hipStream_t st, int stage, int which) -> int {
+        if (piped) HIPCHK(hipStreamWaitEvent(st, c->ev_pc[stage][which], 0));
+        return PSDR_OK;
+    };
+    auto done = [&](hipStream_t st, int stage) -> int {
+        if (piped) HIPCHK(hipEventRecord(c->ev_pc[stage][set], st));
+        return PSDR_OK;
+    };
+    int rc = 0;
+    {  // ---- stage 0: frame offsets, audio rows -> X
+        if (seq >= NS && ((rc = wait(sg, 1, set)) || (rc = wait(sg, 3, set)))) return rc;
+        ProfScope ps(c, K_POST, sg);
+        hipLaunchKernelGGL(k_pc_index, dim3(nall), dim3(64), 0, sg, pa);
+        if (rows4)
+            hipLaunchKernelGGL(k_pc_gather4, dim3(groups, nframes), dim3(256), 0, sg, pa);
+        else
+            hipLaunchKernelGGL(k_pc_gather, dim3(nall, nframes), dim3(256), 0, sg, pa);
+        HIPCHK(hipGetLastError());
+        if ((rc = done(sg, 0))) return rc;
+    }
+    {  // ---- stage 1: the DC blocker's two moving averages (sequential), tails -> the next set's history rows
+        if ((rc = wait(sm, 0, set))) return rc;
+        if (seq >= NS && (rc = wait(sm, 3, set))) return rc;
+        if (seq >= NS - 1 && (rc = wait(sm, 3, nxt))) return rc;
+        ProfScope ps(c, K_POST, sm);
         if (abl & 1) {
         } else if (pa.ma_fused) {
-            hipLaunchKernelGGL(k_pc_ma2, dim3(cb), dim3(64), 0, s1, pa);
+            hipLaunchKernelGGL(k_pc_ma2, dim3(groups), dim3(128), home_lds ? home_lds - 17 * 1024 : 0, sm, pa);
         } else if ((pa.D & (pa.D - 1)) == 0) {
-            hipLaunchKernelGGL((k_pc_ma<false, true>), dim3(cb), dim3(64), 0, s1, pa);
-            hipLaunchKernelGGL((k_pc_ma<true, true>), dim3(cb), dim3(64), 0, s1, pa);
+            hipLaunchKernelGGL((k_pc_ma<false, true>), dim3(groups), dim3(64), 0, sm, pa);
+            hipLaunchKernelGGL((k_pc_ma<true, true>), dim3(groups), dim3(64), 0, sm, pa);
         } else {
-            hipLaunchKernelGGL((k_pc_ma<false, false>), dim3(cb), dim3(64), 0, s1, pa);
-            hipLaunchKernelGGL((k_pc_ma<true, false>), dim3(cb), dim3(64), 0, s1, pa);
+            hipLaunchKernelGGL((k_pc_ma<false, false>), dim3(groups), dim3(64), 0, sm, pa);
+            hipLaunchKernelGGL((k_pc_ma<true, false>), dim3(groups), dim3(64), 0, sm, pa);
         }
-        pa.hist_sel = 0;
-        hipLaunchKernelGGL(k_pc_history, dim3(nall), dim3(256), (size_t)pa.D * sizeof(float), s1, pa);
-        // the look-ahead maxima and w_t are parallel work: they ride in this stage (P and S exist per parity), so
-        // that stage 2 is nothing but the gain recurrence and the output - the two sequential kernels (k_pc_ma2
-        // here, k_pc_gain there: ~1.1 ms each beside the FFT passes) sit in different stages
-        if (!(abl & 4)) {
-            hipLaunchKernelGGL(k_pc_scan, dim3(nall, nblk, 2), dim3(64), 0, s1, pa);
-            hipLaunchKernelGGL(k_pc_want, dim3(nall, (unsigned)((Tb + 255) / 256)), dim3(256), 0, s1, pa);
-        }
-        // w_t is all the gain recurrence needs: it must not wait for the history copy below, which in turn waits
-        // for the previous batch's output kernel (gain -> out -> history -> gain would be one serial chain per batch)
-        if (piped) HIPCHK(hipEventRecord(c->ev_want[par], s1));
-        // V1's tail -> the other parity's history rows (a plain copy, no LDS).  The other parity's stage 2 (the
-        // previous batch: k_pc_out reads those rows) must be done with them
-        if (piped && c->chain_seq >= 1) HIPCHK(hipStreamWaitEvent(s1, c->ev_s2[par ^ 1], 0));
-        pa.hist_sel = 1;
-        hipLaunchKernelGGL(k_pc_history, dim3(nall), dim3(256), 0, s1, pa);
+        hipLaunchKernelGGL(k_pc_history, dim3(nall), dim3(256), 0, sm, pa);
         HIPCHK(hipGetLastError());
+        if ((rc = done(sm, 1))) return rc;
     }
-    if (piped) {
-        HIPCHK(hipEventRecord(c->ev_s1[par], s1));
-        HIPCHK(hipStreamWaitEvent(s2, c->ev_want[par], 0));
+    {  // ---- stage 2: look-ahead peak and w_t (parallel along time)
+        if ((rc = wait(sp, 1, set))) return rc;
+        if (seq >= NS && (rc = wait(sp, 3, set))) return rc;
+        ProfScope ps(c, K_POST, sp);
+        if (!(abl & 4)) {
+            if (pa.nsub > 1) hipLaunchKernelGGL(k_pc_submax, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp, pa);
+            hipLaunchKernelGGL(k_pc_prefix, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp, pa);
+            hipLaunchKernelGGL(k_pc_want, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp, pa);
+        }
+        HIPCHK(hipGetLastError());
+        if ((rc = done(sp, 2))) return rc;
     }
-    {  // ---- stage 2
-        ProfScope ps(c, K_POST, s2);
+    {  // ---- stage 3: the gain recurrence (sequential), int16 output
+        if ((rc = wait(sc, 2, set))) return rc;
+        ProfScope ps(c, K_POST, sc);
         if (abl & 2) {
         } else if (pa.attack >= pa.release)
-            hipLaunchKernelGGL(k_pc_gain<true>, dim3(cb), dim3(64), 0, s2, pa);
+            hipLaunchKernelGGL(k_pc_gain<true>, dim3(groups), dim3(64), home_lds, sc, pa);
         else
-            hipLaunchKernelGGL(k_pc_gain<false>, dim3(cb), dim3(64), 0, s2, pa);
-        if (piped) HIPCHK(hipStreamWaitEvent(s2, c->ev_s1[par], 0));  // k_pc_out reads V1's history rows
-        hipLaunchKernelGGL(k_pc_out, dim3(nall, nframes), dim3(256), 0, s2, pa);
+            hipLaunchKernelGGL(k_pc_gain<false>, dim3(groups), dim3(64), home_lds, sc, pa);
+        if (rows4)
+            hipLaunchKernelGGL(k_pc_out4, dim3(groups, nframes), dim3(256), 0, sc, pa);
+        else
+            hipLaunchKernelGGL(k_pc_out, dim3(nall, nframes), dim3(256), 0, sc, pa);
         HIPCHK(hipGetLastError());
+        if ((rc = done(sc, 3))) return rc;
     }
-    if (piped) {
-        HIPCHK(hipEventRecord(c->ev_s2[par], s2));
-        c->side2_pending = true;
-    }
+    if (piped) c->chain_pending = true;
     c->chain_seq++;
-    *last_user = s2;
+    *last_user = sc;
     return PSDR_OK;
 }

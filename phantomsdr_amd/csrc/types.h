@@ -21,13 +21,16 @@ struct ClientParams {
 };
 
 #ifndef PSDR_PC_RING
-#define PSDR_PC_RING 16  // register sets of 16 samples in the two recurrence kernels (even, >= 6)
+#define PSDR_PC_RING 8  // register sets of 16 samples in the gain recurrence kernel (round 5: 8, 10, 12 and 16 time the same)
 #endif
-// floats of padding behind every client's stream rows: the recurrence kernels read whole blocks ahead of the stream's end
-#define PSDR_PC_PAD (16 * (PSDR_PC_RING + 4))
+// floats of padding behind every slot's stream rows: the recurrence kernels read whole blocks ahead of the stream's end
+// (up to 15 blocks of 16: k_pc_ma2's ring of 12, k_pc_gain's of PSDR_PC_RING)
+#define PSDR_PC_PAD (16 * 20)
+static_assert(PSDR_PC_RING <= 16, "PSDR_PC_PAD covers rings of up to 16 blocks");
 
 struct PostArgs {
-    const ClientParams *clients;  // active clients (compact), .slot = row block
+    const ClientParams *clients;  // this batch's list: the active clients, then the paused ones (empty streams)
+    const int *slot_ci;           // [slots] index into `clients` of the slot's client, -1 = not listed in this batch
     int nact, nframes, max_batch, h;  // h = n/2 samples per frame
     int slots;
     int D, L;                         // DC delay, AGC look-ahead (samples)
@@ -36,14 +39,17 @@ struct PostArgs {
     const int *nan_flags;             // [slots][max_batch]
     int *fstart;                      // [slots][max_batch] stream offset of a frame, -1 = dropped
     int *len;                         // [slots] samples of this batch's stream
-    size_t px, pv;                    // row pitches (floats per client) of X/M1 and of V1/P/S, multiples of 4
-    int vo;                           // V1 only: leading pad so that its NEW rows (from row L-1) are 16-byte aligned
-    float *X;                         // [slots][px]: demodulated audio, rows < D history          (D + T + pad)
-    float *M1;                        // [slots][px]: first moving average, rows < D history
-    float *V1;                        // [slots][pv]: DC-blocked stream, rows < L-1 history         (L-1 + T + pad)
-    float *V1n;                       // the NEXT batch's V1 (double-buffered: k_pc_history moves the tail there)
-    int hist_sel;                     // k_pc_history: 0 = X and M1, 1 = V1 -> V1n
-    float *P, *S;                     // like V1: prefix / suffix maxima; then S = w_t, P = g_t
+    // The streams are LANE-INTERLEAVED per group of 64 slots (round 5; postchain.h pc_at): sample t of slot s sits at
+    // float ((s >> 6) * pitch + (t >> 2) * 4) * 64 + (s & 63) * 4 + (t & 3) - a wave whose lane l owns slot 64 g + l
+    // reads four samples of each of its clients with ONE contiguous 1 KiB access.
+    size_t px, pv;                    // pitches (floats per slot, multiples of 4) of X / M1 and of V1 / P / S
+    int vo;                           // V1 / P / S: leading pad so that sample 0's row (row L-1) is a multiple of 4
+    float *X, *Xn;                    // demodulated audio, rows < D history (D + T + pad); Xn: the NEXT batch's set
+    float *M1, *M1n;                  // first moving average, rows < D history
+    float *V1, *V1n;                  // DC-blocked stream, rows < L-1 history (L-1 + T + pad)
+    float *P, *S;                     // like V1: P = prefix maxima of |V1| per row, then g_t; S = w_t (both at sample t's row vo + L-1 + t)
+    float *SM;                        // [groups][sub-blocks][64] maxima of whole sub-blocks (look-ahead longer than one sub-block)
+    int sb, nsub;                     // sub-block length (rows), sub-blocks per look-ahead block of L rows
     int32_t *pcm;                     // [slots][max_batch][h]
     // carried state
     float *dc_s1, *dc_s2;             // [slots] running sums
