@@ -242,14 +242,14 @@ struct psdr_ctx {
     // post-demodulation chain (postchain.h), allocated by psdr_set_post_chain
     bool post_on = false;
     PostArgs post{};
-    // The chain is a pipeline across batches on three streams of its own (round 5), in the order of a batch's data:
+    // The chain is a pipeline across batches (round 5), in the order of a batch's data:
     //   side     index, gather (behind the demodulation)
     //   pc_s[0]  moving averages (sequential), history
-    //   pc_s[1]  look-ahead peak, w_t    pc_s[2]  gain recurrence (sequential), int16 output
-    // The two sequential kernels (~2 ms per 512 frames each, whatever the client count) are what a stream must not
-    // share: rounds 3-4 had two streams, and the one with k_pc_ma2 AND the six short kernels of its stage was longer
-    // than the step it hid behind (3.2 ms against 2.6).  What the stages hand on rotates over PC_SETS sets, so a
-    // batch's chain may take up to two steps longer than a step.
+    //   pc_s[2]  look-ahead peak, w_t, gain recurrence (sequential), int16 output
+    // (pc_s[1] is created and left idle: postchain.hip says why.)  The two sequential kernels (1.5 - 2 ms per 512 frames each, whatever the client count)
+    // are what a stream must not share: rounds 3-4 had the moving averages AND the six short kernels of their stage on
+    // one stream - longer than the step it hid behind (3.2 ms against 2.6).  What the stages hand on rotates over PC_SETS
+    // sets, so a batch's chain may take up to two steps longer than a step.
     static constexpr int PC_SETS = 3;
     hipStream_t pc_s[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_pc[4][PC_SETS] = {};  // [stage][set]: the stage's kernels of the batch that used the set are done

@@ -97,9 +97,20 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
     int abl = 0;  // (tuning build only: which part of the chain costs the step what)
     if (const char *e = psdr_tuning_env("PSDR_PC_ABL")) abl = atoi(e);
     const bool piped = c->side != c->stream && c->pc_s[0] != nullptr && !(abl & 8);
-    // (stage 0 rides behind the demodulation on `side`: two short kernels, and a process gets few hardware queues - with
-    // four chain streams the fourth shared a queue with the third, the gain recurrence in front of the next batch's peak)
-    hipStream_t sg = c->side, sm = piped ? c->pc_s[0] : c->side, sp = piped ? c->pc_s[1] : c->side, sc = piped ? c->pc_s[2] : c->side;
+    // Streams: stage 0 rides behind the demodulation on `side` (two short kernels), stage 2 in front of stage 3 on ITS stream
+    // (they are a chain anyway), the moving averages on the other.  Hardware queues are what is scarce: with four chain
+    // streams the fourth shared a queue with the third (the gain recurrence in front of the next batch's peak), and with
+    // three - five busy queues with the main and the side stream - every second launch of the PASSES started 50 - 60 us
+    // late (6 - 9 us with four queues, as without the chain): 4 % of the step.
+    // WHICH queues matters as much (tools/runs/r05_w.sh, r05_y.sh; rocprofv3 Queue_Id): the chain on queues 4 and 6 leaves the
+    // passes' launches alone, on 4 and 5 it delays them as three chain queues do - queue 5 shares its pipe of the command
+    // processor with queue 1, the main stream's.  The ids follow the order in which the process creates its streams (main 1,
+    // side 2, these 4 5 6), so the middle one of three is created and left idle.
+    hipStream_t sg = c->side, sm = piped ? c->pc_s[0] : c->side, sc = piped ? c->pc_s[2] : c->side, sp = sc;
+    if (const char *e = psdr_tuning_env("PSDR_PC_STREAMS")) {  // (tuning build)
+        if (atoi(e) == 3 && piped) sp = c->pc_s[1];           // the peak kernels on a stream of their own
+        if (atoi(e) == 2 && piped) sp = sc = c->pc_s[1];       // the two chain streams on neighbouring queues
+    }
     // the recurrence kernels go to the CUs the passes leave free (ctx.h persistent_grid): with this much LDS they do not fit
     // beside a pass's work-group (128 KiB of 160)
     const size_t home_lds = c->post_reserve > 0 ? 40 * 1024 : 0;
@@ -180,7 +191,7 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
         if ((rc = done(sp, 2))) return rc;
     }
     {  // ---- stage 3: the gain recurrence (sequential), int16 output
-        if ((rc = wait(sc, 2, set))) return rc;
+        if (sp != sc && (rc = wait(sc, 2, set))) return rc;
         ProfScope ps(c, K_POST, sc);
         if (abl & 2) {
         } else if (pa.attack >= pa.release)
