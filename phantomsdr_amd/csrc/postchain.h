@@ -428,90 +428,133 @@ __global__ __launch_bounds__(64) void k_pc_want(PostArgs a) {
     }
 }
 
-// the gain recurrence (src/utils/audioprocessing.cpp:55-66); g_t -> P[t] (0 while the
+// the gain recurrence (src/utils/audioprocessing.cpp:55-66); g_t -> sample t's row of P (0 while the
 // look-ahead buffer is still filling: the reference outputs 0 there and leaves the gain alone;
 // an active gain is never 0: w_t > 0)
+// Two waves like k_pc_ma2 (round 5): wave 0 loads w (a ring of register sets, the loads far ahead) and leaves each
+// 16-step block in LDS, wave 1 takes it a barrier later and runs the recurrence - no global load in its loop, so its
+// s_waitcnt never stands behind the acknowledgement of its own stores (with all 64 lanes in use, 1 KiB per store, the
+// one-wave form took 2.2 - 3.0 ms per 512 frames against 1.5 ms with 16 lanes).
+constexpr int PC_GAIN_RING = 12;
+static_assert(16 * (PC_MA_RING + 4) <= PSDR_PC_PAD && 16 * (PC_GAIN_RING + 4) <= PSDR_PC_PAD, "the loader waves read ahead inside the padding");
 template <bool ATT_FASTER>
-__global__ __launch_bounds__(64) void k_pc_gain(PostArgs a) {
-    const int slot = blockIdx.x * 64 + threadIdx.x;  // lane = slot & 63
-    if (slot >= a.slots) return;
-    const int ci = a.slot_ci[slot];
-    if (ci < 0) return;
-    const ClientParams cp = a.clients[ci];
+__global__ __launch_bounds__(128) void k_pc_gain(PostArgs a) {
+    __shared__ pc_f4 hand[2][4][64];  // [buffer][row group of the block][lane]: 8 KiB
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 64 + lane;  // lane = slot & 63
+    const int ci = slot < a.slots ? a.slot_ci[slot] : -1;
+    const bool listed = ci >= 0;
     const int L = a.L;
-    const int T = a.len[slot];
-    float gain = a.agc_gain[slot];
-    int n0 = a.agc_n0[slot];
-    if (cp.agc_reset) {  // AGC::reset() on a demodulation change (src/signal.cpp:322-326)
+    const int T = listed ? a.len[slot] : 0;
+    float gain = listed ? a.agc_gain[slot] : 0.f;
+    int n0 = listed ? a.agc_n0[slot] : 0;
+    if (listed && a.clients[ci].agc_reset) {  // AGC::reset() on a demodulation change (src/signal.cpp:322-326)
         gain = 0.f;
         n0 = 0;
     }
-    constexpr int KB = 16, GR = PSDR_PC_RING, AHEAD = GR - 1;  // blocks of loads in flight: see k_pc_ma2
+    constexpr int KB = 16;
     __builtin_amdgcn_s_setprio(PSDR_PC_SETPRIO);
     // sample t's row in S (w_t) and P (g_t): vo + L - 1 + t, a multiple of 4 at t = 0
     const float *__restrict__ W = a.S + pc_base(slot, a.pv) + (size_t)((a.vo + L - 1) >> 2) * 256;
     float *__restrict__ G = a.P + pc_base(slot, a.pv) + (size_t)((a.vo + L - 1) >> 2) * 256;
+    // While the look-ahead buffer is filling (only right after a reset / for a new client) the reference outputs 0 and leaves
+    // the gain alone: those steps (t < tfill), then single steps up to a row group (t < t0), then whole blocks, then the rest
+    const int tfill = min(T, max(0, L - 1 - n0));
+    const int t0 = min(T, (tfill + 3) & ~3);
+    const int nblk = (T - t0) / KB;
+    int nmax = nblk;
+#pragma unroll
+    for (int d = 32; d; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d, 64));
+    if (wid == 0) {
+        // ---- wave 0: w blocks from memory to LDS (unconditional loads: up to RING blocks past the stream's end, inside the padding)
+        constexpr int RING = PC_GAIN_RING, AHEAD = RING - 1;
+        pc_f4 w[RING][4];
+        // (a lane that starts late - a look-ahead buffer still filling - is walked to the GROUP's block count: clamped to
+        // its own rows, what it reads there is never used)
+        const int qlim = (((int)a.pv - (a.vo + L - 1)) >> 2) - KB / 4;
+        auto fetch = [&](auto kc, int blk) {
+            constexpr int k = decltype(kc)::value;
+            const pc_f4 *src = pc_row4(W, min((t0 + blk * KB) >> 2, qlim));
+#pragma unroll
+            for (int q = 0; q < 4; q++) w[k][q] = src[q * 64];
+        };
+        auto block = [&](auto jc, int b) {
+            constexpr int J = decltype(jc)::value;
+            __syncthreads();  // (publishes the previous block: see k_pc_ma2)
+#pragma unroll
+            for (int q = 0; q < 4; q++) hand[b & 1][q][lane] = w[J][q];
+        };
+        pc_static_for<0, AHEAD>([&](auto kc) { fetch(kc, decltype(kc)::value); });
+        int b = 0;
+        for (; b + RING <= nmax; b += RING)
+            pc_static_for<0, RING>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                fetch(std::integral_constant<int, (J + AHEAD) % RING>{}, b + J + AHEAD);
+                block(jc, b + J);
+            });
+        {
+            const int b0 = b;
+            pc_static_for<0, RING - 1>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                if (b0 + J < nmax) {
+                    fetch(std::integral_constant<int, (J + AHEAD) % RING>{}, b0 + J + AHEAD);
+                    block(jc, b0 + J);
+                }
+            });
+        }
+        __syncthreads();
+        __syncthreads();
+        __syncthreads();
+        return;
+    }
+    // ---- wave 1: the recurrence
     const float att = a.attack, rel = a.release;
     // gain <- gain + (w < gain ? attack : release) * (w - gain): three operations per sample
     // (fma(-a, g - w, g) and fma(a, w - g, g) are the same value: negating both factors is exact)
-    // The coefficient is picked by the sign BIT of d (arithmetic shift + bit-field insert): a compare would
-    // go through VCC, and VCC -> v_cndmask costs two wait states on this part in a loop that is nothing but
-    // its own instruction stream.  (d = -0 picks the attack coefficient where the reference picks release:
-    // the product is a zero either way and the sum is the same.)
-    // Round 3: the loop is ONE wave's dependent chain (~8 cycles from an instruction to the next that needs its
-    // result: 36 cycles per sample measured), so what counts is the DEPTH per sample.  Both candidates are computed
-    // side by side and the choice is a min / max: with attack > release (the reference's 50 ms against 300 ms)
-    // d < 0 makes attack * d the smaller product and d > 0 the larger, and fma rounds monotonically - min(A, R) IS
-    // the reference's pick, bit for bit (d = 0: both are the gain).  sub -> fma, fma -> min: depth 3 instead of 4.
-    // (ATT_FASTER = attack >= release, a template parameter: as a run-time flag the compiler computed min AND max and
-    // selected - six instructions and depth 4 again)
+    // The loop is ONE wave's dependent chain (~8 cycles from an instruction to the next that needs its result), so what
+    // counts is the DEPTH per sample.  Both candidates are computed side by side and the choice is a min / max: with
+    // attack > release (the reference's 50 ms against 300 ms) d < 0 makes attack * d the smaller product and d > 0 the
+    // larger, and fma rounds monotonically - min(A, R) IS the reference's pick, bit for bit (d = 0: both are the gain).
+    // sub -> fma, fma -> min: depth 3 instead of 4.  (ATT_FASTER = attack >= release, a template parameter: as a run-time
+    // flag the compiler computed min AND max and selected - six instructions and depth 4 again)
     auto step = [&](float w) -> float {
         const float d = __fsub_rn(w, gain);
         const float ga = __fmaf_rn(att, d, gain), gr = __fmaf_rn(rel, d, gain);
         gain = ATT_FASTER ? fminf(ga, gr) : fmaxf(ga, gr);
         return gain;
     };
-    // while the look-ahead buffer is filling (only right after a reset / for a new client) the
-    // reference outputs 0 and leaves the gain alone: those steps, then (once 16-byte aligned) whole
-    // blocks with the loads three blocks ahead, then the rest
-    int t = 0;
-    for (; t < T && n0 + t + 1 < L; t++) G[pc_el(t)] = 0.f;
-    for (; t < T && (t & 3); t++) G[pc_el(t)] = step(W[pc_el(t)]);
-    const int nblk = (T - t) / KB;
-    pc_f4 w[GR][4];
-    auto fetch = [&](auto kc, int blk) {
-        constexpr int k = decltype(kc)::value;
-        // (unconditional, like k_pc_ma2's: blocks up to nblk + AHEAD stay inside the row's padding)
-        const pc_f4 *src = pc_row4(W, (t + blk * KB) >> 2);
+    for (int t = 0; t < tfill; t++) G[pc_el(t)] = 0.f;
+    for (int t = tfill; t < t0; t++) G[pc_el(t)] = step(W[pc_el(t)]);
+    pc_f4 wv[2][4];
+    auto take = [&](auto pc, int r) {
+        constexpr int P = decltype(pc)::value;
 #pragma unroll
-        for (int q = 0; q < 4; q++) w[k][q] = src[q * 64];
+        for (int q = 0; q < 4; q++) wv[P][q] = hand[r & 1][q][lane];
     };
-    auto block = [&](const pc_f4 (&wv)[4], int blk) {
-        pc_f4 g[4];
+    auto block = [&](auto pc, int b) {
+        constexpr int P = decltype(pc)::value;
+        if (b + 1 < nmax) take(std::integral_constant<int, P ^ 1>{}, b + 1);
+        if (b < nblk) {
+            pc_f4 g[4];
 #pragma unroll
-        for (int i = 0; i < KB; i++) g[i >> 2][i & 3] = step(wv[i >> 2][i & 3]);
+            for (int i = 0; i < KB; i++) g[i >> 2][i & 3] = step(wv[P][i >> 2][i & 3]);
 #pragma unroll
-        for (int q = 0; q < 4; q++) *pc_row4(G, ((t + blk * KB) >> 2) + q) = g[q];
+            for (int q = 0; q < 4; q++) *pc_row4(G, ((t0 + b * KB) >> 2) + q) = g[q];
+        }
+        __syncthreads();
     };
-    pc_static_for<0, AHEAD>([&](auto kc) { fetch(kc, decltype(kc)::value); });
+    __syncthreads();
+    __syncthreads();  // block 0 is in LDS
+    if (nmax > 0) take(std::integral_constant<int, 0>{}, 0);
+    __syncthreads();
     int b = 0;
-    for (; b + GR <= nblk; b += GR)
-        pc_static_for<0, GR>([&](auto jc) {
-            constexpr int J = decltype(jc)::value;
-            fetch(std::integral_constant<int, (J + AHEAD) % GR>{}, b + J + AHEAD);
-            block(w[J], b + J);
-        });
-    {
-        const int b0 = b;
-        pc_static_for<0, GR - 1>([&](auto jc) {
-            constexpr int J = decltype(jc)::value;
-            if (b0 + J < nblk) {
-                fetch(std::integral_constant<int, (J + AHEAD) % GR>{}, b0 + J + AHEAD);
-                block(w[J], b0 + J);
-            }
-        });
+    for (; b + 2 <= nmax; b += 2) {
+        block(std::integral_constant<int, 0>{}, b);
+        block(std::integral_constant<int, 1>{}, b + 1);
     }
-    for (t += nblk * KB; t < T; t++) G[pc_el(t)] = step(W[pc_el(t)]);
+    if (b < nmax) block(std::integral_constant<int, 0>{}, b);
+    if (!listed) return;
+    for (int t = t0 + nblk * KB; t < T; t++) G[pc_el(t)] = step(W[pc_el(t)]);
     a.agc_gain[slot] = gain;
     a.agc_n0[slot] = min(n0 + T, L);
 }

@@ -110,6 +110,7 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
     if (const char *e = psdr_tuning_env("PSDR_PC_STREAMS")) {  // (tuning build)
         if (atoi(e) == 3 && piped) sp = c->pc_s[1];           // the peak kernels on a stream of their own
         if (atoi(e) == 2 && piped) sp = sc = c->pc_s[1];       // the two chain streams on neighbouring queues
+        if (atoi(e) == 1 && piped) sp = sm;                    // the peak kernels behind the moving averages
     }
     // the recurrence kernels go to the CUs the passes leave free (ctx.h persistent_grid): with this much LDS they do not fit
     // beside a pass's work-group (128 KiB of 160)
@@ -195,9 +196,9 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
         ProfScope ps(c, K_POST, sc);
         if (abl & 2) {
         } else if (pa.attack >= pa.release)
-            hipLaunchKernelGGL(k_pc_gain<true>, dim3(groups), dim3(64), home_lds, sc, pa);
+            hipLaunchKernelGGL(k_pc_gain<true>, dim3(groups), dim3(128), home_lds ? home_lds - 8 * 1024 : 0, sc, pa);
         else
-            hipLaunchKernelGGL(k_pc_gain<false>, dim3(groups), dim3(64), home_lds, sc, pa);
+            hipLaunchKernelGGL(k_pc_gain<false>, dim3(groups), dim3(128), home_lds ? home_lds - 8 * 1024 : 0, sc, pa);
         if (rows4)
             hipLaunchKernelGGL(k_pc_out4, dim3(groups, nframes), dim3(256), 0, sc, pa);
         else

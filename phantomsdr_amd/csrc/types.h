@@ -20,13 +20,9 @@ struct ClientParams {
                     // double-buffered streams must carry the client's history across the batch it sits out)
 };
 
-#ifndef PSDR_PC_RING
-#define PSDR_PC_RING 8  // register sets of 16 samples in the gain recurrence kernel (round 5: 8, 10, 12 and 16 time the same)
-#endif
-// floats of padding behind every slot's stream rows: the recurrence kernels read whole blocks ahead of the stream's end
-// (up to 15 blocks of 16: k_pc_ma2's ring of 12, k_pc_gain's of PSDR_PC_RING)
+// floats of padding behind every slot's stream rows: the recurrence kernels' loader waves read whole blocks of 16 ahead of
+// the stream's end (rings of 12 register sets: postchain.h PC_MA_RING, PC_GAIN_RING)
 #define PSDR_PC_PAD (16 * 20)
-static_assert(PSDR_PC_RING <= 16, "PSDR_PC_PAD covers rings of up to 16 blocks");
 
 struct PostArgs {
     const ClientParams *clients;  // this batch's list: the active clients, then the paused ones (empty streams)

@@ -393,17 +393,19 @@ def test_error_paths():
         ctx.close()
 
 
-@pytest.mark.parametrize("audio_rate,F,nb", [(12000, 8, 5), (192000, 128, 5)])
-def test_post_chain_bit_exact(audio_rate, F, nb):
+@pytest.mark.parametrize("audio_rate,F,nb,n", [(12000, 8, 5, 248), (192000, 128, 5, 248), (12000, 7, 6, 252)])
+def test_post_chain_bit_exact(audio_rate, F, nb, n):
     """DC blocker + AGC + int16 conversion on the GPU (psdr_set_post_chain) against the oracle's
     chain fed with the SAME float audio (the GPU's own demodulator output): the recurrences are
     sequential f32, so the PCM must be identical.  Covers the AGC look-ahead start-up (2400
     samples at 12 kHz), several batches, a mode change (AGC reset, src/signal.cpp:316-328) and a
     client added late.  192000 is the audio_sps of the reference's shipped config.toml (WBFM): DC delay
     512 (the generic moving-average kernels), look-ahead 38400 samples (k_pc_scan in chunks; the batch
-    is sized so that the look-ahead fills: 640 frames of 124 samples)."""
+    is sized so that the look-ahead fills: 640 frames of 124 samples).  n = 252: frames of 126 samples - not whole row
+    groups of the chain's lane-interleaved streams (the scalar gather / output kernels), 7 of them: streams that are
+    not whole 16-step blocks."""
     from phantomsdr_amd import AudioClient, Context
-    N, n = 1 << 14, 248
+    N = 1 << 14
     R, levels = N, levels_for(N)
     nframes = nb * F
     x = synth_stream((nframes + 1) * (N // 2), False, seed=77, fft_size=N)
@@ -494,7 +496,8 @@ def test_post_chain_many_clients():
 
 def test_post_chain_skips_nan_frames():
     """A frame whose audio contains a NaN is dropped by the reference before the chain
-    (src/signal.cpp:266-271): the chain's state must advance only over the surviving frames."""
+    (src/signal.cpp:266-271): the chain's state must advance only over the surviving frames.  A second client beside it
+    loses none: the two lanes of the chain's kernels (lane = slot) walk streams of different lengths in the same wave."""
     import ctypes as C
     from phantomsdr_amd import AudioClient, Context
     from phantomsdr_amd._lib import check
@@ -503,7 +506,7 @@ def test_post_chain_skips_nan_frames():
     x = synth_stream((nb * F + 1) * (N // 2), False, seed=78, fft_size=N)
     raw = quantize_raw(x, "s16", False)
     ctx = Context(N, False, levels, additional_size=n, audio_fft_size=n, audio_rate=12000,
-                  input_format="s16", max_batch=F, max_clients=2)
+                  input_format="s16", max_batch=F, max_clients=3)
     try:
         ctx.set_post_chain(True)
         d = ctx.dev_alloc(raw.nbytes)
@@ -512,6 +515,10 @@ def test_post_chain_skips_nan_frames():
         g.set_audio_demodulation("USB")
         g.set_audio_range(3000, 3010.0, 3200)
         ch = O.PostChain(12000)
+        g2 = AudioClient(ctx)
+        g2.set_audio_demodulation("AM")
+        g2.set_audio_range(8000, 8100.0, 8200)
+        ch2 = O.PostChain(12000)
         hb = ctx.half_frame_bytes()
         poison = np.full(4, np.nan, np.float32)
         dropped_total = 0
@@ -531,6 +538,11 @@ def test_post_chain_skips_nan_frames():
                     continue
                 want = ch.process(audio[f])
                 assert np.array_equal(pcm[f], want), f"batch {b} frame {f}"
+            audio2, _, nan2 = g2.read_audio(F)
+            pcm2 = g2.read_pcm(F)
+            assert not nan2.any()
+            for f in range(F):
+                assert np.array_equal(pcm2[f], ch2.process(audio2[f])), f"batch {b} frame {f}: the client beside the poisoned one"
         assert dropped_total >= 5
         ctx.dev_free(d)
     finally:
