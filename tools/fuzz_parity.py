@@ -46,7 +46,12 @@ def one_case(rng, case):
     raw = quantize_raw(x, fmt, is_real)
     conv = O.convert(raw, fmt)
     halves = (conv if is_real else conv.view(np.complex64)).reshape(nframes + 1, N // 2)
-    ncl = int(rng.integers(1, 7))
+    ncl = int(rng.integers(1, 7)) if rng.random() < 0.9 else int(rng.integers(60, 72))  # (now and then more than one group of 64 slots)
+    # half of the cases: the post chain on (DC blocker + AGC + int16, bit-exact against the oracle's chain fed with the GPU's
+    # float audio), at audio rates that give it other delays / look-aheads (D = rate / 750 * 2: 32, 8, 20, 58 - the last
+    # not a multiple of 4: the scalar gather / output kernels; L = rate / 5)
+    post = rng.random() < 0.5
+    rate = int(rng.choice([12000, 3000, 8000, 22050])) if post else 12000
     clients = []
     for _ in range(ncl):
         mode = MODES[int(rng.integers(0, 4))]
@@ -74,18 +79,21 @@ def one_case(rng, case):
             l = r
         midf = float(mid) + float(rng.choice([0.0, 0.25, 0.5, 0.75]))
         clients.append((mode, l, midf, r))
-    desc = f"case {case}: N=2^{int(np.log2(N))} real={int(is_real)} fmt={fmt} n={n} splits={splits} skip={skip} clients={clients}"
-    ctx = Context(N, is_real, levels, additional_size=n, audio_fft_size=n, audio_rate=12000, input_format=fmt,
+    desc = f"case {case}: N=2^{int(np.log2(N))} real={int(is_real)} fmt={fmt} n={n} splits={splits} skip={skip} post={int(post)} rate={rate} clients={clients[:8]}"
+    ctx = Context(N, is_real, levels, additional_size=n, audio_fft_size=n, audio_rate=rate, input_format=fmt,
                   max_batch=F, max_clients=ncl, max_waterfall_clients=3, skip_num=skip)
     try:
+        if post:
+            ctx.set_post_chain(True)
         d = ctx.dev_alloc(raw.nbytes)
         ctx.h2d(d, raw)
         gcl, ocl = [], []
+        chains = [O.PostChain(rate) for _ in clients]
         for mode, l, mid, r in clients:
             g = AudioClient(ctx)
             g.set_audio_demodulation(mode)
             ok_g = g.on_window_message(l, mid, r)
-            o = O.AudioClient(is_real, n, 12000, R)
+            o = O.AudioClient(is_real, n, rate, R)
             o.set_audio_demodulation(mode)
             ok_o = o.on_window_message(l, mid, r)
             assert bool(ok_g) == bool(ok_o), desc
@@ -111,6 +119,7 @@ def one_case(rng, case):
             if bi == 1 and rng.integers(0, 2):  # a mode switch between batches
                 ci = int(rng.integers(0, ncl))
                 mode = MODES[int(rng.integers(0, 4))]
+                chains[ci].reset_agc()  # (every demodulation message resets the AGC, src/signal.cpp:316-328)
                 gcl[ci].set_audio_demodulation(mode)
                 ocl[ci].set_audio_demodulation(mode)
             # a third of the cases: every client sits out this batch with probability 1/4
@@ -121,6 +130,7 @@ def one_case(rng, case):
             ctx.demod_batch(frame)
             ctx.waterfall_batch(frame)
             got = [None if pz else g.read_audio(nf) for g, pz in zip(gcl, paused)]
+            pcm = [None if (pz or not post) else g.read_pcm(nf) for g, pz in zip(gcl, paused)]
             sent = [f for f in range(nf) if (frame + f) % skip == 0]
             wgot = [w.read_waterfall() for w in wcl]
             for f in range(nf):
@@ -140,6 +150,9 @@ def one_case(rng, case):
                     a_g, p_g, nan_g = got[ci][0][f], got[ci][1][f], got[ci][2][f]
                     tag = desc + f" client {ci} frame {frame}"
                     assert not dropped and nan_g == 0, tag
+                    if post:
+                        want = chains[ci].process(a_g)
+                        assert np.array_equal(pcm[ci][f], want), tag + f": pcm, {np.count_nonzero(pcm[ci][f] != want)} of {want.size} differ"
                     assert abs(p_g - p_o) <= pwr_tolerance(p_o, o.fwd_scale), tag + f": pwr {p_g} vs {p_o}"
                     scale = max(np.abs(a_o).max(), 1e-30)
                     if o.mode == O.FM:
