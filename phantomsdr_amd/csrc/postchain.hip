@@ -94,9 +94,7 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
     constexpr int NS = psdr_ctx::PC_SETS;
     const int set = (int)(c->chain_seq % NS), nxt = (set + 1) % NS;
     const uint64_t seq = c->chain_seq;
-    int abl = 0;  // (tuning build only: which part of the chain costs the step what)
-    if (const char *e = psdr_tuning_env("PSDR_PC_ABL")) abl = atoi(e);
-    const bool piped = c->side != c->stream && c->pc_s[0] != nullptr && !(abl & 8);
+    const bool piped = c->side != c->stream && c->pc_s[0] != nullptr;
     // Streams: stage 0 rides behind the demodulation on `side` (two short kernels), stage 2 in front of stage 3 on ITS stream
     // (they are a chain anyway), the moving averages on the other.  Hardware queues are what is scarce: with four chain
     // streams the fourth shared a queue with the third (the gain recurrence in front of the next batch's peak), and with
@@ -165,8 +163,7 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
         if (seq >= NS && (rc = wait(sm, 3, set))) return rc;
         if (seq >= NS - 1 && (rc = wait(sm, 3, nxt))) return rc;
         ProfScope ps(c, K_POST, sm);
-        if (abl & 1) {
-        } else if (pa.ma_fused) {
+        if (pa.ma_fused) {
             hipLaunchKernelGGL(k_pc_ma2, dim3(groups), dim3(128), home_lds ? home_lds - 17 * 1024 : 0, sm, pa);
         } else if ((pa.D & (pa.D - 1)) == 0) {
             hipLaunchKernelGGL((k_pc_ma<false, true>), dim3(groups), dim3(64), 0, sm, pa);
@@ -183,19 +180,16 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
         if ((rc = wait(sp, 1, set))) return rc;
         if (seq >= NS && (rc = wait(sp, 3, set))) return rc;
         ProfScope ps(c, K_POST, sp);
-        if (!(abl & 4)) {
-            if (pa.nsub > 1) hipLaunchKernelGGL(k_pc_submax, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp, pa);
-            hipLaunchKernelGGL(k_pc_prefix, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp, pa);
-            hipLaunchKernelGGL(k_pc_want, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp, pa);
-        }
+        if (pa.nsub > 1) hipLaunchKernelGGL(k_pc_submax, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp, pa);
+        hipLaunchKernelGGL(k_pc_prefix, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp, pa);
+        hipLaunchKernelGGL(k_pc_want, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp, pa);
         HIPCHK(hipGetLastError());
         if ((rc = done(sp, 2))) return rc;
     }
     {  // ---- stage 3: the gain recurrence (sequential), int16 output
         if (sp != sc && (rc = wait(sc, 2, set))) return rc;
         ProfScope ps(c, K_POST, sc);
-        if (abl & 2) {
-        } else if (pa.attack >= pa.release)
+        if (pa.attack >= pa.release)
             hipLaunchKernelGGL(k_pc_gain<true>, dim3(groups), dim3(128), home_lds ? home_lds - 8 * 1024 : 0, sc, pa);
         else
             hipLaunchKernelGGL(k_pc_gain<false>, dim3(groups), dim3(128), home_lds ? home_lds - 8 * 1024 : 0, sc, pa);
