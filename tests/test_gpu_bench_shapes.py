@@ -127,9 +127,11 @@ def test_handoff_plan_bit_identical_to_whole_frame_segments(log2n, monkeypatch):
     assert not bad_x and not bad_q, (bad_x[:8], bad_q[:8])
 
 
-@pytest.mark.parametrize("wl_name", ["cfg2", "cfg3"])
-def test_bench_launch_256_frames_vs_oracle(wl_name):
-    """bench.py's own launch: SingleGpuRun.step() twice with F = bench.DEFAULT_BATCH (512; 256 up to round 3), then
+@pytest.mark.parametrize("wl_name,post", [("cfg2", False), ("cfg3", False), ("cfg3", True), ("cfg2", True)])
+def test_bench_launch_256_frames_vs_oracle(wl_name, post):
+    """post: with psdr_set_post_chain(1) - the passes then leave a CU per XCD free (248 work-groups: the real plan's chain
+    segments and hand-offs on another grid than the one their plan was sized for), the chain's kernels run beside them.
+    bench.py's own launch: SingleGpuRun.step() twice with F = bench.DEFAULT_BATCH (512; 256 up to round 3), then
     frames {0, 2, F/2 - 1, F - 1} of the second launch against the oracle (which runs frames g-2, g-1, g: the overlap-add tail and FM's last sample are
     functions of the two preceding frames)."""
     import torch
@@ -146,6 +148,8 @@ def test_bench_launch_256_frames_vs_oracle(wl_name):
         assert run.nbatches == 2
         eng, p = run.eng, run.params
         R, n, levels, skip = p["fft_result_size"], p["audio_fft_size"], p["downsample_levels"], p["skip_num"]
+        if post:
+            eng.ctx.set_post_chain(True)
         run.step(0)
         run.step(1)
         run.sync()
