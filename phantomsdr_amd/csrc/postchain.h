@@ -167,8 +167,12 @@ __global__ __launch_bounds__(128) void k_pc_ma2(PostArgs a) {
     __shared__ pc_f4 hand[2][8][64];  // [buffer][0-3: x of the block, 4-7: s1 of the block][lane]: 16 KiB
     __shared__ float fin[64];         // wave 0's s1 after its last block
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int slot = blockIdx.x * 64 + lane;  // lane = slot & 63 (the streams of a group are allocated whole)
-    const int ci = slot < a.slots ? a.slot_ci[slot] : -1;
+    // a work-group owns a.lanes (16, 32 or 64) consecutive slots of a group of 64: lane = slot & (a.lanes - 1), the other
+    // lanes leave below.  (A recurrence costs the same for 1 lane or 64, but its memory operations do not: 1 KiB loads and
+    // stores per wave are acknowledged later than 256-byte ones beside the passes - 2.8 against 2.0 ms per 512 frames.)
+    const int wpg = 64 / a.lanes;
+    const int slot = ((int)blockIdx.x / wpg) * 64 + ((int)blockIdx.x % wpg) * a.lanes + lane;  // (the streams of a group are allocated whole)
+    const int ci = (lane < a.lanes && slot < a.slots) ? a.slot_ci[slot] : -1;
     const bool listed = ci >= 0;
     const bool fresh = listed && a.clients[ci].agc_reset == 2;  // a new client in this slot: zero sums, zero history rows
     constexpr int KB = 16, D = 32;
@@ -178,6 +182,7 @@ __global__ __launch_bounds__(128) void k_pc_ma2(PostArgs a) {
     int nmax = nfull;
 #pragma unroll
     for (int d = 32; d; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d, 64));
+    if (lane >= a.lanes) return;  // (the wave goes on, barriers included, with the lanes that own a slot)
     float *__restrict__ X = a.X + pc_base(slot, a.px);
     float *__restrict__ M1 = a.M1 + pc_base(slot, a.px);
     float *__restrict__ M1n = a.M1n + pc_base(slot, a.px);
@@ -441,8 +446,9 @@ template <bool ATT_FASTER>
 __global__ __launch_bounds__(128) void k_pc_gain(PostArgs a) {
     __shared__ pc_f4 hand[2][4][64];  // [buffer][row group of the block][lane]: 8 KiB
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int slot = blockIdx.x * 64 + lane;  // lane = slot & 63
-    const int ci = slot < a.slots ? a.slot_ci[slot] : -1;
+    const int wpg = 64 / a.lanes;  // (a.lanes slots per work-group: see k_pc_ma2)
+    const int slot = ((int)blockIdx.x / wpg) * 64 + ((int)blockIdx.x % wpg) * a.lanes + lane;
+    const int ci = (lane < a.lanes && slot < a.slots) ? a.slot_ci[slot] : -1;
     const bool listed = ci >= 0;
     const int L = a.L;
     const int T = listed ? a.len[slot] : 0;
@@ -465,6 +471,7 @@ __global__ __launch_bounds__(128) void k_pc_gain(PostArgs a) {
     int nmax = nblk;
 #pragma unroll
     for (int d = 32; d; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d, 64));
+    if (lane >= a.lanes) return;
     if (wid == 0) {
         // ---- wave 0: w blocks from memory to LDS (unconditional loads: up to RING blocks past the stream's end, inside the padding)
         constexpr int RING = PC_GAIN_RING, AHEAD = RING - 1;

@@ -112,7 +112,7 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
     }
     // the recurrence kernels go to the CUs the passes leave free (ctx.h persistent_grid): with this much LDS they do not fit
     // beside a pass's work-group (128 KiB of 160)
-    const size_t home_lds = c->post_reserve > 0 ? 40 * 1024 : 0;
+    size_t home_lds = c->post_reserve > 0 ? 34 * 1024 : 0;
     const bool rows4 = (c->post.h & 3) == 0 && (c->post.D & 3) == 0;  // every frame starts on a row group: the lane = slot gather / output
     PostArgs pa = c->post;
     pa.clients = d_clients;
@@ -130,6 +130,13 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
     pa.ma_fused = pa.D == 32 ? 1 : 0;  // both averages in one loop (postchain.h)
     const int nall = nact + npaused;
     const unsigned groups = (unsigned)((pa.slots + 63) / 64);
+    // 32 slots per work-group of the recurrence kernels (half a wave in use: 512-byte memory operations; 256 clients: 3.55-3.67 ms
+    // per step against 3.80-3.90 with 64, level with 16 clients; 16 lanes: in between - profiles/r05_post_chain_lanes.jsonl),
+    // up to 512 slots; beyond, whole waves (the free CUs would not hold the work-groups' LDS)
+    pa.lanes = groups <= 8 ? 32 : 64;
+    if (const char *e = psdr_tuning_env("PSDR_PC_LANES")) pa.lanes = atoi(e) == 16 ? 16 : atoi(e) == 32 ? 32 : 64;  // (tuning build)
+    const unsigned rgroups = groups * (unsigned)(64 / pa.lanes);  // work-groups of each of the two recurrence kernels
+    if (rgroups > 16) home_lds = 0;  // (2 x rgroups work-groups over 8 free CUs, 34 KiB each: no more than four per CU)
     const size_t Tb = (size_t)nframes * pa.h;  // longest possible stream of this batch
     const unsigned nblk = (unsigned)((pa.L - 1 + Tb + pa.L - 1) / pa.L);
     // Who touched what last (sets rotate: batch b uses set b mod 3 and writes the history rows of set b + 1):
@@ -164,7 +171,7 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
         if (seq >= NS - 1 && (rc = wait(sm, 3, nxt))) return rc;
         ProfScope ps(c, K_POST, sm);
         if (pa.ma_fused) {
-            hipLaunchKernelGGL(k_pc_ma2, dim3(groups), dim3(128), home_lds ? home_lds - 17 * 1024 : 0, sm, pa);
+            hipLaunchKernelGGL(k_pc_ma2, dim3(rgroups), dim3(128), home_lds ? home_lds - 17 * 1024 : 0, sm, pa);
         } else if ((pa.D & (pa.D - 1)) == 0) {
             hipLaunchKernelGGL((k_pc_ma<false, true>), dim3(groups), dim3(64), 0, sm, pa);
             hipLaunchKernelGGL((k_pc_ma<true, true>), dim3(groups), dim3(64), 0, sm, pa);
@@ -190,9 +197,9 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
         if (sp != sc && (rc = wait(sc, 2, set))) return rc;
         ProfScope ps(c, K_POST, sc);
         if (pa.attack >= pa.release)
-            hipLaunchKernelGGL(k_pc_gain<true>, dim3(groups), dim3(128), home_lds ? home_lds - 8 * 1024 : 0, sc, pa);
+            hipLaunchKernelGGL(k_pc_gain<true>, dim3(rgroups), dim3(128), home_lds ? home_lds - 8 * 1024 : 0, sc, pa);
         else
-            hipLaunchKernelGGL(k_pc_gain<false>, dim3(groups), dim3(128), home_lds ? home_lds - 8 * 1024 : 0, sc, pa);
+            hipLaunchKernelGGL(k_pc_gain<false>, dim3(rgroups), dim3(128), home_lds ? home_lds - 8 * 1024 : 0, sc, pa);
         if (rows4)
             hipLaunchKernelGGL(k_pc_out4, dim3(groups, nframes), dim3(256), 0, sc, pa);
         else

@@ -52,6 +52,7 @@ struct PostArgs {
     float *agc_gain;
     int *agc_n0;  // samples pushed since the last reset, saturating at L
     int ma_fused;  // k_pc_ma2 keeps M1's history itself (k_pc_history leaves M1 alone)
+    int lanes;     // k_pc_ma2 / k_pc_gain: slots per work-group (16, 32 or 64 lanes of its waves in use)
 };
 
 struct WfClient {
