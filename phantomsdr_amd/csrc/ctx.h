@@ -259,6 +259,8 @@ struct psdr_ctx {
     uint64_t chain_seq = 0;
     bool chain_pending = false;
     int post_reserve = 8;  // CUs the FFT passes leave free while the chain is on (a multiple of 8: one per XCD); 0: none
+    int post_lanes = 32;   // slots per work-group of the chain's two recurrence kernels
+    bool post_own = true;  // their waves allocate a whole SIMD's registers
     std::vector<void *> post_allocs;
     float *d_pwr = nullptr, *d_audio = nullptr, *d_real_prev = nullptr;
     int *d_nan = nullptr;
@@ -353,9 +355,10 @@ inline int pick_T(int L, int other) { return std::min(16384 / L, other); }
 // round-robin of the TileQueue), or one per tile when there are fewer tiles than that
 inline unsigned persistent_grid(psdr_ctx *c, unsigned blocks, size_t lds) {
     unsigned cap = ((unsigned)c->num_cus * (unsigned)std::max<size_t>(1, 160 * 1024 / lds)) & ~7u;
-    // post chain on: one CU per XCD stays free of the passes' work-groups - the home of the chain's recurrence waves
-    // (postchain.hip: they ask for more LDS than a pass leaves, so they land THERE and nowhere else; beside a pass's eight
-    // waves a recurrence runs 1.9 - 2.8 ms per 512 frames, longer than the step).  0.5 % of the plain step.
+    // post chain on: one to three CUs per XCD stay free of the passes' work-groups - the home of the chain's recurrence waves
+    // (postchain.hip: they allocate a whole SIMD's registers each, or ask for more LDS than a pass leaves, so they land
+    // THERE and nowhere else; beside a pass's eight waves and the other consumers a recurrence runs 1.9 - 2.8 ms per 512
+    // frames, longer than the step).  0.5 % of the plain step per CU and XCD.
     unsigned reserve = c->post_on ? (unsigned)c->post_reserve : 0u;
     if (const char *e = psdr_tuning_env("PSDR_GRID_RESERVE")) reserve = (unsigned)atoi(e) & ~7u;  // (tuning build)
     if (lds * 2 > 160 * 1024 && cap >= reserve + 8u) cap -= reserve;

@@ -51,6 +51,11 @@ typedef float pc_f4 __attribute__((ext_vector_type(4)));
 #ifndef PSDR_PC_SETPRIO
 #define PSDR_PC_SETPRIO 3
 #endif
+// A recurrence wave that owns its SIMD: naming the last vector and accumulator register makes the kernel's allocation the
+// whole register file of a SIMD lane (512), so no other wave shares the SIMD - and the wave only fits where the passes
+// left a CU free (postchain.hip).
+// (256 clients: 3.46 -> 3.17 ms per step with two CUs per XCD free; level with fewer clients - profiles/r05_post_chain_reserve_own.jsonl)
+#define PC_OWN_SIMD() asm volatile("; the wave owns its SIMD" ::: "v255", "a255")
 
 // the lane-interleaved stream layout (see above): a slot's lane base, and the offset of its row t from there
 __device__ __forceinline__ size_t pc_base(int slot, size_t pitch) { return (size_t)(slot >> 6) * pitch * 64 + (size_t)(slot & 63) * 4; }
@@ -163,6 +168,7 @@ __global__ __launch_bounds__(64) void k_pc_ma(PostArgs a) {
 // the in-memory history (wave 1).  Lanes of a group may have streams of different lengths (dropped frames, paused
 // clients): the trip count is the group's maximum, a lane past its own end keeps its state.
 constexpr int PC_MA_RING = 12;  // wave 0's register sets of x: blocks b-2 .. b (in use), b+1 .. b+9 in flight
+template <bool OWN>
 __global__ __launch_bounds__(128) void k_pc_ma2(PostArgs a) {
     __shared__ pc_f4 hand[2][8][64];  // [buffer][0-3: x of the block, 4-7: s1 of the block][lane]: 16 KiB
     __shared__ float fin[64];         // wave 0's s1 after its last block
@@ -176,7 +182,8 @@ __global__ __launch_bounds__(128) void k_pc_ma2(PostArgs a) {
     const bool listed = ci >= 0;
     const bool fresh = listed && a.clients[ci].agc_reset == 2;  // a new client in this slot: zero sums, zero history rows
     constexpr int KB = 16, D = 32;
-    __builtin_amdgcn_s_setprio(PSDR_PC_SETPRIO);  // a few waves next to the FFT passes' issue-bound ones: let them issue first
+    __builtin_amdgcn_s_setprio(PSDR_PC_SETPRIO);
+    if constexpr (OWN) PC_OWN_SIMD();  // a few waves next to the FFT passes' issue-bound ones: let them issue first
     const int T = listed ? a.len[slot] : 0;
     const int nfull = T / KB;
     int nmax = nfull;
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(64) void k_pc_want(PostArgs a) {
 // one-wave form took 2.2 - 3.0 ms per 512 frames against 1.5 ms with 16 lanes).
 constexpr int PC_GAIN_RING = 12;
 static_assert(16 * (PC_MA_RING + 4) <= PSDR_PC_PAD && 16 * (PC_GAIN_RING + 4) <= PSDR_PC_PAD, "the loader waves read ahead inside the padding");
-template <bool ATT_FASTER>
+template <bool ATT_FASTER, bool OWN>
 __global__ __launch_bounds__(128) void k_pc_gain(PostArgs a) {
     __shared__ pc_f4 hand[2][4][64];  // [buffer][row group of the block][lane]: 8 KiB
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -460,6 +467,7 @@ __global__ __launch_bounds__(128) void k_pc_gain(PostArgs a) {
     }
     constexpr int KB = 16;
     __builtin_amdgcn_s_setprio(PSDR_PC_SETPRIO);
+    if constexpr (OWN) PC_OWN_SIMD();
     // sample t's row in S (w_t) and P (g_t): vo + L - 1 + t, a multiple of 4 at t = 0
     const float *__restrict__ W = a.S + pc_base(slot, a.pv) + (size_t)((a.vo + L - 1) >> 2) * 256;
     float *__restrict__ G = a.P + pc_base(slot, a.pv) + (size_t)((a.vo + L - 1) >> 2) * 256;

@@ -80,8 +80,21 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
         a.audio = c->d_audio;
         a.nan_flags = c->d_nan;
     }
-    c->post_reserve = 8;
-    if (const char *e = psdr_tuning_env("PSDR_PC_RESERVE")) c->post_reserve = atoi(e) & ~7;  // (tuning build)
+    {
+        // The two recurrence kernels (k_pc_ma2, k_pc_gain: postchain.h): 32 slots per work-group (half a wave in use, 512-byte
+        // memory operations: 256 clients 3.80-3.90 -> 3.55-3.67 ms per step, level at 16 - profiles/r05_post_chain_lanes.jsonl),
+        // whole waves beyond 512 slots.  Their waves own a SIMD each (512 registers allocated) as long as the CUs the passes
+        // leave free hold them all: 2 kernels x 2 waves per work-group = one CU per work-group of either; one, two or three
+        // CUs per XCD stay free (8: +0.5 % on the plain step, 16: +1 %, 24: +2.5 %).
+        const unsigned groups = (unsigned)((c->aslots.size() + 63) / 64);
+        c->post_lanes = groups <= 8 ? 32 : 64;
+        if (const char *e = psdr_tuning_env("PSDR_PC_LANES")) c->post_lanes = atoi(e) == 16 ? 16 : atoi(e) == 32 ? 32 : 64;  // (tuning build)
+        const unsigned rgroups = groups * (unsigned)(64 / c->post_lanes);
+        c->post_reserve = (int)std::min(24u, 8u * (1u + rgroups / 8u));
+        if (const char *e = psdr_tuning_env("PSDR_PC_RESERVE")) c->post_reserve = atoi(e) & ~7;  // (tuning build)
+        c->post_own = (int)rgroups <= c->post_reserve;
+        if (const char *e = psdr_tuning_env("PSDR_PC_OWN")) c->post_own = atoi(e) != 0;  // (tuning build)
+    }
     c->post_on = true;
     return PSDR_OK;
 }
@@ -130,13 +143,9 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
     pa.ma_fused = pa.D == 32 ? 1 : 0;  // both averages in one loop (postchain.h)
     const int nall = nact + npaused;
     const unsigned groups = (unsigned)((pa.slots + 63) / 64);
-    // 32 slots per work-group of the recurrence kernels (half a wave in use: 512-byte memory operations; 256 clients: 3.55-3.67 ms
-    // per step against 3.80-3.90 with 64, level with 16 clients; 16 lanes: in between - profiles/r05_post_chain_lanes.jsonl),
-    // up to 512 slots; beyond, whole waves (the free CUs would not hold the work-groups' LDS)
-    pa.lanes = groups <= 8 ? 32 : 64;
-    if (const char *e = psdr_tuning_env("PSDR_PC_LANES")) pa.lanes = atoi(e) == 16 ? 16 : atoi(e) == 32 ? 32 : 64;  // (tuning build)
+    pa.lanes = c->post_lanes;
     const unsigned rgroups = groups * (unsigned)(64 / pa.lanes);  // work-groups of each of the two recurrence kernels
-    if (rgroups > 16) home_lds = 0;  // (2 x rgroups work-groups over 8 free CUs, 34 KiB each: no more than four per CU)
+    if (rgroups > 16 || c->post_own) home_lds = 0;  // (waves that own a SIMD fit nowhere else anyway)
     const size_t Tb = (size_t)nframes * pa.h;  // longest possible stream of this batch
     const unsigned nblk = (unsigned)((pa.L - 1 + Tb + pa.L - 1) / pa.L);
     // Who touched what last (sets rotate: batch b uses set b mod 3 and writes the history rows of set b + 1):
@@ -171,7 +180,10 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
         if (seq >= NS - 1 && (rc = wait(sm, 3, nxt))) return rc;
         ProfScope ps(c, K_POST, sm);
         if (pa.ma_fused) {
-            hipLaunchKernelGGL(k_pc_ma2, dim3(rgroups), dim3(128), home_lds ? home_lds - 17 * 1024 : 0, sm, pa);
+            if (c->post_own)
+                hipLaunchKernelGGL(k_pc_ma2<true>, dim3(rgroups), dim3(128), 0, sm, pa);
+            else
+                hipLaunchKernelGGL(k_pc_ma2<false>, dim3(rgroups), dim3(128), home_lds ? home_lds - 17 * 1024 : 0, sm, pa);
         } else if ((pa.D & (pa.D - 1)) == 0) {
             hipLaunchKernelGGL((k_pc_ma<false, true>), dim3(groups), dim3(64), 0, sm, pa);
             hipLaunchKernelGGL((k_pc_ma<true, true>), dim3(groups), dim3(64), 0, sm, pa);
@@ -196,10 +208,18 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
     {  // ---- stage 3: the gain recurrence (sequential), int16 output
         if (sp != sc && (rc = wait(sc, 2, set))) return rc;
         ProfScope ps(c, K_POST, sc);
-        if (pa.attack >= pa.release)
-            hipLaunchKernelGGL(k_pc_gain<true>, dim3(rgroups), dim3(128), home_lds ? home_lds - 8 * 1024 : 0, sc, pa);
-        else
-            hipLaunchKernelGGL(k_pc_gain<false>, dim3(rgroups), dim3(128), home_lds ? home_lds - 8 * 1024 : 0, sc, pa);
+        const size_t glds = home_lds ? home_lds - 8 * 1024 : 0;
+        if (pa.attack >= pa.release) {
+            if (c->post_own)
+                hipLaunchKernelGGL((k_pc_gain<true, true>), dim3(rgroups), dim3(128), 0, sc, pa);
+            else
+                hipLaunchKernelGGL((k_pc_gain<true, false>), dim3(rgroups), dim3(128), glds, sc, pa);
+        } else {
+            if (c->post_own)
+                hipLaunchKernelGGL((k_pc_gain<false, true>), dim3(rgroups), dim3(128), 0, sc, pa);
+            else
+                hipLaunchKernelGGL((k_pc_gain<false, false>), dim3(rgroups), dim3(128), glds, sc, pa);
+        }
         if (rows4)
             hipLaunchKernelGGL(k_pc_out4, dim3(groups, nframes), dim3(256), 0, sc, pa);
         else
