@@ -9,8 +9,11 @@ for wl in cfg2 cfg3 cfg5 clients256; do
   timeout 900 tools/profile_round.sh $TAG $wl > $O/round_$wl.log 2>&1
 done
 cd /tmp; export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/post_stats -o p -- python $R/tools/kernel_times.py --fft 20 --clients 16 --batch 512 --steps 12 --post --mode 0 > $O/post_stats.log 2>&1
-cp $O/post_stats/p_kernel_stats.csv $O/profiles/${TAG}_cfg2_post_chain_kernel_stats.csv 2>/dev/null
+for c in 16 256; do  # the step with the post chain on: kernel stats + a two-step timeline (queue ids included)
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/post_c$c -o p -- python $R/tools/kernel_times.py --fft 20 --clients $c --batch 512 --steps 60 --ring-mib 1100 --post --mode 0 > $O/post_c$c.log 2>&1
+  cp $O/post_c$c/p_kernel_stats.csv $O/profiles/${TAG}_cfg2_post_chain_c${c}_kernel_stats.csv 2>/dev/null
+  python $R/tools/trace_timeline.py $O/post_c$c/p_kernel_trace.csv 2 > $O/profiles/${TAG}_cfg2_post_chain_c${c}_timeline.txt
+done
 cd $R
 python tools/consumers_alone.py cfg2 cfg3 cfg5 clients256 --batch 512 > $O/profiles/${TAG}_consumers_alone_vs_beside.jsonl 2> $O/consumers.err
 ls -la $O/profiles
