@@ -193,7 +193,8 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     // Both passes in ONE launch, Y a ring of ring_frames frames (fft_pass.h: FlowArgs): IQ batches of ring_min_batch frames
     // and more on the context's own stream pair; everything else - small batches, band regions, a caller's pipelined
     // first-pass stream - keeps the two launches
-    const bool ring = c->ring_on && !c->nbands && c->p1 == c->stream && nframes >= c->ring_min_batch && a1.ymask == ~0u &&
+    // (not beside the post chain: its recurrence waves need the CUs the two-launch passes leave free, ctx.h persistent_grid)
+    const bool ring = c->ring_on && !c->post_on && !c->nbands && c->p1 == c->stream && nframes >= c->ring_min_batch && a1.ymask == ~0u &&
                       fused_supported(c, sb);
     FlowArgs fl{};
     if (ring) {
