@@ -414,7 +414,7 @@ def path_roofline(b_frame, frames_per_s):
 
 def post_chain_measure(run, eng, params, wl, F, N, nclients, plain_ms):
     """SURVEY 8f-2 (widened row): the step with the optional post-demodulation chain on (DC blocker + AGC + int16).  NOT part
-    of `value` (the metric's clients end at float audio).  The chain is a pipeline over three side streams and three
+    of `value` (the metric's clients end at float audio).  The chain is a pipeline over the side stream, two chain streams and three
     rotating buffer sets: a batch's PCM is ready about two steps after its passes, so a repetition of K steps carries
     about two steps of drain - 200 steps per repetition (a server never drains), 50-step repetitions beside it."""
     try:

@@ -1,5 +1,5 @@
 // postchain.hip - the post-demodulation chain of AudioClient::send_audio (src/signal.cpp:277-284) for all clients of a
-// batch: DC blocker, AGC, int16 conversion (postchain.h) as a two-stage pipeline across batches.
+// batch: DC blocker, AGC, int16 conversion (postchain.h) as a four-stage pipeline across batches over three rotating buffer sets.
 #include "ctx.h"
 #include "postchain.h"
 
