@@ -123,6 +123,10 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
         if (atoi(e) == 2 && piped) sp = sc = c->pc_s[1];       // the two chain streams on neighbouring queues
         if (atoi(e) == 1 && piped) sp = sm;                    // the peak kernels behind the moving averages
     }
+    // the prefix maxima ride behind the moving averages, w_t in front of the gain recurrence (with 256 clients the gain's
+    // stream is the longer one: 0.8 ms of peak kernels + 1.9 + 0.3 against 2.3)
+    bool split_peak = piped && sp == sc;
+    if (const char *e = psdr_tuning_env("PSDR_PC_SPLIT_PEAK")) split_peak = split_peak && atoi(e) != 0;  // (tuning build)
     // the recurrence kernels go to the CUs the passes leave free (ctx.h persistent_grid): with this much LDS they do not fit
     // beside a pass's work-group (128 KiB of 160)
     size_t home_lds = c->post_reserve > 0 ? 34 * 1024 : 0;
@@ -196,14 +200,23 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
         if ((rc = done(sm, 1))) return rc;
     }
     {  // ---- stage 2: look-ahead peak and w_t (parallel along time)
-        if ((rc = wait(sp, 1, set))) return rc;
-        if (seq >= NS && (rc = wait(sp, 3, set))) return rc;
-        ProfScope ps(c, K_POST, sp);
-        if (pa.nsub > 1) hipLaunchKernelGGL(k_pc_submax, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp, pa);
-        hipLaunchKernelGGL(k_pc_prefix, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp, pa);
-        hipLaunchKernelGGL(k_pc_want, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp, pa);
+        hipStream_t sp1 = split_peak ? sm : sp;  // (P[set]'s last readers - gain / output of batch b - 3 - were waited for in stage 1)
+        if (sp1 != sm && (rc = wait(sp1, 1, set))) return rc;
+        if (seq >= NS && sp1 != sm && (rc = wait(sp1, 3, set))) return rc;
+        {
+            ProfScope ps(c, K_POST, sp1);
+            if (pa.nsub > 1) hipLaunchKernelGGL(k_pc_submax, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp1, pa);
+            hipLaunchKernelGGL(k_pc_prefix, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp1, pa);
+        }
+        if (split_peak) {
+            if ((rc = done(sp1, 2)) || (rc = wait(sp, 2, set))) return rc;
+        }
+        {
+            ProfScope ps(c, K_POST, sp);
+            hipLaunchKernelGGL(k_pc_want, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp, pa);
+        }
         HIPCHK(hipGetLastError());
-        if ((rc = done(sp, 2))) return rc;
+        if (!split_peak && (rc = done(sp, 2))) return rc;
     }
     {  // ---- stage 3: the gain recurrence (sequential), int16 output
         if (sp != sc && (rc = wait(sc, 2, set))) return rc;
