@@ -27,7 +27,8 @@
 //   k_pc_index    stream offset of every frame of every client (NaN-flagged frames dropped)
 //   k_pc_gather   audio[slot][frame][j] -> X[slot][D + t]
 //   k_pc_ma2      both running sums in one loop (D = 32)          (sequential)
-//   k_pc_ma<0|1>  the two running sums, any D                      (sequential, fallback)
+//   k_pc_mad      the same for any power-of-two D (48 kHz: 128, 192 kHz: 512): the sums of the last D steps in an LDS ring
+//   k_pc_ma<0|1>  the two running sums, any D                      (sequential, one wave, fallback)
 //   k_pc_history  the last D / L-1 rows become the next set's history
 //   k_pc_submax / k_pc_prefix / k_pc_want
 //                 AGC look-ahead peak: the sliding maximum of |x| over L samples (the reference's monotonic deque) as
@@ -343,6 +344,193 @@ __global__ __launch_bounds__(128) void k_pc_ma2(PostArgs a) {
     }
     // the last 32 m1 values in time order become rows 0..31 of the NEXT set (X's own history is moved by k_pc_history)
 #pragma unroll
+    for (int i = 0; i < D; i++) M1n[pc_el(i)] = M1[pc_el(T + i)];
+    a.dc_s1[slot] = s1;
+    a.dc_s2[slot] = s2;
+}
+
+// The same two waves for any delay D that is a power of two and a multiple of 16 (48 kHz: 128, 192 kHz: 512 - the audio
+// rates of the reference's shipped configs; the generic k_pc_ma pair takes 19 / 81 ms per 92 160 / 368 640 samples there,
+// this one the 2 ms per 92 160 of k_pc_ma2).  What k_pc_ma2 keeps in registers for D = 32 does not fit for D = 512:
+//   wave 0  loads the stream TWICE - the block it inserts (rows D + 16 b ..) and the block it evicts (rows 16 b .., read D
+//           samples earlier as the new one: L2) - and hands the EVICTED block on (x_{t-D+1} is its neighbour)
+//   wave 1  keeps the first running sums of the last D steps in an LDS ring it alone reads and writes (D x lanes x 4 bytes:
+//           64 KiB for D = 512 and 32 lanes - the kernel lives on a CU the passes leave free, postchain.hip)
+// The arithmetic is k_pc_ma2's (1 / D exact).  dynamic LDS: D * a.lanes floats.
+constexpr int PC_MAD_RING = 6;  // wave 0: register sets of either stream (5 blocks in flight)
+template <bool OWN>
+__global__ __launch_bounds__(128) void k_pc_mad(PostArgs a) {
+    __shared__ pc_f4 hand[2][8][64];  // [buffer][0-3: the evicted x of the block, 4-7: s1 of the block][lane]: 16 KiB
+    __shared__ float fin[64];         // wave 0's s1 after its last block
+    extern __shared__ pc_f4 sring[];  // [D / 16][4][a.lanes]: wave 1's ring of s1 blocks
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wpg = 64 / a.lanes;  // (a.lanes slots per work-group: see k_pc_ma2)
+    const int slot = ((int)blockIdx.x / wpg) * 64 + ((int)blockIdx.x % wpg) * a.lanes + lane;
+    const int ci = (lane < a.lanes && slot < a.slots) ? a.slot_ci[slot] : -1;
+    const bool listed = ci >= 0;
+    const bool fresh = listed && a.clients[ci].agc_reset == 2;
+    constexpr int KB = 16;
+    const int D = a.D, NBD = D / KB;
+    __builtin_amdgcn_s_setprio(PSDR_PC_SETPRIO);
+    if constexpr (OWN) PC_OWN_SIMD();
+    const int T = listed ? a.len[slot] : 0;
+    const int nfull = T / KB;
+    int nmax = nfull;
+#pragma unroll
+    for (int d = 32; d; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d, 64));
+    if (lane >= a.lanes) return;
+    float *__restrict__ X = a.X + pc_base(slot, a.px);
+    float *__restrict__ M1 = a.M1 + pc_base(slot, a.px);
+    float *__restrict__ M1n = a.M1n + pc_base(slot, a.px);
+    float *__restrict__ V1 = a.V1 + pc_base(slot, a.pv);
+    const float fD = (float)D, rD = 1.0f / fD, nrD = -rD;
+    if (wid == 0) {
+        // ---- wave 0: s1_t = (s1 - x_{t-D}) + x_t
+        constexpr int RING = PC_MAD_RING, AHEAD = RING - 1;
+        if (fresh)
+            for (int r = 0; r < D; r++) X[pc_el(r)] = 0.f;
+        float s1 = (fresh || !listed) ? 0.f : a.dc_s1[slot];
+        pc_f4 xn[RING][4], xo[RING][4];
+        const int dq = D >> 2;
+        auto fetch = [&](auto kc, int blk) {  // (unconditional, inside the padding: see k_pc_ma2)
+            constexpr int k = decltype(kc)::value;
+            const pc_f4 *src = pc_row4(X, (blk * KB) >> 2);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                xo[k][q] = src[q * 64];
+                xn[k][q] = src[(size_t)(dq + q) * 64];
+            }
+        };
+        pc_f4 sv[4] = {};
+        auto block = [&](auto jc, int b) {
+            constexpr int J = decltype(jc)::value;
+            if (b < nfull) {
+#pragma unroll
+                for (int i = 0; i < KB; i++) {
+                    s1 = __fadd_rn(__fsub_rn(s1, xo[J][i >> 2][i & 3]), xn[J][i >> 2][i & 3]);
+                    sv[i >> 2][i & 3] = s1;
+                }
+            }
+            __syncthreads();  // (publishes the previous block: see k_pc_ma2)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                hand[b & 1][q][lane] = xo[J][q];
+                hand[b & 1][4 + q][lane] = sv[q];
+            }
+            if (b + 1 == nmax) fin[lane] = s1;
+        };
+        pc_static_for<0, AHEAD>([&](auto kc) { fetch(kc, decltype(kc)::value); });
+        int b = 0;
+        for (; b + RING <= nmax; b += RING)
+            pc_static_for<0, RING>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                fetch(std::integral_constant<int, (J + AHEAD) % RING>{}, b + J + AHEAD);
+                block(jc, b + J);
+            });
+        {
+            const int b0 = b;
+            pc_static_for<0, RING - 1>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                if (b0 + J < nmax) {
+                    fetch(std::integral_constant<int, (J + AHEAD) % RING>{}, b0 + J + AHEAD);
+                    block(jc, b0 + J);
+                }
+            });
+        }
+        // one more evicted block for wave 1: x_{t-D+1} of the last step of block nmax - 1 is the first of block nmax
+        {
+            const pc_f4 *src = pc_row4(X, (nmax * KB) >> 2);
+            pc_f4 t[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) t[q] = src[q * 64];
+            if (nmax == 0) fin[lane] = s1;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; q++) hand[nmax & 1][q][lane] = t[q];
+        }
+        __syncthreads();  // (nmax + 3 barriers in either wave)
+        __syncthreads();
+        return;
+    }
+    // ---- wave 1: s2_t = (s2 - m1_{t-D}) + m1_t, out_t = x_{t-D+1} - s2_t / D, three blocks behind wave 0
+    if (fresh)
+        for (int r = 0; r < D; r++) M1[pc_el(r)] = 0.f;
+    float s2 = (fresh || !listed) ? 0.f : a.dc_s2[slot];
+    const int vq = (a.vo + a.L - 1) >> 2;
+    auto ring = [&](int blk, int q) -> pc_f4 & { return sring[((size_t)(blk & (NBD - 1)) * 4 + q) * a.lanes + lane]; };  // (D: a power of two)
+    for (int k = 0; k < NBD; k++)  // the carried averages of the last D steps as sums (s1 = D m1 exactly)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            pc_f4 v;
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = __fmul_rn(M1[pc_el(k * KB + 4 * q + i)], fD);
+            ring(k, q) = v;
+        }
+    // the evicted x in three register sets (blocks b, b + 1 and the one being read), the incoming s1 in two
+    pc_f4 xb[3][4], svs[2][4];
+    auto take = [&](auto jc, int r, bool sums) {  // block r (r mod 6 == J) from LDS into its register sets
+        constexpr int J = decltype(jc)::value;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            xb[J % 3][q] = hand[r & 1][q][lane];
+            if (sums) svs[J & 1][q] = hand[r & 1][4 + q][lane];
+        }
+    };
+    auto block = [&](auto jc, int b) {
+        constexpr int J = decltype(jc)::value, C = J % 3, N1 = (J + 1) % 3, P = J & 1;
+        take(std::integral_constant<int, (J + 1) % 6>{}, b + 1, b + 1 < nmax);  // (block nmax: the evicted x only)
+        if (b < nfull) {
+            pc_f4 o[4], so[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) so[q] = ring(b, q);
+#pragma unroll
+            for (int i = 0; i < KB; i++) {
+                const float s1 = svs[P][i >> 2][i & 3];
+                const float t2 = __fmaf_rn(so[i >> 2][i & 3], nrD, s2);
+                s2 = __fmaf_rn(s1, rD, t2);
+                const float xd = i + 1 < KB ? xb[C][(i + 1) >> 2][(i + 1) & 3] : xb[N1][0][0];
+                o[i >> 2][i & 3] = __fmaf_rn(s2, nrD, xd);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                ring(b, q) = svs[P][q];
+                *pc_row4(V1, vq + b * (KB / 4) + q) = o[q];
+            }
+        }
+        __syncthreads();
+    };
+    __syncthreads();
+    __syncthreads();  // block 0 is in LDS
+    take(std::integral_constant<int, 0>{}, 0, nmax > 0);
+    __syncthreads();
+    int b = 0;
+    for (; b + 6 <= nmax; b += 6) pc_static_for<0, 6>([&](auto jc) { block(jc, b + decltype(jc)::value); });
+    {
+        const int b0 = b;
+        pc_static_for<0, 5>([&](auto jc) {
+            if (b0 + decltype(jc)::value < nmax) block(jc, b0 + decltype(jc)::value);
+        });
+    }
+    if (!listed) return;
+    float s1 = fin[lane];
+    // the ring in time order (oldest: the slot block nfull would take) goes to rows t1.. of M1 for the remaining
+    // T - nfull * KB (< KB) steps, one by one, as in the two-kernel form
+    const int t1 = nfull * KB;
+    for (int k = 0; k < NBD; k++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const pc_f4 v = ring(nfull + k, q);
+#pragma unroll
+            for (int i = 0; i < 4; i++) M1[pc_el(t1 + k * KB + 4 * q + i)] = __fmul_rn(v[i], rD);
+        }
+    const int v0 = a.vo + a.L - 1;
+    for (int t = t1; t < T; t++) {
+        s1 = __fadd_rn(__fadd_rn(s1, -X[pc_el(t)]), X[pc_el(D + t)]);
+        const float m1 = __fmul_rn(s1, rD);
+        s2 = __fadd_rn(__fadd_rn(s2, -M1[pc_el(t)]), m1);
+        M1[pc_el(D + t)] = m1;
+        V1[pc_el(v0 + t)] = __fsub_rn(X[pc_el(t + 1)], __fmul_rn(s2, rD));
+    }
     for (int i = 0; i < D; i++) M1n[pc_el(i)] = M1[pc_el(T + i)];
     a.dc_s1[slot] = s1;
     a.dc_s2[slot] = s2;

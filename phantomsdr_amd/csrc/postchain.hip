@@ -188,6 +188,15 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
                 hipLaunchKernelGGL(k_pc_ma2<true>, dim3(rgroups), dim3(128), 0, sm, pa);
             else
                 hipLaunchKernelGGL(k_pc_ma2<false>, dim3(rgroups), dim3(128), home_lds ? home_lds - 17 * 1024 : 0, sm, pa);
+        } else if ((pa.D & (pa.D - 1)) == 0 && pa.D >= 16) {
+            // any other power-of-two delay (48 kHz: 128, 192 kHz: 512): the two-wave form with its ring of sums in LDS
+            const size_t ring_lds = (size_t)pa.D * pa.lanes * sizeof(float);
+            const void *fn = c->post_own ? (const void *)k_pc_mad<true> : (const void *)k_pc_mad<false>;
+            if (c->lds_attr_done.insert(fn).second) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+            if (c->post_own)
+                hipLaunchKernelGGL(k_pc_mad<true>, dim3(rgroups), dim3(128), ring_lds, sm, pa);
+            else
+                hipLaunchKernelGGL(k_pc_mad<false>, dim3(rgroups), dim3(128), ring_lds, sm, pa);
         } else if ((pa.D & (pa.D - 1)) == 0) {
             hipLaunchKernelGGL((k_pc_ma<false, true>), dim3(groups), dim3(64), 0, sm, pa);
             hipLaunchKernelGGL((k_pc_ma<true, true>), dim3(groups), dim3(64), 0, sm, pa);

@@ -393,7 +393,8 @@ def test_error_paths():
         ctx.close()
 
 
-@pytest.mark.parametrize("audio_rate,F,nb,n", [(12000, 8, 5, 248), (192000, 128, 5, 248), (12000, 7, 6, 252)])
+@pytest.mark.parametrize("audio_rate,F,nb,n", [(12000, 8, 5, 248), (192000, 128, 5, 248), (12000, 7, 6, 252), (48000, 33, 5, 248),
+                                                  (6000, 9, 4, 360), (44100, 40, 5, 248)])
 def test_post_chain_bit_exact(audio_rate, F, nb, n):
     """DC blocker + AGC + int16 conversion on the GPU (psdr_set_post_chain) against the oracle's
     chain fed with the SAME float audio (the GPU's own demodulator output): the recurrences are
@@ -403,7 +404,9 @@ def test_post_chain_bit_exact(audio_rate, F, nb, n):
     512 (the generic moving-average kernels), look-ahead 38400 samples (k_pc_scan in chunks; the batch
     is sized so that the look-ahead fills: 640 frames of 124 samples).  n = 252: frames of 126 samples - not whole row
     groups of the chain's lane-interleaved streams (the scalar gather / output kernels), 7 of them: streams that are
-    not whole 16-step blocks."""
+    not whole 16-step blocks.  48000 (the other shipped configs' rate: D = 128) and 6000 (D = 16): the two-wave kernel for
+    any power-of-two delay, its ring of sums in LDS, streams that end inside a block (33 and 9 frames); 44100: D = 116,
+    the generic two-kernel path with a division."""
     from phantomsdr_amd import AudioClient, Context
     N = 1 << 14
     R, levels = N, levels_for(N)

@@ -51,7 +51,7 @@ def one_case(rng, case):
     # float audio), at audio rates that give it other delays / look-aheads (D = rate / 750 * 2: 32, 8, 20, 58 - the last
     # not a multiple of 4: the scalar gather / output kernels; L = rate / 5)
     post = rng.random() < 0.5
-    rate = int(rng.choice([12000, 3000, 8000, 22050])) if post else 12000
+    rate = int(rng.choice([12000, 3000, 8000, 22050, 48000, 24000, 6000])) if post else 12000  # (D = 128, 64, 16: the LDS-ring kernel)
     clients = []
     for _ in range(ncl):
         mode = MODES[int(rng.integers(0, 4))]

@@ -20,6 +20,7 @@ ap.add_argument("--clients", type=int, default=16)
 ap.add_argument("--ring-mib", type=int, default=512)
 ap.add_argument("--tag", default="")
 ap.add_argument("--post", action="store_true", help="enable the post-demodulation chain")
+ap.add_argument("--audio-sps", type=int, default=12000, help="audio rate (the post chain's delays and look-ahead follow it)")
 ap.add_argument("--mode", type=int, default=2, help="1: hipEvent brackets around every kernel; 2: device-clock stamps of the two passes")
 args = ap.parse_args()
 
@@ -28,7 +29,7 @@ from phantomsdr_amd import SpectrumEngine  # noqa: E402
 N, F = 1 << args.fft, args.batch
 sps = 70_000_000 if args.real else 35_000_000
 eng = SpectrumEngine(sps, N, args.real, input_format="s16", max_batch=F, max_clients=max(args.clients, 1),
-                     max_waterfall_clients=4)
+                     max_waterfall_clients=4, audio_sps=args.audio_sps)
 if args.post:
     eng.ctx.set_post_chain(True)
 hb = eng.ctx.half_frame_bytes()
@@ -39,7 +40,7 @@ eng.upload_ring(raw)
 R = eng.params["fft_result_size"]
 for i in range(args.clients):
     m = int(rng.uniform(0.05 * R, 0.95 * R))
-    eng.add_audio_client(m, float(m), m + 89, "USB" if i % 2 == 0 else "LSB")
+    eng.add_audio_client(m, float(m), m + 89 * args.audio_sps // 12000, "USB" if i % 2 == 0 else "LSB")
 eng.add_waterfall_client()
 for i in range(5):
     eng.step((i % nb) * F, F)
