@@ -1,9 +1,139 @@
 // postchain.hip - the post-demodulation chain of AudioClient::send_audio (src/signal.cpp:277-284) for all clients of a
 // batch: DC blocker, AGC, int16 conversion (postchain.h) as a four-stage pipeline across batches over three rotating buffer sets.
+#include <chrono>
+
 #include "ctx.h"
 #include "postchain.h"
 
 // ---- post-demodulation chain ---------------------------------------------------
+// Which hardware queue a stream gets is the runtime's business (round robin over the process's queues: it depends on every
+// stream the process ever made), and it matters: a busy queue on the SAME pipe of the command processor as the main
+// stream's makes every launch of the passes start 50 - 60 us late instead of 6 - 9 (4 % of the step; in a second context of
+// the same process - bench.py's sub-workloads - the chain's stream landed exactly there: +35 % instead of +16 % with 256
+// clients; on the side stream's pipe it is worse: its many short kernels wait, the passes wait for them, +52 %).  HIP
+// does not tell, so the streams are CHOSEN BY MEASUREMENT when the chain is first enabled: of six candidates, the two
+// beside which sixteen empty kernels on the main stream AND on the side stream take the least time while the candidate
+// runs a 2 ms kernel (2 us against 6 per launch) - and which run side by side with each other and with the side stream
+// (two streams can share a queue).  ~60 ms, once per context.
+namespace {
+__global__ void k_pc_spin(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+__global__ void k_pc_nop() {}
+
+int pc_launch_gap_us(psdr_ctx *c, hipStream_t cand, hipStream_t on, double *us) {
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    const unsigned long long ticks = (unsigned long long)(c->wall_clock_khz * 2.0);  // 2 ms
+    hipLaunchKernelGGL(k_pc_spin, dim3(1), dim3(64), 0, cand, ticks);
+    HIPCHK(hipEventRecord(a, on));
+    for (int i = 0; i < 16; i++) hipLaunchKernelGGL(k_pc_nop, dim3(1), dim3(64), 0, on);
+    HIPCHK(hipEventRecord(b, on));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    HIPCHK(hipStreamSynchronize(cand));
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    *us = ms * 1e3 / 16.0;
+    return PSDR_OK;
+}
+// do two streams run side by side?  (2 ms on either: ~2 ms together, ~4 ms in the same queue)
+int pc_side_by_side(psdr_ctx *c, hipStream_t s1, hipStream_t s2, bool *yes) {
+    const unsigned long long ticks = (unsigned long long)(c->wall_clock_khz * 2.0);
+    HIPCHK(hipStreamSynchronize(s1));
+    HIPCHK(hipStreamSynchronize(s2));
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(k_pc_spin, dim3(1), dim3(64), 0, s1, ticks);
+    hipLaunchKernelGGL(k_pc_spin, dim3(1), dim3(64), 0, s2, ticks);
+    HIPCHK(hipStreamSynchronize(s1));
+    HIPCHK(hipStreamSynchronize(s2));
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *yes = ms < 3.2;
+    return PSDR_OK;
+}
+int pc_pick_streams(psdr_ctx *c) {
+    constexpr int NC = 6;
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    hipStream_t cand[NC] = {};
+    double gap[NC] = {};
+    for (hipStream_t &st : cand) HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
+    hipLaunchKernelGGL(k_pc_nop, dim3(1), dim3(64), 0, c->stream);  // (code objects loaded, queues created)
+    if (c->side != c->stream) hipLaunchKernelGGL(k_pc_nop, dim3(1), dim3(64), 0, c->side);
+    for (hipStream_t st : cand) hipLaunchKernelGGL(k_pc_spin, dim3(1), dim3(64), 0, st, 1ull);
+    HIPCHK(hipDeviceSynchronize());
+    int order[NC];
+    double gside[NC] = {}, score[NC] = {};
+    for (int i = 0; i < NC; i++) {  // (the better of two readings each: beside the main stream, beside the side stream)
+        double g1 = 0, g2 = 0, g3 = 0, g4 = 0;
+        int rc = pc_launch_gap_us(c, cand[i], c->stream, &g1);
+        if (!rc) rc = pc_launch_gap_us(c, cand[i], c->stream, &g2);
+        if (!rc && c->side != c->stream) rc = pc_launch_gap_us(c, cand[i], c->side, &g3);
+        if (!rc && c->side != c->stream) rc = pc_launch_gap_us(c, cand[i], c->side, &g4);
+        if (rc) return rc;
+        gap[i] = std::min(g1, g2);
+        gside[i] = std::min(g3, g4);
+        order[i] = i;
+    }
+    {
+        const double m0 = std::max(*std::min_element(gap, gap + NC), 0.1), m1 = std::max(*std::min_element(gside, gside + NC), 0.1);
+        for (int i = 0; i < NC; i++) score[i] = std::max(gap[i] / m0, c->side != c->stream ? gside[i] / m1 : 0.0);
+    }
+    std::stable_sort(order, order + NC, [&](int x, int y) { return score[x] < score[y]; });
+    // The moving averages' stream: the quietest candidate (beside both).  The gain's stream: one that is quiet beside the
+    // MAIN stream but shares the side stream's pipe, if there is one - two chain streams on the same quiet pipe measured
+    // +46 % with 256 clients, quiet + side's pipe +14-16 % (five runs; the first context of a process gets that by itself) -
+    // else the next quietest.  Either must run side by side with the other and with the side stream.
+    auto beside = [&](int i, int j, bool *ok) -> int {  // j < 0: the side stream
+        *ok = true;
+        if (j < 0 && c->side == c->stream) return PSDR_OK;
+        return pc_side_by_side(c, cand[i], j < 0 ? c->side : cand[j], ok);
+    };
+    int first = -1, second = -1;
+    for (int k = 0; k < NC && first < 0; k++) {
+        bool ok = true;
+        int rc = beside(order[k], -1, &ok);
+        if (rc) return rc;
+        if (ok) first = order[k];
+    }
+    if (first < 0) first = order[0];
+    const double m0 = std::max(*std::min_element(gap, gap + NC), 0.1), m1 = std::max(*std::min_element(gside, gside + NC), 0.1);
+    for (int pass = 0; pass < 2 && second < 0; pass++)
+        for (int k = 0; k < NC && second < 0; k++) {
+            const int i = order[k];
+            if (i == first) continue;
+            const bool quiet_main = gap[i] < 1.6 * m0, on_side_pipe = c->side != c->stream && gside[i] > 1.6 * m1;
+            if (pass == 0 && !(quiet_main && on_side_pipe)) continue;
+            bool ok = true, ok2 = true;
+            int rc = beside(i, first, &ok);
+            if (!rc) rc = beside(i, -1, &ok2);
+            if (rc) return rc;
+            if (ok && ok2) second = i;
+        }
+    if (second < 0) second = order[0] == first ? order[1] : order[0];
+    int third = -1;
+    for (int k = 0; k < NC; k++)
+        if (order[k] != first && order[k] != second) {
+            third = order[k];
+            break;
+        }
+    if (psdr_tuning_env("PSDR_PC_VERBOSE")) {
+        fprintf(stderr, "psdr post chain: launch gap of the main / side stream beside each candidate stream [us]:");
+        for (int i = 0; i < NC; i++) fprintf(stderr, " %.1f/%.1f", gap[i], gside[i]);
+        fprintf(stderr, " -> streams %d and %d\n", first, second);
+    }
+    c->pc_s[0] = cand[first];
+    c->pc_s[2] = cand[second];
+    c->pc_s[1] = cand[third];
+    for (int i = 0; i < NC; i++)
+        if (i != first && i != second && i != third) hipStreamDestroy(cand[i]);
+    return PSDR_OK;
+}
+}  // namespace
+
 extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
     if (!c) return fail(PSDR_ERR_INVALID, "null argument");
     if (c->n <= 0) return fail(PSDR_ERR_STATE, "context created with audio_fft_size 0");
@@ -67,9 +197,15 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
                 if (!stage[i]) HIPCHK(hipEventCreateWithFlags(&stage[i], hipEventDisableTiming));
         }
         if (!c->pc_s[0]) {
-            int lo = 0, hi = 0;
-            HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            for (hipStream_t &st : c->pc_s) HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
+            const char *e = psdr_tuning_env("PSDR_PC_PICK");  // (tuning build: 0 = three streams in creation order, the first and the third used)
+            if (e && atoi(e) == 0) {
+                int lo = 0, hi = 0;
+                HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                for (hipStream_t &st : c->pc_s) HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
+            } else {
+                int prc = pc_pick_streams(c);
+                if (prc) return prc;
+            }
         }
         rc |= alloc((void **)&a.pcm, S * Tm * sizeof(int32_t));
         rc |= alloc((void **)&a.dc_s1, S * sizeof(float));
@@ -115,8 +251,7 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
     // late (6 - 9 us with four queues, as without the chain): 4 % of the step.
     // WHICH queues matters as much (tools/runs/r05_w.sh, r05_y.sh; rocprofv3 Queue_Id): the chain on queues 4 and 6 leaves the
     // passes' launches alone, on 4 and 5 it delays them as three chain queues do - queue 5 shares its pipe of the command
-    // processor with queue 1, the main stream's.  The ids follow the order in which the process creates its streams (main 1,
-    // side 2, these 4 5 6), so the middle one of three is created and left idle.
+    // processor with queue 1, the main stream's.  pc_pick_streams() chose pc_s[0] and pc_s[2] by that measure.
     hipStream_t sg = c->side, sm = piped ? c->pc_s[0] : c->side, sc = piped ? c->pc_s[2] : c->side, sp = sc;
     if (const char *e = psdr_tuning_env("PSDR_PC_STREAMS")) {  // (tuning build)
         if (atoi(e) == 3 && piped) sp = c->pc_s[1];           // the peak kernels on a stream of their own
