@@ -162,8 +162,8 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
         a.desired = 0.2f;
         a.attack = (float)(1 - std::exp((double)(-1.0f / (50.0f * 0.001f * sr))));
         a.release = (float)(1 - std::exp((double)(-1.0f / (300.0f * 0.001f * sr))));
-        // the DC blocker's history (D floats) is moved in place through LDS (k_pc_history): 12288 floats = 48 KiB, i.e.
-        // audio rates up to 4.6 MHz; the AGC look-ahead L has no such limit (k_pc_scan walks it in chunks)
+        // (D up to 12288 - audio rates up to 4.6 MHz - as in rounds 2-4; the AGC look-ahead L has no such limit: k_pc_submax /
+        // k_pc_prefix / k_pc_want walk it in 256-row pieces)
         if (a.D < 1 || a.L < 2 || a.D > 12288)
             return fail(PSDR_ERR_UNSUPPORTED, "audio_rate %d: DC delay %d / look-ahead %d unsupported", rate, a.D, a.L);
         auto alloc = [&](void **ptr, size_t bytes) -> int {

@@ -401,7 +401,7 @@ def test_post_chain_bit_exact(audio_rate, F, nb, n):
     sequential f32, so the PCM must be identical.  Covers the AGC look-ahead start-up (2400
     samples at 12 kHz), several batches, a mode change (AGC reset, src/signal.cpp:316-328) and a
     client added late.  192000 is the audio_sps of the reference's shipped config.toml (WBFM): DC delay
-    512 (the generic moving-average kernels), look-ahead 38400 samples (k_pc_scan in chunks; the batch
+    512 (k_pc_mad: the sums of the last 512 steps in an LDS ring), look-ahead 38400 samples (150 pieces per block; the batch
     is sized so that the look-ahead fills: 640 frames of 124 samples).  n = 252: frames of 126 samples - not whole row
     groups of the chain's lane-interleaved streams (the scalar gather / output kernels), 7 of them: streams that are
     not whole 16-step blocks.  48000 (the other shipped configs' rate: D = 128) and 6000 (D = 16): the two-wave kernel for
