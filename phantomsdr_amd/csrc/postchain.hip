@@ -323,7 +323,7 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
                 hipLaunchKernelGGL(k_pc_ma2<true>, dim3(rgroups), dim3(128), 0, sm, pa);
             else
                 hipLaunchKernelGGL(k_pc_ma2<false>, dim3(rgroups), dim3(128), home_lds ? home_lds - 17 * 1024 : 0, sm, pa);
-        } else if ((pa.D & (pa.D - 1)) == 0 && pa.D >= 16) {
+        } else if ((pa.D & (pa.D - 1)) == 0 && pa.D >= 16 && (size_t)pa.D * pa.lanes * sizeof(float) <= 128 * 1024) {
             // any other power-of-two delay (48 kHz: 128, 192 kHz: 512): the two-wave form with its ring of sums in LDS
             const size_t ring_lds = (size_t)pa.D * pa.lanes * sizeof(float);
             const void *fn = c->post_own ? (const void *)k_pc_mad<true> : (const void *)k_pc_mad<false>;
