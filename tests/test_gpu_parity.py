@@ -457,15 +457,17 @@ def test_post_chain_bit_exact(audio_rate, F, nb, n):
         ctx.close()
 
 
-def test_post_chain_many_clients():
+@pytest.mark.parametrize("max_clients", [70, 600])
+def test_post_chain_many_clients(max_clients):
     """70 clients (more than the 64 lanes of one wave of the chain's client-per-lane kernels),
-    n = 360 (h = 180 is not a multiple of the kernels' 32-sample blocks), three batches."""
+    n = 360 (h = 180 is not a multiple of the kernels' 32-sample blocks), three batches.  600 slots: more than eight
+    groups of 64 - the recurrence kernels then use whole waves (64 slots per work-group instead of 32)."""
     from phantomsdr_amd import AudioClient, Context
     N, n, F, nb = 1 << 14, 360, 6, 3
     x = synth_stream((nb * F + 1) * (N // 2), False, seed=78, fft_size=N)
     raw = quantize_raw(x, "s16", False)
     ctx = Context(N, False, levels_for(N), additional_size=n, audio_fft_size=n, audio_rate=12000,
-                  input_format="s16", max_batch=F, max_clients=70)
+                  input_format="s16", max_batch=F, max_clients=max_clients)
     try:
         ctx.set_post_chain(True)
         d = ctx.dev_alloc(raw.nbytes)
