@@ -418,7 +418,9 @@ def post_chain_measure(run, eng, params, wl, F, N, nclients, plain_ms):
     rotating buffer sets: a batch's PCM is ready about two steps after its passes, so a repetition of K steps carries
     about two steps of drain - 200 steps per repetition (a server never drains), 50-step repetitions beside it."""
     try:
-        eng.ctx.set_post_chain(True)
+        # (this process creates several contexts: the chain's streams by measurement - psdr.h PSDR_OPT_POST_CHAIN_STREAMS = 1;
+        # a server's one context gets the quiet hardware queues from the default creation order)
+        eng.ctx.set_post_chain(True, measured_streams=True)
         pk = 200
         pt = run.timed(pk, 5, min_reps=3, min_total_s=0.1)
         pt50 = run.timed(50, 3, min_reps=3, min_total_s=0.05)
@@ -433,10 +435,80 @@ def post_chain_measure(run, eng, params, wl, F, N, nclients, plain_ms):
                 "realtime_factor": round(F * (N // 2) / pdt / wl["sps"], 1),
                 "steps_per_repetition": pk,
                 "ms_per_step_50_step_repetitions": round(float(np.median(pt50)) / 50 * 1e3, 3),
+                "chain_streams": "chosen by measurement (PSDR_OPT_POST_CHAIN_STREAMS = 1)",
                 "note": "whole step with psdr_set_post_chain(1): three f32 recurrences, sequential per client (one lane each); "
                         "repetitions of 200 steps between full synchronisations (50-step repetitions, as in round 4, beside it)"}
     except Exception as e:
         return {"error": repr(e)}
+
+
+def with_fetch_measure(run, eng, params, wl, F, N, nclients, plain_ms, post):
+    """The SERVED end of the path: the reference's send_audio / send_waterfall end in host memory
+    (src/signal.cpp:283-291 -> src/audio.cpp:26-44, src/waterfall.cpp:44-51); `value`'s timed step leaves every client's
+    results in HBM.  Here every step is followed by psdr_fetch_begin (the batch's audio + pwr + NaN flags + waterfall rows to
+    pinned host memory on a copy stream, behind its kernels), the NEXT step is enqueued, then psdr_fetch_end of the previous
+    batch: the copies run beside the next batch's passes.  Float audio without the post chain; with it the int32 PCM the
+    reference hands its encoder INSTEAD of the floats.  NOT part of `value`."""
+    ctx = eng.ctx
+    h = params["audio_fft_size"] // 2
+    wf_bytes = 0
+    for lv, l, r in run.waterfalls:
+        wf_bytes += (F + params["skip_num"] - 1) // params["skip_num"] * (r - l)
+    d2h = nclients * F * (h * 4 + 8) + wf_bytes
+
+    def reps(what, steps, nrep, warm=3):
+        def one(n):
+            for i in range(n):
+                run.step(run.next_step + i)
+                ctx.fetch_begin(what)
+                if i > 0:
+                    ctx.fetch_end()
+            ctx.fetch_end()
+            run.sync()
+            run.next_step += n
+        one(warm)
+        ts = []
+        for _ in range(nrep):
+            run.sync()
+            t0 = time.perf_counter()
+            one(steps)
+            ts.append((time.perf_counter() - t0) / steps)
+        return float(np.median(ts))
+
+    def alone(what):  # the copies of one batch with nothing beside them
+        run.step(run.next_step)
+        run.next_step += 1
+        run.sync()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            ctx.fetch_begin(what)
+            ctx.fetch_end()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    def block(dt, base_ms, copy_s):
+        return {"ms_per_step": round(dt * 1e3, 4), "step_without_fetch_ms": base_ms,
+                "over_step_without_fetch": round(dt * 1e3 / base_ms, 4) if base_ms else None,
+                "MSamples_per_s_ingest": round(F * (N // 2) / dt / 1e6, 1),
+                "d2h_bytes_per_step": int(d2h), "d2h_GB_per_s_sustained": round(d2h / dt / 1e9, 2),
+                "copies_alone_ms": round(copy_s * 1e3, 4), "copies_alone_GB_per_s": round(d2h / copy_s / 1e9, 2)}
+
+    out = {"audio_clients": nclients, "frames_per_step": F,
+           "pattern": "step(b); psdr_fetch_begin(b); step(b+1); psdr_fetch_end(b) ... - two pinned host sets, one copy stream; "
+                      "repetitions of 50 steps between full synchronisations, median of 5"}
+    try:
+        what = ctx.FETCH_AUDIO | ctx.FETCH_WATERFALL
+        out["float_audio"] = block(reps(what, 50, 5), plain_ms, alone(what))
+        if post and post.get("ms_per_step"):
+            ctx.set_post_chain(True)
+            what = ctx.FETCH_PCM | ctx.FETCH_WATERFALL
+            out["post_chain_pcm"] = block(reps(what, 50, 5, warm=6), post.get("ms_per_step_50_step_repetitions") or post["ms_per_step"], alone(what))
+            out["post_chain_pcm"]["step_without_fetch_is"] = "post_chain.ms_per_step_50_step_repetitions (the same repetition length)"
+            ctx.set_post_chain(False)
+    except Exception as e:
+        out["error"] = repr(e)
+    return out
 
 
 def kernel_roofline(ctx, step, first_step, nsteps, wl, wl_name, params, clients, waterfalls, frames_per_launch,
@@ -1100,6 +1172,9 @@ def main():
     post = None
     if clients and not args.no_post_chain:
         post = post_chain_measure(run, eng, params, wl, F, N, len(clients), head["ms_per_step"])
+    served = None
+    if clients and not args.no_extra:
+        served = with_fetch_measure(run, eng, params, wl, F, N, len(clients), head["ms_per_step"], post)
     nhalves, hb = run.nhalves, run.hb
     run.close()
     del run
@@ -1121,6 +1196,9 @@ def main():
                            "realtime_factor": round(sm["value"] * 1e6 / w2["sps"], 1)})
                 if nc is not None and not args.no_post_chain:  # the chain with all 64 lanes of four waves in use
                     sm["post_chain"] = post_chain_measure(r2, r2.eng, r2.eng.params, w2, F, w2["fft_size"], len(r2.clients), sm["ms_per_step"])
+                if nc is not None:  # the served end at the target's 256 clients: ~95 MB of results per step to the host
+                    sm["with_fetch"] = with_fetch_measure(r2, r2.eng, r2.eng.params, w2, F, w2["fft_size"], len(r2.clients), sm["ms_per_step"],
+                                                          sm.get("post_chain"))
                 extra[key] = sm
                 r2.close()
                 del r2
@@ -1182,8 +1260,8 @@ def main():
                              "of the loop carries the passes' device-clock stamps instead (mode 2) and is NOT part of `value` "
                              "(path.instrumentation has both medians); inputs resident in "
                              "HBM before, results (spectrum, pyramid, audio, waterfall rows) resident in HBM after: "
-                             "the device-to-host copy of the results is NOT in the timed region (audio + waterfall rows: "
-                             "a few MB per step against GBs of device traffic)"},
+                             "the device-to-host copy of the results is NOT in the timed region - `with_fetch` (and "
+                             "clients256.with_fetch) time the same step WITH it, overlapped with the next step"},
         "roofline": roofline,
         "path": {"algorithmic_bytes_per_frame": head["algorithmic_bytes_per_frame"], "frames_per_s": head["frames_per_s"],
                  "frac_of_hbm_peak": head["frac_of_hbm_peak"], "two_pass_model": head.get("two_pass_model"),
@@ -1197,6 +1275,7 @@ def main():
         "real_input_client_scaling": scaling,
         "c_group_single_device_plumbing": c_group,
         "post_chain": post,
+        "with_fetch": served,
         "cpu_baseline": cpu,
     }
     emit(out)

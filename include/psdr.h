@@ -80,6 +80,13 @@ typedef struct psdr_config {
 
 const char *psdr_last_error(void);
 const char *psdr_version(void);
+/* ABI number of this header: bumped whenever a signature or a struct changes incompatibly.  A caller built against another
+ * header should compare psdr_abi_version() (the library's) with the PSDR_ABI_VERSION it was compiled with.
+ *   2 (library 0.2, round 4): psdr_group_client_set_audio_range(g, int *gid, ...), gid = (rank << 16) | slot
+ *   3 (library 0.3, round 5/6): psdr_group_client_set_audio_range takes the gid BY VALUE and gids are stable handles;
+ *     psdr_fetch_begin / _end / psdr_fetched_waterfall added (additions alone do not bump the number) */
+#define PSDR_ABI_VERSION 3
+int psdr_abi_version(void);
 
 /* ---- lifetime -------------------------------------------------------------------- */
 int psdr_create(const psdr_config *cfg, psdr_ctx **out);
@@ -213,6 +220,27 @@ int psdr_read_audio(psdr_ctx *ctx, int id, int nframes, float *audio, float *pwr
 int psdr_fetch_batch(psdr_ctx *ctx);
 int psdr_fetched_audio(psdr_ctx *ctx, int id, int frame, const float **audio, float *pwr, int32_t *nan_flag,
                        const int32_t **pcm);
+/* The same read-back WITHOUT a stall of the frame loop - the served end of the path: every send_audio / send_waterfall of
+ * the reference ends in host memory (src/signal.cpp:283-291 -> src/audio.cpp:26-44; src/waterfall.cpp:44-51).
+ * psdr_fetch_begin enqueues the device-to-host copies of the last psdr_demod_batch* (pwr and NaN flags always; float audio
+ * with PSDR_FETCH_AUDIO; the post chain's PCM with PSDR_FETCH_PCM) and of the last psdr_waterfall_batch
+ * (PSDR_FETCH_WATERFALL) on a copy stream of the context, behind the kernels that produce them, into one of TWO pinned
+ * host sets, and returns at once.  The caller then enqueues the next batch (psdr_process_* / psdr_demod_batch /
+ * psdr_waterfall_batch): the copies run beside its FFT passes; the kernels that overwrite the device-side results wait for
+ * the copies in stream order (no host wait).  psdr_fetch_end waits for the OLDEST fetch in flight; from then on
+ * psdr_fetched_audio / _window / _waterfall answer from that set, until the psdr_fetch_end after the next (two sets: the
+ * pointers of batch b stay valid while batch b + 1 is being copied).  A third psdr_fetch_begin without a psdr_fetch_end
+ * waits for the oldest copy and gives its results up.  Frame-loop thread only.  psdr_fetch_batch = every outstanding
+ * psdr_fetch_end + a full drain + begin(all) + end.  bench.py's `with_fetch` times this pattern. */
+#define PSDR_FETCH_AUDIO 1u
+#define PSDR_FETCH_PCM 2u
+#define PSDR_FETCH_WATERFALL 4u
+int psdr_fetch_begin(psdr_ctx *ctx, unsigned what);
+int psdr_fetch_end(psdr_ctx *ctx);
+/* rows [nsent][r - l] of waterfall client `id` in the fetched set (pointer into pinned host memory, valid like
+ * psdr_fetched_audio's), with the level and window they were GATHERED with.  PSDR_ERR_NO_DATA: the client was not
+ * active in that batch.  Any output pointer may be NULL. */
+int psdr_fetched_waterfall(psdr_ctx *ctx, int id, const int8_t **rows, int *nsent_out, int *level_out, int *l_out, int *r_out);
 /* the window [l, r) and audio_mid client `id` was DEMODULATED with in the fetched batch (set_audio_range may have run on
  * another thread since, or have been refused): what the packet labels of src/signal.cpp:104-105, 287 must be computed
  * from.  Same error behaviour as psdr_fetched_audio. */
@@ -229,6 +257,16 @@ int psdr_audio_device_ptr(psdr_ctx *ctx, int id, const float **d_audio, const fl
  * hands to its audio encoder.  Frames whose NaN flag is set are skipped by the chain (the
  * reference drops them before it, src/signal.cpp:266-271); their PCM rows are zero. */
 int psdr_set_post_chain(psdr_ctx *ctx, int enable);
+/* Knobs that are not part of psdr_config (whose layout is frozen per PSDR_ABI_VERSION).
+ * PSDR_OPT_POST_CHAIN_STREAMS (before the first psdr_set_post_chain(ctx, 1); PSDR_ERR_STATE after it): which HIP streams the
+ *   post chain's two sequential stages run on.  0 (default): streams created in a fixed order - deterministic, and in the
+ *   FIRST context of a process these are the hardware queues that leave the FFT passes' launches alone.  1: chosen by a
+ *   ~60 ms measurement of launch gaps (the chain's kernels beside empty launches on the main and the side stream) - for a
+ *   process that creates several contexts, where creation order lands on a busy pipe of the command processor (+15 %
+ *   instead of +3 % on the step); the outcome depends on wall-clock thresholds, and a failed
+ *   measurement falls back to 0. */
+enum { PSDR_OPT_POST_CHAIN_STREAMS = 1 };
+int psdr_set_option(psdr_ctx *ctx, int option, int value);
 /* pcm: [frames of the last demod_batch][audio_fft_size/2]; nframes = rows pcm holds (as psdr_read_audio) */
 int psdr_read_pcm(psdr_ctx *ctx, int id, int nframes, int32_t *pcm, int *nframes_out);
 
@@ -286,7 +324,10 @@ int psdr_read_quantized(psdr_ctx *ctx, int frame, int8_t *out);
  * be listed more than once: n ranks on fewer GPUs, which is how a one-GPU box runs the multi-rank logic (placement, band
  * regions and halos, migration, fetch) for real.
  * Everything of a rank is ordered on one stream per device; psdr_group_step returns without synchronising.  The calls
- * below may come from different threads (the server's websocket threads and its frame loop): the group serialises them.
+ * below may come from different threads (the server's websocket threads and its frame loop): the group serialises the
+ * client calls (add / remove / set_* / fetched_*) against each other and against a step's enqueue.  psdr_group_step*,
+ * psdr_group_fetch, psdr_group_synchronize and psdr_group_link_stats belong to the FRAME-LOOP thread alone (they wait for
+ * devices and read the step's timing events: no lock is held while they do).
  * The process-per-GPU twin of this (torch.distributed over RCCL) is phantomsdr_amd/distributed.py.
  * Time sharding (batch g on device g mod n, no collective) needs no group: n independent contexts.
  * STATUS: no group of more than one physical device has run on hardware yet (every round's GPU box had one MI355X): the

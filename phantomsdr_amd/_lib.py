@@ -76,6 +76,7 @@ SYMBOLS = [
     ("psdr_read_audio", _i, [_vp, _i, _i, _vp, _vp, _vp, C.POINTER(_i)]),
     ("psdr_audio_device_ptr", _i, [_vp, _i, _pp, _pp]),
     ("psdr_set_post_chain", _i, [_vp, _i]),
+    ("psdr_set_option", _i, [_vp, _i, _i]),
     ("psdr_read_pcm", _i, [_vp, _i, _i, _vp, C.POINTER(_i)]),
     ("psdr_waterfall_add", _i, [_vp, C.POINTER(_i)]),
     ("psdr_waterfall_remove", _i, [_vp, _i]),
@@ -95,6 +96,10 @@ SYMBOLS = [
     ("psdr_fetched_audio", _i, [_vp, _i, _i, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_float), C.POINTER(C.c_int32),
                                 C.POINTER(C.POINTER(C.c_int32))]),
     ("psdr_fetched_window", _i, [_vp, _i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    ("psdr_abi_version", _i, []),
+    ("psdr_fetch_begin", _i, [_vp, C.c_uint]),
+    ("psdr_fetch_end", _i, [_vp]),
+    ("psdr_fetched_waterfall", _i, [_vp, _i, C.POINTER(C.POINTER(C.c_int8)), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     ("psdr_get_kernel_samples", _i, [_vp, C.c_char_p, C.POINTER(C.c_double), _i, C.POINTER(_i)]),
     ("psdr_get_flow_stats", _i, [_vp, C.POINTER(C.c_uint64)]),
     ("psdr_reset_kernel_stats", _i, [_vp]),

@@ -150,13 +150,58 @@ class Context:
         check(self.lib.psdr_process_batch(self.h, C.c_void_p(base + offset_bytes), nframes))
         self.last_nframes = nframes
 
-    def set_post_chain(self, enable=True):
-        """batched DC blocker + AGC + int16 conversion after every demod_batch"""
+    OPT_POST_CHAIN_STREAMS = 1
+
+    def set_option(self, option, value):
+        check(self.lib.psdr_set_option(self.h, int(option), int(value)))
+
+    def set_post_chain(self, enable=True, measured_streams=None):
+        """batched DC blocker + AGC + int16 conversion after every demod_batch.  measured_streams (first enable only): choose
+        the chain's streams by measurement (psdr.h: PSDR_OPT_POST_CHAIN_STREAMS = 1) instead of creation order"""
+        if measured_streams is not None and not getattr(self, "post_chain_on", False) and not getattr(self, "_pc_set_up", False):
+            self.set_option(self.OPT_POST_CHAIN_STREAMS, 1 if measured_streams else 0)
+        if enable:
+            self._pc_set_up = True
         check(self.lib.psdr_set_post_chain(self.h, 1 if enable else 0))
         self.post_chain_on = bool(enable)
 
     def demod_batch(self, first_frame_num):
         check(self.lib.psdr_demod_batch(self.h, first_frame_num))
+
+    # --- the served end: results to pinned host memory (psdr_fetch_*) ------------------
+    FETCH_AUDIO, FETCH_PCM, FETCH_WATERFALL = 1, 2, 4
+
+    def fetch_batch(self):
+        check(self.lib.psdr_fetch_batch(self.h))
+
+    def fetch_begin(self, what=FETCH_AUDIO | FETCH_WATERFALL):
+        """enqueue the device-to-host copies of the last demodulation / waterfall batch (returns at once)"""
+        check(self.lib.psdr_fetch_begin(self.h, int(what)))
+
+    def fetch_end(self):
+        """wait for the oldest fetch in flight; fetched_audio / fetched_waterfall answer from it afterwards"""
+        check(self.lib.psdr_fetch_end(self.h))
+
+    def fetched_audio(self, cid, frame, pcm=False):
+        """(audio[n/2] copy or None, pwr, nan flag[, pcm[n/2] copy or None]) of one frame of the fetched batch"""
+        a, pc = C.POINTER(C.c_float)(), C.POINTER(C.c_int32)()
+        pw, nan = C.c_float(0), C.c_int32(0)
+        check(self.lib.psdr_fetched_audio(self.h, int(cid), int(frame), C.byref(a), C.byref(pw), C.byref(nan), C.byref(pc)))
+        h = self.cfg.audio_fft_size // 2
+        au = np.ctypeslib.as_array(a, shape=(h,)).copy() if a else None
+        if not pcm:
+            return au, pw.value, nan.value
+        return au, pw.value, nan.value, (np.ctypeslib.as_array(pc, shape=(h,)).copy() if pc else None)
+
+    def fetched_waterfall(self, wid):
+        """(rows [nsent][r - l] copy, level, l, r) of a waterfall client in the fetched batch"""
+        rows = C.POINTER(C.c_int8)()
+        ns, lv, l, r = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        check(self.lib.psdr_fetched_waterfall(self.h, int(wid), C.byref(rows), C.byref(ns), C.byref(lv), C.byref(l), C.byref(r)))
+        ln = r.value - l.value
+        if ns.value == 0 or ln == 0:
+            return np.zeros((0, ln), np.int8), lv.value, l.value, r.value
+        return np.ctypeslib.as_array(rows, shape=(ns.value, ln)).copy(), lv.value, l.value, r.value
         self.last_demod_frames = self.last_nframes
 
     # --- streaming ingest (psdr_ring_*): pinned host half-frames -> HBM ring on a copy stream -----

@@ -13,11 +13,12 @@ int psdr_fail(int code, const char *fmt, ...) {
     return code;
 }
 extern "C" const char *psdr_last_error(void) { return g_err.c_str(); }
+extern "C" int psdr_abi_version(void) { return PSDR_ABI_VERSION; }
 extern "C" const char *psdr_version(void) {
 #ifdef PSDR_TUNING_BUILD
-    return "phantomsdr_amd 0.2 (gfx950, tuning build)";  // reads the A/B knobs of psdr_tuning_env(); not the library that ships
+    return "phantomsdr_amd 0.3 (gfx950, tuning build)";  // reads the A/B knobs of psdr_tuning_env(); not the library that ships
 #else
-    return "phantomsdr_amd 0.2 (gfx950)";
+    return "phantomsdr_amd 0.3 (gfx950)";
 #endif
 }
 
@@ -183,6 +184,7 @@ void free_all(psdr_ctx *c) {
     F(c->d_audio);
     F(c->d_real_prev);
     F(c->d_nan);
+    F(c->d_ssb_mark);
     c->client_ring.destroy();
     c->wf_ring.destroy();
     F(c->d_wfout);
@@ -191,10 +193,16 @@ void free_all(psdr_ctx *c) {
     };
     H(c->h_out);
     H(c->h_q);
-    H(c->h_audio);
-    H(c->h_pwr);
-    H(c->h_nan);
-    H(c->h_pcm);
+    for (auto &fs : c->fset) {
+        H(fs.audio);
+        H(fs.pwr);
+        H(fs.nan);
+        H(fs.pcm);
+        H(fs.wf);
+        if (fs.done) hipEventDestroy(fs.done);
+    }
+    if (c->ev_fetch_src) hipEventDestroy(c->ev_fetch_src);
+    if (c->fetch_stream) hipStreamDestroy(c->fetch_stream);
     for (auto &p : c->pending) {
         hipEventDestroy(p.a);
         hipEventDestroy(p.b);
@@ -424,6 +432,8 @@ int build(psdr_ctx *c) {
         HIPCHK(hipMemset(c->d_audio, 0, S * F * (n / 2) * sizeof(float)));
         HIPCHK(hipMemset(c->d_pwr, 0, S * F * sizeof(float)));
         HIPCHK(hipMemset(c->d_nan, 0, S * F * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&c->d_ssb_mark, S * sizeof(unsigned)));
+        HIPCHK(hipMemset(c->d_ssb_mark, 0, S * sizeof(unsigned)));
         if (c->lds_mode == 2) HIPCHK(hipMalloc((void **)&c->d_gscratch, S * F * 2 * n * sizeof(cf)));
         if (c->client_ring.init(S * (sizeof(ClientParams) + sizeof(int))))  // the batch's client list + the slot -> list index table
             return fail(PSDR_ERR_HIP, "client parameter ring allocation failed");
@@ -755,6 +765,7 @@ int psdr::drain(psdr_ctx *c) {
     if (c->side != c->stream) HIPCHK(hipStreamSynchronize(c->side));
     for (hipStream_t st : c->pc_s)
         if (st) HIPCHK(hipStreamSynchronize(st));
+    if (c->fetch_stream) HIPCHK(hipStreamSynchronize(c->fetch_stream));
     // one-launch transforms (k_fft_fused): a flow-control wait that timed out left wrong results behind - say so, once
     if (c->h_flow_sticky && *c->h_flow_sticky != c->flow_timeouts_seen) {
         const unsigned n = *c->h_flow_sticky - c->flow_timeouts_seen;

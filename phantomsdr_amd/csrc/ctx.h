@@ -63,10 +63,8 @@ struct AudioSlot {
     int agc_reset = 2;  // post chain: 1 = AGC::reset pending (set_audio_demodulation), 2 = fresh client
     bool paused = false;  // psdr_client_set_paused: sits out the demodulation batches, all state frozen
     uint64_t last_seq = 0;  // the demodulation batch (ctx->demod_seq) that last included this slot; 0: none yet
-    int b_l = 0, b_r = 0;   // the window that batch was demodulated with ...
+    int b_l = 0, b_r = 0;   // the window that batch was demodulated with (psdr_fetch_begin copies it into its FetchSet)
     double b_mid = 0;
-    int f_l = 0, f_r = 0;   // ... and the one of the batch psdr_fetch_batch copied
-    double f_mid = 0;
 };
 struct WfSlot {
     bool active = false;
@@ -241,6 +239,8 @@ struct psdr_ctx {
        *d_bb_last = nullptr;
     // post-demodulation chain (postchain.h), allocated by psdr_set_post_chain
     bool post_on = false;
+    bool post_ready = false;   // the chain's buffers, events and streams exist (psdr_set_post_chain's one-time set-up went through)
+    int opt_pc_streams = 0;    // PSDR_OPT_POST_CHAIN_STREAMS: 0 = creation order (deterministic), 1 = chosen by measurement
     PostArgs post{};
     // The chain is a pipeline across batches (round 5), in the order of a batch's data:
     //   side     index, gather (behind the demodulation)
@@ -264,15 +264,38 @@ struct psdr_ctx {
     std::vector<void *> post_allocs;
     float *d_pwr = nullptr, *d_audio = nullptr, *d_real_prev = nullptr;
     int *d_nan = nullptr;
+    unsigned *d_ssb_mark = nullptr;  // [slots] DemodArgs::ssb_mark (demod.h): USB / LSB batches that need the frame-ordered NaN guard
     ParamRing client_ring;
     int last_demod_frames = 0;
     uint64_t demod_seq = 0;  // number of demodulation batches so far (AudioSlot::last_seq)
-    // psdr_fetch_batch: pinned host mirror of the last batch's results, [slot][frame][...]
-    float *h_audio = nullptr, *h_pwr = nullptr;
-    int32_t *h_nan = nullptr, *h_pcm = nullptr;
-    int fetched_frames = 0;
-    uint64_t fetched_seq = 0;
-    bool fetched_pcm = false;
+    // psdr_fetch_begin / _end / psdr_fetch_batch: the served end of the path (src/signal.cpp:283-291, src/audio.cpp:26-44,
+    // src/waterfall.cpp:44-51 hand HOST buffers to the encoders).  Two pinned host sets, [slot][frame][...] each; a fetch is
+    // enqueued on `fetch_stream` behind the kernels that produce the batch's results and runs beside the next batch's passes;
+    // the device buffers it reads exist once, so the next batch's WRITERS (demodulation, waterfall gather, the chain's
+    // output kernel) wait for `done` of the newest fetch in stream order (fetch_guard).
+    struct FetchSet {
+        float *audio = nullptr, *pwr = nullptr;
+        int32_t *nan = nullptr, *pcm = nullptr;
+        int8_t *wf = nullptr;
+        size_t wf_cap = 0;
+        hipEvent_t done = nullptr;
+        bool inflight = false;
+        unsigned what = 0;     // PSDR_FETCH_* bits the copies covered
+        int frames = 0;        // frames of the demodulation batch (0: none was fetched)
+        uint64_t seq = 0;      // its demod_seq
+        struct Win {
+            uint64_t last_seq = 0;
+            int l = 0, r = 0;
+            double mid = 0;
+        };
+        std::vector<Win> win;      // per audio slot: the window the batch was demodulated with
+        std::vector<WfSlot> wfm;   // per waterfall slot: what psdr_waterfall_batch gathered (out_off, nsent, b_*)
+    } fset[2];
+    int fetch_fill = 0;            // the set the next psdr_fetch_begin fills
+    int fetch_cur = -1;            // the set psdr_fetched_* read: completed by the last psdr_fetch_end
+    hipStream_t fetch_stream = nullptr;
+    hipEvent_t ev_fetch_src = nullptr;
+    hipEvent_t fetch_guard = nullptr;  // `done` of the newest fetch still to be waited for by the next writers (or nullptr)
 
     // waterfall clients
     std::vector<WfSlot> wslots;
@@ -367,6 +390,8 @@ inline unsigned persistent_grid(psdr_ctx *c, unsigned blocks, size_t lds) {
 
 // context.hip
 int drain(psdr_ctx *c);
+// demod.hip: the next writer of the device-side result buffers on stream `st` waits for the newest result fetch
+int fetch_guard_wait(psdr_ctx *c, hipStream_t st);
 void resolve_pending(psdr_ctx *c);
 void resolve_kclock(psdr_ctx *c);
 int reset_kclock(psdr_ctx *c);

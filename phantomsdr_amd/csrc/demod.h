@@ -58,7 +58,18 @@ struct DemodArgs {
     cf *bb_tail;       // [2][slots][n/2]
     cf *bb_last;       // [2][slots]
     int slots;
+    // The NaN guard of USB / LSB (src/signal.cpp:266-275) is a recurrence over a client's frames: frame f is dropped iff
+    // y_f[0..n/2) + prev has a NaN, and prev moves on only if it was not.  The batched kernels evaluate it per chain of frames
+    // with "the frame before was dropped iff its transform carries NaN" - exact as long as every value is finite or a
+    // transform is NaN throughout (a NaN input sample).  A client whose batch shows ANY non-finite value (an Inf sample, a
+    // tail that went bad in an earlier batch) is marked here and walked again, strictly in frame order, by one wave
+    // (`replay`: k_demod_chain_fixed with the whole batch as one chain / k_demod_ola_seq) - the reference's rule on the
+    // values at hand, whatever they are.  Integer input formats never get there.
+    unsigned *ssb_mark;   // [slots]: == mark_epoch: the slot's batch needs the sequential walk
+    unsigned mark_epoch;  // of this batch (never 0)
+    int replay;           // 1: the sequential walk itself (marked slots only)
 };
+__device__ __forceinline__ bool not_finite(float v) { return !(fabsf(v) <= 3.402823466e38f); }  // NaN or +-Inf
 
 __device__ __forceinline__ bool flip_frame(unsigned long long frame_num, int m_idx, int is_real) {
     // src/signal.cpp:160-162 with C++ remainder semantics for negative m_idx
@@ -577,9 +588,17 @@ __global__ __launch_bounds__(256) void k_demod_ola(DemodArgs a, int nact) {
         const bool last = (f == F - 1);
         if (cp.mode < 2) {
             // the half to add is the second half of the latest EARLIER frame that survived the NaN guard: a dropped
-            // frame throws at src/signal.cpp:266-271, before audio_real_prev is replaced (:273-275).  A transform has a
-            // NaN in every output or in none (each output sums all inputs), so "frame g was dropped" is read off the
-            // half that is loaded anyway; the carried tail is clean by the same rule.
+            // frame throws at src/signal.cpp:266-271, before audio_real_prev is replaced (:273-275).  With finite values
+            // nothing is ever dropped, and a NaN input sample makes a transform NaN throughout: "frame g was dropped" is
+            // then read off the half that is loaded anyway.  Anything else non-finite: the slot is marked and
+            // k_demod_ola_seq walks its batch in frame order afterwards (DemodArgs::ssb_mark).
+            {
+                int bad = 0;
+                for (int j = tid; j < n; j += NT) bad |= not_finite(y[j].x) ? 1 : 0;
+                if (f == 0)
+                    for (int j = tid; j < h; j += NT) bad |= not_finite(rp_old[j]) ? 1 : 0;
+                if (__any(bad) && tid == 0) a.ssb_mark[srow] = a.mark_epoch;
+            }
             int g = f - 1;
             while (g >= 0) {
                 int d = 0;
@@ -641,6 +660,38 @@ __global__ __launch_bounds__(256) void k_demod_ola(DemodArgs a, int nact) {
     }
 }
 
+// The NaN guard of USB / LSB as the recurrence it is (src/signal.cpp:266-275), for the slots k_demod_ola marked: one wave
+// per client walks the batch in frame order - v = y_f[0..h) + prev; dropped iff v has a NaN; prev = y_f[h..n) unless dropped -
+// and writes audio, flags and the carried tail again.  grid = ceil(nact / 4) work-groups of 256 threads.
+__global__ __launch_bounds__(256) void k_demod_ola_seq(DemodArgs a, int nact) {
+    const int n = a.n, h = n / 2, tid = threadIdx.x & 63, NT = 64;
+    const int ci = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ci >= nact) return;
+    const ClientParams cp = a.clients[ci];
+    const size_t srow = (size_t)cp.slot;
+    if (cp.mode >= 2 || a.ssb_mark[srow] != a.mark_epoch) return;
+    const cf *yp = a.ypost + (srow * a.max_batch) * n;
+    const int cur = cp.state_cur, nxt = cur ^ 1;
+    const float *rp_old = a.real_prev + ((size_t)cur * a.slots + srow) * h;
+    float *rp_new = a.real_prev + ((size_t)nxt * a.slots + srow) * h;
+    int g = -1;  // the latest frame that survived (-1: the carried tail)
+    for (int f = 0; f < a.nframes; f++) {
+        const cf *y = yp + (size_t)f * n;
+        float *out = a.audio + (srow * a.max_batch + f) * h;
+        int s_nan = 0;
+        for (int j = tid; j < h; j += NT) {
+            const float prev = (g < 0) ? rp_old[j] : yp[(size_t)g * n + h + j].x;
+            const float v = y[j].x + prev;  // dsp_add_float :171
+            out[j] = v;
+            if (isnan(v)) s_nan = 1;
+        }
+        const int dropped = __any(s_nan);
+        if (tid == 0) a.nan_flags[srow * a.max_batch + f] = dropped ? 1 : 0;
+        if (!dropped) g = f;
+    }
+    for (int j = tid; j < h; j += NT) rp_new[j] = (g < 0) ? rp_old[j] : yp[(size_t)g * n + h + j].x;  // :273-275
+}
+
 // ---- transform + overlap-add + demodulation in ONE kernel (compile-time plans) -------------------------------
 // One wave walks a CHAIN of K consecutive frames of one client: the second half of frame f-1's transform stays in
 // registers until frame f adds it (src/signal.cpp:171-172, 235-237), so the n complex values per item that
@@ -666,6 +717,9 @@ __global__ __launch_bounds__(256, N <= 512 ? PSDR_IDFT_WPE : PSDR_IDFT_WPE - 1) 
     const int ci = item / nch, f0 = (item - ci * nch) * K;
     const int f1 = f0 + K < F ? f0 + K : F;
     ClientParams cp = a.clients[ci];
+    // replay (DemodArgs::ssb_mark): the whole batch as ONE chain (K >= F: no warm-up frame, every decision in frame order),
+    // for the USB / LSB slots the first launch marked
+    if (a.replay && (cp.mode >= 2 || a.ssb_mark[cp.slot] != a.mark_epoch)) return;
     cp.l = __builtin_amdgcn_readfirstlane(cp.l);
     cp.r = __builtin_amdgcn_readfirstlane(cp.r);
     cp.m_floor = __builtin_amdgcn_readfirstlane(cp.m_floor);
@@ -694,6 +748,11 @@ __global__ __launch_bounds__(256, N <= 512 ? PSDR_IDFT_WPE : PSDR_IDFT_WPE - 1) 
         if (fs == 0 && j < h) tail[u] = ssb ? make_float2(rp_old[j], 0.f) : bt_old[j];
     }
     if (fs == 0 && cp.mode == 3) blast = a.bb_last[(size_t)cur * a.slots + srow];
+    int bad = 0;  // USB / LSB: a non-finite value seen (per lane)
+    if (ssb) {
+#pragma unroll
+        for (int u = 0; u < NH; u++) bad |= not_finite(tail[u].x) ? 1 : 0;
+    }
     int f = fs;
     // PSDR_DEMOD_PREFETCH=1: the slice of the NEXT frame is fetched while this frame is transformed (a wave that walks its
     // chain frame by frame has one frame's loads in flight at a time).  Measured on the round-4 build, same box, three
@@ -810,9 +869,12 @@ __global__ __launch_bounds__(256, N <= 512 ? PSDR_IDFT_WPE : PSDR_IDFT_WPE - 1) 
         }
         const int any_nan = __any(s_nan);
         if (ssb) {
+#pragma unroll
+            for (int u = 0; u < NH; u++) bad |= (not_finite(yv[u].x) || not_finite(yn[u].x)) ? 1 : 0;
             // A dropped USB / LSB frame throws at src/signal.cpp:266-271, BEFORE audio_real_prev is replaced (:273-275):
-            // the next frame adds the tail of the latest frame that survived.  (A transform has a NaN in every output
-            // or in none, so for a warm-up frame - whose own tail is unknown here - "y + 0 has a NaN" says the same.)
+            // the next frame adds the tail of the latest frame that survived.  (With finite values nothing is dropped; a
+            // NaN input sample makes a transform NaN throughout, so for a warm-up frame - whose own tail is unknown here -
+            // "y + 0 has a NaN" says the same; any other non-finite value marks the slot for the sequential replay.)
             if (!emit) {
                 // the warm-up frame of a chain that does not start the batch: if it was dropped, look further back
                 if (any_nan && f > 0) {
@@ -845,6 +907,7 @@ __global__ __launch_bounds__(256, N <= 512 ? PSDR_IDFT_WPE : PSDR_IDFT_WPE - 1) 
         wave_lds_sync();  // buf is read out: the next frame's transform may overwrite it
         f++;
     }
+    if (ssb && !a.replay && __any(bad) && lane_ == 0) a.ssb_mark[srow] = a.mark_epoch;
 }
 
 }  // namespace psdr

@@ -159,6 +159,10 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     }
     c->last_demod_frames = nframes;
     if (nact == 0) return PSDR_OK;
+    {  // d_audio / d_pwr / d_nan exist once: a result fetch in flight (psdr_fetch_begin) reads them first
+        int rc = fetch_guard_wait(c, c->side);
+        if (rc) return rc;
+    }
     HIPCHK(hipMemcpyAsync(d_clients, h_clients, c->post_on ? S * (sizeof(ClientParams) + sizeof(int)) : (size_t)nact * sizeof(ClientParams),
                           hipMemcpyHostToDevice, c->side));
     DemodArgs a{};
@@ -198,6 +202,12 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     a.bb_tail = c->d_bb_tail;
     a.bb_last = c->d_bb_last;
     a.slots = (int)c->aslots.size();
+    a.ssb_mark = c->d_ssb_mark;
+    a.mark_epoch = (unsigned)(c->demod_seq % 0xFFFFFFFFull) + 1u;  // never 0
+    a.replay = 0;
+    // the frame-ordered second walk of marked USB / LSB slots (demod.h: DemodArgs::ssb_mark) can only find work where
+    // non-finite values can arise: float input formats, or a spectrum that comes from the caller
+    const bool can_be_nonfinite = c->cfg.input_format >= PSDR_FMT_F32 || spec != c->d_spec;
     bool ola_done = false;
     {
         ProfScope ps(c, K_IDFT, c->side);
@@ -222,6 +232,17 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
             else
                 hipLaunchKernelGGL((k_demod_chain_fixed<720, 8, 9, 10>), dim3((items + W - 1) / W), dim3(64 * W), lds,
                                    c->side, a, nact, K);
+            if (can_be_nonfinite) {
+                DemodArgs ar = a;
+                ar.replay = 1;
+                const int KF = nframes;  // one chain = the whole batch
+                if (c->n == 360)
+                    hipLaunchKernelGGL((k_demod_chain_fixed<360, 8, 9, 5>), dim3(((unsigned)nact + W - 1) / W), dim3(64 * W), lds,
+                                       c->side, ar, nact, KF);
+                else
+                    hipLaunchKernelGGL((k_demod_chain_fixed<720, 8, 9, 10>), dim3(((unsigned)nact + W - 1) / W), dim3(64 * W), lds,
+                                       c->side, ar, nact, KF);
+            }
             ola_done = true;
         } else if (fixed_plan) {
             // compile-time plans (demod.h): 360 = 8*9*5, 720 = 8*9*10; W items per work-group in
@@ -253,6 +274,7 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
         ProfScope ps(c, K_OLA, c->side);
         const unsigned items = (unsigned)nact * (unsigned)((nframes + PSDR_OLA_FG - 1) / PSDR_OLA_FG);
         hipLaunchKernelGGL(k_demod_ola, dim3((items + 3) / 4), dim3(256), 0, c->side, a, nact);
+        if (can_be_nonfinite) hipLaunchKernelGGL(k_demod_ola_seq, dim3(((unsigned)nact + 3) / 4), dim3(256), 0, c->side, a, nact);
         HIPCHK(hipGetLastError());
     }
     hipStream_t last_user = c->side;
@@ -280,43 +302,126 @@ static int slot_in_last_batch(psdr_ctx *c, int id) {
     return PSDR_OK;
 }
 
-// ---- batched read-back: ONE synchronisation and at most four copies per batch for ALL clients ----------------
-// (src/websocket.cpp:156-185 makes one pass over signal_slices per frame; per-client psdr_read_audio would pay a
-// synchronisation and three copies per client and frame)
+// ---- batched read-back: the served end of the path --------------------------------------------------------------
+// (src/websocket.cpp:156-185 makes one pass over signal_slices per frame and every send_audio ends in host memory:
+// src/signal.cpp:283-291 -> src/audio.cpp:26-44; send_waterfall: src/waterfall.cpp:44-51.  Per-client psdr_read_audio
+// would pay a synchronisation and three copies per client and frame.)
+// psdr_fetch_begin ENQUEUES the copies of the last demodulation batch (and of the last waterfall batch) into one of two
+// pinned host sets on a copy stream, behind the kernels that produce them, and returns; psdr_fetch_end waits for the
+// oldest fetch in flight and makes its set the one psdr_fetched_* read.  Between the two the caller enqueues the NEXT batch:
+// the copies run beside its FFT passes.  The device-side result buffers exist once: the next batch's demodulation,
+// waterfall gather and PCM output wait (in stream order, no host wait) for the newest fetch's copies.
+int psdr::fetch_guard_wait(psdr_ctx *c, hipStream_t st) {
+    if (c->fetch_guard) HIPCHK(hipStreamWaitEvent(st, c->fetch_guard, 0));
+    return PSDR_OK;
+}
+extern "C" int psdr_fetch_begin(psdr_ctx *c, unsigned what) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    if (what == 0 || (what & ~(PSDR_FETCH_AUDIO | PSDR_FETCH_PCM | PSDR_FETCH_WATERFALL))) return fail(PSDR_ERR_INVALID, "PSDR_FETCH_* bits 0x%x", what);
+    const bool want_audio = (what & (PSDR_FETCH_AUDIO | PSDR_FETCH_PCM)) != 0;
+    if (want_audio && c->n <= 0) return fail(PSDR_ERR_STATE, "context created with audio_fft_size 0");
+    const size_t F = (size_t)c->last_demod_frames, h = (size_t)c->n / 2, mb = (size_t)c->max_batch, S = c->aslots.size();
+    if (want_audio && (F == 0 || c->demod_seq == 0)) return fail(PSDR_ERR_STATE, "no demodulated batch to fetch");
+    if ((what & PSDR_FETCH_PCM) && !c->post_on) return fail(PSDR_ERR_STATE, "PSDR_FETCH_PCM: post chain not enabled (psdr_set_post_chain)");
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->fetch_stream) HIPCHK(hipStreamCreateWithFlags(&c->fetch_stream, hipStreamNonBlocking));
+    if (!c->ev_fetch_src) HIPCHK(hipEventCreateWithFlags(&c->ev_fetch_src, hipEventDisableTiming));
+    psdr_ctx::FetchSet &fs = c->fset[c->fetch_fill];
+    if (fs.inflight) {  // both sets in flight: the older one has to land first (its results are given up: psdr_fetch_end was not called)
+        HIPCHK(hipEventSynchronize(fs.done));
+        fs.inflight = false;
+    }
+    if (c->fetch_cur == c->fetch_fill) c->fetch_cur = -1;  // its pointers die now
+    // (each block on its own: a failed allocation leaves nothing half-initialised behind for the next call)
+    if (!fs.done) HIPCHK(hipEventCreateWithFlags(&fs.done, hipEventDisableTiming));
+    if (want_audio && !fs.pwr) HIPCHK(hipHostMalloc((void **)&fs.pwr, S * mb * sizeof(float), hipHostMallocDefault));
+    if (want_audio && !fs.nan) HIPCHK(hipHostMalloc((void **)&fs.nan, S * mb * sizeof(int32_t), hipHostMallocDefault));
+    if ((what & PSDR_FETCH_AUDIO) && !fs.audio) HIPCHK(hipHostMalloc((void **)&fs.audio, S * mb * h * sizeof(float), hipHostMallocDefault));
+    if ((what & PSDR_FETCH_PCM) && !fs.pcm) HIPCHK(hipHostMalloc((void **)&fs.pcm, S * mb * h * sizeof(int32_t), hipHostMallocDefault));
+    size_t wf_bytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(c->mtx);
+        fs.win.resize(S);
+        for (size_t i = 0; i < S; i++) {
+            const AudioSlot &sl = c->aslots[i];
+            fs.win[i].last_seq = sl.active ? sl.last_seq : 0;
+            fs.win[i].l = sl.b_l, fs.win[i].r = sl.b_r, fs.win[i].mid = sl.b_mid;
+        }
+        fs.wfm.assign(c->wslots.begin(), c->wslots.end());
+        if (what & PSDR_FETCH_WATERFALL)
+            for (const WfSlot &w : fs.wfm)
+                if (w.active && w.nsent > 0) wf_bytes = std::max(wf_bytes, (w.out_off + (size_t)w.nsent * (size_t)(w.b_r - w.b_l) + 15) & ~(size_t)15);
+    }
+    if (wf_bytes > fs.wf_cap) {
+        if (fs.wf) HIPCHK(hipHostFree(fs.wf));
+        fs.wf = nullptr, fs.wf_cap = 0;
+        HIPCHK(hipHostMalloc((void **)&fs.wf, wf_bytes, hipHostMallocDefault));
+        fs.wf_cap = wf_bytes;
+    }
+    hipStream_t fst = c->fetch_stream;
+    // behind the demodulation and the waterfall gather of the last batch (both on `side`) ...
+    HIPCHK(hipEventRecord(c->ev_fetch_src, c->side));
+    HIPCHK(hipStreamWaitEvent(fst, c->ev_fetch_src, 0));
+    // rows [slot][0..F) of the device arrays [slot][max_batch][...]: one strided copy each
+    if (want_audio) {
+        HIPCHK(hipMemcpy2DAsync(fs.pwr, mb * sizeof(float), c->d_pwr, mb * sizeof(float), F * sizeof(float), S, hipMemcpyDeviceToHost, fst));
+        HIPCHK(hipMemcpy2DAsync(fs.nan, mb * sizeof(int32_t), c->d_nan, mb * sizeof(int), F * sizeof(int32_t), S, hipMemcpyDeviceToHost, fst));
+    }
+    if (what & PSDR_FETCH_AUDIO)
+        HIPCHK(hipMemcpy2DAsync(fs.audio, mb * h * sizeof(float), c->d_audio, mb * h * sizeof(float), F * h * sizeof(float), S,
+                                hipMemcpyDeviceToHost, fst));
+    if (wf_bytes) HIPCHK(hipMemcpyAsync(fs.wf, c->d_wfout, wf_bytes, hipMemcpyDeviceToHost, fst));
+    if (what & PSDR_FETCH_PCM) {
+        // ... and behind the chain's output kernel of that batch (its own stream: up to two steps after the passes)
+        if (c->chain_seq > 0 && c->pc_s[0] && c->side != c->stream)
+            HIPCHK(hipStreamWaitEvent(fst, c->ev_pc[3][(c->chain_seq - 1) % psdr_ctx::PC_SETS], 0));
+        HIPCHK(hipMemcpy2DAsync(fs.pcm, mb * h * sizeof(int32_t), c->post.pcm, mb * h * sizeof(int32_t), F * h * sizeof(int32_t), S,
+                                hipMemcpyDeviceToHost, fst));
+    }
+    HIPCHK(hipEventRecord(fs.done, fst));
+    fs.inflight = true;
+    fs.what = what;
+    fs.frames = want_audio ? (int)F : 0;
+    fs.seq = want_audio ? c->demod_seq : 0;
+    c->fetch_guard = fs.done;
+    c->fetch_fill ^= 1;
+    return PSDR_OK;
+}
+extern "C" int psdr_fetch_end(psdr_ctx *c) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    // the oldest fetch in flight: the set that would be filled next if it is in flight, else the other one
+    int k = c->fset[c->fetch_fill].inflight ? c->fetch_fill : (c->fetch_fill ^ 1);
+    psdr_ctx::FetchSet &fs = c->fset[k];
+    if (!fs.inflight) return fail(PSDR_ERR_STATE, "psdr_fetch_end without a psdr_fetch_begin in flight");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventSynchronize(fs.done));
+    fs.inflight = false;
+    if (c->fetch_guard == fs.done) c->fetch_guard = nullptr;  // nothing left for the next writers to wait for
+    c->fetch_cur = k;
+    // one-launch transforms: a flow-control timeout of the batches since the last synchronisation is reported by drain();
+    // a fetch does not drain (that is its point) - psdr_synchronize still does
+    return PSDR_OK;
+}
 extern "C" int psdr_fetch_batch(psdr_ctx *c) {
     if (!c) return fail(PSDR_ERR_INVALID, "null argument");
     if (c->n <= 0) return fail(PSDR_ERR_STATE, "context created with audio_fft_size 0");
-    const size_t F = (size_t)c->last_demod_frames, h = (size_t)c->n / 2, mb = (size_t)c->max_batch, S = c->aslots.size();
-    if (F == 0 || c->demod_seq == 0) return fail(PSDR_ERR_STATE, "no demodulated batch to fetch");
-    HIPCHK(hipSetDevice(c->device));
-    // (each block on its own: a failed allocation leaves nothing half-initialised behind for the next call)
-    if (!c->h_audio) HIPCHK(hipHostMalloc((void **)&c->h_audio, S * mb * h * sizeof(float), hipHostMallocDefault));
-    if (!c->h_pwr) HIPCHK(hipHostMalloc((void **)&c->h_pwr, S * mb * sizeof(float), hipHostMallocDefault));
-    if (!c->h_nan) HIPCHK(hipHostMalloc((void **)&c->h_nan, S * mb * sizeof(int32_t), hipHostMallocDefault));
-    if (c->post_on && !c->h_pcm) HIPCHK(hipHostMalloc((void **)&c->h_pcm, S * mb * h * sizeof(int32_t), hipHostMallocDefault));
+    if (c->last_demod_frames == 0 || c->demod_seq == 0) return fail(PSDR_ERR_STATE, "no demodulated batch to fetch");
+    // the synchronous form: everything there is, and the device drained (errors of the batch surface here)
+    while (c->fset[0].inflight || c->fset[1].inflight) {
+        int rc = psdr_fetch_end(c);
+        if (rc) return rc;
+    }
     {
         int rc = drain(c);
         if (rc) return rc;
     }
-    // rows [slot][0..F) of the device arrays [slot][max_batch][...]: one strided copy each
-    HIPCHK(hipMemcpy2DAsync(c->h_audio, mb * h * sizeof(float), c->d_audio, mb * h * sizeof(float), F * h * sizeof(float), S,
-                            hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpy2DAsync(c->h_pwr, mb * sizeof(float), c->d_pwr, mb * sizeof(float), F * sizeof(float), S,
-                            hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpy2DAsync(c->h_nan, mb * sizeof(int32_t), c->d_nan, mb * sizeof(int), F * sizeof(int32_t), S,
-                            hipMemcpyDeviceToHost, c->stream));
-    if (c->post_on)
-        HIPCHK(hipMemcpy2DAsync(c->h_pcm, mb * h * sizeof(int32_t), c->post.pcm, mb * h * sizeof(int32_t), F * h * sizeof(int32_t), S,
-                                hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    {
-        std::lock_guard<std::mutex> lk(c->mtx);
-        for (auto &s : c->aslots)
-            if (s.last_seq == c->demod_seq) s.f_l = s.b_l, s.f_r = s.b_r, s.f_mid = s.b_mid;
-        c->fetched_frames = (int)F;
-        c->fetched_seq = c->demod_seq;
-        c->fetched_pcm = c->post_on;
-    }
+    int rc = psdr_fetch_begin(c, PSDR_FETCH_AUDIO | (c->post_on ? PSDR_FETCH_PCM : 0u) | PSDR_FETCH_WATERFALL);
+    if (rc) return rc;
+    return psdr_fetch_end(c);
+}
+static int fetched_set(psdr_ctx *c, const psdr_ctx::FetchSet **out) {
+    if (c->fetch_cur < 0) return fail(PSDR_ERR_STATE, "psdr_fetch_batch() / psdr_fetch_end() first");
+    *out = &c->fset[c->fetch_cur];
     return PSDR_OK;
 }
 extern "C" int psdr_fetched_window(psdr_ctx *c, int id, int *l, double *audio_mid, int *r) {
@@ -324,31 +429,50 @@ extern "C" int psdr_fetched_window(psdr_ctx *c, int id, int *l, double *audio_mi
     std::lock_guard<std::mutex> lk(c->mtx);
     int rc = check_slot(c, id);
     if (rc) return rc;
-    if (c->fetched_seq == 0) return fail(PSDR_ERR_STATE, "psdr_fetch_batch() first");
-    const AudioSlot &s = c->aslots[id];
-    if (s.last_seq != c->fetched_seq) return fail(PSDR_ERR_NO_DATA, "client %d was not part of the fetched batch", id);
-    if (l) *l = s.f_l;
-    if (audio_mid) *audio_mid = s.f_mid;
-    if (r) *r = s.f_r;
+    const psdr_ctx::FetchSet *fs = nullptr;
+    if ((rc = fetched_set(c, &fs))) return rc;
+    if (fs->seq == 0) return fail(PSDR_ERR_STATE, "the fetched batch carries no audio (PSDR_FETCH_AUDIO / _PCM)");
+    if ((size_t)id >= fs->win.size() || fs->win[id].last_seq != fs->seq)
+        return fail(PSDR_ERR_NO_DATA, "client %d was not part of the fetched batch", id);
+    if (l) *l = fs->win[id].l;
+    if (audio_mid) *audio_mid = fs->win[id].mid;
+    if (r) *r = fs->win[id].r;
     return PSDR_OK;
 }
 extern "C" int psdr_fetched_audio(psdr_ctx *c, int id, int frame, const float **audio, float *pwr, int32_t *nan_flag,
                                   const int32_t **pcm) {
     if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    const psdr_ctx::FetchSet *fs = nullptr;
     {
         std::lock_guard<std::mutex> lk(c->mtx);
         int rc = check_slot(c, id);
         if (rc) return rc;
-        if (c->fetched_seq == 0) return fail(PSDR_ERR_STATE, "psdr_fetch_batch() first");
-        if (c->aslots[id].last_seq != c->fetched_seq)
+        if ((rc = fetched_set(c, &fs))) return rc;
+        if (fs->seq == 0) return fail(PSDR_ERR_STATE, "the fetched batch carries no audio (PSDR_FETCH_AUDIO / _PCM)");
+        if ((size_t)id >= fs->win.size() || fs->win[id].last_seq != fs->seq)
             return fail(PSDR_ERR_NO_DATA, "client %d was not part of the fetched batch", id);
     }
-    if (frame < 0 || frame >= c->fetched_frames) return fail(PSDR_ERR_INVALID, "frame %d not in the fetched batch of %d", frame, c->fetched_frames);
+    if (frame < 0 || frame >= fs->frames) return fail(PSDR_ERR_INVALID, "frame %d not in the fetched batch of %d", frame, fs->frames);
     const size_t h = (size_t)c->n / 2, mb = (size_t)c->max_batch, row = (size_t)id * mb + (size_t)frame;
-    if (audio) *audio = c->h_audio + row * h;
-    if (pwr) *pwr = c->h_pwr[row];
-    if (nan_flag) *nan_flag = c->h_nan[row];
-    if (pcm) *pcm = c->fetched_pcm ? c->h_pcm + row * h : nullptr;
+    if (audio) *audio = (fs->what & PSDR_FETCH_AUDIO) ? fs->audio + row * h : nullptr;
+    if (pwr) *pwr = fs->pwr[row];
+    if (nan_flag) *nan_flag = fs->nan[row];
+    if (pcm) *pcm = (fs->what & PSDR_FETCH_PCM) ? fs->pcm + row * h : nullptr;
+    return PSDR_OK;
+}
+extern "C" int psdr_fetched_waterfall(psdr_ctx *c, int id, const int8_t **rows, int *nsent_out, int *level_out, int *l_out, int *r_out) {
+    if (!c) return fail(PSDR_ERR_INVALID, "null argument");
+    const psdr_ctx::FetchSet *fs = nullptr;
+    int rc = fetched_set(c, &fs);
+    if (rc) return rc;
+    if (!(fs->what & PSDR_FETCH_WATERFALL)) return fail(PSDR_ERR_STATE, "the fetched batch carries no waterfall rows (PSDR_FETCH_WATERFALL)");
+    if (id < 0 || (size_t)id >= fs->wfm.size() || !fs->wfm[id].active) return fail(PSDR_ERR_NO_DATA, "waterfall client %d was not part of the fetched batch", id);
+    const WfSlot &w = fs->wfm[id];
+    if (rows) *rows = w.nsent > 0 ? fs->wf + w.out_off : nullptr;
+    if (nsent_out) *nsent_out = w.nsent;
+    if (level_out) *level_out = w.b_level;
+    if (l_out) *l_out = w.b_l;
+    if (r_out) *r_out = w.b_r;
     return PSDR_OK;
 }
 

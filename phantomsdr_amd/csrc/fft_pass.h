@@ -238,12 +238,12 @@ __device__ __forceinline__ void tile_read(c2 (&u)[16], const float4 *tile, int i
 //                 loads there, so they trickle through the compute phases instead of
 //                 blocking the memory pipe in one burst
 // every stage but the last (the last stage's outputs go to the caller's emit)
-template <int L, int T, bool SWZ, typename Tick, typename Mark>
+template <int L, int T, bool SWZ, bool kX2 = true, typename Tick, typename Mark>
 __device__ __forceinline__ void run_front_stages(float4 *tile, const cf *Wl, int i0, int p, c2 (&u)[16], Tick tick,
                                                  Mark mark, const StageTw<L> *stw = nullptr) {
     using P = Plan<L>;
     constexpr int H = T / 2;
-    constexpr bool kX1 = true, kX2 = true;  // (round 3's timing-only ablations - a stage without its LDS exchange - are in docs/history.md 5.2)
+    constexpr bool kX1 = true;  // (kX1 / kX2 = false: timing-only ablations - a stage without its LDS exchange; docs/history.md 5.2)
 #define PSDR_P1_BARRIER() __syncthreads()
     if constexpr (kX1) {
         stage_compute<L, P::R0, 1>(u, i0, Wl,
@@ -307,11 +307,11 @@ __device__ __forceinline__ void run_last_stage(const cf *Wl, int i0, c2 (&u)[16]
             u, i0, Wl, [&](int b, int s, int pos, c2 x) { emit_last(b, s, pos, x); }, stw ? stw->s1 : nullptr);
     }
 }
-template <int L, int T, bool SWZ, typename PreLast, typename EmitLast, typename Tick, typename Mark>
+template <int L, int T, bool SWZ, bool kX2 = true, typename PreLast, typename EmitLast, typename Tick, typename Mark>
 __device__ __forceinline__ void run_stages(float4 *tile, const cf *Wl, int i0, int p, c2 (&u)[16],
                                            PreLast pre_last, EmitLast emit_last, Tick tick, Mark mark,
                                            const StageTw<L> *stw_front = nullptr, const StageTw<L> *stw_last = nullptr) {
-    run_front_stages<L, T, SWZ>(tile, Wl, i0, p, u, tick, mark, stw_front);
+    run_front_stages<L, T, SWZ, kX2>(tile, Wl, i0, p, u, tick, mark, stw_front);
     pre_last();
     run_last_stage<L>(Wl, i0, u, emit_last, stw_last);
 }
@@ -857,7 +857,12 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsi
         cf tbA[NBL], tbB[NBL], tsA[RL], tsB[RL], w00A, w00B;  // inter-pass twiddles
         cf cWA = make_float2(1.f, 0.f), cWB = cWA;             // PAIR: W_M2^{n2} of the two columns
         cf tmA[RL], tmB[RL];                                   // PAIR: conj(ts[q]) * W_M2^{n2}, q >= RL/2 (the mirror rows)
-        run_stages<L, T, false>(
+#ifdef PSDR_ABL_P1_NOX2  // (timing-only: the second stage without its LDS exchange - wrong results)
+        constexpr bool kP1X2 = false;
+#else
+        constexpr bool kP1X2 = true;
+#endif
+        run_stages<L, T, false, kP1X2>(
             tile, Wl, i0, p, u,
             // ---- inter-pass twiddle W_M^{n2*kappa}, kappa = i0 + b*L/16 + s*P, as
             // base * stepB^b * stepS^s (three table look-ups per column); client order
@@ -1798,9 +1803,13 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             static_assert((RL == 4 || RL == 8) && NBL * RL == 16, "outputs t and t + 8 of a thread are RL / 2 last-stage outputs apart");
             cf wsv[RL / 2];  // sigma * W_N^k of outputs t = b + NBL * sidx, sidx < RL / 2
             run_last_stage<L>(Wl, i0, u, [&](int b, int sidx, int c2i, c2 x) {
+                v2f mine, send;
+#ifdef PSDR_ABL_R2_NOUNT  // (timing-only: no untangle arithmetic - wrong results)
+                mine = to_v2f(x.a), send = to_v2f(x.b);
+                (void)wsv;
+#else
                 const cf sm = cadd(x.a, x.b), d = csub(x.a, x.b);
                 const cf e = make_float2(d.y, -d.x);  // (-i)(a-b)
-                v2f mine, send;
                 if (sidx < RL / 2) {
                     wsv[sidx] = cmul(w0, w32(b + NBL * sidx));
                     const cf wo = cmul(wsv[sidx], e);  // sigma * W_N^k * (-i)(a-b)
@@ -1815,6 +1824,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                 }
                 mine.y = __uint_as_float(__float_as_uint(mine.y) ^ sgn_mine);
                 send.y = __uint_as_float(__float_as_uint(send.y) ^ sgn_send);
+#endif
                 (void)c2i;  // = i0 + (L/16) * (b + NBL * sidx)
                 if ((sidx & 1) == 0) {
                     mineA = from_v2f(mine);
@@ -1880,6 +1890,9 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                 for (int k0 = 0; k0 < NG; k0 += GRP) {
                     float4 v[GRP];
                     float cin[GRP];
+                    uint2 rec_prev = make_uint2(0u, 0u);
+                    float pf_prev = 0.f;
+                    (void)rec_prev, (void)pf_prev;
 #pragma unroll
                     for (int j = 0; j < GRP; j++) {
                         const int kk = k0 + j, sd = kk & 1, c2i = (kk >> 1) * NT + tidx;
@@ -1903,8 +1916,19 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                         const size_t rp = (size_t)g * (2 * L) + (size_t)sd * L + c2i;  // RecMap mode 2
                         uint2 rec;
                         pyr_record4(pw, a.size_log2, rec);
+#ifdef PSDR_ABL_R2_REC16  // (timing-only: the two sides' quartet records of a column in ONE 16-byte store, their sums in one 8-byte store - wrong layout)
+                        if (sd) {
+                            const size_t rq = (size_t)g * (2 * L) + 2 * (size_t)c2i;
+                            *reinterpret_cast<uint4 *>(Qf + rq * 8) = make_uint4(rec.x, rec.y, rec_prev.x, rec_prev.y);
+                            *reinterpret_cast<float2 *>(Pf + rq) = make_float2(pw[0], pf_prev);
+                        } else {
+                            rec_prev = rec;
+                            pf_prev = pw[0];
+                        }
+#else
                         *reinterpret_cast<uint2 *>(Qf + rp * 8) = rec;
                         Pf[rp] = pw[0];
+#endif
                     }
                     PSDR_SCHED_FENCE();
                 }

@@ -703,6 +703,10 @@ extern "C" int psdr_waterfall_batch(psdr_ctx *c, uint64_t first_frame_num) {
         HIPCHK(hipMalloc((void **)&c->d_wfout, total));
         c->wfout_cap = total;
     }
+    {  // d_wfout exists once: a result fetch in flight (psdr_fetch_begin) reads it first
+        int rc = fetch_guard_wait(c, c->side);
+        if (rc) return rc;
+    }
     HIPCHK(hipMemcpyAsync(d_wf, h_wf, (size_t)(maxid + 1) * sizeof(WfClient), hipMemcpyHostToDevice,
                           c->side));
     HIPCHK(hipMemcpyAsync(d_sent, h_sent, (size_t)nsent * sizeof(int), hipMemcpyHostToDevice,

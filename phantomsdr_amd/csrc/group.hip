@@ -356,7 +356,7 @@ extern "C" int psdr_group_client_set_audio_range(psdr_group *g, int gid, int l, 
     // the state rows: [parity][slot][n/2] (ctx.h); the fresh slot reads parity 0 first.  Ordered on the two ranks' streams:
     // after everything the old device has enqueued, before anything the new one enqueues from here on; the old slot may be
     // handed out again only after the copy has read it.
-    {
+    auto move_state = [&]() -> int {
         const size_t h = (size_t)src->n / 2, Ss = src->aslots.size(), Sd = dst->aslots.size();
         HIPCHK(hipSetDevice(g->dev[rank]));
         HIPCHK(hipEventRecord(g->ev_rank[rank], g->st[rank]));
@@ -372,6 +372,13 @@ extern "C" int psdr_group_client_set_audio_range(psdr_group *g, int gid, int l, 
         HIPCHK(hipEventRecord(g->ev_rank[want], g->st[want]));
         HIPCHK(hipSetDevice(g->dev[rank]));
         HIPCHK(hipStreamWaitEvent(g->st[rank], g->ev_rank[want], 0));
+        return PSDR_OK;
+    };
+    rc = move_state();
+    if (rc) {  // the client stays where it was (gid -> src), the half-made slot on the new device is given back
+        const std::string msg = psdr_last_error();
+        psdr_client_remove(dst, nid);
+        return fail(rc, "%s", msg.c_str());
     }
     psdr_client_remove(src, id);
     g->clients[gid] = GroupClient{want, nid};
@@ -613,19 +620,15 @@ extern "C" int psdr_group_fetch(psdr_group *g) {
 }
 extern "C" int psdr_group_fetched_audio(psdr_group *g, int gid, int frame, const float **audio, float *pwr, int32_t *nan_flag, const int32_t **pcm) {
     if (!g) return fail(PSDR_ERR_INVALID, "null argument");
-    int rank, id, rc;
-    {
-        std::lock_guard<std::mutex> lk(g->mtx);
-        rc = gid_split(g, gid, &rank, &id);
-    }
+    // (the lock is held across the lookup AND the answer: a migration or a remove + add between the two would make the call act
+    // on a stale (rank, id); psdr_fetched_* never wait for a device)
+    std::lock_guard<std::mutex> lk(g->mtx);
+    int rank, id, rc = gid_split(g, gid, &rank, &id);
     return rc ? rc : psdr_fetched_audio(g->ctx[rank], id, frame, audio, pwr, nan_flag, pcm);
 }
 extern "C" int psdr_group_fetched_window(psdr_group *g, int gid, int *l, double *audio_mid, int *r) {
     if (!g) return fail(PSDR_ERR_INVALID, "null argument");
-    int rank, id, rc;
-    {
-        std::lock_guard<std::mutex> lk(g->mtx);
-        rc = gid_split(g, gid, &rank, &id);
-    }
+    std::lock_guard<std::mutex> lk(g->mtx);
+    int rank, id, rc = gid_split(g, gid, &rank, &id);
     return rc ? rc : psdr_fetched_window(g->ctx[rank], id, l, audio_mid, r);
 }

@@ -327,6 +327,96 @@ def test_fetch_batch_matches_per_client_reads_and_guards_late_clients():
         ctx.close()
 
 
+def test_fetch_begin_end_pipelined_over_batches_matches_synchronous_reads():
+    """The served end of the path (src/signal.cpp:283-291, src/waterfall.cpp:44-51 end in host memory): psdr_fetch_begin
+    enqueues the copies of batch b behind its kernels, the caller enqueues batch b + 1, psdr_fetch_end(b) - and what
+    psdr_fetched_audio / _waterfall hand out for every batch is bit for bit what a run with a full synchronisation and
+    per-client reads after every batch gives (float audio, pwr, NaN flags, PCM of the post chain, waterfall rows and the
+    windows they were gathered with); the pointers of batch b stay valid while batch b + 1 is in flight."""
+    from phantomsdr_amd import AudioClient, Context, WaterfallClient
+    N, F, n, B = 1 << 16, 6, 248, 5
+    raw = quantize_raw(synth_stream((B * F + 1) * (N // 2), False, seed=21, fft_size=N), "s16", False)
+    specs = [("USB", 9000, 9000.0, 9061), ("LSB", 20000, 20061.0, 20061), ("AM", 30000, 30100.5, 30200), ("FM", 41000, 41100.0, 41200)]
+
+    def run(pipelined):
+        ctx = Context(N, False, _levels(N), additional_size=n, audio_fft_size=n, input_format="s16", max_batch=F, max_clients=6,
+                      max_waterfall_clients=2, skip_num=2)
+        out = []
+        try:
+            d = ctx.dev_alloc(raw.nbytes)
+            ctx.h2d(d, raw)
+            ctx.set_post_chain(True)
+            cl = []
+            for mode, l, m, r in specs:
+                g = AudioClient(ctx)
+                g.set_audio_demodulation(mode)
+                g.set_audio_range(l, m, r)
+                cl.append(g)
+            wf = [WaterfallClient(ctx), WaterfallClient(ctx)]
+            wf[0].set_waterfall_range(_levels(N) - 1, 0, 1024)
+            wf[1].set_waterfall_range(2, 1000, 1700)
+            hb = ctx.half_frame_bytes()
+            what = ctx.FETCH_AUDIO | ctx.FETCH_PCM | ctx.FETCH_WATERFALL
+
+            def collect():
+                rec = {"a": [], "w": []}
+                for g in cl:
+                    rec["a"].append([ctx.fetched_audio(g.id, f, pcm=True) for f in range(F)])
+                for w in wf:
+                    rec["w"].append(ctx.fetched_waterfall(w.id))
+                return rec
+
+            for b in range(B):
+                if b == 2:  # a window change between two batches: the fetched window is the batch's, not the live one
+                    wf[1].set_waterfall_range(3, 500, 900)
+                    cl[0].set_audio_range(9500, 9500.0, 9561)
+                ctx.process_batch(d, F, offset_bytes=b * F * hb)
+                ctx.demod_batch(b * F)
+                ctx.waterfall_batch(b * F)
+                if pipelined:
+                    ctx.fetch_begin(what)
+                    if b > 0:
+                        ctx.fetch_end()          # batch b - 1 lands while batch b runs
+                        out.append(collect())
+                else:
+                    ctx.synchronize()
+                    rec = {"a": [], "w": []}
+                    for g in cl:
+                        a, p, nan = g.read_audio()
+                        pcm = g.read_pcm()
+                        rec["a"].append([(a[f], p[f], nan[f], pcm[f]) for f in range(F)])
+                    for w in wf:
+                        rows, _ = w.read_waterfall()
+                        ns, lv, l, r = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+                        assert ctx.lib.psdr_read_waterfall(ctx.h, w.id, None, 0, C.byref(ns), C.byref(lv), C.byref(l), C.byref(r)) == 0
+                        rec["w"].append((rows, lv.value, l.value, r.value))
+                    out.append(rec)
+            if pipelined:
+                ctx.fetch_end()
+                out.append(collect())
+                assert ctx.lib.psdr_fetch_end(ctx.h) == -2  # PSDR_ERR_STATE: nothing in flight
+            ctx.dev_free(d)
+        finally:
+            ctx.close()
+        return out
+
+    want, got = run(False), run(True)
+    assert len(want) == len(got) == B
+    for b in range(B):
+        for ci in range(len(specs)):
+            for f in range(F):
+                wa, wp, wn, wpcm = want[b]["a"][ci][f]
+                ga, gp, gn, gpcm = got[b]["a"][ci][f]
+                assert np.array_equal(ga.view(np.uint32), wa.view(np.uint32)), (b, ci, f)
+                assert np.float32(gp) == np.float32(wp) and gn == wn
+                assert np.array_equal(gpcm, wpcm), (b, ci, f)
+        for wi in range(2):
+            wr, wl_, wlo, whi = want[b]["w"][wi]
+            gr, gl_, glo, ghi = got[b]["w"][wi]
+            assert (gl_, glo, ghi) == (wl_, wlo, whi), (b, wi)
+            assert np.array_equal(gr, wr), (b, wi)
+
+
 def test_band_demodulation_ignores_clients_without_a_window():
     """psdr_demod_batch_from_band: a client between psdr_client_add and its first set_audio_range has the empty
     window [0, 0) - outside every band but the first - and reads no bin: it must not fail the batch for everyone
