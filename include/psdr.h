@@ -323,7 +323,12 @@ int psdr_read_quantized(psdr_ctx *ctx, int frame, int8_t *out);
  * on its own stream (n - 1 independent copies, one per root-to-peer xGMI link, ordered by events).  With it a device may
  * be listed more than once: n ranks on fewer GPUs, which is how a one-GPU box runs the multi-rank logic (placement, band
  * regions and halos, migration, fetch) for real.
- * Everything of a rank is ordered on one stream per device; psdr_group_step returns without synchronising.  The calls
+ * The exchange of batch b runs BESIDE the root's transform of batch b + 1 (spectrum broadcast, and band regions written by
+ * the root's second pass): the root alternates its two result sets and issues its side of the collective on an exchange
+ * stream of its own; a set is overwritten only after its exchange has completed (stream-ordered, no host wait).
+ * | PSDR_SHARD_SERIAL: exchange and transform strictly one after the other on the root's stream (round 5's schedule; A/B
+ * and the bit-identity test of the overlapped schedule).  Raw sharding and packed band buffers are always serial.
+ * Everything else of a rank is ordered on one stream per device; psdr_group_step returns without synchronising.  The calls
  * below may come from different threads (the server's websocket threads and its frame loop): the group serialises the
  * client calls (add / remove / set_* / fetched_*) against each other and against a step's enqueue.  psdr_group_step*,
  * psdr_group_fetch, psdr_group_synchronize and psdr_group_link_stats belong to the FRAME-LOOP thread alone (they wait for
@@ -334,7 +339,8 @@ int psdr_read_quantized(psdr_ctx *ctx, int frame, int8_t *out);
  * RCCL calls have executed with one rank only, the multi-rank logic through PSDR_SHARD_PEER_COPY on one device.  Treat
  * ndevices > 1 - and PSDR_SHARD_BAND over RCCL in particular - as EXPERIMENTAL until a node run exists. */
 typedef struct psdr_group psdr_group;
-enum { PSDR_SHARD_CLIENTS = 0, PSDR_SHARD_RAW = 1, PSDR_SHARD_BAND = 2, PSDR_SHARD_FORCE_COMM = 0x100, PSDR_SHARD_PEER_COPY = 0x200 };
+enum { PSDR_SHARD_CLIENTS = 0, PSDR_SHARD_RAW = 1, PSDR_SHARD_BAND = 2, PSDR_SHARD_FORCE_COMM = 0x100, PSDR_SHARD_PEER_COPY = 0x200,
+       PSDR_SHARD_SERIAL = 0x400 };
 int psdr_group_create(const psdr_config *cfg, const int *devices, int ndevices, int shard, psdr_group **out);
 void psdr_group_destroy(psdr_group *g);
 int psdr_group_size(const psdr_group *g);

@@ -167,6 +167,7 @@ class Context:
 
     def demod_batch(self, first_frame_num):
         check(self.lib.psdr_demod_batch(self.h, first_frame_num))
+        self.last_demod_frames = self.last_nframes
 
     # --- the served end: results to pinned host memory (psdr_fetch_*) ------------------
     FETCH_AUDIO, FETCH_PCM, FETCH_WATERFALL = 1, 2, 4
@@ -202,7 +203,6 @@ class Context:
         if ns.value == 0 or ln == 0:
             return np.zeros((0, ln), np.int8), lv.value, l.value, r.value
         return np.ctypeslib.as_array(rows, shape=(ns.value, ln)).copy(), lv.value, l.value, r.value
-        self.last_demod_frames = self.last_nframes
 
     # --- streaming ingest (psdr_ring_*): pinned host half-frames -> HBM ring on a copy stream -----
     def ring_create(self, nhalves):
@@ -499,13 +499,14 @@ class Group:
     RCCL, the peers pull with hipMemcpyPeerAsync (a device may then be listed more than once)."""
     SHARDS = {"clients": 0, "raw": 1, "band": 2}
 
-    def __init__(self, devices, shard, fft_size, is_real, downsample_levels, force_comm=False, peer_copy=False, **ctx_kwargs):
+    def __init__(self, devices, shard, fft_size, is_real, downsample_levels, force_comm=False, peer_copy=False, serial=False, **ctx_kwargs):
         # a throw-away Context object only to build the psdr_config the same way Context does
         self.lib = _lib.load()
         cfg = Context._config(fft_size, is_real, downsample_levels, **ctx_kwargs)
         devs = (C.c_int * len(devices))(*devices)
         self.h = C.c_void_p()
-        flag = self.SHARDS[shard] | (0x100 if force_comm else 0) | (0x200 if peer_copy else 0)
+        # serial: PSDR_SHARD_SERIAL - exchange and transform one after the other (default: the exchange of batch b beside the transform of b + 1)
+        flag = self.SHARDS[shard] | (0x100 if force_comm else 0) | (0x200 if peer_copy else 0) | (0x400 if serial else 0)
         check(self.lib.psdr_group_create(C.byref(cfg), devs, len(devices), flag, C.byref(self.h)))
         self.n = len(devices)
         self.cfg = cfg

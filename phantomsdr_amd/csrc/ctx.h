@@ -196,6 +196,7 @@ struct psdr_ctx {
     // ever waits for the consumers of batch b-1.  d_spec/d_q/d_qt/d_pscr point at the set of
     // the LAST processed batch.
     int cur_set = 0;
+    bool alt_sets = false;  // alternate the sets also on a caller's stream (a group's root: the peers read batch b's spectrum while b + 1 is transformed)
     cf *spec_pool[2] = {nullptr, nullptr};
     int8_t *q_pool[2] = {nullptr, nullptr}, *qt_pool[2] = {nullptr, nullptr};
     float *pscr_pool[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};

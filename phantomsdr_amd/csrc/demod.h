@@ -331,13 +331,103 @@ __global__ __launch_bounds__(64 * PSDR_IDFT_WAVES) void k_demod_idft_wave(DemodA
 // (s, R-s) sharing their sums), every LDS access is base + immediate, the twiddle exponent
 // q*(i%p)*n/(p*R) never wraps, and each stage runs IN PLACE (all reads of a stage precede its
 // first write; LDS operations of one wave execute in order) so four items share 15 KiB.
+// ---- in-register INVERSE (sign +) butterflies of the compile-time plans: x[s] <- sum_q x[q] exp(+2 pi i q s / R) ----------
+// Round 5's stage computed every butterfly as a direct R-point DFT (conjugate pairs sharing their sums: ~R^2 scalar FMAs -
+// 124 / 160 / 48 instructions for R = 8 / 9 / 5), and with hundreds of clients the demodulation is VALU-bound beside the
+// passes (1024 clients: a third of the step).  Here R = 8 = 2.2.2, 9 = 3.3, 5 (the symmetric form) and 10 = 2.5 with literal
+// roots on packed (re, im) pairs: 30 / 44 / 18 packed instructions.  butterfly.h's add_mi(a, d) = a - i d, sub_mi(a, d) = a + i d.
+__device__ __forceinline__ cf id_scale(cf a, float k) { return make_float2(a.x * k, a.y * k); }
+__device__ __forceinline__ cf id_fma(cf a, float k, cf c) { return make_float2(fmaf(a.x, k, c.x), fmaf(a.y, k, c.y)); }  // a k + c
+__device__ __forceinline__ void idft3(cf &x0, cf &x1, cf &x2) {
+    constexpr float S3 = 0.86602540378443864676f;  // sin(2 pi / 3)
+    const cf t = cadd(x1, x2), d = csub(x1, x2);
+    const cf u = id_fma(t, -0.5f, x0), e = id_scale(d, S3);
+    x0 = cadd(x0, t);
+    x1 = sub_mi(u, e);  // u + i e
+    x2 = add_mi(u, e);  // u - i e
+}
+__device__ __forceinline__ void idft4(cf &x0, cf &x1, cf &x2, cf &x3) {
+    const cf s02 = cadd(x0, x2), d02 = csub(x0, x2), s13 = cadd(x1, x3), d13 = csub(x1, x3);
+    x0 = cadd(s02, s13);
+    x2 = csub(s02, s13);
+    x1 = sub_mi(d02, d13);  // d02 + i d13
+    x3 = add_mi(d02, d13);
+}
+__device__ __forceinline__ void idft5(cf &x0, cf &x1, cf &x2, cf &x3, cf &x4) {
+    constexpr float C1 = 0.30901699437494742410f, C2 = -0.80901699437494742410f;   // cos(2 pi / 5), cos(4 pi / 5)
+    constexpr float S1 = 0.95105651629515357212f, S2 = 0.58778525229247312917f;    // sin(2 pi / 5), sin(4 pi / 5)
+    const cf t1 = cadd(x1, x4), t2 = cadd(x2, x3), d1 = csub(x1, x4), d2 = csub(x2, x3);
+    const cf a1 = id_fma(t2, C2, id_fma(t1, C1, x0)), a2 = id_fma(t2, C1, id_fma(t1, C2, x0));
+    const cf b1 = id_fma(d2, S2, id_scale(d1, S1)), b2 = id_fma(d2, -S1, id_scale(d1, S2));
+    x0 = cadd(x0, cadd(t1, t2));
+    x1 = sub_mi(a1, b1);
+    x4 = add_mi(a1, b1);
+    x2 = sub_mi(a2, b2);
+    x3 = add_mi(a2, b2);
+}
+template <int R>
+__device__ __forceinline__ void idft_bfly(cf (&x)[R]) {
+    if constexpr (R == 5) {
+        idft5(x[0], x[1], x[2], x[3], x[4]);
+    } else if constexpr (R == 8) {
+        // q = 2 q1 + q2, s = s1 + 4 s2: four-point transforms of the even and the odd inputs, odd branch times W8^{s1}
+        idft4(x[0], x[2], x[4], x[6]);
+        idft4(x[1], x[3], x[5], x[7]);
+        const cf e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6], o0 = x[1], o2 = x[5];
+        const cf o1 = id_scale(sub_mi(x[3], x[3]), PSDR_SQRT1_2);  // (1 + i) / sqrt 2 * o1
+        const cf t3 = id_scale(sub_mi(x[7], x[7]), PSDR_SQRT1_2);  // W8^3 o3 = i * this
+        x[0] = cadd(e0, o0);
+        x[4] = csub(e0, o0);
+        x[1] = cadd(e1, o1);
+        x[5] = csub(e1, o1);
+        x[2] = sub_mi(e2, o2);  // + i o2
+        x[6] = add_mi(e2, o2);
+        x[3] = sub_mi(e3, t3);
+        x[7] = add_mi(e3, t3);
+    } else if constexpr (R == 9) {
+        // q = 3 q1 + q2, s = s1 + 3 s2: three-point transforms over q1, y[s1][q2] *= W9^{q2 s1}, three-point transforms over q2
+        idft3(x[0], x[3], x[6]);
+        idft3(x[1], x[4], x[7]);
+        idft3(x[2], x[5], x[8]);
+        const cf w1 = make_float2(0.76604444311897803520f, 0.64278760968653932632f);   // exp(+2 pi i 1/9)
+        const cf w2 = make_float2(0.17364817766693034885f, 0.98480775301220805937f);   // exp(+2 pi i 2/9)
+        const cf w4 = make_float2(-0.93969262078590838405f, 0.34202014332566873304f);  // exp(+2 pi i 4/9)
+        // after the first step x[3 s1 + q2] holds y[s1][q2]
+        cmul_pair(x[4], x[4], w1, x[5], x[5], w2);
+        cmul_pair(x[7], x[7], w2, x[8], x[8], w4);
+        idft3(x[0], x[1], x[2]);  // s1 = 0: X[0], X[3], X[6]
+        idft3(x[3], x[4], x[5]);  // s1 = 1: X[1], X[4], X[7]
+        idft3(x[6], x[7], x[8]);  // s1 = 2: X[2], X[5], X[8]
+        // x[3 s1 + s2] = X[s1 + 3 s2]: transpose to natural order
+        cf t;
+        t = x[1], x[1] = x[3], x[3] = t;
+        t = x[2], x[2] = x[6], x[6] = t;
+        t = x[5], x[5] = x[7], x[7] = t;
+    } else {
+        static_assert(R == 10, "butterflies with literal roots: 5, 8, 9, 10");
+        // q = 2 q1 + q2, s = s1 + 5 s2
+        idft5(x[0], x[2], x[4], x[6], x[8]);
+        idft5(x[1], x[3], x[5], x[7], x[9]);
+        const cf w1 = make_float2(0.80901699437494742410f, 0.58778525229247312917f);   // exp(+2 pi i 1/10)
+        const cf w2 = make_float2(0.30901699437494742410f, 0.95105651629515357212f);
+        const cf w3 = make_float2(-0.30901699437494742410f, 0.95105651629515357212f);
+        const cf w4 = make_float2(-0.80901699437494742410f, 0.58778525229247312917f);
+        cf o1, o2, o3, o4;
+        cmul_pair(o1, x[3], w1, o2, x[5], w2);
+        cmul_pair(o3, x[7], w3, o4, x[9], w4);
+        const cf e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6], e4 = x[8], o0 = x[1];
+        x[0] = cadd(e0, o0), x[5] = csub(e0, o0);
+        x[1] = cadd(e1, o1), x[6] = csub(e1, o1);
+        x[2] = cadd(e2, o2), x[7] = csub(e2, o2);
+        x[3] = cadd(e3, o3), x[8] = csub(e3, o3);
+        x[4] = cadd(e4, o4), x[9] = csub(e4, o4);
+    }
+}
+
 template <int N, int R, int PP>
 __device__ __forceinline__ void idft_stage_fixed(cf *buf, const cf *Wn, int lane) {
-    constexpr int TLEN = N / R, ROUNDS = (TLEN + 63) / 64, STEP = N / (PP * R), HR = R / 2;
+    constexpr int TLEN = N / R, ROUNDS = (TLEN + 63) / 64, STEP = N / (PP * R);
     constexpr bool RAGGED = (TLEN % 64) != 0;
-    cf root[HR + 1];  // exp(+2 pi i t/R), t <= R/2
-#pragma unroll
-    for (int t = 0; t <= HR; t++) root[t] = Wn[t * TLEN];
     cf x[ROUNDS][R];
     int jo[ROUNDS];
 #pragma unroll
@@ -350,12 +440,10 @@ __device__ __forceinline__ void idft_stage_fixed(cf *buf, const cf *Wn, int lane
 #pragma unroll
             for (int q = 1; q < R; q++) {
                 const cf v = buf[i + q * TLEN];
-                if (PP > 1) {
-                    const cf w = Wn[q * k * STEP];
-                    x[rr][q] = make_float2(fmaf(v.x, w.x, -v.y * w.y), fmaf(v.x, w.y, v.y * w.x));
-                } else {
+                if (PP > 1)
+                    x[rr][q] = cmul(v, Wn[q * k * STEP]);
+                else
                     x[rr][q] = v;
-                }
             }
         }
     }
@@ -369,51 +457,9 @@ __device__ __forceinline__ void idft_stage_fixed(cf *buf, const cf *Wn, int lane
         const int i = lane + 64 * rr;
         if (!RAGGED || rr + 1 < ROUNDS || i < TLEN) {
             cf *o = buf + jo[rr];
-            const cf *xr = x[rr];
-            {  // s = 0
-                float ar = xr[0].x, ai = xr[0].y;
+            idft_bfly<R>(x[rr]);
 #pragma unroll
-                for (int q = 1; q < R; q++) {
-                    ar += xr[q].x;
-                    ai += xr[q].y;
-                }
-                o[0] = make_float2(ar, ai);
-            }
-            if constexpr (R % 2 == 0) {  // s = R/2: alternating sum
-                float ar = xr[0].x, ai = xr[0].y;
-#pragma unroll
-                for (int q = 1; q < R; q++) {
-                    ar += (q & 1) ? -xr[q].x : xr[q].x;
-                    ai += (q & 1) ? -xr[q].y : xr[q].y;
-                }
-                o[HR * PP] = make_float2(ar, ai);
-            }
-            // pairs (s, R-s): out = C +- i*D, C = sum x_q cos, D = sum x_q sin
-#pragma unroll
-            for (int s = 1; 2 * s < R; s++) {
-                float cx = xr[0].x, cy = xr[0].y, dx = 0.f, dy = 0.f;
-#pragma unroll
-                for (int q = 1; q < R; q++) {
-                    const int t = (q * s) % R;
-                    if (t == 0) {
-                        cx += xr[q].x;
-                        cy += xr[q].y;
-                    } else if (2 * t == R) {
-                        cx -= xr[q].x;
-                        cy -= xr[q].y;
-                    } else {
-                        const int tt = t <= HR ? t : R - t;
-                        const float c = root[tt].x;
-                        const float sn = t <= HR ? root[tt].y : -root[tt].y;
-                        cx = fmaf(xr[q].x, c, cx);
-                        cy = fmaf(xr[q].y, c, cy);
-                        dx = fmaf(xr[q].x, sn, dx);
-                        dy = fmaf(xr[q].y, sn, dy);
-                    }
-                }
-                o[s * PP] = make_float2(cx - dy, cy + dx);
-                o[(R - s) * PP] = make_float2(cx + dy, cy - dx);
-            }
+            for (int s = 0; s < R; s++) o[s * PP] = x[rr][s];
         }
     }
 }
@@ -429,6 +475,33 @@ __device__ __forceinline__ void idft_load_slice(const DemodArgs &a, const Client
     for (int u = 0; u < (N + 63) / 64; u++) {
         const int t = lane + 64 * u;
         sv[u] = t < len ? S[a.lay.pos(cp.l + t)] : make_float2(0.f, 0.f);
+    }
+}
+// the same in two steps for a wave that walks SEVERAL frames of one client: where bin t of the slice sits inside a frame
+// (SpecLayout::pos: ~25 instructions per bin in the tile-major layouts) does not depend on the frame - computed once per
+// chain, a frame's load is base + offset (k_demod_chain_fixed: a fifth of its instructions per frame were these).  The
+// first HO rounds of 64 bins only (registers: the kernel lives in the ~80 a pass leaves per SIMD lane): slices of up to
+// 64 HO bins - every SSB / AM / FM window of the usual widths - never compute a position inside the frame loop
+template <int N, int HO>
+__device__ __forceinline__ void idft_slice_offsets(const DemodArgs &a, const ClientParams &cp, int lane, unsigned (&so)[HO]) {
+    const int len = cp.r - cp.l;
+#pragma unroll
+    for (int u = 0; u < HO; u++) {
+        const int t = lane + 64 * u;
+        so[u] = t < len ? (unsigned)a.lay.pos(cp.l + t) : 0u;  // (element index inside a frame / band region: < 2^32)
+    }
+}
+template <int N, int HO>
+__device__ __forceinline__ void idft_load_slice_at(const DemodArgs &a, const ClientParams &cp, int f, const unsigned (&so)[HO], int lane, cf (&sv)[(N + 63) / 64]) {
+    const int len = cp.r - cp.l;
+    const cf *S = a.spec + (size_t)f * a.spec_stride;
+#pragma unroll
+    for (int u = 0; u < (N + 63) / 64; u++) {
+        const int t = lane + 64 * u;
+        if (u < HO)
+            sv[u] = t < len ? S[so[u]] : make_float2(0.f, 0.f);
+        else
+            sv[u] = t < len ? S[a.lay.pos(cp.l + t)] : make_float2(0.f, 0.f);
     }
 }
 template <int N, int R0, int R1, int R2>
@@ -457,10 +530,17 @@ __device__ __forceinline__ float idft_slice_fixed(const ClientParams &cp, const 
         if (t < len) {
             const cf v = sv[u];
             pw += fmaf(v.x, v.x, v.y * v.y);
-            if (cp.mode == 0) {  // USB :125-137
-                if (t >= m && t < m + N) buf[t - m] = v;
-            } else if (cp.mode == 1) {  // LSB :139-153
-                if (t >= m - N + 1 && t < m + 1) buf[m - t] = v;
+            // USB / LSB are c2r transforms (fftwf_plan_dft_c2r_1d, src/signal.cpp:138, 154): only bins 0..N/2 of the input
+            // array are read, Im of bins 0 and N/2 is ignored, the rest is the Hermitian mirror.  The scatter writes a bin
+            // AND its mirror (round 5: a second pass over the buffer behind an LDS round trip)
+            if (cp.mode < 2) {
+                const int idx = cp.mode == 0 ? t - m : m - t;  // USB :125-137 / LSB :139-153
+                if (idx == 0 || idx == N / 2) {
+                    buf[idx] = make_float2(v.x, 0.f);
+                } else if (idx > 0 && idx < N / 2) {
+                    buf[idx] = v;
+                    buf[N - idx] = make_float2(v.x, -v.y);
+                }
             } else {  // AM/FM :175-198
                 if (t >= m && t < m + N / 2) buf[t - m] = v;
                 if (t >= m - N / 2 + 1 && t < m) buf[N - m + t] = v;
@@ -469,21 +549,6 @@ __device__ __forceinline__ float idft_slice_fixed(const ClientParams &cp, const 
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) pw += __shfl_xor(pw, d, 64);
-    if (cp.mode < 2) {  // c2r semantics, see k_demod_idft
-        wave_lds_sync();
-#pragma unroll
-        for (int u = 0; u < (N / 2 + 63) / 64; u++) {
-            const int k = lane + 1 + 64 * u;
-            if (k < N / 2) {
-                const cf v = buf[k];
-                buf[N - k] = make_float2(v.x, -v.y);
-            }
-        }
-        if (lane == 0) {
-            buf[0].y = 0.f;
-            buf[N / 2].y = 0.f;
-        }
-    }
     wave_lds_sync();
     idft_stage_fixed<N, R0, 1>(buf, Wn, lane);
     wave_lds_sync();
@@ -765,6 +830,9 @@ __global__ __launch_bounds__(256, N <= 512 ? PSDR_IDFT_WPE : PSDR_IDFT_WPE - 1) 
     constexpr int NR = (N + 63) / 64;
     cf svn[NR];
     int fpre = -1;  // frame whose slice svn holds
+    constexpr int HO = NR < 3 ? NR : (N <= 512 ? 3 : 6);
+    unsigned so[HO];  // where the slice's first 64 HO bins sit inside a frame: the same for every frame of the chain
+    idft_slice_offsets<N, HO>(a, cp, lane_, so);
     while (f < f1) {
         const bool emit = f >= f0;
         // (an opaque copy per iteration: with the loop-invariant lane the compiler keeps every address of every stage
@@ -779,15 +847,17 @@ __global__ __launch_bounds__(256, N <= 512 ? PSDR_IDFT_WPE : PSDR_IDFT_WPE - 1) 
 #pragma unroll
                 for (int u = 0; u < NR; u++) sv[u] = svn[u];
             } else {
-                idft_load_slice<N>(a, cp, f, lane, sv);  // the chain's first frame; a warm-up frame looked for further back
+                idft_load_slice_at<N, HO>(a, cp, f, so, lane, sv);  // the chain's first frame; a warm-up frame looked for further back
             }
             if (f + 1 < f1) {
-                idft_load_slice<N>(a, cp, f + 1, lane, svn);
+                idft_load_slice_at<N, HO>(a, cp, f + 1, so, lane, svn);
                 fpre = f + 1;
             }
             pw = idft_slice_fixed<N, R0, R1, R2>(cp, sv, buf, Wn, lane);
         } else {
-            pw = idft_item_fixed<N, R0, R1, R2>(a, cp, f, buf, Wn, lane);
+            cf sv[NR];  // loads first, LDS after
+            idft_load_slice_at<N, HO>(a, cp, f, so, lane, sv);
+            pw = idft_slice_fixed<N, R0, R1, R2>(cp, sv, buf, Wn, lane);
         }
         if (emit && lane == 0) a.pwr[srow * a.max_batch + f] = pw;
         const float sg = sign_of(f);

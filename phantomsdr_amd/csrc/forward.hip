@@ -159,7 +159,7 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     // alternate the result set when the consumers run on their own stream
     // (banded spectrum: also on a caller's stream - the regions of batch b are read by the peers, asynchronously,
     // while batch b+1 is transformed)
-    if (c->side != c->stream || c->nbands) select_set(c, c->cur_set ^ 1);
+    if (c->side != c->stream || c->nbands || c->alt_sets) select_set(c, c->cur_set ^ 1);
     const int cols = 1;
     const int sb = fmt <= PSDR_FMT_S8 ? 2 : (fmt <= PSDR_FMT_S16 ? 4 : 8);  // image bytes per sample
     const unsigned tiles1 = (unsigned)(c->M2 / (c->T1 * cols)), tiles2 = (unsigned)(c->M1 / c->T2);

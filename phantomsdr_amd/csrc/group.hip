@@ -82,8 +82,17 @@ struct psdr_group {
     std::vector<GroupClient> clients;  // gid -> (rank, slot): the gid a caller holds never changes
     std::vector<hipEvent_t> ev_rank;   // per rank, on its device: migration hand-over / peer copy done
     std::vector<hipEvent_t> ev_t0, ev_t1;  // peer copy: the copy's own duration on the peer's stream
-    hipEvent_t ev_x = nullptr;         // peer copy: the root's data of this step is ready
+    hipEvent_t ev_x = nullptr;         // the root's data of this step is ready (peer copy; overlapped exchange)
     bool copies_pending = false;       // peer copy: ev_rank[r] of the last step not yet waited for by the root
+    // The exchange of batch b beside the root's transform of batch b + 1 (PSDR_SHARD_CLIENTS, banded PSDR_SHARD_BAND): the
+    // root alternates its two result sets (psdr_ctx::alt_sets) and issues ITS side of the collective on a stream of its
+    // own (`xs`), behind ev_x; what it waits for - before it overwrites a set two steps later - is that set's exchange
+    // (ev_xdone[set]; peer copies: ev_pull[set][r], recorded by the peers).  PSDR_SHARD_SERIAL switches it off (A/B, tests).
+    bool overlap = false;
+    hipStream_t xs = nullptr;
+    hipEvent_t ev_xdone[2] = {nullptr, nullptr};
+    bool xpending[2] = {false, false};
+    std::vector<hipEvent_t> ev_pull[2];
     std::vector<int> dev;
     std::vector<psdr_ctx *> ctx;
     std::vector<hipStream_t> st;    // the one stream per device everything of that rank is ordered on
@@ -140,6 +149,12 @@ extern "C" void psdr_group_destroy(psdr_group *g) {
                 if (p) hipFree(p);
         if (r == 0 && g->ev0) hipEventDestroy(g->ev0), hipEventDestroy(g->ev1);
         if (r == 0 && g->ev_x) hipEventDestroy(g->ev_x);
+        if (r == 0)
+            for (hipEvent_t e : g->ev_xdone)
+                if (e) hipEventDestroy(e);
+        for (auto &v : g->ev_pull)
+            if (r < (int)v.size() && v[r]) hipEventDestroy(v[r]);
+        if (r == 0 && g->xs) hipStreamDestroy(g->xs);
         if (r < (int)g->ev_rank.size() && g->ev_rank[r]) hipEventDestroy(g->ev_rank[r]);
         if (r < (int)g->ev_t0.size() && g->ev_t0[r]) hipEventDestroy(g->ev_t0[r]), hipEventDestroy(g->ev_t1[r]);
         if (g->ctx[r]) psdr_destroy(g->ctx[r]);
@@ -151,7 +166,8 @@ extern "C" void psdr_group_destroy(psdr_group *g) {
 extern "C" int psdr_group_create(const psdr_config *cfg, const int *devices, int ndevices, int shard, psdr_group **out) {
     if (!cfg || !devices || !out) return fail(PSDR_ERR_INVALID, "null argument");
     const bool force_comm = (shard & PSDR_SHARD_FORCE_COMM) != 0, peer_copy = (shard & PSDR_SHARD_PEER_COPY) != 0;
-    shard &= ~(PSDR_SHARD_FORCE_COMM | PSDR_SHARD_PEER_COPY);
+    const bool serial = (shard & PSDR_SHARD_SERIAL) != 0;
+    shard &= ~(PSDR_SHARD_FORCE_COMM | PSDR_SHARD_PEER_COPY | PSDR_SHARD_SERIAL);
     if (ndevices < 1 || ndevices > 16) return fail(PSDR_ERR_INVALID, "a group has 1..16 devices, not %d", ndevices);
     if (shard < PSDR_SHARD_CLIENTS || shard > PSDR_SHARD_BAND) return fail(PSDR_ERR_INVALID, "unknown sharding %d", shard);
     if (force_comm && peer_copy) return fail(PSDR_ERR_INVALID, "PSDR_SHARD_FORCE_COMM (RCCL) and PSDR_SHARD_PEER_COPY (no RCCL) exclude each other");
@@ -262,6 +278,21 @@ extern "C" int psdr_group_create(const psdr_config *cfg, const int *devices, int
         hipEventCreateWithFlags(&g->ev_x, hipEventDisableTiming) != hipSuccess) {
         fail(PSDR_ERR_HIP, "event creation failed");
         return bail(PSDR_ERR_HIP);
+    }
+    // the exchange beside the next transform: spectrum broadcast, and band regions the root's second pass writes itself
+    g->overlap = !serial && (g->comm_on || g->peer_copy) && (shard == PSDR_SHARD_CLIENTS || (shard == PSDR_SHARD_BAND && g->banded));
+    if (g->overlap) {
+        c0->alt_sets = true;
+        bool ok = hipStreamCreateWithFlags(&g->xs, hipStreamNonBlocking) == hipSuccess;
+        for (hipEvent_t &e : g->ev_xdone) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        for (auto &v : g->ev_pull) {
+            v.assign(ndevices, nullptr);
+            for (int r = 1; r < ndevices && ok; r++) ok = hipSetDevice(devices[r]) == hipSuccess && hipEventCreateWithFlags(&v[r], hipEventDisableTiming) == hipSuccess;
+        }
+        if (!ok) {
+            fail(PSDR_ERR_HIP, "exchange stream / events could not be created");
+            return bail(PSDR_ERR_HIP);
+        }
     }
     *out = g;
     return PSDR_OK;
@@ -426,7 +457,55 @@ static int group_step(psdr_group *g, const void *raw_root, uint64_t first_half, 
         g->link_bytes = (double)bytes;
         return PSDR_OK;
     };
-    rc = root_waits_for_copies();
+    // overlapped exchange: the result set the root's transform is about to overwrite (the OTHER one: process_frames toggles)
+    // was the source of the exchange two steps ago - that, and only that, is waited for
+    auto root_waits_for_set = [&](int set) -> int {
+        HIPCHK(hipSetDevice(g->dev[0]));
+        if (g->xpending[set]) {
+            if (g->comm_on) HIPCHK(hipStreamWaitEvent(g->st[0], g->ev_xdone[set], 0));
+            if (g->peer_copy)
+                for (int r = 1; r < g->n; r++) HIPCHK(hipStreamWaitEvent(g->st[0], g->ev_pull[set][r], 0));
+            g->xpending[set] = false;
+        }
+        return PSDR_OK;
+    };
+    // ... its side of the collective goes to the exchange stream, behind the transform; the peers' sides stay on their streams
+    auto exchange_begin = [&]() -> int {
+        HIPCHK(hipSetDevice(g->dev[0]));
+        HIPCHK(hipEventRecord(g->ev_x, g->st[0]));
+        HIPCHK(hipStreamWaitEvent(g->xs, g->ev_x, 0));
+        HIPCHK(hipEventRecord(g->ev0, g->xs));
+        return PSDR_OK;
+    };
+    auto exchange_end = [&](int set, double bytes) -> int {
+        HIPCHK(hipSetDevice(g->dev[0]));
+        HIPCHK(hipEventRecord(g->ev1, g->xs));
+        HIPCHK(hipEventRecord(g->ev_xdone[set], g->xs));
+        g->xpending[set] = true;
+        g->timed = true;
+        g->link_bytes = bytes;
+        return PSDR_OK;
+    };
+    auto peers_pull_set = [&](int set, const std::vector<const void *> &src, const std::vector<void *> &dst, size_t bytes) -> int {
+        HIPCHK(hipSetDevice(g->dev[0]));
+        HIPCHK(hipEventRecord(g->ev_x, g->st[0]));
+        for (int r = 1; r < g->n; r++) {
+            HIPCHK(hipSetDevice(g->dev[r]));
+            HIPCHK(hipStreamWaitEvent(g->st[r], g->ev_x, 0));
+            HIPCHK(hipEventRecord(g->ev_t0[r], g->st[r]));
+            if (g->dev[r] == g->dev[0])
+                HIPCHK(hipMemcpyAsync(dst[r], src[r], bytes, hipMemcpyDeviceToDevice, g->st[r]));
+            else
+                HIPCHK(hipMemcpyPeerAsync(dst[r], g->dev[r], src[r], g->dev[0], bytes, g->st[r]));
+            HIPCHK(hipEventRecord(g->ev_t1[r], g->st[r]));
+            HIPCHK(hipEventRecord(g->ev_pull[set][r], g->st[r]));
+        }
+        g->xpending[set] = true;
+        g->timed = true;
+        g->link_bytes = (double)bytes;
+        return PSDR_OK;
+    };
+    rc = g->overlap ? root_waits_for_set(c0->cur_set ^ 1) : root_waits_for_copies();
     if (rc) return rc;
     if (g->shard == PSDR_SHARD_RAW) {
         // the raw half-frames cross the links, every GPU transforms them itself
@@ -481,23 +560,37 @@ static int group_step(psdr_group *g, const void *raw_root, uint64_t first_half, 
         if (g->shard == PSDR_SHARD_CLIENTS) {
             const size_t count = F * c0->spec_stride * 2;  // floats: the device layout, frames spec_stride bins apart
             if (g->comm_on) {
-                HIPCHK(hipSetDevice(g->dev[0]));
-                HIPCHK(hipEventRecord(g->ev0, g->st[0]));
+                // overlap: the root's side on the exchange stream (its own stream goes on with the demodulation and the next
+                // batch's transform into the other result set)
+                hipStream_t s0 = g->overlap ? g->xs : g->st[0];
+                if (g->overlap) {
+                    rc = exchange_begin();
+                    if (rc) return rc;
+                } else {
+                    HIPCHK(hipSetDevice(g->dev[0]));
+                    HIPCHK(hipEventRecord(g->ev0, g->st[0]));
+                }
                 NCCLCHK(g_rccl.GroupStart());
                 for (int r = 0; r < g->n; r++) {
                     HIPCHK(hipSetDevice(g->dev[r]));
                     // straight out of the root's spectrum buffer into every rank's own
-                    NCCLCHK(g_rccl.Broadcast(c0->d_spec, r == 0 ? (void *)c0->d_spec : (void *)g->ctx[r]->d_spec, count, ncclFloat, 0, g->comm[r], g->st[r]));
+                    NCCLCHK(g_rccl.Broadcast(c0->d_spec, r == 0 ? (void *)c0->d_spec : (void *)g->ctx[r]->d_spec, count, ncclFloat, 0, g->comm[r], r == 0 ? s0 : g->st[r]));
                 }
                 NCCLCHK(g_rccl.GroupEnd());
-                HIPCHK(hipSetDevice(g->dev[0]));
-                HIPCHK(hipEventRecord(g->ev1, g->st[0]));
-                g->timed = true;
-                g->link_bytes = (double)count * sizeof(float);
+                if (g->overlap) {
+                    rc = exchange_end(c0->cur_set, (double)count * sizeof(float));
+                    if (rc) return rc;
+                } else {
+                    HIPCHK(hipSetDevice(g->dev[0]));
+                    HIPCHK(hipEventRecord(g->ev1, g->st[0]));
+                    g->timed = true;
+                    g->link_bytes = (double)count * sizeof(float);
+                }
             } else if (g->peer_copy) {
                 std::vector<void *> dst(g->n, nullptr);
                 for (int r = 1; r < g->n; r++) dst[r] = g->ctx[r]->d_spec;
-                rc = peers_pull(std::vector<const void *>(g->n, c0->d_spec), dst, count * sizeof(float));
+                rc = g->overlap ? peers_pull_set(c0->cur_set, std::vector<const void *>(g->n, c0->d_spec), dst, count * sizeof(float))
+                                : peers_pull(std::vector<const void *>(g->n, c0->d_spec), dst, count * sizeof(float));
                 if (rc) return rc;
             }
             rc = psdr_demod_batch(c0, first_frame_num);
@@ -525,24 +618,35 @@ static int group_step(psdr_group *g, const void *raw_root, uint64_t first_half, 
                 send[0] = (const float *)g->sbuf[0];
             }
             if (g->comm_on) {
-                HIPCHK(hipSetDevice(g->dev[0]));
-                HIPCHK(hipEventRecord(g->ev0, g->st[0]));
+                hipStream_t s0 = g->overlap ? g->xs : g->st[0];  // (overlap: banded regions only - they alternate with the result sets)
+                if (g->overlap) {
+                    rc = exchange_begin();
+                    if (rc) return rc;
+                } else {
+                    HIPCHK(hipSetDevice(g->dev[0]));
+                    HIPCHK(hipEventRecord(g->ev0, g->st[0]));
+                }
                 NCCLCHK(g_rccl.GroupStart());
                 for (int b = self_loop ? 0 : 1; b < g->n; b++) {
                     HIPCHK(hipSetDevice(g->dev[0]));
-                    NCCLCHK(g_rccl.Send(send[b], count, ncclFloat, b, g->comm[0], g->st[0]));
+                    NCCLCHK(g_rccl.Send(send[b], count, ncclFloat, b, g->comm[0], s0));
                     HIPCHK(hipSetDevice(g->dev[b]));
                     NCCLCHK(g_rccl.Recv(g->rbuf[b], count, ncclFloat, 0, g->comm[b], g->st[b]));
                 }
                 NCCLCHK(g_rccl.GroupEnd());
-                HIPCHK(hipSetDevice(g->dev[0]));
-                HIPCHK(hipEventRecord(g->ev1, g->st[0]));
-                g->timed = true;
-                g->link_bytes = (double)count * sizeof(float);
+                if (g->overlap) {
+                    rc = exchange_end(c0->cur_set, (double)count * sizeof(float));
+                    if (rc) return rc;
+                } else {
+                    HIPCHK(hipSetDevice(g->dev[0]));
+                    HIPCHK(hipEventRecord(g->ev1, g->st[0]));
+                    g->timed = true;
+                    g->link_bytes = (double)count * sizeof(float);
+                }
             } else if (g->peer_copy) {
                 std::vector<const void *> src(g->n, nullptr);
                 for (int b = 1; b < g->n; b++) src[b] = send[b];
-                rc = peers_pull(src, g->rbuf, count * sizeof(float));
+                rc = g->overlap ? peers_pull_set(c0->cur_set, src, g->rbuf, count * sizeof(float)) : peers_pull(src, g->rbuf, count * sizeof(float));
                 if (rc) return rc;
             }
             // the root's own clients read its spectrum through SpecLayout::pos (self_loop: the band buffer that came back)
@@ -576,6 +680,10 @@ extern "C" int psdr_group_synchronize(psdr_group *g) {
     for (int r = 0; r < g->n; r++) {
         int rc = psdr_synchronize(g->ctx[r]);
         if (rc) return rc;
+    }
+    if (g->xs) {
+        HIPCHK(hipSetDevice(g->dev[0]));
+        HIPCHK(hipStreamSynchronize(g->xs));
     }
     return PSDR_OK;
 }

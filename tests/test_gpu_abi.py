@@ -394,7 +394,7 @@ def test_fetch_begin_end_pipelined_over_batches_matches_synchronous_reads():
             if pipelined:
                 ctx.fetch_end()
                 out.append(collect())
-                assert ctx.lib.psdr_fetch_end(ctx.h) == -2  # PSDR_ERR_STATE: nothing in flight
+                assert ctx.lib.psdr_fetch_end(ctx.h) == -4  # PSDR_ERR_STATE: nothing in flight
             ctx.dev_free(d)
         finally:
             ctx.close()

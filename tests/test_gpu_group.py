@@ -150,6 +150,57 @@ def test_n_ranks_on_one_device_with_peer_copies_match_a_plain_context(shard, N, 
     assert links[-1][0] > 0 and links[-1][1] > 0
 
 
+def _run_group_unsynced(devices, shard, force, peer_copy, serial, N, is_real, n, F, steps, raw, clients, levels):
+    """`steps` batches enqueued back to back - no fetch, no synchronisation in between - then the LAST batch's results"""
+    from phantomsdr_amd import Group
+    g = Group(devices, shard, N, is_real, levels, force_comm=force, peer_copy=peer_copy, serial=serial, additional_size=n, audio_fft_size=n,
+              input_format="s16", max_batch=F, max_clients=len(clients), max_waterfall_clients=2)
+    try:
+        root = g.root
+        d = root.dev_alloc(raw.nbytes)
+        root.h2d(d, raw)
+        gids = [g.client_add(l, m, r, mode) for mode, l, m, r in clients]
+        hb = root.half_frame_bytes()
+        for b in range(steps):
+            g.step(d, F, b * F, offset_bytes=b * F * hb)
+        g.fetch()
+        g.synchronize()
+        batch = []
+        for gid in gids:
+            rows = [g.fetched_audio(gid, f) for f in range(F)]
+            batch.append((np.stack([x[0] for x in rows]), np.array([x[1] for x in rows], np.float32), np.array([x[2] for x in rows], np.int32)))
+        spec = root.read_spectrum(F - 1)
+        root.dev_free(d)
+        return batch, spec
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("how,ndev,shard", [("peer_copy", 8, "clients"), ("peer_copy", 4, "band"), ("rccl_forced", 1, "clients")])
+def test_overlapped_exchange_is_bit_identical_to_the_serial_step(how, ndev, shard):
+    """The exchange of batch b runs beside the root's transform of batch b + 1 (the root alternates its result sets, its
+    side of the collective sits on an exchange stream, a set is overwritten only after its exchange: group.hip).  k batches
+    enqueued WITHOUT any synchronisation in between, k = 1 .. 5: the k-th batch's audio on every rank, and the root's
+    spectrum, are the bits of the serial schedule (PSDR_SHARD_SERIAL) and of a plain context that steps batch by batch -
+    through n ranks on one device with peer copies (clients; band regions of the 2^20-point IQ second pass) and through
+    RCCL forced on one rank."""
+    N, is_real, n, F, nb = 1 << 20, 0, 360, 3, 5
+    R = N
+    levels = levels_for(R)
+    x = synth_stream((nb * F + 1) * (N // 2), False, seed=41, fft_size=N)
+    raw = quantize_raw(x, "s16", False)
+    clients = _clients(N, R, n, 16)
+    ref, _, _ = _run_plain(N, is_real, n, F, nb, raw, clients, levels)
+    for k in range(1, nb + 1):
+        res = {}
+        for serial in (True, False):
+            res[serial] = _run_group_unsynced([0] * ndev, shard, how == "rccl_forced", how == "peer_copy", serial, N, is_real, n, F, k, raw,
+                                              clients, levels)
+        _same([ref[k - 1]], [res[True][0]], f"serial {how} x{ndev} {shard}, batch {k} of {k} unsynchronised")
+        _same([ref[k - 1]], [res[False][0]], f"overlapped {how} x{ndev} {shard}, batch {k} of {k} unsynchronised")
+        assert np.array_equal(res[True][1].view(np.uint32), res[False][1].view(np.uint32))
+
+
 @pytest.mark.parametrize("N,is_real,n", [(1 << 16, 0, 248), (1 << 20, 0, 360)])
 def test_band_migration_keeps_the_gid_and_the_demodulation_state(N, is_real, n):
     """Band sharding, 4 ranks (on one device): clients retune across band edges between batches - the gid stays, the rank

@@ -21,6 +21,7 @@ ap.add_argument("--ring-mib", type=int, default=512)
 ap.add_argument("--tag", default="")
 ap.add_argument("--post", action="store_true", help="enable the post-demodulation chain")
 ap.add_argument("--audio-sps", type=int, default=12000, help="audio rate (the post chain's delays and look-ahead follow it)")
+ap.add_argument("--mixed", action="store_true", help="clients alternate USB / LSB / AM / FM (default: USB / LSB)")
 ap.add_argument("--mode", type=int, default=2, help="1: hipEvent brackets around every kernel; 2: device-clock stamps of the two passes")
 args = ap.parse_args()
 
@@ -40,7 +41,12 @@ eng.upload_ring(raw)
 R = eng.params["fft_result_size"]
 for i in range(args.clients):
     m = int(rng.uniform(0.05 * R, 0.95 * R))
-    eng.add_audio_client(m, float(m), m + 89 * args.audio_sps // 12000, "USB" if i % 2 == 0 else "LSB")
+    md = ("USB", "LSB", "AM", "FM")[i % 4] if args.mixed else ("USB" if i % 2 == 0 else "LSB")
+    w = 89 * args.audio_sps // 12000
+    if md in ("AM", "FM"):
+        eng.add_audio_client(m - w, float(m), m + w, md)
+    else:
+        eng.add_audio_client(m, float(m), m + w, md)
 eng.add_waterfall_client()
 for i in range(5):
     eng.step((i % nb) * F, F)
