@@ -544,9 +544,6 @@ def kernel_roofline(ctx, step, first_step, nsteps, wl, wl_name, params, clients,
     # transforms: the untangle pass); the demodulation kernels read slices and write audio; intermediates count zero.
     three_pass_real = wl["is_real"] and "untangle_real" in per_chunk
     per_kernel_bytes = {
-        # both passes in ONE launch (k_fft_fused: the roles run side by side, Y never leaves the Infinity Cache): the launch
-        # reads the raw input once and writes spectrum + pyramid once
-        "fft_fused": (ab["input"] + ab["spectrum"] + ab["pyramid"]) * Fl,
         "fft_pass1": ab["input"] * Fl,
         "fft_pass2": 0 if three_pass_real else (ab["spectrum"] + ab["pyramid"]) * Fl,
         "untangle_real": (ab["spectrum"] + ab["pyramid"]) * Fl if three_pass_real else 0,
@@ -563,9 +560,6 @@ def kernel_roofline(ctx, step, first_step, nsteps, wl, wl_name, params, clients,
                                   "device_clock_us_min_max": [round(float(np.min(v)), 2), round(float(np.max(v)), 2)],
                                   "device_clock_launches": int(len(v))})
     dur = {name: clock_med.get(name, float(np.median(v))) for name, v in per_chunk.items()}
-    fused = "fft_fused" in dur
-    if fused:  # the roles' own spans (fft_pass1 / fft_pass2 stamps) overlap inside the one launch: the launch is the kernel
-        dur = {k: v for k, v in dur.items() if k not in ("fft_pass1", "fft_pass2")}
     dom = max(dur, key=lambda k: dur[k]) if dur else None
     roofline = None
     if dom:
@@ -584,7 +578,7 @@ def kernel_roofline(ctx, step, first_step, nsteps, wl, wl_name, params, clients,
                 step_traffic = int(tot * scale) if tot else None
             except Exception:
                 traffic = step_traffic = None
-        ev = {k: float(np.median(per_chunk[k])) for k in ("fft_fused", "fft_pass1", "fft_pass2", "untangle_real") if k in per_chunk}
+        ev = {k: float(np.median(per_chunk[k])) for k in ("fft_pass1", "fft_pass2", "untangle_real") if k in per_chunk}
         fps = frames_per_s if frames_per_s else (Fl / (ms_per_step * 1e-3) if ms_per_step else 0.0)
         roofline = path_roofline(ab["total"], fps)
         roofline.update({
@@ -604,13 +598,10 @@ def kernel_roofline(ctx, step, first_step, nsteps, wl, wl_name, params, clients,
             # than the step unless the measurement itself lengthened them
             roofline["passes_sum_over_step"] = {
                 # (against the step of the repetitions that carried the stamps)
-                "device_clock": round((clock_med.get("fft_fused", 0.0) if fused else sum(clock_med.get(k, 0.0) for k in ("fft_pass1", "fft_pass2")))
+                "device_clock": round(sum(clock_med.get(k, 0.0) for k in ("fft_pass1", "fft_pass2"))
                                       / ((ms_per_step_stamped or ms_per_step) * 1e3), 4)
                 if clock_med else None,
                 "hip_events": round(sum(ev.values()) / (ms_per_step * 1e3), 4)}
-            if fused:
-                roofline["one_launch"] = ("both FFT passes run side by side in ONE launch (k_fft_fused): fft_pass1 / fft_pass2 in `kernels` are the "
-                                          "two roles' own first-entry-to-last-exit spans inside it, not separate kernels")
             roofline["perturbed"] = bool(sum(ev.values()) > 1.03 * ms_per_step * 1e3)
             roofline["perturbed_note"] = ("hipEvent figures only: the marker packets between the kernels lengthen the "
                                           "passes; `achieved` does not use them when device-clock stamps exist")
@@ -1014,7 +1005,7 @@ class SingleGpuRun:
             stamped.append(time.perf_counter() - t0)
             k += steps
         ctx.set_profiling(2)
-        self.clock_us = {name: ctx.kernel_samples(name) for name in ("fft_pass1", "fft_pass2", "fft_fused")}
+        self.clock_us = {name: ctx.kernel_samples(name) for name in ("fft_pass1", "fft_pass2")}
         ctx.set_profiling(0)
         self.times_stamped = stamped
         self.next_step = k
@@ -1042,12 +1033,6 @@ class SingleGpuRun:
                                       "ms_per_step_with_device_clock_stamps": round(float(np.median(st)) / steps * 1e3, 4),
                                       "stamped_repetitions": len(st)}
         clk = getattr(self, "clock_us", None) or {}
-        if len(clk.get("fft_fused", ())):
-            out["one_launch_device_clock_us"] = round(float(np.median(clk["fft_fused"])), 2)
-            try:
-                out["one_launch_flow_control"] = self.eng.ctx.flow_stats()
-            except Exception:
-                pass
         if all(len(clk.get(k, ())) for k in ("fft_pass1", "fft_pass2")):
             # the two passes on the device clock, from the timed loop itself; pass 2 (IQ and fused real alike)
             # finishes the spectrum and the pyramid: those are its algorithmic bytes
@@ -1266,9 +1251,7 @@ def main():
         "path": {"algorithmic_bytes_per_frame": head["algorithmic_bytes_per_frame"], "frames_per_s": head["frames_per_s"],
                  "frac_of_hbm_peak": head["frac_of_hbm_peak"], "two_pass_model": head.get("two_pass_model"),
                  "ms_per_step_min_max": head["ms_per_step_min_max"],
-                 "instrumentation": head.get("instrumentation"), "kernels": kernels,
-                 "one_launch": ({"device_clock_us": head.get("one_launch_device_clock_us"), "flow_control_waits": head.get("one_launch_flow_control")}
-                                if head.get("one_launch_device_clock_us") else None)},
+                 "instrumentation": head.get("instrumentation"), "kernels": kernels},
         "clients256": extra.get("clients256"),
         "cfg3": extra.get("cfg3"),
         "cfg5_share": extra.get("cfg5_share"),

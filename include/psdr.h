@@ -441,11 +441,6 @@ int psdr_get_kernel_samples(psdr_ctx *ctx, const char *name, double *us_out, int
 int psdr_get_kernel_stats(psdr_ctx *ctx, int max_entries, const char **names, double *total_ms,
                           int64_t *launches, int *n_out);
 int psdr_reset_kernel_stats(psdr_ctx *ctx);
-/* one-launch transforms (both FFT passes side by side in one launch, PSDR_RING): flow-control waits since psdr_create -
- * out[0] / out[1] = how often a pass-1 work-group waited for a ring slot and for how many ticks of the 100 MHz clock in
- * total, out[2] / out[3] = the same for pass-2 work-groups waiting for a frame, out[4] = waits that timed out (their
- * batches' results are invalid; every synchronising call reports that as PSDR_ERR_HIP).  Synchronises the context. */
-int psdr_get_flow_stats(psdr_ctx *ctx, uint64_t out[5]);
 /* hipEvent-timed wall time of a region on the context's stream */
 int psdr_timer_start(psdr_ctx *ctx);
 int psdr_timer_stop_ms(psdr_ctx *ctx, double *ms_out);

@@ -101,7 +101,6 @@ SYMBOLS = [
     ("psdr_fetch_end", _i, [_vp]),
     ("psdr_fetched_waterfall", _i, [_vp, _i, C.POINTER(C.POINTER(C.c_int8)), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     ("psdr_get_kernel_samples", _i, [_vp, C.c_char_p, C.POINTER(C.c_double), _i, C.POINTER(_i)]),
-    ("psdr_get_flow_stats", _i, [_vp, C.POINTER(C.c_uint64)]),
     ("psdr_reset_kernel_stats", _i, [_vp]),
     ("psdr_timer_start", _i, [_vp]),
     ("psdr_timer_stop_ms", _i, [_vp, C.POINTER(C.c_double)]),

@@ -7,11 +7,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-# context: lifetime / Level 1 / ingest / instrumentation; pass1, pass2: the FFT pass launchers; fused: both passes in one
-# launch (IQ); forward: the frame loop,
+# context: lifetime / Level 1 / ingest / instrumentation; pass1, pass2: the FFT pass launchers; forward: the frame loop,
 # read-back, band layout, waterfall; demod: audio clients; postchain: DC blocker / AGC / int16; group: n GPUs from one
 # process over RCCL; wire: packet formats
-UNITS = ["context", "pass1", "pass2", "fused", "forward", "demod", "postchain", "group", "wire"]
+UNITS = ["context", "pass1", "pass2", "forward", "demod", "postchain", "group", "wire"]
 OUT = os.path.join(_HERE, "libpsdr_hip.so")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-fPIC"]

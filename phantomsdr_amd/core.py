@@ -263,12 +263,6 @@ class Context:
                                                C.byref(n)))
         return out[: n.value]
 
-    def flow_stats(self):
-        """one-launch transforms: dict(p1_waits, p1_wait_us, p2_waits, p2_wait_us, timeouts) since the context was created"""
-        o = (C.c_uint64 * 5)()
-        check(self.lib.psdr_get_flow_stats(self.h, o))
-        return {"p1_waits": int(o[0]), "p1_wait_us": o[1] / 100.0, "p2_waits": int(o[2]), "p2_wait_us": o[3] / 100.0, "timeouts": int(o[4])}
-
     def reset_kernel_stats(self):
         check(self.lib.psdr_reset_kernel_stats(self.h))
 

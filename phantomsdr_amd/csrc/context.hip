@@ -25,7 +25,7 @@ extern "C" const char *psdr_version(void) {
 namespace psdr {
 const char *kKernelNames[K_COUNT] = {"fft_pass1",  "fft_pass2", "untangle_real", "pyramid_tail",
                                      "demod_idft", "demod_ola", "waterfall_gather", "post_chain",
-                                     "real_seam",  "band_pack", "fft_fused"};
+                                     "real_seam",  "band_pack"};
 
 void resolve_pending(psdr_ctx *c) {
     if (c->pending.empty()) return;
@@ -70,19 +70,6 @@ void resolve_kclock(psdr_ctx *c) {
         }
         c->kclk_done[w] = end;
     }
-    // one-launch steps: the launch = first entry of either role -> last exit of either role
-    const unsigned endf = std::min(std::min(c->kclk_pos[0], c->kclk_pos[1]), psdr_ctx::KCLK_SLOTS);
-    for (unsigned i = c->kclk_fused_done; i < endf; i++) {
-        if (i >= c->kclk_fused.size() || !c->kclk_fused[i]) continue;
-        const unsigned long long b0 = h[(size_t)i * 2], e0 = h[(size_t)i * 2 + 1];
-        const unsigned long long b1 = h[((size_t)psdr_ctx::KCLK_SLOTS + i) * 2], e1 = h[((size_t)psdr_ctx::KCLK_SLOTS + i) * 2 + 1];
-        if (e0 <= b0 || e1 <= b1) continue;
-        const double us = (double)(std::max(e0, e1) - std::min(b0, b1)) * 1e3 / c->wall_clock_khz;
-        c->k_ms[K_FUSED] += us * 1e-3;
-        c->k_n[K_FUSED] += 1;
-        if (c->k_samples[K_FUSED].size() < 65536) c->k_samples[K_FUSED].push_back((float)us);
-    }
-    c->kclk_fused_done = endf;
 }
 // re-arm the whole ring: begin = ~0, end = 0 (streams drained by the caller)
 int reset_kclock(psdr_ctx *c) {
@@ -91,8 +78,6 @@ int reset_kclock(psdr_ctx *c) {
     for (size_t i = 0; i < h.size(); i += 2) h[i] = ~0ull, h[i + 1] = 0ull;
     HIPCHK(hipMemcpy(c->d_kclk, h.data(), h.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
     c->kclk_pos[0] = c->kclk_pos[1] = c->kclk_done[0] = c->kclk_done[1] = 0;
-    c->kclk_fused_done = 0;
-    c->kclk_fused.assign(psdr_ctx::KCLK_SLOTS, 0);
     return PSDR_OK;
 }
 
@@ -141,9 +126,6 @@ void free_all(psdr_ctx *c) {
     F(c->d_TA);
     F(c->d_trace);
     F(c->d_kclk);
-    F(c->d_flow);
-    F(c->d_flow_sticky);
-    if (c->h_flow_sticky) hipHostFree(c->h_flow_sticky);
     F(c->d_TB);
     F(c->d_UA);
     F(c->d_UB);
@@ -324,14 +306,6 @@ int build(psdr_ctx *c) {
             if (!rc && c->max_batch > 1) rc = seg_plan(c, 1, &sp);
             if (rc) return rc;
         }
-    }
-    if (c->ring_on) {
-        HIPCHK(hipMalloc((void **)&c->d_flow, (16 + 4 * F) * sizeof(unsigned)));
-        HIPCHK(hipMemset(c->d_flow, 0, (16 + 4 * F) * sizeof(unsigned)));
-        HIPCHK(hipMalloc((void **)&c->d_flow_sticky, 16 * sizeof(unsigned)));
-        HIPCHK(hipMemset(c->d_flow_sticky, 0, 16 * sizeof(unsigned)));
-        HIPCHK(hipHostMalloc((void **)&c->h_flow_sticky, 16 * sizeof(unsigned), hipHostMallocDefault));
-        *c->h_flow_sticky = 0;
     }
     for (int s = 0; s < 2; s++) {
         HIPCHK(hipMalloc((void **)&c->spec_pool[s], F * c->spec_stride * sizeof(cf)));
@@ -549,19 +523,6 @@ extern "C" int psdr_create(const psdr_config *cfg, psdr_ctx **out) {
         }
     }
     c->p_stride = std::max<size_t>(c->R >> c->LT, 64);
-    {   // both passes in one launch, Y a ring in the Infinity Cache (fft_pass.h: k_fft_fused)
-        const char *e = getenv("PSDR_RING");
-        c->ring_on = !is_real && c->lay.mode == 1 && c->T2 == 16 && (c->M1 == 1024 || c->M1 == 2048) && e != nullptr && atoi(e) != 0;
-        if (const char *w = getenv("PSDR_RING_FRAMES")) {
-            int v = atoi(w), p2 = 4;
-            while (p2 * 2 <= v && p2 * 2 <= 64) p2 *= 2;
-            c->ring_frames = p2;
-        }
-        if (const char *w = getenv("PSDR_RING_P1_WGS")) c->ring_n1 = (unsigned)std::max(8, atoi(w)) & ~7u;
-        if (const char *w = getenv("PSDR_RING_MIN_BATCH")) c->ring_min_batch = std::max(2 * c->ring_frames, atoi(w));
-        c->ring_min_batch = std::max(c->ring_min_batch, 4 * c->ring_frames);
-        if (c->max_batch < c->ring_min_batch) c->ring_on = false;
-    }
     if (cfg->skip_num < 1) c->cfg.skip_num = 1;
     if (cfg->waterfall_size < 0) {
         delete c;
@@ -766,13 +727,6 @@ int psdr::drain(psdr_ctx *c) {
     for (hipStream_t st : c->pc_s)
         if (st) HIPCHK(hipStreamSynchronize(st));
     if (c->fetch_stream) HIPCHK(hipStreamSynchronize(c->fetch_stream));
-    // one-launch transforms (k_fft_fused): a flow-control wait that timed out left wrong results behind - say so, once
-    if (c->h_flow_sticky && *c->h_flow_sticky != c->flow_timeouts_seen) {
-        const unsigned n = *c->h_flow_sticky - c->flow_timeouts_seen;
-        c->flow_timeouts_seen = *c->h_flow_sticky;
-        return fail(PSDR_ERR_HIP, "one-launch transform: %u flow-control wait(s) timed out (the launch's work-groups were not resident "
-                                  "together for %d ms?); the results of the batches since the last synchronisation are invalid - PSDR_RING=0 selects the two-launch form", n, 2000);
-    }
     return PSDR_OK;
 }
 
@@ -794,19 +748,6 @@ extern "C" int psdr_set_profiling(psdr_ctx *c, int mode) {
         if (rc) return rc;
     }
     c->kclock = mode == 2;
-    return PSDR_OK;
-}
-extern "C" int psdr_get_flow_stats(psdr_ctx *c, uint64_t out[5]) {
-    if (!c || !out) return fail(PSDR_ERR_INVALID, "null argument");
-    for (int i = 0; i < 5; i++) out[i] = 0;
-    if (!c->d_flow_sticky) return PSDR_OK;
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    unsigned h[16];
-    HIPCHK(hipMemcpy(h, c->d_flow_sticky, sizeof h, hipMemcpyDeviceToHost));
-    const unsigned long long *st = (const unsigned long long *)(h + 4);
-    for (int i = 0; i < 4; i++) out[i] = st[i];
-    out[4] = h[0];
     return PSDR_OK;
 }
 extern "C" int psdr_get_kernel_samples(psdr_ctx *c, const char *name, double *us_out, int cap, int *n_out) {

@@ -47,7 +47,7 @@ inline const char *psdr_tuning_env(const char *name) {
 
 namespace psdr {
 
-enum KernelId { K_PASS1, K_PASS2, K_UNTANGLE, K_TAIL, K_IDFT, K_OLA, K_WFALL, K_POST, K_SEAM, K_BAND, K_FUSED, K_COUNT };
+enum KernelId { K_PASS1, K_PASS2, K_UNTANGLE, K_TAIL, K_IDFT, K_OLA, K_WFALL, K_POST, K_SEAM, K_BAND, K_COUNT };
 extern const char *kKernelNames[K_COUNT];
 
 struct PendingEvent {
@@ -65,6 +65,7 @@ struct AudioSlot {
     uint64_t last_seq = 0;  // the demodulation batch (ctx->demod_seq) that last included this slot; 0: none yet
     int b_l = 0, b_r = 0;   // the window that batch was demodulated with (psdr_fetch_begin copies it into its FetchSet)
     double b_mid = 0;
+    uint64_t born = 0;      // psdr_client_add's serial number: a fetched set answers only for the occupant it was filled with
 };
 struct WfSlot {
     bool active = false;
@@ -138,17 +139,6 @@ struct psdr_ctx {
     bool real_fused = false;
     SpecLayout lay{};                // device layout of the spectrum (natural unless real_fused)
     int nbands = 0, band_H = 0;      // psdr_set_band_layout: band regions (SpecLayout mode 3), halo columns per band
-    // Both passes in ONE launch with Y as a ring of a few frames that stays in the Infinity Cache (fft_pass.h: FlowArgs,
-    // k_fft_fused): 2^20- and 2^21-point IQ frames, batches of ring_min_batch frames and more (smaller ones fit the cache
-    // anyway and keep the two launches).  PSDR_RING=0 switches it off, PSDR_RING_FRAMES / PSDR_RING_P1_WGS size it.
-    bool ring_on = false;
-    int ring_frames = 16, ring_min_batch = 64;
-    unsigned ring_n1 = 0;            // work-groups of the pass-1 role (0: by shape)
-    unsigned *d_flow = nullptr;      // [16 + 2 * max_batch]: abort word, then done1[], done2[] (zeroed per launch)
-    unsigned *d_flow_sticky = nullptr, *h_flow_sticky = nullptr;  // flow-control timeouts since create (device word, pinned mirror)
-    unsigned flow_timeouts_seen = 0;
-    std::vector<char> kclk_fused;    // per stamped launch: the two roles ran in one launch
-    unsigned kclk_fused_done = 0;
     int seg_len_env = 0;             // PSDR_SEG_LEN: tiles per chain segment (uniform segments, every one with a seam)
     float *d_seamP = nullptr, *d_seamC = nullptr;  // of the current result set
     float *seam_pool[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
@@ -285,13 +275,14 @@ struct psdr_ctx {
         int frames = 0;        // frames of the demodulation batch (0: none was fetched)
         uint64_t seq = 0;      // its demod_seq
         struct Win {
-            uint64_t last_seq = 0;
+            uint64_t last_seq = 0, born = 0;
             int l = 0, r = 0;
             double mid = 0;
         };
         std::vector<Win> win;      // per audio slot: the window the batch was demodulated with
         std::vector<WfSlot> wfm;   // per waterfall slot: what psdr_waterfall_batch gathered (out_off, nsent, b_*)
     } fset[2];
+    uint64_t slot_births = 0;      // psdr_client_add calls so far (AudioSlot::born)
     int fetch_fill = 0;            // the set the next psdr_fetch_begin fills
     int fetch_cur = -1;            // the set psdr_fetched_* read: completed by the last psdr_fetch_end
     hipStream_t fetch_stream = nullptr;
@@ -409,9 +400,6 @@ int launch_pass1(psdr_ctx *c, int L, int T, int sb, const Pass1Args &a, unsigned
 int launch_pass2(psdr_ctx *c, int L, int T, bool fused, const Pass2Args &a, unsigned blocks);
 int launch_pass2_band(psdr_ctx *c, const Pass2Args &a, unsigned blocks);
 int launch_pass2_real(psdr_ctx *c, const Pass2Args &a);
-// fused.hip: both passes in one launch (IQ); false from fused_supported(): this shape keeps the two launches
-bool fused_supported(const psdr_ctx *c, int sb);
-int launch_fused(psdr_ctx *c, int sb, const Pass1Args &a1, const Pass2Args &a2);
 // postchain.hip: the chain's kernels for the batch demod_impl has just enqueued; *last_user = the last stream that reads
 // the client parameter block
 int post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const int *d_slot_ci, int nact, int npaused, int nframes,

@@ -19,6 +19,7 @@ extern "C" int psdr_client_add(psdr_ctx *c, int *id_out) {
             AudioSlot &s = c->aslots[i];
             s = AudioSlot();
             s.active = true;
+            s.born = ++c->slot_births;
             // a fresh AudioClient starts from zeroed buffers (src/signal.h:42-51)
             const size_t S = c->aslots.size(), h = (size_t)c->n / 2;
             for (int b = 0; b < 2; b++) {
@@ -345,6 +346,7 @@ extern "C" int psdr_fetch_begin(psdr_ctx *c, unsigned what) {
         for (size_t i = 0; i < S; i++) {
             const AudioSlot &sl = c->aslots[i];
             fs.win[i].last_seq = sl.active ? sl.last_seq : 0;
+            fs.win[i].born = sl.born;
             fs.win[i].l = sl.b_l, fs.win[i].r = sl.b_r, fs.win[i].mid = sl.b_mid;
         }
         fs.wfm.assign(c->wslots.begin(), c->wslots.end());
@@ -432,7 +434,7 @@ extern "C" int psdr_fetched_window(psdr_ctx *c, int id, int *l, double *audio_mi
     const psdr_ctx::FetchSet *fs = nullptr;
     if ((rc = fetched_set(c, &fs))) return rc;
     if (fs->seq == 0) return fail(PSDR_ERR_STATE, "the fetched batch carries no audio (PSDR_FETCH_AUDIO / _PCM)");
-    if ((size_t)id >= fs->win.size() || fs->win[id].last_seq != fs->seq)
+    if ((size_t)id >= fs->win.size() || fs->win[id].last_seq != fs->seq || fs->win[id].born != c->aslots[id].born)
         return fail(PSDR_ERR_NO_DATA, "client %d was not part of the fetched batch", id);
     if (l) *l = fs->win[id].l;
     if (audio_mid) *audio_mid = fs->win[id].mid;
@@ -449,7 +451,8 @@ extern "C" int psdr_fetched_audio(psdr_ctx *c, int id, int frame, const float **
         if (rc) return rc;
         if ((rc = fetched_set(c, &fs))) return rc;
         if (fs->seq == 0) return fail(PSDR_ERR_STATE, "the fetched batch carries no audio (PSDR_FETCH_AUDIO / _PCM)");
-        if ((size_t)id >= fs->win.size() || fs->win[id].last_seq != fs->seq)
+        // (a slot handed to a new client since the batch was demodulated holds the previous occupant's rows: not this client's)
+        if ((size_t)id >= fs->win.size() || fs->win[id].last_seq != fs->seq || fs->win[id].born != c->aslots[id].born)
             return fail(PSDR_ERR_NO_DATA, "client %d was not part of the fetched batch", id);
     }
     if (frame < 0 || frame >= fs->frames) return fail(PSDR_ERR_INVALID, "frame %d not in the fetched batch of %d", frame, fs->frames);

@@ -76,9 +76,9 @@
 #endif
 
 // The passes fetch the NEXT tile while they work on the current one, under `if (there is a next tile)`.  The fused real
-// second pass - and the first pass's role in the one-launch form - issue those loads unconditionally (counted waits behind
-// them: see there).  For the plain first pass and the IQ second pass the same change measured -1.2 ... -1.4 % on cfg2 (same
-// box, three interleaved repetitions: the IQ second pass goes from 212 to 247 VGPRs and +1.4 %): conditional there.
+// second pass issues those loads unconditionally (counted waits behind them: see there).  For the plain first pass and
+// the IQ second pass the same change measured -1.2 ... -1.4 % on cfg2 (same box, three interleaved repetitions: the IQ
+// second pass goes from 212 to 247 VGPRs and +1.4 %): conditional there.
 
 namespace psdr {
 
@@ -343,7 +343,6 @@ struct TileQueue {
     unsigned owner;        // the thread that draws (0 unless the kernel has a loader wave)
     unsigned level;        // 0: drawing from the own XCD's queue, k: from the queue of XCD x ^ k
     unsigned vb, vgrid;    // this work-group's index among the work-groups that share the queue, and their number
-                           // (blockIdx.x / gridDim.x unless the launch is split into roles: k_fft_fused)
     bool dynamic, global, own_done;
     // global_: ONE counter for the whole chip (perfect balance, no XCD affinity)
     __device__ __forceinline__ void init(unsigned *t, unsigned total_, bool global_, unsigned owner_, unsigned vb_, unsigned vgrid_) {
@@ -424,89 +423,6 @@ struct TileQueue {
     }
 };
 
-// ---- both passes in ONE persistent launch, Y a ring of a few frames that never leaves the Infinity Cache (k_fft_fused) ----
-// A launch's work-groups are split into a pass-1 role and a pass-2 role that run SIDE BY SIDE, a few frames apart: pass 2
-// starts a tile of frame f once every pass-1 tile of f has its rows of Y in memory (done1[f] == tiles1), pass 1 overwrites
-// the ring slot of frame f - ring only after every pass-2 tile of that frame has read it (done2[f - ring] == tiles2).
-// With the two launches a batch's Y (8 MB per 2^20-point frame, 4 GB per 512 frames) goes out to HBM and
-// comes back; here a row of Y is read ~5 frames after it was written and re-written `ring` frames later, both while it is
-// still in the 256 MiB memory-side cache: per frame 16.8 MB of the 31.5 MB of HBM traffic go away (measured bound with all
-// frames aliased onto 4 / 16 frames of Y: +14 % / +5 % on cfg2's step, profiles/r05_*).
-// Visibility (cdna_hip_programming.md G16, sc1 form): Y is stored write-through (buffer_store ... sc1 - an XCD's L2 keeps no
-// dirty copy), every storing wave drains its stores with a COUNTED wait a tile later, a barrier, ONE lane adds to done1[f]
-// (relaxed, agent scope); the consumer's lane 0 polls the counter relaxed, a barrier, then sc1 loads (past the CU's L1; the
-// L2s are kept coherent for device memory by the memory-side probes).  Waits are bounded: a wait that outlasts
-// `timeout` ticks of the 100 MHz clock raises *abort, every later wait returns at once, and the host reports the launch
-// as failed instead of hanging (a work-group waits only for work that was handed out BEFORE its own tile - tiles are
-// drawn in frame order - so with the launch's work-groups resident nothing can wait in a circle).
-struct FlowArgs {
-    // done1[f] / done2[f] are FLAGS (0, or the tile count once the frame is complete): written ONCE, by the work-group whose
-    // increment of cnt1[f] / cnt2[f] was the last one; the other role samples and polls the flags only.  (First form: the
-    // other role polled the counters themselves - a word that ~100 work-groups read while 64 atomics per frame change it
-    // keeps bouncing between the XCDs' L2s, every increment waits for the probes, and an increment that takes
-    // microseconds holds up wave 0's in-order vmcnt queue: the whole launch ran 1.5 x slower than without flow control.)
-    unsigned *done1;  // [nframes] (zeroed per launch); nullptr: two launches, no flow control
-    unsigned *done2;  // [nframes]
-    unsigned *cnt1;   // [nframes] pass-1 tiles of frame f whose rows of Y are in memory (atomic increments only)
-    unsigned *cnt2;   // [nframes] pass-2 tiles of frame f that have read their rows
-    unsigned *abort;  // [1] (zeroed per launch): a wait timed out - nobody waits any longer
-    unsigned *sticky; // [1] (never zeroed): timeouts since the context was created, read by the host at its synchronisations
-    unsigned ring;    // frames of Y (a power of two; Pass*Args::ymask == ring - 1)
-    unsigned tiles1, tiles2;  // tiles per frame of the two passes
-    unsigned n1;              // work-groups of the pass-1 role (a multiple of 8; the rest are pass 2)
-    unsigned long long timeout;
-};
-typedef __attribute__((address_space(1))) unsigned flow_gu32;
-__device__ __forceinline__ unsigned flow_peek(const unsigned *p) {
-    return __hip_atomic_load((const flow_gu32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// ONE lane: until *ctr >= want (true), or the launch was aborted / the wait timed out (false)
-// role: 0 = a pass-1 work-group waiting for a ring slot, 1 = a pass-2 work-group waiting for a frame.  The waits are
-// counted (how many, how many clock ticks) behind fl.sticky: psdr_get_flow_stats.
-__device__ __forceinline__ bool flow_wait(const unsigned *ctr, unsigned want, const FlowArgs &fl, int role) {
-    typedef __attribute__((address_space(1))) unsigned long long flow_gu64;
-    flow_gu64 *st = (flow_gu64 *)(fl.sticky + 4) + 2 * role;
-    const unsigned long long t0 = wall_clock64();
-    bool ok = false;
-    for (;;) {
-        if (flow_peek(ctr) >= want) {
-            ok = true;
-            break;
-        }
-        if (flow_peek(fl.abort)) break;
-        if (wall_clock64() - t0 > fl.timeout) {
-            __hip_atomic_store((flow_gu32 *)fl.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            (void)__hip_atomic_fetch_add((flow_gu32 *)fl.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-        __builtin_amdgcn_s_sleep(40);
-    }
-    (void)__hip_atomic_fetch_add(st, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    (void)__hip_atomic_fetch_add(st + 1, wall_clock64() - t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return ok;
-}
-// ONE lane: count a tile; the increment that completes the frame raises the flag the other role looks at.  _begin / _end:
-// the same with the atomic's result used later (its round trip hides behind whatever lies in between)
-__device__ __forceinline__ unsigned flow_count_begin(unsigned *cnt) {
-    // (the address through a vector register the compiler cannot see through: with a uniform address its atomic optimiser
-    // makes this "one lane adds, v_readfirstlane broadcasts", and the broadcast wants the result at once - s_waitcnt
-    // vmcnt(0) on the spot, every tile; see TileQueue::draw_begin)
-    flow_gu32 *p = (flow_gu32 *)cnt;
-    asm volatile("" : "+v"(p));
-    return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// (called under `if (tid == 0)`: the empty asm pins the comparison - and the wait for the atomic's result in front of it -
-// inside that branch; hoisted out of it, every wave of the work-group waits, with vmcnt(0))
-__device__ __forceinline__ void flow_count_end(unsigned old, unsigned *flag, unsigned tiles) {
-    asm volatile("" : "+v"(old));
-    if (old + 1u == tiles) __hip_atomic_store((flow_gu32 *)flag, tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void flow_count(unsigned *cnt, unsigned *flag, unsigned tiles) {
-    flow_count_end(flow_count_begin(cnt), flag, tiles);
-}
-typedef unsigned ring_u32x4 __attribute__((ext_vector_type(4)));
-enum { PSDR_AUX_SC1 = 16 };  // raw_buffer_load / _store aux: sc1 (loads: past L1; stores: write-through)
-
 struct Pass1Args {
     const void *raw;  // nframes+1 raw half-frames, contiguous
     cf *Y;            // !PAIR: [nframes][pass-1 tile][M1][T]; PAIR: [nframes][pass-2 tile][pass-1 tile][row in tile][T]
@@ -530,7 +446,6 @@ struct Pass1Args {
     unsigned long long *trace;
     unsigned long long *kclk;  // device-clock stamps of this launch (kclk_begin / kclk_end) or nullptr
     unsigned ymask;            // frame index mask of Y (~0u; a timing-only experiment aliases frames: PSDR_Y_ALIAS)
-    FlowArgs flow;             // k_fft_fused (RING): flow control of the one-launch form; flow.done1 == nullptr otherwise
     float yscale;              // a power of two carried by the window weights, so that Y - and with it the second pass's
                                // outputs - arrive scaled: 1/N for IQ input, 0.5/N for the fused real path (the untangle's
                                // 1/2 with it), 1 for the three-pass real path.  Scaling by a power of two commutes with every
@@ -627,14 +542,10 @@ __device__ __forceinline__ constexpr float image_scale() {
 //   * mirror rows (c1 > M1/2) are stored as conj(Y[c1][n2]) * W_M2^{n2}: the plain forward row
 //     transform of that sequence is G[c2] = conj(Z[c1][M2-1-c2]), exactly the partner of the
 //     couple's other half at the same output index c2.
-// RING (k_fft_fused): this work-group is number vb of the vgrid work-groups of the launch that run pass 1; tiles are drawn
-// in frame order from ONE counter, Y is a ring of flow.ring frames stored write-through, and the FlowArgs counters order
-// the tiles against pass 2's (see FlowArgs)
 // CP (PAIR): (row, mirror row) couples per pass-2 tile - 8 for 1024-point rows (tiles of 16 rows), 4 for 2048-point rows
 // (tiles of 8 rows: 2^22-point real frames split 1024 x 2048)
-template <int L, int T, int SB, bool PAIR = false, bool RING = false, int CP = 8>
+template <int L, int T, int SB, bool PAIR = false, int CP = 8>
 __device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsigned vgrid) {
-    static_assert(!RING || (!PAIR && Plan<L>::NS == 3), "one-launch form: IQ first passes with three stages");
     static_assert(CP == 8 || CP == 4, "couples per pass-2 tile");
     constexpr int L2CP = CP == 8 ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -683,7 +594,7 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsi
     unsigned rq[NCHK][WPL];
     const unsigned char *nxt = nullptr;
     auto point_at = [&](unsigned sidx) {
-        const unsigned slot = RING ? sidx : xcd_slot(sidx, total);  // (RING: frame order; XCD affinity is moot with one queue)
+        const unsigned slot = xcd_slot(sidx, total);
         const unsigned f = slot / a.tiles_per_frame;
         const unsigned tl = slot - f * a.tiles_per_frame;
         nxt = reinterpret_cast<const unsigned char *>(a.raw) + ((size_t)f * (M / 2) + (size_t)tl * T) * gsb + g_lane;
@@ -710,28 +621,17 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsi
             rq[i][0] = *reinterpret_cast<const unsigned *>(q);
         }
     };
-    __shared__ unsigned s_next[4];  // [0..1]: TileQueue; RING: [2] = this tile's ring slot is not free yet (thread 0's view)
+    __shared__ unsigned s_next[4];  // [0..1]: TileQueue
     TileQueue tq;
-    tq.init(a.tickets, total, RING, 0, vb, vgrid);
+    tq.init(a.tickets, total, false, 0, vb, vgrid);
     unsigned s = vb, snext = vb + vgrid;
     if (s < total) {
         point_at(s);
         static_for<0, NCHK>(issue);
     }
-    // RING: Y through a buffer descriptor (write-through stores carry the sc1 bit in their aux field); the frame whose
-    // tile's rows are stored but not yet counted in done1; this tile's sample of the counter that frees its ring slot
-    __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)a.Y, 0, RING ? (int)(((size_t)a.flow.ring * a.yframe) * sizeof(cf)) : 0, 0x00020000);
-    constexpr unsigned NOFRAME = 0xFFFFFFFFu;
-    unsigned post_f = NOFRAME, post_f2 = NOFRAME, slot_seen = 0;  // frames of the previous tile and of the one before it
-    unsigned pub_f = NOFRAME, pub_old = 0;  // the frame whose count thread 0 incremented at tick 3, and what the atomic returned
-    (void)yrs, (void)post_f, (void)post_f2, (void)slot_seen, (void)pub_f, (void)pub_old;
     // table staging after the first tile's loads are in flight (one latency, not two)
     for (int i = tid; i < L; i += NT) Wl[i] = a.Wl[i];
     for (int i = tid; i < M2; i += NT) ldsTB[i] = a.TB[i];
-    if constexpr (RING) {
-        const unsigned f0 = (s < total ? s : 0u) / a.tiles_per_frame;
-        slot_seen = flow_peek(a.flow.done2 + (f0 >= a.flow.ring ? f0 - a.flow.ring : 0u));
-    }
     tq.draw_first();
     __syncthreads();  // Wl and the twiddle table are visible
     PSDR_WGTRACE(a.trace, 1);
@@ -750,25 +650,11 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsi
     int it = 0;
     for (; s < total; it++) {
         PSDR_TRACE(a.trace, it, 0);
-        const unsigned slot = RING ? s : xcd_slot(s, total);
+        const unsigned slot = xcd_slot(s, total);
         const unsigned f = slot / a.tiles_per_frame;
         const unsigned tl = slot - f * a.tiles_per_frame;
-        // RING: the ring slot of this frame was last read by pass 2 for frame f - ring.  slot_seen is a sample of that frame's
-        // done2 count taken at tick 3 of the PREVIOUS tile (before the loop for the first): by EVERY lane and behind the
-        // last conditional load of that tile, so that the wait the compiler puts in front of its use here is a counted one
-        // (the last stage's sixteen stores are younger).  A load under `if (tid == 0)`, or one with `if (more)` loads
-        // between it and its use, is waited for with vmcnt(0) in every wave: a drain of the next tile's loads per tile.
-        // Thread 0's view decides for the work-group (s_next[2], read behind the first stage's barriers: tick 1).  A
-        // work-group that has to wait first PUBLISHES what it still holds (drain, barrier, done1 of its last two tiles):
-        // pass 2 may be waiting for exactly those tiles' frame before it can free the slot - waiting while holding
-        // unpublished work closes a circle (first form of this kernel: a flow-control timeout with every ring <= 16).
-        if constexpr (RING) {
-            if (tid == 0) s_next[2] = (f >= a.flow.ring && slot_seen < a.flow.tiles2) ? 1u : 0u;
-        }
         // this tile's block (plain) / its chunk of pass-2 tile 0 (PAIR: pass-2 tiles have 16 rows)
         cf *Yb = a.Y + (size_t)(f & a.ymask) * a.yframe + (PAIR ? (size_t)tl * a.ytl : (size_t)tl * a.yblk);
-        const unsigned yb_bytes = (unsigned)(((size_t)(f & a.ymask) * a.yframe + (size_t)tl * a.yblk) * sizeof(cf));  // RING: inside the ring
-        (void)yb_bytes;
         // PAIR: where the lane's part of a row index puts it (see the store below)
         cf *Ylo = Yb + (size_t)(i0_ >> L2CP) * a.ytile + (i0_ & (CP - 1)) * T + 2 * p_;
         cf *Yhi = Yb - (size_t)((i0_ + CP - 1) >> L2CP) * a.ytile + (CP + ((-i0_) & (CP - 1))) * T + 2 * p_;
@@ -776,10 +662,7 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsi
         (void)Yhi;
         const bool has_next = snext < total;
         if (has_next) point_at(snext);
-        // (the loads below; nxt stays on this tile without a next one.  RING: unconditional - a work-group's last tile fetches
-        // its own rows once more - so that every wait behind them is a counted one: the drain of the write-through stores and
-        // the atomic's result below)
-        const bool more = RING ? true : has_next;
+        const bool more = has_next;  // (the loads below; nxt stays on this tile without a next one)
         // the index after `snext`: drawn one tile ago, published now, read after the barrier
         tq.draw_end(&s_next[it & 1], s);
         tq.draw_begin();
@@ -942,15 +825,7 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsi
                 } else {
                     dst = Yb + (size_t)c1 * T + 2 * p;
                 }
-                if constexpr (RING) {
-                    // write-through (sc1): the reader is a work-group of the same launch on another XCD.  (No SGPR offset:
-                    // a 128-bit buffer store with one, followed closely by inline-asm VALU that overwrites its data
-                    // registers, stores corrupted data on gfx950 - docs/history.md 3.1.)
-                    const ring_u32x4 v = {__float_as_uint(yA.x), __float_as_uint(yA.y), __float_as_uint(yB.x), __float_as_uint(yB.y)};
-                    __builtin_amdgcn_raw_buffer_store_b128(v, yrs, (int)(yb_bytes + (unsigned)((c1 * T + 2 * p) * (int)sizeof(cf))), 0, PSDR_AUX_SC1);
-                } else {
-                    *reinterpret_cast<float4 *>(dst) = make_float4(yA.x, yA.y, yB.x, yB.y);
-                }
+                *reinterpret_cast<float4 *>(dst) = make_float4(yA.x, yA.y, yB.x, yB.y);
             },
             // ---- trickle the rest of the next tile's loads through the stages
             [&](int k) {
@@ -961,56 +836,8 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsi
                         constexpr int hi = lo + LPT < NCHK ? lo + LPT : NCHK;
                         static_for<lo, hi>(issue);
                     });
-                if constexpr (RING) {
-                    if (k == 1 && s_next[2]) {  // (uniform; rare: pass 2 has fallen a whole ring behind)
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __syncthreads();
-                        if (tid == 0) {
-                            if (post_f2 != NOFRAME) flow_count(a.flow.cnt1 + post_f2, a.flow.done1 + post_f2, a.flow.tiles1);
-                            if (post_f != NOFRAME) flow_count(a.flow.cnt1 + post_f, a.flow.done1 + post_f, a.flow.tiles1);
-                            (void)flow_wait(a.flow.done2 + (f - a.flow.ring), a.flow.tiles2, a.flow, 0);
-                        }
-                        post_f = post_f2 = NOFRAME;
-                        __syncthreads();  // (the last stage's stores come behind this)
-                    }
-                    if (k == 2) {
-                        // (a) the rows of Y of the tile BEFORE THE PREVIOUS one: every wave drains ITS stores of that tile with
-                        // a counted wait - younger than them are the previous tile's NCHK loads (issued during the tile
-                        // before) and NCHK stores and, when there is a next tile, the EARLY + 3 LPT loads issued in this one;
-                        // a wave that issued more (wave 0's ticket and samples) only waits longer.  Write-through stores are
-                        // acknowledged from the memory side, later than a tile lasts: counted a tile earlier (the previous
-                        // tile's stores, a stage and a half old) every tile of the pass stalled here (first form of this
-                        // kernel: 12.4 us per tile instead of 7.8).  The stage's barrier follows, thread 0 counts at tick 3.
-                        static_assert(2 * NCHK + EARLY + 3 * LPT <= 63, "vmcnt is a 6-bit field");
-                        if (post_f2 != NOFRAME) {
-                            if (more)
-                                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCHK + EARLY + 3 * LPT) : "memory");
-                            else
-                                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCHK) : "memory");  // (the previous tile's stores may stay out)
-                        }
-                    }
-                    if (k == 3) {
-                        // (the atomic's result is looked at behind the last stage's stores: pub_old / pub_f)
-                        pub_f = post_f2;
-                        if (post_f2 != NOFRAME) {
-                            if (tid == 0) pub_old = flow_count_begin(a.flow.cnt1 + post_f2);
-                        }
-                        post_f2 = post_f;
-                        post_f = NOFRAME;
-                        // (b) the NEXT tile's ring slot is free once pass 2 has read all of the frame `ring` before its own
-                        const unsigned fn = (has_next ? snext : s) / a.tiles_per_frame;
-                        slot_seen = flow_peek(a.flow.done2 + (fn >= a.flow.ring ? fn - a.flow.ring : 0u));
-                    }
-                }
             },
             [&](int k) { PSDR_TRACE(a.trace, it, k); }, stw_front, stw_last);
-        if constexpr (RING) {
-            post_f = f;
-            if (pub_f != NOFRAME) {
-                if (tid == 0) flow_count_end(pub_old, a.flow.done1 + pub_f, a.flow.tiles1);
-                pub_f = NOFRAME;
-            }
-        }
         PSDR_TRACE(a.trace, it, 10);
         PSDR_WGTRACE(a.trace, 2 + it);
         // (published by thread 0 before the stages' barriers)
@@ -1018,20 +845,12 @@ __device__ __forceinline__ void pass1_body(const Pass1Args &a, unsigned vb, unsi
         s = snext;
         snext = s2;
     }
-    if constexpr (RING) {
-        if (post_f != NOFRAME || post_f2 != NOFRAME) {  // the work-group's last two tiles
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0 && post_f2 != NOFRAME) flow_count(a.flow.cnt1 + post_f2, a.flow.done1 + post_f2, a.flow.tiles1);
-            if (tid == 0 && post_f != NOFRAME) flow_count(a.flow.cnt1 + post_f, a.flow.done1 + post_f, a.flow.tiles1);
-        }
-    }
     PSDR_WGTRACE(a.trace, 7);
     kclk_end(a.kclk);
 }
 template <int L, int T, int SB, bool PAIR = false, int CP = 8>
 __global__ __launch_bounds__(L *T / 32) void k_fft_pass1(Pass1Args a) {
-    pass1_body<L, T, SB, PAIR, false, CP>(a, blockIdx.x, gridDim.x);
+    pass1_body<L, T, SB, PAIR, CP>(a, blockIdx.x, gridDim.x);
 }
 
 struct Pass2Args {
@@ -1060,7 +879,6 @@ struct Pass2Args {
     unsigned long long *trace;
     unsigned long long *kclk;  // device-clock stamps of this launch (kclk_begin / kclk_end) or nullptr
     unsigned ymask;            // as Pass1Args::ymask
-    FlowArgs flow;             // as Pass1Args::flow
     // BAND kernels: the spectrum goes out in band regions (SpecLayout mode 3, quantize.h): column c2 of tile tl is the
     // line ((c2 >> l2Lb) * band_stride) + (tl * Lw + (c2 & lbmask)) * 16 of the frame's slot in its band's region
     int l2Lb, lbmask, Lw;
@@ -1087,13 +905,9 @@ enum { PSDR_SEG_CARRY_MEM = 1 };  // segtab flags: the first tile's carry-in com
 // TWC: pass-1 tile width when known at compile time (all fill addresses fold), 0: a.TW
 // BAND: banded spectrum layout (band sharding without a pack pass: every band's lines of a whole batch form one
 // contiguous region, which is what is sent over the link)
-// RING (k_fft_fused): as in pass1_body - work-group vb of the vgrid that run pass 2 in a launch that runs both passes; Y is
-// read with sc1 loads (past the CU's L1: a ring slot was read here `ring` frames ago), a tile's loads wait for its
-// frame's done1 count, and done2 counts the tiles whose rows of Y have landed in registers
-template <int L, int T, bool FUSED, int TWC, bool BAND = false, bool RING = false>
+template <int L, int T, bool FUSED, int TWC, bool BAND = false>
 __device__ __forceinline__ void pass2_body(const Pass2Args &a, unsigned vb, unsigned vgrid) {
     static_assert(!BAND || (FUSED && L == 1024 && T == 16), "banded layout: the tile-major IQ spectrum only");
-    static_assert(!RING || FUSED, "one-launch form: the fused IQ second pass");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *tile = reinterpret_cast<float4 *>(smem);
     cf *tile_cf = reinterpret_cast<cf *>(smem);
@@ -1129,20 +943,12 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, unsigned vb, unsi
     const size_t blk = a.yblk;
     float4 r[NLD];
     const cf *nxt = nullptr;
-    unsigned nxt_b = 0;  // RING: byte offset of the next tile's first piece inside the ring
-    (void)nxt_b;
     const unsigned lane_off = (unsigned)((size_t)((2 * tid) >> lc) * blk + ((2 * tid) & (chunk - 1)));
-    __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)a.Y, 0, RING ? (int)(((size_t)a.flow.ring * a.yframe) * sizeof(cf)) : 0, 0x00020000);
-    (void)yrs;
-    auto frame_of = [&](unsigned sidx) { return xcd_slot(sidx, total) / a.tiles_per_frame; };
     auto point_at = [&](unsigned sidx) {
         const unsigned slot = xcd_slot(sidx, total);
         const unsigned f = slot / a.tiles_per_frame;
         const unsigned tl = slot - f * a.tiles_per_frame;
-        if constexpr (RING)
-            nxt_b = (unsigned)(((size_t)(f & a.ymask) * a.yframe + (size_t)(tl * T) * TW) * sizeof(cf));
-        else
-            nxt = a.Y + (size_t)(f & a.ymask) * a.yframe + (size_t)(tl * T) * TW;
+        nxt = a.Y + (size_t)(f & a.ymask) * a.yframe + (size_t)(tl * T) * TW;
     };
     // SPLIT (fused kernels): register i holds the tile's load number i ^ 8, so that the loads issued FIRST (i < 8) are
     // the upper half of the LDS tile (n2 >= L/2).  The powers the record loop reads (Pst) live in the lower half only,
@@ -1153,37 +959,16 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, unsigned vb, unsi
         constexpr int i = decltype(qc)::value;
         constexpr int ip = SPLIT ? (i ^ (NLD / 2)) : i;  // which sixteenth of the tile
         // uniform part of idx = 2*ip*NT: block (2*ip*NT)>>lc, offset (2*ip*NT)&(chunk-1)
-        constexpr int kAux = PSDR_AUX_SC1;
-        if constexpr (RING) {
-            // scalar part in the instruction's SGPR offset, the lane's part (loop-invariant) in its VGPR offset; sc1: past L1
-            const unsigned ub = nxt_b + (unsigned)(((size_t)((2 * ip * NT) >> lc) * blk + ((2 * ip * NT) & (chunk - 1))) * sizeof(cf));
-            const ring_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)(lane_off * (unsigned)sizeof(cf)), (int)ub, kAux);
-            r[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-        } else {
-            const cf *q = nxt + (size_t)((2 * ip * NT) >> lc) * blk + ((2 * ip * NT) & (chunk - 1)) + lane_off;
-            r[i] = *reinterpret_cast<const float4 *>(q);
-        }
+        const cf *q = nxt + (size_t)((2 * ip * NT) >> lc) * blk + ((2 * ip * NT) & (chunk - 1)) + lane_off;
+        r[i] = *reinterpret_cast<const float4 *>(q);
     };
-    __shared__ unsigned s_next[4];  // [0..1]: TileQueue; RING: [2] = the next tile's frame is not complete yet (thread 0's view)
+    __shared__ unsigned s_next[4];  // [0..1]: TileQueue
     TileQueue tq;
     // pass 2 has no use for XCD affinity (full-line stores, tile-major records) and the XCDs
     // differ by ~10 % in speed: one chip-wide counter (pass 1 keeps the per-XCD queues: adjacent
     // tiles share the 128-byte lines of the raw rows)
     tq.init(a.tickets, total, true, 0, vb, vgrid);
     unsigned s = vb, snext = vb + vgrid;
-    // RING: thread 0's sample of done1[frame of the tile after next], taken when that index is published and looked at a
-    // tile later, right before the tile's loads begin
-    unsigned rdy_seen = 0;
-    constexpr unsigned NOFRAME2 = 0xFFFFFFFFu;
-    unsigned cnt_f = NOFRAME2, cnt_old = 0;  // the frame whose count thread 0 incremented at the end of the previous tile; the atomic's result
-    (void)rdy_seen, (void)cnt_f, (void)cnt_old;
-    if constexpr (RING) {
-        if (s < total) {
-            if (tid == 0) (void)flow_wait(a.flow.done1 + frame_of(s), a.flow.tiles1, a.flow, 1);
-            __syncthreads();
-            rdy_seen = flow_peek(a.flow.done1 + frame_of(snext < total ? snext : s));  // (every lane: see pass 1)
-        }
-    }
     if (s < total) {
         point_at(s);
         static_for<0, NLD>(issue);
@@ -1205,12 +990,6 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, unsigned vb, unsi
         const bool has_next = snext < total;
         if (has_next) point_at(snext);
         const bool more = has_next;  // (the loads below; nxt stays on this tile without a next one)
-        // RING: the next tile's loads start behind the fill: its frame's rows of Y must be in memory by then.  Thread 0's
-        // sample (a tile old) decides for the work-group; a work-group that has to wait first COUNTS the tile it holds
-        // (done2, behind the fill) - pass 1 may need exactly that slot before it can complete the frame waited for.
-        if constexpr (RING) {
-            if (tid == 0) s_next[2] = (has_next && rdy_seen < a.flow.tiles1) ? 1u : 0u;
-        }
         // the index after `snext`: drawn one tile ago, published now, read after the barrier
         tq.draw_end(&s_next[it & 1], s);
         tq.draw_begin();
@@ -1233,40 +1012,18 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, unsigned vb, unsi
             }
         }
         PSDR_SCHED_FENCE();
-        bool late_early = false;  // RING: the next tile's first loads wait until its frame is complete (uniform)
-        if constexpr (RING) {
-            late_early = s_next[2] != 0;  // (written before the fill's barrier)
-            if (cnt_f != NOFRAME2) {      // the previous tile's count: was it the frame's last?  (the atomic is a tile old)
-                if (tid == 0) flow_count_end(cnt_old, a.flow.done2 + cnt_f, a.flow.tiles2);
-                cnt_f = NOFRAME2;
-            }
-        }
-        if (more && !late_early) static_for<0, EARLY>(issue);
+        if (more) static_for<0, EARLY>(issue);
         PSDR_SCHED_FENCE();
         PSDR_TRACE(a.trace, it, 1);
         __syncthreads();
         PSDR_TRACE(a.trace, it, 2);
-        // (RING: every thread's rows of this tile have left the ring - they are in LDS; the tile is counted at the end of
-        // the loop body, or right now if the work-group is about to wait)
         // stage-0 input comes from the tile itself: all reads, then a barrier, before any
         // in-place write
         c2 u[16];
         tile_read<L, H, true>(u, tile, i0, p);
-        if constexpr (RING) {
-            if (late_early) {  // (rare: pass 2 has caught up with pass 1)
-                if (tid == 0) {
-                    flow_count(a.flow.cnt2 + f, a.flow.done2 + f, a.flow.tiles2);  // never wait while holding an uncounted tile
-                    (void)flow_wait(a.flow.done1 + frame_of(snext), a.flow.tiles1, a.flow, 1);
-                }
-            }
-        }
         __syncthreads();
-        if (late_early && more) static_for<0, EARLY>(issue);
         PSDR_TRACE(a.trace, it, 3);
         const unsigned s2 = s_next[it & 1];
-        // RING: the tile after next is known to every thread now - every lane samples its frame's count (one word, no
-        // condition: the wait for it, a tile from here, is a counted one)
-        if constexpr (RING) rdy_seen = flow_peek(a.flow.done1 + frame_of(s2 < total ? s2 : s));
 
         cf *Xf = a.X + (size_t)f * a.spec_stride;
         cf *Xt = Xf + (size_t)tl * (L * T);  // the tile's block of a tile-major frame
@@ -1358,22 +1115,11 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, unsigned vb, unsi
             }
         }
         PSDR_TRACE(a.trace, it, 12);
-        if constexpr (RING) {
-            if (!late_early) {  // count the tile; the result is looked at behind the next tile's fill
-                if (tid == 0) cnt_old = flow_count_begin(a.flow.cnt2 + f);
-                cnt_f = f;
-            }
-        }
         if (!SPLIT) __syncthreads();  // the tile is free again (SPLIT: between the next tile's two half-fills)
         PSDR_TRACE(a.trace, it, 13);
         PSDR_WGTRACE(a.trace, 2 + it);
         s = snext;
         snext = s2;
-    }
-    if constexpr (RING) {
-        if (cnt_f != NOFRAME2) {
-            if (tid == 0) flow_count_end(cnt_old, a.flow.done2 + cnt_f, a.flow.tiles2);
-        }
     }
     PSDR_WGTRACE(a.trace, 7);
     kclk_end(a.kclk);
@@ -1382,21 +1128,6 @@ __device__ __forceinline__ void pass2_body(const Pass2Args &a, unsigned vb, unsi
 template <int L, int T, bool FUSED, int TWC, bool BAND = false>
 __global__ __launch_bounds__(L *T / 32) void k_fft_pass2(Pass2Args a) {
     pass2_body<L, T, FUSED, TWC, BAND>(a, blockIdx.x, gridDim.x);
-}
-
-// ---- both passes of an IQ transform in ONE persistent launch (see FlowArgs) ----
-// The launch's work-groups are split by their index INSIDE their XCD (work-group b runs on XCD b % 8: every XCD gets both
-// roles, so whichever part of the grid is resident first holds producers and consumers alike): of every XCD's gridDim.x / 8
-// work-groups flow.n1 / 8 run pass 1, spread evenly (Bresenham), the rest pass 2.
-template <int L1, int T1, int SB, int L2, int T2, int TWC>
-__global__ __launch_bounds__(512) void k_fft_fused(Pass1Args a1, Pass2Args a2) {
-    static_assert(L1 * T1 / 32 == 512 && L2 * T2 / 32 == 512, "512-thread work-groups in both roles");
-    const unsigned x = blockIdx.x & 7u, y = blockIdx.x >> 3, ny = gridDim.x >> 3, n1x = a1.flow.n1 >> 3;
-    const unsigned lo = (y * n1x) / ny, hi = ((y + 1) * n1x) / ny;  // pass-1 work-groups of this XCD below y, up to and including y
-    if (hi > lo)
-        pass1_body<L1, T1, SB, false, true>(a1, lo * 8u + x, n1x * 8u);
-    else
-        pass2_body<L2, T2, true, TWC, false, true>(a2, (y - lo) * 8u + x, (ny - n1x) * 8u);
 }
 
 // ---- pass 2 for REAL input, fused with the Hermitian untangle, /N, |X|^2 and pyramid levels 0..3 ----

@@ -190,45 +190,15 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
     a1.yscale = !c->is_real ? 1.0f / (float)c->N : (c->real_fused ? 0.5f / (float)c->N : 1.0f);
     // (tuning builds only: a timing-only experiment with WRONG results - all frames of a launch share a few frames of Y)
     if (const char *e = psdr_tuning_env("PSDR_Y_ALIAS")) a1.ymask = (unsigned)atoi(e) - 1u;
-    // Both passes in ONE launch, Y a ring of ring_frames frames (fft_pass.h: FlowArgs): IQ batches of ring_min_batch frames
-    // and more on the context's own stream pair; everything else - small batches, band regions, a caller's pipelined
-    // first-pass stream - keeps the two launches
-    // (not beside the post chain: its recurrence waves need the CUs the two-launch passes leave free, ctx.h persistent_grid)
-    const bool ring = c->ring_on && !c->post_on && !c->nbands && c->p1 == c->stream && nframes >= c->ring_min_batch && a1.ymask == ~0u &&
-                      fused_supported(c, sb);
-    FlowArgs fl{};
-    if (ring) {
-        const size_t F = (size_t)c->max_batch;
-        fl.abort = c->d_flow;
-        fl.done1 = c->d_flow + 16;
-        fl.done2 = c->d_flow + 16 + F;
-        fl.cnt1 = c->d_flow + 16 + 2 * F;
-        fl.cnt2 = c->d_flow + 16 + 3 * F;
-        fl.ring = (unsigned)c->ring_frames;
-        fl.tiles1 = tiles1;
-        fl.tiles2 = tiles2;
-        const unsigned grid = ((unsigned)c->num_cus) & ~7u;
-        // the roles' shares follow the two passes' costs (1000 : 1620 us per 512 frames of 2^20 points, 2500 : 3200 at 2^21)
-        const unsigned dflt = (unsigned)((c->M1 == 1024 ? 0.375 : 0.4375) * (double)(grid / 8) + 0.5) * 8u;
-        fl.n1 = std::min(std::max(c->ring_n1 ? c->ring_n1 : dflt, 8u), grid - 8u);
-        fl.timeout = (unsigned long long)(c->wall_clock_khz * 2000.0);  // 2 s
-        fl.sticky = c->d_flow_sticky;
-        a1.ymask = fl.ring - 1u;
-        a1.flow = fl;
-        HIPCHK(hipMemsetAsync(c->d_flow, 0, (16 + 4 * F) * sizeof(unsigned), c->stream));
-    }
     {
         int rc = next_tickets(c, 0, c->p1, &a1.tickets);
         if (rc) return rc;
     }
     a1.tiles_per_frame = tiles1;
     a1.total_slots = tiles1 * (unsigned)nframes;
-    int rc = PSDR_OK;
-    if (!ring) {
-        rc = launch_pass1(c, c->M1, c->T1, sb, a1, a1.total_slots, c->real_fused);
-        if (rc) return rc;
-        if (ev_raw_consumed) HIPCHK(hipEventRecord(ev_raw_consumed, c->p1));  // pass 1 is the only reader of the raw halves
-    }
+    int rc = launch_pass1(c, c->M1, c->T1, sb, a1, a1.total_slots, c->real_fused);
+    if (rc) return rc;
+    if (ev_raw_consumed) HIPCHK(hipEventRecord(ev_raw_consumed, c->p1));  // pass 1 is the only reader of the raw halves
 
     Pass2Args a2{};
     a2.Y = Y;
@@ -278,13 +248,6 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
                                    c->spec_stride, c->lay, c->nbands, nframes, c->M1 / 16, c->band_H);
                 HIPCHK(hipGetLastError());
             }
-        } else if (ring) {
-            a2.flow = fl;
-            if (c->kclock && c->kclk_pos[1] >= 1 && c->kclk_pos[1] - 1 < c->kclk_fused.size()) c->kclk_fused[c->kclk_pos[1] - 1] = 1;
-            rc = launch_fused(c, sb, a1, a2);
-            if (rc) return rc;
-            if (ev_raw_consumed) HIPCHK(hipEventRecord(ev_raw_consumed, c->stream));
-            HIPCHK(hipMemcpyAsync(c->h_flow_sticky, c->d_flow_sticky, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         } else {
             rc = run_pass2(true);
             if (rc) return rc;
@@ -387,12 +350,13 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
         t.out_stride = c->p_stride;
         ProfScope ps(c, K_TAIL, c->side);
         const dim3 grid((unsigned)(c->M2 / 64), (unsigned)nframes);
+        // (waves per work-group: they share ONE image in LDS - epilogue.h; 2 / 4 / 4: the chunk pairs of a row divide evenly)
         if (ng == 64)
-            hipLaunchKernelGGL(k_col_tail<64>, grid, dim3(64), 0, c->side, t);
+            hipLaunchKernelGGL((k_col_tail<64, 2>), grid, dim3(128), 0, c->side, t);
         else if (ng == 128)
-            hipLaunchKernelGGL(k_col_tail<128>, grid, dim3(64), 0, c->side, t);
+            hipLaunchKernelGGL((k_col_tail<128, 4>), grid, dim3(256), 0, c->side, t);
         else
-            hipLaunchKernelGGL(k_col_tail<256>, grid, dim3(64), 0, c->side, t);
+            hipLaunchKernelGGL((k_col_tail<256, 4>), grid, dim3(256), 0, c->side, t);
         HIPCHK(hipGetLastError());
         lvl += ilog2((size_t)ng);
         len = (size_t)c->M2;
