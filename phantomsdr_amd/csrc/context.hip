@@ -720,6 +720,10 @@ extern "C" int psdr_process_ring(psdr_ctx *c, uint64_t first_half, int nframes) 
 }
 
 int psdr::drain(psdr_ctx *c) {
+    {
+        int rc = enqueue_tails(c);
+        if (rc) return rc;
+    }
     if (c->ring.copy) HIPCHK(hipStreamSynchronize(c->ring.copy));
     if (c->p1 != c->stream) HIPCHK(hipStreamSynchronize(c->p1));
     HIPCHK(hipStreamSynchronize(c->stream));

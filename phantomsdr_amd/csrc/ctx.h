@@ -185,6 +185,10 @@ struct psdr_ctx {
     // into the other set while the side stream still consumes batch b, so the FFT stream only
     // ever waits for the consumers of batch b-1.  d_spec/d_q/d_qt/d_pscr point at the set of
     // the LAST processed batch.
+    // the pyramid levels above the tile of the last transformed batch are still to be enqueued (forward.hip: enqueue_tails)
+    bool tails_pending = false;
+    const struct SegPlan *tails_plan = nullptr;
+    int tails_nframes = 0;
     int cur_set = 0;
     bool alt_sets = false;  // alternate the sets also on a caller's stream (a group's root: the peers read batch b's spectrum while b + 1 is transformed)
     cf *spec_pool[2] = {nullptr, nullptr};
@@ -393,6 +397,7 @@ int real_seg_len(const psdr_ctx *c, int nframes);
 void seg_plan_counts(const psdr_ctx *c, int nframes, unsigned *nsegs, unsigned *nseam, bool *handoff);
 int seg_plan(psdr_ctx *c, int nframes, const psdr_ctx::SegPlan **out);  // (built and uploaded on first use of a batch size)
 int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipEvent_t ev_raw_consumed = nullptr);
+int enqueue_tails(psdr_ctx *c);  // (no-op unless process_frames left them pending)
 // pass1.hip / pass2.hip (Pass1Args / Pass2Args: fft_pass.h)
 struct Pass1Args;
 struct Pass2Args;

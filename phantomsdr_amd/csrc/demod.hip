@@ -284,6 +284,10 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
         if (rc) return rc;
     }
     HIPCHK(c->client_ring.release(ring, last_user));
+    {  // the batch's pyramid tails ride behind its demodulation (forward.hip: enqueue_tails)
+        int rc = enqueue_tails(c);
+        if (rc) return rc;
+    }
     if (c->side != c->stream) {
         HIPCHK(hipEventRecord(c->ev_side_done, c->side));
         c->side_pending = true;

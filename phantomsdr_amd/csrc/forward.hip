@@ -154,8 +154,107 @@ void select_set(psdr_ctx *c, int set) {
     c->d_seamC = c->seam_pool[set][1];
 }
 
+// the pyramid levels above the tile for the batch process_frames has just transformed (see there)
+int enqueue_tails(psdr_ctx *c) {
+    if (!c->tails_pending) return PSDR_OK;
+    c->tails_pending = false;
+    const psdr_ctx::SegPlan *plan = c->tails_plan;
+    const int nframes = c->tails_nframes;
+    if (plan) {  // fused real input: the mirror octets of the first tile of every chain segment without a carry-in (epilogue.h)
+        SeamArgs sa{};
+        sa.seamP = c->d_seamP;
+        sa.seamC = c->d_seamC;
+        sa.segtab = plan->d_tab;
+        sa.segmark = c->d_segflag + (size_t)(1 + c->cur_set) * c->seg_cap;
+        sa.epoch = c->seg_epoch;
+        sa.L = c->M2;
+        sa.cp = c->T2 / 2;
+        sa.size_log2 = c->size_log2;
+        sa.Qt = c->d_qt;
+        sa.qt_stride = c->qt_stride;
+        sa.Pscr = c->d_pscr[0];
+        sa.p_stride = c->p_stride;
+        ProfScope ps(c, K_SEAM, c->side);
+        hipLaunchKernelGGL(k_real_seam, dim3(plan->handoff ? plan->nsegs : plan->nseam), dim3(256), 0, c->side, sa);
+        HIPCHK(hipGetLastError());
+    }
+    // remaining pyramid levels from the partial level in scratch
+    int lvl = c->LT;
+    size_t len = c->R >> lvl;
+    int cur = 0;
+    // tile-major sums of a fused pass 2 (rows of 1024 outputs): one thread per output row takes the
+    // levels inside a row (k_col_tail), the generic kernel the few above
+    const int ng = (int)(len >> c->log2M2);  // groups per output row
+    const bool col_tail = c->recmap.mapped && (c->M2 == 1024 || (c->M2 == 2048 && c->real_fused)) && c->recmap.l2gpt == 0 &&
+                          (ng == 64 || ng == 128 || ng == 256);
+    if (col_tail && lvl + 1 < c->levels) {
+        ColTailArgs t{};
+        t.Pin = c->d_pscr[0];
+        t.in_stride = c->p_stride;
+        t.mode = c->recmap.mapped;
+        t.L = c->M2;
+        t.l2L = c->log2M2;
+        t.lvl_in = lvl;
+        t.nlevels = c->levels;
+        t.size_log2 = c->size_log2;
+        t.Q = c->d_q;
+        t.q_stride = c->q_stride;
+        t.R = c->R;
+        t.Pout = c->d_pscr[1];
+        t.out_stride = c->p_stride;
+        ProfScope ps(c, K_TAIL, c->side);
+        const dim3 grid((unsigned)(c->M2 / 64), (unsigned)nframes);
+        // (waves per work-group: they share ONE image in LDS - epilogue.h; 2 / 4 / 4: the chunk pairs of a row divide evenly)
+        if (ng == 64)
+            hipLaunchKernelGGL((k_col_tail<64, 2>), grid, dim3(128), 0, c->side, t);
+        else if (ng == 128)
+            hipLaunchKernelGGL((k_col_tail<128, 4>), grid, dim3(256), 0, c->side, t);
+        else
+            hipLaunchKernelGGL((k_col_tail<256, 4>), grid, dim3(256), 0, c->side, t);
+        HIPCHK(hipGetLastError());
+        lvl += ilog2((size_t)ng);
+        len = (size_t)c->M2;
+        cur = 1;
+    }
+    const int lvl_mapped = col_tail ? -1 : c->LT;  // the level whose sums are still in RecMap order
+    while (lvl + 1 < c->levels && len >= 2) {
+        TailArgs t{};
+        t.Pin = c->d_pscr[cur];
+        t.in_stride = c->p_stride;
+        t.len_in = len;
+        t.lvl_in = lvl;
+        t.nlevels = c->levels;
+        t.size_log2 = c->size_log2;
+        t.Q = c->d_q;
+        t.q_stride = c->q_stride;
+        t.R = c->R;
+        t.Pout = c->d_pscr[cur ^ 1];
+        t.out_stride = c->p_stride;
+        t.map = c->recmap;
+        if (lvl != lvl_mapped) t.map.mapped = 0;  // only pass 2's own output is tile-major
+        ProfScope ps(c, K_TAIL, c->side);
+        const unsigned nb = (unsigned)((len / 2 + 255) / 256);
+        hipLaunchKernelGGL(k_pyramid_tail, dim3(nb, nframes), dim3(256), 0, c->side, t);
+        HIPCHK(hipGetLastError());
+        lvl += 7;
+        len >>= 7;
+        cur ^= 1;
+    }
+    if (c->side != c->stream) {
+        HIPCHK(hipEventRecord(c->ev_side_done, c->side));
+        c->side_pending = true;
+        HIPCHK(hipEventRecord(c->ev_set_done[c->cur_set], c->side));
+        c->set_pending[c->cur_set] = true;
+    }
+    return PSDR_OK;
+}
+
 // forward FFT + power + int8 pyramid for nframes frames (src/fft.cpp:61-98 per frame)
 int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipEvent_t ev_raw_consumed) {
+    {  // (the previous batch's tails, if nobody asked for them yet: they belong to the set that is current NOW)
+        int rc0 = enqueue_tails(c);
+        if (rc0) return rc0;
+    }
     // alternate the result set when the consumers run on their own stream
     // (banded spectrum: also on a caller's stream - the regions of batch b are read by the peers, asynchronously,
     // while batch b+1 is transformed)
@@ -306,91 +405,20 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
         HIPCHK(hipEventRecord(c->ev_fft_done, c->stream));
         HIPCHK(hipStreamWaitEvent(c->side, c->ev_fft_done, 0));
     }
-    if (plan) {  // fused real input: the mirror octets of the first tile of every chain segment without a carry-in (epilogue.h)
-        SeamArgs sa{};
-        sa.seamP = c->d_seamP;
-        sa.seamC = c->d_seamC;
-        sa.segtab = plan->d_tab;
-        sa.segmark = c->d_segflag + (size_t)(1 + c->cur_set) * c->seg_cap;
-        sa.epoch = c->seg_epoch;
-        sa.L = c->M2;
-        sa.cp = c->T2 / 2;
-        sa.size_log2 = c->size_log2;
-        sa.Qt = c->d_qt;
-        sa.qt_stride = c->qt_stride;
-        sa.Pscr = c->d_pscr[0];
-        sa.p_stride = c->p_stride;
-        ProfScope ps(c, K_SEAM, c->side);
-        hipLaunchKernelGGL(k_real_seam, dim3(plan->handoff ? plan->nsegs : plan->nseam), dim3(256), 0, c->side, sa);
-        HIPCHK(hipGetLastError());
-    }
-    // remaining pyramid levels from the partial level in scratch
-    int lvl = c->LT;
-    size_t len = c->R >> lvl;
-    int cur = 0;
-    // tile-major sums of a fused pass 2 (rows of 1024 outputs): one thread per output row takes the
-    // levels inside a row (k_col_tail), the generic kernel the few above
-    const int ng = (int)(len >> c->log2M2);  // groups per output row
-    const bool col_tail = c->recmap.mapped && (c->M2 == 1024 || (c->M2 == 2048 && c->real_fused)) && c->recmap.l2gpt == 0 &&
-                          (ng == 64 || ng == 128 || ng == 256);
-    if (col_tail && lvl + 1 < c->levels) {
-        ColTailArgs t{};
-        t.Pin = c->d_pscr[0];
-        t.in_stride = c->p_stride;
-        t.mode = c->recmap.mapped;
-        t.L = c->M2;
-        t.l2L = c->log2M2;
-        t.lvl_in = lvl;
-        t.nlevels = c->levels;
-        t.size_log2 = c->size_log2;
-        t.Q = c->d_q;
-        t.q_stride = c->q_stride;
-        t.R = c->R;
-        t.Pout = c->d_pscr[1];
-        t.out_stride = c->p_stride;
-        ProfScope ps(c, K_TAIL, c->side);
-        const dim3 grid((unsigned)(c->M2 / 64), (unsigned)nframes);
-        // (waves per work-group: they share ONE image in LDS - epilogue.h; 2 / 4 / 4: the chunk pairs of a row divide evenly)
-        if (ng == 64)
-            hipLaunchKernelGGL((k_col_tail<64, 2>), grid, dim3(128), 0, c->side, t);
-        else if (ng == 128)
-            hipLaunchKernelGGL((k_col_tail<128, 4>), grid, dim3(256), 0, c->side, t);
-        else
-            hipLaunchKernelGGL((k_col_tail<256, 4>), grid, dim3(256), 0, c->side, t);
-        HIPCHK(hipGetLastError());
-        lvl += ilog2((size_t)ng);
-        len = (size_t)c->M2;
-        cur = 1;
-    }
-    const int lvl_mapped = col_tail ? -1 : c->LT;  // the level whose sums are still in RecMap order
-    while (lvl + 1 < c->levels && len >= 2) {
-        TailArgs t{};
-        t.Pin = c->d_pscr[cur];
-        t.in_stride = c->p_stride;
-        t.len_in = len;
-        t.lvl_in = lvl;
-        t.nlevels = c->levels;
-        t.size_log2 = c->size_log2;
-        t.Q = c->d_q;
-        t.q_stride = c->q_stride;
-        t.R = c->R;
-        t.Pout = c->d_pscr[cur ^ 1];
-        t.out_stride = c->p_stride;
-        t.map = c->recmap;
-        if (lvl != lvl_mapped) t.map.mapped = 0;  // only pass 2's own output is tile-major
-        ProfScope ps(c, K_TAIL, c->side);
-        const unsigned nb = (unsigned)((len / 2 + 255) / 256);
-        hipLaunchKernelGGL(k_pyramid_tail, dim3(nb, nframes), dim3(256), 0, c->side, t);
-        HIPCHK(hipGetLastError());
-        lvl += 7;
-        len >>= 7;
-        cur ^= 1;
-    }
-    if (c->side != c->stream) {
-        HIPCHK(hipEventRecord(c->ev_side_done, c->side));
-        c->side_pending = true;
-        HIPCHK(hipEventRecord(c->ev_set_done[c->cur_set], c->side));
-        c->set_pending[c->cur_set] = true;
+    // The pyramid levels above the tile (seam, column tail, generic tail) are needed by the waterfall gather and by reads of
+    // the pyramid only; the demodulation needs the spectrum alone.  On a side stream of its own they are enqueued BEHIND
+    // the demodulation of the batch (enqueue_tails: called by psdr_demod_batch*, psdr_waterfall_batch, every drain and the
+    // next batch's transform): the demodulation then starts with the next batch's FIRST pass, beside which it runs twice
+    // as fast as beside a second pass (1.1 against 2.5 ms per 512 frames with 1024 clients on cfg3's stream,
+    // profiles/r06_side_stream_timeline.txt), and the tails take the second pass's company instead.
+    c->tails_plan = plan;
+    c->tails_nframes = nframes;
+    c->tails_pending = true;
+    bool defer = c->side != c->stream;
+    if (const char *e = psdr_tuning_env("PSDR_TAILS_FIRST")) defer = defer && atoi(e) == 0;  // (tuning build: round 5's order)
+    if (!defer) {
+        rc = enqueue_tails(c);
+        if (rc) return rc;
     }
     c->last_nframes = nframes;
     c->out_valid = c->q_valid = false;
@@ -627,6 +655,10 @@ extern "C" int psdr_waterfall_batch(psdr_ctx *c, uint64_t first_frame_num) {
     if (!c) return fail(PSDR_ERR_INVALID, "null argument");
     if (c->last_nframes < 1) return fail(PSDR_ERR_STATE, "waterfall_batch before process_batch/execute");
     HIPCHK(hipSetDevice(c->device));
+    {
+        int rc = enqueue_tails(c);  // the gather reads the levels above the tile
+        if (rc) return rc;
+    }
     std::lock_guard<std::mutex> lk(c->mtx);
     const int ring = c->wf_ring.acquire();
     if (ring < 0) return fail(PSDR_ERR_HIP, "waterfall parameter ring: event wait failed");
