@@ -140,7 +140,12 @@ def load():
             "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
             "phantomsdr_amd has no CPU fallback.")
     L = C.CDLL(_SO)
+    # PSDR_LIB_LENIENT=1 (tools only: A/B against a library of an EARLIER round through PSDR_LIB): entry points that library
+    # does not have yet are skipped instead of refusing to load
+    lenient = os.environ.get("PSDR_LIB_LENIENT") == "1"
     for name, res, args in SYMBOLS:
+        if lenient and not hasattr(L, name):
+            continue
         fn = getattr(L, name)  # AttributeError if the ABI and the header drift apart
         fn.restype = res
         fn.argtypes = args

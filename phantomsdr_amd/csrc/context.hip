@@ -162,10 +162,12 @@ void free_all(psdr_ctx *c) {
     F(c->d_bb_tail);
     F(c->d_bb_last);
     for (void *q : c->post_allocs) hipFree(q);
-    F(c->d_pwr);
-    F(c->d_audio);
+    for (int k = 0; k < 2; k++) {
+        F(c->pwr_pool[k]);
+        F(c->audio_pool[k]);
+        F(c->nan_pool[k]);
+    }
     F(c->d_real_prev);
-    F(c->d_nan);
     F(c->d_ssb_mark);
     c->client_ring.destroy();
     c->wf_ring.destroy();
@@ -182,6 +184,8 @@ void free_all(psdr_ctx *c) {
         H(fs.pcm);
         H(fs.wf);
         if (fs.done) hipEventDestroy(fs.done);
+        if (fs.ev_wf) hipEventDestroy(fs.ev_wf);
+        if (fs.ev_audio) hipEventDestroy(fs.ev_audio);
     }
     if (c->ev_fetch_src) hipEventDestroy(c->ev_fetch_src);
     if (c->fetch_stream) hipStreamDestroy(c->fetch_stream);
@@ -394,18 +398,21 @@ int build(psdr_ctx *c) {
         const size_t S = (size_t)std::max(1, g.max_clients);
         c->aslots.resize(S);
         HIPCHK(hipMalloc((void **)&c->d_ypost, S * F * n * sizeof(cf)));
-        HIPCHK(hipMalloc((void **)&c->d_pwr, S * F * sizeof(float)));
-        HIPCHK(hipMalloc((void **)&c->d_audio, S * F * (n / 2) * sizeof(float)));
-        HIPCHK(hipMalloc((void **)&c->d_nan, S * F * sizeof(int)));
+        for (int k = 0; k < 2; k++) {
+            HIPCHK(hipMalloc((void **)&c->pwr_pool[k], S * F * sizeof(float)));
+            HIPCHK(hipMalloc((void **)&c->audio_pool[k], S * F * (n / 2) * sizeof(float)));
+            HIPCHK(hipMalloc((void **)&c->nan_pool[k], S * F * sizeof(int)));
+            HIPCHK(hipMemset(c->audio_pool[k], 0, S * F * (n / 2) * sizeof(float)));
+            HIPCHK(hipMemset(c->pwr_pool[k], 0, S * F * sizeof(float)));
+            HIPCHK(hipMemset(c->nan_pool[k], 0, S * F * sizeof(int)));
+        }
+        c->d_pwr = c->pwr_pool[0], c->d_audio = c->audio_pool[0], c->d_nan = c->nan_pool[0];
         HIPCHK(hipMalloc((void **)&c->d_real_prev, 2 * S * (n / 2) * sizeof(float)));
         HIPCHK(hipMalloc((void **)&c->d_bb_tail, 2 * S * (n / 2) * sizeof(cf)));
         HIPCHK(hipMalloc((void **)&c->d_bb_last, 2 * S * sizeof(cf)));
         HIPCHK(hipMemset(c->d_real_prev, 0, 2 * S * (n / 2) * sizeof(float)));
         HIPCHK(hipMemset(c->d_bb_tail, 0, 2 * S * (n / 2) * sizeof(cf)));
         HIPCHK(hipMemset(c->d_bb_last, 0, 2 * S * sizeof(cf)));
-        HIPCHK(hipMemset(c->d_audio, 0, S * F * (n / 2) * sizeof(float)));
-        HIPCHK(hipMemset(c->d_pwr, 0, S * F * sizeof(float)));
-        HIPCHK(hipMemset(c->d_nan, 0, S * F * sizeof(int)));
         HIPCHK(hipMalloc((void **)&c->d_ssb_mark, S * sizeof(unsigned)));
         HIPCHK(hipMemset(c->d_ssb_mark, 0, S * sizeof(unsigned)));
         if (c->lds_mode == 2) HIPCHK(hipMalloc((void **)&c->d_gscratch, S * F * 2 * n * sizeof(cf)));
@@ -495,6 +502,7 @@ extern "C" int psdr_create(const psdr_config *cfg, psdr_ctx **out) {
         c->recmap.l2gpt = 0;
         c->recmap.l2rows = c->log2M2;
         c->recmap.mapped = 2;
+        c->recmap.pair = cp == 4 ? 1 : 0;  // quartets: a column's two records side by side (quantize.h)
         c->qt_stride = 2 * c->R;
         c->lay.mode = 2;
         c->lay.m1 = c->M1;
@@ -720,10 +728,6 @@ extern "C" int psdr_process_ring(psdr_ctx *c, uint64_t first_half, int nframes) 
 }
 
 int psdr::drain(psdr_ctx *c) {
-    {
-        int rc = enqueue_tails(c);
-        if (rc) return rc;
-    }
     if (c->ring.copy) HIPCHK(hipStreamSynchronize(c->ring.copy));
     if (c->p1 != c->stream) HIPCHK(hipStreamSynchronize(c->p1));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -185,7 +185,7 @@ struct psdr_ctx {
     // into the other set while the side stream still consumes batch b, so the FFT stream only
     // ever waits for the consumers of batch b-1.  d_spec/d_q/d_qt/d_pscr point at the set of
     // the LAST processed batch.
-    // the pyramid levels above the tile of the last transformed batch are still to be enqueued (forward.hip: enqueue_tails)
+    // (forward.hip: enqueue_tails - what the tail kernels of the batch just transformed need)
     bool tails_pending = false;
     const struct SegPlan *tails_plan = nullptr;
     int tails_nframes = 0;
@@ -257,8 +257,15 @@ struct psdr_ctx {
     int post_lanes = 32;   // slots per work-group of the chain's two recurrence kernels
     bool post_own = true;  // their waves allocate a whole SIMD's registers
     std::vector<void *> post_allocs;
+    // Results of the LAST demodulation batch: d_audio / d_pwr / d_nan point into one of TWO sets that alternate from batch to
+    // batch, so that the copies of batch b to the host (psdr_fetch_begin) run beside the demodulation of batch b + 1 instead
+    // of holding it up (256 clients: 96 MB per step, 1.7 ms on the link - longer than the demodulation it follows)
     float *d_pwr = nullptr, *d_audio = nullptr, *d_real_prev = nullptr;
     int *d_nan = nullptr;
+    float *audio_pool[2] = {nullptr, nullptr}, *pwr_pool[2] = {nullptr, nullptr};
+    int *nan_pool[2] = {nullptr, nullptr};
+    int32_t *pcm_pool[2] = {nullptr, nullptr};  // post chain: post.pcm points at the last batch's
+    int out_set = 0, pcm_set = 0;
     unsigned *d_ssb_mark = nullptr;  // [slots] DemodArgs::ssb_mark (demod.h): USB / LSB batches that need the frame-ordered NaN guard
     ParamRing client_ring;
     int last_demod_frames = 0;
@@ -273,7 +280,9 @@ struct psdr_ctx {
         int32_t *nan = nullptr, *pcm = nullptr;
         int8_t *wf = nullptr;
         size_t wf_cap = 0;
-        hipEvent_t done = nullptr;
+        hipEvent_t done = nullptr;       // every copy of the fetch has landed
+        hipEvent_t ev_wf = nullptr;      // ... the waterfall rows (first in the copy stream: d_wfout exists once)
+        hipEvent_t ev_audio = nullptr;   // ... pwr, NaN flags, float audio (what the demodulation of batch b + 2 overwrites)
         bool inflight = false;
         unsigned what = 0;     // PSDR_FETCH_* bits the copies covered
         int frames = 0;        // frames of the demodulation batch (0: none was fetched)
@@ -291,7 +300,8 @@ struct psdr_ctx {
     int fetch_cur = -1;            // the set psdr_fetched_* read: completed by the last psdr_fetch_end
     hipStream_t fetch_stream = nullptr;
     hipEvent_t ev_fetch_src = nullptr;
-    hipEvent_t fetch_guard = nullptr;  // `done` of the newest fetch still to be waited for by the next writers (or nullptr)
+    // what the next WRITER of a device-side result buffer waits for (stream-ordered): the newest fetch that read it
+    hipEvent_t guard_wf = nullptr, guard_audio[2] = {nullptr, nullptr}, guard_pcm[2] = {nullptr, nullptr};
 
     // waterfall clients
     std::vector<WfSlot> wslots;
@@ -386,8 +396,8 @@ inline unsigned persistent_grid(psdr_ctx *c, unsigned blocks, size_t lds) {
 
 // context.hip
 int drain(psdr_ctx *c);
-// demod.hip: the next writer of the device-side result buffers on stream `st` waits for the newest result fetch
-int fetch_guard_wait(psdr_ctx *c, hipStream_t st);
+// demod.hip: the next writer of a device-side result buffer on stream `st` waits for the fetch that read it (ev may be null)
+int fetch_guard_wait(psdr_ctx *c, hipStream_t st, hipEvent_t ev);
 void resolve_pending(psdr_ctx *c);
 void resolve_kclock(psdr_ctx *c);
 int reset_kclock(psdr_ctx *c);
@@ -397,7 +407,6 @@ int real_seg_len(const psdr_ctx *c, int nframes);
 void seg_plan_counts(const psdr_ctx *c, int nframes, unsigned *nsegs, unsigned *nseam, bool *handoff);
 int seg_plan(psdr_ctx *c, int nframes, const psdr_ctx::SegPlan **out);  // (built and uploaded on first use of a batch size)
 int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipEvent_t ev_raw_consumed = nullptr);
-int enqueue_tails(psdr_ctx *c);  // (no-op unless process_frames left them pending)
 // pass1.hip / pass2.hip (Pass1Args / Pass2Args: fft_pass.h)
 struct Pass1Args;
 struct Pass2Args;

@@ -160,9 +160,13 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
     }
     c->last_demod_frames = nframes;
     if (nact == 0) return PSDR_OK;
-    {  // d_audio / d_pwr / d_nan exist once: a result fetch in flight (psdr_fetch_begin) reads them first
-        int rc = fetch_guard_wait(c, c->side);
+    {  // this batch's results go to the OTHER set (the copies of the last batch to the host may still be reading theirs); what
+       // read this set two batches ago must have landed
+        c->out_set ^= 1;
+        c->d_audio = c->audio_pool[c->out_set], c->d_pwr = c->pwr_pool[c->out_set], c->d_nan = c->nan_pool[c->out_set];
+        int rc = fetch_guard_wait(c, c->side, c->guard_audio[c->out_set]);
         if (rc) return rc;
+        c->guard_audio[c->out_set] = nullptr;
     }
     HIPCHK(hipMemcpyAsync(d_clients, h_clients, c->post_on ? S * (sizeof(ClientParams) + sizeof(int)) : (size_t)nact * sizeof(ClientParams),
                           hipMemcpyHostToDevice, c->side));
@@ -284,10 +288,6 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
         if (rc) return rc;
     }
     HIPCHK(c->client_ring.release(ring, last_user));
-    {  // the batch's pyramid tails ride behind its demodulation (forward.hip: enqueue_tails)
-        int rc = enqueue_tails(c);
-        if (rc) return rc;
-    }
     if (c->side != c->stream) {
         HIPCHK(hipEventRecord(c->ev_side_done, c->side));
         c->side_pending = true;
@@ -316,8 +316,9 @@ static int slot_in_last_batch(psdr_ctx *c, int id) {
 // oldest fetch in flight and makes its set the one psdr_fetched_* read.  Between the two the caller enqueues the NEXT batch:
 // the copies run beside its FFT passes.  The device-side result buffers exist once: the next batch's demodulation,
 // waterfall gather and PCM output wait (in stream order, no host wait) for the newest fetch's copies.
-int psdr::fetch_guard_wait(psdr_ctx *c, hipStream_t st) {
-    if (c->fetch_guard) HIPCHK(hipStreamWaitEvent(st, c->fetch_guard, 0));
+int psdr::fetch_guard_wait(psdr_ctx *c, hipStream_t st, hipEvent_t ev) {
+    (void)c;
+    if (ev) HIPCHK(hipStreamWaitEvent(st, ev, 0));
     return PSDR_OK;
 }
 extern "C" int psdr_fetch_begin(psdr_ctx *c, unsigned what) {
@@ -339,6 +340,8 @@ extern "C" int psdr_fetch_begin(psdr_ctx *c, unsigned what) {
     if (c->fetch_cur == c->fetch_fill) c->fetch_cur = -1;  // its pointers die now
     // (each block on its own: a failed allocation leaves nothing half-initialised behind for the next call)
     if (!fs.done) HIPCHK(hipEventCreateWithFlags(&fs.done, hipEventDisableTiming));
+    if (!fs.ev_wf) HIPCHK(hipEventCreateWithFlags(&fs.ev_wf, hipEventDisableTiming));
+    if (!fs.ev_audio) HIPCHK(hipEventCreateWithFlags(&fs.ev_audio, hipEventDisableTiming));
     if (want_audio && !fs.pwr) HIPCHK(hipHostMalloc((void **)&fs.pwr, S * mb * sizeof(float), hipHostMallocDefault));
     if (want_audio && !fs.nan) HIPCHK(hipHostMalloc((void **)&fs.nan, S * mb * sizeof(int32_t), hipHostMallocDefault));
     if ((what & PSDR_FETCH_AUDIO) && !fs.audio) HIPCHK(hipHostMalloc((void **)&fs.audio, S * mb * h * sizeof(float), hipHostMallocDefault));
@@ -365,31 +368,42 @@ extern "C" int psdr_fetch_begin(psdr_ctx *c, unsigned what) {
         fs.wf_cap = wf_bytes;
     }
     hipStream_t fst = c->fetch_stream;
+    // rows [slot][0..F) of a device array [slot][max_batch][row_bytes]: ONE plain copy when the batch fills max_batch (the
+    // DMA engines' case; a pitched copy may be done by a copy kernel on the CUs the passes are using), else one strided copy
+    auto rows_d2h = [&](void *dst, const void *src, size_t row_bytes) -> hipError_t {
+        if (F == mb) return hipMemcpyAsync(dst, src, S * mb * row_bytes, hipMemcpyDeviceToHost, fst);
+        return hipMemcpy2DAsync(dst, mb * row_bytes, src, mb * row_bytes, F * row_bytes, S, hipMemcpyDeviceToHost, fst);
+    };
     // behind the demodulation and the waterfall gather of the last batch (both on `side`) ...
     HIPCHK(hipEventRecord(c->ev_fetch_src, c->side));
     HIPCHK(hipStreamWaitEvent(fst, c->ev_fetch_src, 0));
+    // the waterfall rows first (small; their device buffer exists once: the next gather waits for ev_wf alone)
+    if (wf_bytes) {
+        HIPCHK(hipMemcpyAsync(fs.wf, c->d_wfout, wf_bytes, hipMemcpyDeviceToHost, fst));
+        HIPCHK(hipEventRecord(fs.ev_wf, fst));
+        c->guard_wf = fs.ev_wf;
+    }
     // rows [slot][0..F) of the device arrays [slot][max_batch][...]: one strided copy each
     if (want_audio) {
-        HIPCHK(hipMemcpy2DAsync(fs.pwr, mb * sizeof(float), c->d_pwr, mb * sizeof(float), F * sizeof(float), S, hipMemcpyDeviceToHost, fst));
-        HIPCHK(hipMemcpy2DAsync(fs.nan, mb * sizeof(int32_t), c->d_nan, mb * sizeof(int), F * sizeof(int32_t), S, hipMemcpyDeviceToHost, fst));
+        HIPCHK(rows_d2h(fs.pwr, c->d_pwr, sizeof(float)));
+        HIPCHK(rows_d2h(fs.nan, c->d_nan, sizeof(int32_t)));
+        if (what & PSDR_FETCH_AUDIO) HIPCHK(rows_d2h(fs.audio, c->d_audio, h * sizeof(float)));
+        HIPCHK(hipEventRecord(fs.ev_audio, fst));
+        c->guard_audio[c->out_set] = fs.ev_audio;
     }
-    if (what & PSDR_FETCH_AUDIO)
-        HIPCHK(hipMemcpy2DAsync(fs.audio, mb * h * sizeof(float), c->d_audio, mb * h * sizeof(float), F * h * sizeof(float), S,
-                                hipMemcpyDeviceToHost, fst));
-    if (wf_bytes) HIPCHK(hipMemcpyAsync(fs.wf, c->d_wfout, wf_bytes, hipMemcpyDeviceToHost, fst));
     if (what & PSDR_FETCH_PCM) {
-        // ... and behind the chain's output kernel of that batch (its own stream: up to two steps after the passes)
+        // ... the PCM behind the chain's output kernel of that batch (its own stream: up to two steps after the passes) -
+        // LAST in the copy stream, so that nothing else of the fetch waits for the chain
         if (c->chain_seq > 0 && c->pc_s[0] && c->side != c->stream)
             HIPCHK(hipStreamWaitEvent(fst, c->ev_pc[3][(c->chain_seq - 1) % psdr_ctx::PC_SETS], 0));
-        HIPCHK(hipMemcpy2DAsync(fs.pcm, mb * h * sizeof(int32_t), c->post.pcm, mb * h * sizeof(int32_t), F * h * sizeof(int32_t), S,
-                                hipMemcpyDeviceToHost, fst));
+        HIPCHK(rows_d2h(fs.pcm, c->post.pcm, h * sizeof(int32_t)));
+        c->guard_pcm[c->pcm_set] = fs.done;
     }
     HIPCHK(hipEventRecord(fs.done, fst));
     fs.inflight = true;
     fs.what = what;
     fs.frames = want_audio ? (int)F : 0;
     fs.seq = want_audio ? c->demod_seq : 0;
-    c->fetch_guard = fs.done;
     c->fetch_fill ^= 1;
     return PSDR_OK;
 }
@@ -402,7 +416,12 @@ extern "C" int psdr_fetch_end(psdr_ctx *c) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventSynchronize(fs.done));
     fs.inflight = false;
-    if (c->fetch_guard == fs.done) c->fetch_guard = nullptr;  // nothing left for the next writers to wait for
+    // (everything of this fetch has landed: nothing left for a writer to wait for)
+    if (c->guard_wf == fs.ev_wf) c->guard_wf = nullptr;
+    for (int i = 0; i < 2; i++) {
+        if (c->guard_audio[i] == fs.ev_audio) c->guard_audio[i] = nullptr;
+        if (c->guard_pcm[i] == fs.done) c->guard_pcm[i] = nullptr;
+    }
     c->fetch_cur = k;
     // one-launch transforms: a flow-control timeout of the batches since the last synchronisation is reported by drain();
     // a fetch does not drain (that is its point) - psdr_synchronize still does

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void k_pyramid_tail(TailArgs a) {
 struct ColTailArgs {
     const float *Pin;  // [nframes][in_stride]
     size_t in_stride;
+    int pair;  // RecMap::pair (mode 2, quartets): group g's low / mirror sums of column c at (g*L + c)*2 + {0, 1}
     int mode;  // RecMap::mapped: 1 = IQ tiles of 16 rows (group i of row c at i*L + c),
                // 2 = fused real: low octet of tile g of column c at (2g)*L + c, its mirror octet at (2g+1)*L + c
     int L, l2L;
@@ -179,10 +180,19 @@ __global__ __launch_bounds__(64 * WV, PSDR_CT_WPE) void k_col_tail(ColTailArgs a
         for (int j = 0; j < CPW / 2; j++) {
             const int ch = wv + WV * j;
             float lo[16], hi[16];
+            if (a.pair) {  // (uniform) the two sums of a (tile, column) side by side: one 8-byte load
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                lo[i] = Pf[((size_t)(2 * (16 * ch + i)) << a.l2L) + c];
-                hi[15 - i] = Pf[((size_t)(2 * (16 * ch + i) + 1) << a.l2L) + c];
+                for (int i = 0; i < 16; i++) {
+                    const float2 lh = *reinterpret_cast<const float2 *>(Pf + ((((size_t)(16 * ch + i) << a.l2L) + c) << 1));
+                    lo[i] = lh.x;
+                    hi[15 - i] = lh.y;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    lo[i] = Pf[((size_t)(2 * (16 * ch + i)) << a.l2L) + c];
+                    hi[15 - i] = Pf[((size_t)(2 * (16 * ch + i) + 1) << a.l2L) + c];
+                }
             }
             cs[2 * j] = col_chunk16<NG>(lo, ch, cl, a, sq, soff);
             cs[2 * j + 1] = col_chunk16<NG>(hi, NC - 1 - ch, cl, a, sq, soff);
@@ -428,7 +438,7 @@ __global__ __launch_bounds__(256) void k_real_seam(SeamArgs a) {
         for (int c = threadIdx.x; c < a.L; c += blockDim.x) {
             const float4 v = reinterpret_cast<const float4 *>(P)[c];
             float pw[4] = {Cc[c], v.x, v.y, v.z};  // elements 1..3 at [0..3)
-            const size_t rp = ((size_t)g * 2 + 1) * a.L + c;
+            const size_t rp = ((size_t)g * a.L + c) * 2 + 1;  // RecMap::pair: the HIGH quartet of column c of tile g
             uint2 rec;
             pyr_record4(pw, a.size_log2, rec);
             *reinterpret_cast<uint2 *>(Qf + rp * 8) = rec;

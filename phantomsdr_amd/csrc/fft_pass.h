@@ -1614,8 +1614,8 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             if constexpr (CP == 4) {
                 // Quartets (2048-point rows, four couples per tile): group kk of the thread is side kk & 1 of column
                 // (kk >> 1) * NT + tidx; a staging row is [low quartet | elements 1..3 of the high quartet, carry-out]: one
-                // 16-byte quarter per side.  Records of 8 bytes [q0 x4 | q1 x2 | q2 | pad], levels 0..2; the level-2 sum
-                // goes to Pf for the column tail.
+                // 16-byte quarter per side.  Records of 8 bytes [q0 x4 | q1 x2 | q2 | pad], levels 0..2, the two of a column
+                // side by side; the level-2 sums go to Pf in the same order for the column tail.
                 const float4 *P4 = reinterpret_cast<const float4 *>(Pst);
 #pragma unroll
                 for (int k0 = 0; k0 < NG; k0 += GRP) {
@@ -1623,7 +1623,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                     float cin[GRP];
                     uint2 rec_prev = make_uint2(0u, 0u);
                     float pf_prev = 0.f;
-                    (void)rec_prev, (void)pf_prev;
+                    static_assert(GRP == 2, "a group = the two sides of one column");
 #pragma unroll
                     for (int j = 0; j < GRP; j++) {
                         const int kk = k0 + j, sd = kk & 1, c2i = (kk >> 1) * NT + tidx;
@@ -1644,22 +1644,19 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                         } else {
                             pw[0] = v[j].x, pw[1] = v[j].y, pw[2] = v[j].z, pw[3] = v[j].w;
                         }
-                        const size_t rp = (size_t)g * (2 * L) + (size_t)sd * L + c2i;  // RecMap mode 2
                         uint2 rec;
                         pyr_record4(pw, a.size_log2, rec);
-#ifdef PSDR_ABL_R2_REC16  // (timing-only: the two sides' quartet records of a column in ONE 16-byte store, their sums in one 8-byte store - wrong layout)
+                        // the LOW quartet's record waits for the HIGH one of the same column (the next group of this
+                        // iteration): ONE 16-byte store for the two records, one 8-byte store for their level-2 sums
+                        // (RecMap::pair: [tile][column][side])
                         if (sd) {
-                            const size_t rq = (size_t)g * (2 * L) + 2 * (size_t)c2i;
-                            *reinterpret_cast<uint4 *>(Qf + rq * 8) = make_uint4(rec.x, rec.y, rec_prev.x, rec_prev.y);
-                            *reinterpret_cast<float2 *>(Pf + rq) = make_float2(pw[0], pf_prev);
+                            const size_t rq = ((size_t)g * L + c2i) * 2;
+                            *reinterpret_cast<uint4 *>(Qf + rq * 8) = make_uint4(rec_prev.x, rec_prev.y, rec.x, rec.y);
+                            *reinterpret_cast<float2 *>(Pf + rq) = make_float2(pf_prev, pw[0]);
                         } else {
                             rec_prev = rec;
                             pf_prev = pw[0];
                         }
-#else
-                        *reinterpret_cast<uint2 *>(Qf + rp * 8) = rec;
-                        Pf[rp] = pw[0];
-#endif
                     }
                     PSDR_SCHED_FENCE();
                 }

@@ -154,9 +154,8 @@ void select_set(psdr_ctx *c, int set) {
     c->d_seamC = c->seam_pool[set][1];
 }
 
-// the pyramid levels above the tile for the batch process_frames has just transformed (see there)
-int enqueue_tails(psdr_ctx *c) {
-    if (!c->tails_pending) return PSDR_OK;
+// the pyramid levels above the tile for the batch process_frames has just transformed, on the side stream
+static int enqueue_tails(psdr_ctx *c) {
     c->tails_pending = false;
     const psdr_ctx::SegPlan *plan = c->tails_plan;
     const int nframes = c->tails_nframes;
@@ -192,6 +191,7 @@ int enqueue_tails(psdr_ctx *c) {
         t.Pin = c->d_pscr[0];
         t.in_stride = c->p_stride;
         t.mode = c->recmap.mapped;
+        t.pair = c->recmap.pair;
         t.L = c->M2;
         t.l2L = c->log2M2;
         t.lvl_in = lvl;
@@ -251,10 +251,6 @@ int enqueue_tails(psdr_ctx *c) {
 
 // forward FFT + power + int8 pyramid for nframes frames (src/fft.cpp:61-98 per frame)
 int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipEvent_t ev_raw_consumed) {
-    {  // (the previous batch's tails, if nobody asked for them yet: they belong to the set that is current NOW)
-        int rc0 = enqueue_tails(c);
-        if (rc0) return rc0;
-    }
     // alternate the result set when the consumers run on their own stream
     // (banded spectrum: also on a caller's stream - the regions of batch b are read by the peers, asynchronously,
     // while batch b+1 is transformed)
@@ -405,21 +401,16 @@ int process_frames(psdr_ctx *c, const void *d_halves, int nframes, int fmt, hipE
         HIPCHK(hipEventRecord(c->ev_fft_done, c->stream));
         HIPCHK(hipStreamWaitEvent(c->side, c->ev_fft_done, 0));
     }
-    // The pyramid levels above the tile (seam, column tail, generic tail) are needed by the waterfall gather and by reads of
-    // the pyramid only; the demodulation needs the spectrum alone.  On a side stream of its own they are enqueued BEHIND
-    // the demodulation of the batch (enqueue_tails: called by psdr_demod_batch*, psdr_waterfall_batch, every drain and the
-    // next batch's transform): the demodulation then starts with the next batch's FIRST pass, beside which it runs twice
-    // as fast as beside a second pass (1.1 against 2.5 ms per 512 frames with 1024 clients on cfg3's stream,
-    // profiles/r06_side_stream_timeline.txt), and the tails take the second pass's company instead.
+    // The pyramid levels above the tile (seam, column tail, generic tail) go FIRST on the side stream, the demodulation behind
+    // them.  Round 6 measured the other order (tails enqueued behind the batch's demodulation, which then starts beside the
+    // next batch's first pass) and a delayed start of all consumers (beside the next second pass): bench.py's cfg2 level,
+    // cfg3 level or 1 % worse, cfg5's share 1.2 % worse - where a batch's consumers run is a zero-sum choice between the
+    // two passes, what they cost is their instruction count (profiles/r06_consumer_placement.json).
     c->tails_plan = plan;
     c->tails_nframes = nframes;
     c->tails_pending = true;
-    bool defer = c->side != c->stream;
-    if (const char *e = psdr_tuning_env("PSDR_TAILS_FIRST")) defer = defer && atoi(e) == 0;  // (tuning build: round 5's order)
-    if (!defer) {
-        rc = enqueue_tails(c);
-        if (rc) return rc;
-    }
+    rc = enqueue_tails(c);
+    if (rc) return rc;
     c->last_nframes = nframes;
     c->out_valid = c->q_valid = false;
     std::fill(c->q_untiled.begin(), c->q_untiled.end(), 0);
@@ -655,10 +646,6 @@ extern "C" int psdr_waterfall_batch(psdr_ctx *c, uint64_t first_frame_num) {
     if (!c) return fail(PSDR_ERR_INVALID, "null argument");
     if (c->last_nframes < 1) return fail(PSDR_ERR_STATE, "waterfall_batch before process_batch/execute");
     HIPCHK(hipSetDevice(c->device));
-    {
-        int rc = enqueue_tails(c);  // the gather reads the levels above the tile
-        if (rc) return rc;
-    }
     std::lock_guard<std::mutex> lk(c->mtx);
     const int ring = c->wf_ring.acquire();
     if (ring < 0) return fail(PSDR_ERR_HIP, "waterfall parameter ring: event wait failed");
@@ -700,8 +687,9 @@ extern "C" int psdr_waterfall_batch(psdr_ctx *c, uint64_t first_frame_num) {
         c->wfout_cap = total;
     }
     {  // d_wfout exists once: a result fetch in flight (psdr_fetch_begin) reads it first
-        int rc = fetch_guard_wait(c, c->side);
+        int rc = fetch_guard_wait(c, c->side, c->guard_wf);
         if (rc) return rc;
+        c->guard_wf = nullptr;
     }
     HIPCHK(hipMemcpyAsync(d_wf, h_wf, (size_t)(maxid + 1) * sizeof(WfClient), hipMemcpyHostToDevice,
                           c->side));

@@ -175,6 +175,7 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
             for (void *q : c->post_allocs) hipFree(q);
             c->post_allocs.clear();
             c->post = PostArgs{};
+            c->pcm_pool[0] = c->pcm_pool[1] = nullptr;
             for (int i = 0; i < psdr_ctx::PC_SETS; i++)
                 c->post_fstart[i] = c->post_len[i] = nullptr, c->post_x[i] = c->post_m1[i] = c->post_v1[i] = c->post_p[i] = c->post_s[i] = c->post_sm[i] = nullptr;
         };
@@ -228,7 +229,8 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
                 if (!rc && !stage[i] && hipEventCreateWithFlags(&stage[i], hipEventDisableTiming) != hipSuccess)
                     rc = fail(PSDR_ERR_HIP, "post chain: event creation failed");
         }
-        if (!rc) rc = alloc((void **)&a.pcm, S * Tm * sizeof(int32_t));
+        for (int k = 0; k < 2 && !rc; k++) rc = alloc((void **)&c->pcm_pool[k], S * Tm * sizeof(int32_t));
+        a.pcm = c->pcm_pool[0];
         if (!rc) rc = alloc((void **)&a.dc_s1, S * sizeof(float));
         if (!rc) rc = alloc((void **)&a.dc_s2, S * sizeof(float));
         if (!rc) rc = alloc((void **)&a.agc_gain, S * sizeof(float));
@@ -269,8 +271,6 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
                 }
             }
         }
-        a.audio = c->d_audio;
-        a.nan_flags = c->d_nan;
         c->post_ready = true;
     }
     {
@@ -323,7 +323,12 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
     // beside a pass's work-group (128 KiB of 160)
     size_t home_lds = c->post_reserve > 0 ? 34 * 1024 : 0;
     const bool rows4 = (c->post.h & 3) == 0 && (c->post.D & 3) == 0;  // every frame starts on a row group: the lane = slot gather / output
+    // this batch's PCM goes to the other of two buffers (the copy of the last batch's to the host may still read its own)
+    c->pcm_set ^= 1;
+    c->post.pcm = c->pcm_pool[c->pcm_set];
     PostArgs pa = c->post;
+    pa.audio = c->d_audio;  // (of THIS demodulation batch: the result sets alternate)
+    pa.nan_flags = c->d_nan;
     pa.clients = d_clients;
     pa.slot_ci = d_slot_ci;
     pa.nact = nact + npaused;
@@ -434,7 +439,8 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
             else
                 hipLaunchKernelGGL((k_pc_gain<false, false>), dim3(rgroups), dim3(128), glds, sc, pa);
         }
-        if ((rc = fetch_guard_wait(c, sc))) return rc;  // the PCM buffer exists once: a result fetch in flight reads it first
+        if ((rc = fetch_guard_wait(c, sc, c->guard_pcm[c->pcm_set]))) return rc;  // what read this PCM buffer two batches ago has landed
+        c->guard_pcm[c->pcm_set] = nullptr;
         if (rows4)
             hipLaunchKernelGGL(k_pc_out4, dim3(groups, nframes), dim3(256), 0, sc, pa);
         else
