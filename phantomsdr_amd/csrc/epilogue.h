@@ -89,7 +89,6 @@ __global__ __launch_bounds__(256) void k_pyramid_tail(TailArgs a) {
 struct ColTailArgs {
     const float *Pin;  // [nframes][in_stride]
     size_t in_stride;
-    int pair;  // RecMap::pair (mode 2, quartets): group g's low / mirror sums of column c at (g*L + c)*2 + {0, 1}
     int mode;  // RecMap::mapped: 1 = IQ tiles of 16 rows (group i of row c at i*L + c),
                // 2 = fused real: low octet of tile g of column c at (2g)*L + c, its mirror octet at (2g+1)*L + c
     int L, l2L;
@@ -124,28 +123,26 @@ __device__ __forceinline__ float col_chunk16(float (&v)[16], int ch, int cl, con
     }
     return v[0];
 }
-// One work-group = 64 adjacent rows.  Stores: a row's bytes of level lvl_in + d are NG >> d <= 128 bytes, so a lane that
+// One wave = 64 adjacent rows.  Stores: a row's bytes of level lvl_in + d are NG >> d <= 128 bytes, so a lane that
 // stored its own row's pieces straight to HBM wrote 1 .. 8 bytes at a time, 32 .. 128 bytes apart (measured: 129 MB
-// written per 256 frames of cfg3 for 33 MB of output, 457 MB for 67 MB at 2^22 points).  The 64 rows of one level are
-// ONE contiguous piece of the level-major buffer: they are collected in LDS and go out as whole lines.
-// WV waves share the image (round 5: one wave per work-group).  Beside a pass's work-group a CU has ~16 KiB of LDS left:
-// two images of 8 KiB (NG = 128), ONE of 16 KiB (NG = 256) - two or one wave per CU, each with NG dependent-latency loads
-// of 256 bytes in front of its ~1500 instructions: 0.9 - 1.0 ms per 512 frames on the side stream IN FRONT OF the
-// demodulation (rocprofv3 timeline, profiles/r06_side_stream_timeline.txt), which made the side stream - not the passes -
-// the step's critical path from 256 clients on real input.  Now wave w takes the chunks (16 groups each) w, w + WV, ...
-// (fused real input: the chunk PAIRS), all waves flush the image, the chunk sums meet in LDS and wave 0 finishes the levels
-// above the chunks.
+// written per 256 frames of cfg3 for 33 MB of output, 457 MB for 67 MB at 2^22 points).  The wave's 64 rows of one
+// level are ONE contiguous piece of the level-major buffer: they are collected in LDS and go out as whole lines.
+// One wave per image.  Beside a pass's work-group a CU has ~16 KiB of LDS left - two images of 8 KiB (NG = 128), ONE of
+// 16 KiB (NG = 256) - so the kernel takes 0.9 - 1.0 ms per 512 frames of 2^21 points on the side stream.  Round 6 built the
+// form in which FOUR waves share an image (chunks dealt round robin, the chunk sums meeting in LDS): 0.45 ms
+// (profiles/r06_side_stream_timeline.txt) - and 60 % more instructions per image (every wave's offset tables, the exchange),
+// concentrated beside the first pass: bench.py's cfg3 2 % SLOWER (first pass +11 %), level with 1024 clients, where the side
+// stream is the critical path (profiles/r06_col_tail_waves.json).  What a consumer costs the step is its instruction
+// count, not its duration: taken out again.
 #ifndef PSDR_CT_WPE
 #define PSDR_CT_WPE 1
 #endif
-template <int NG, int WV>
-__global__ __launch_bounds__(64 * WV, PSDR_CT_WPE) void k_col_tail(ColTailArgs a) {
+template <int NG, bool PAIRED = false>
+__global__ __launch_bounds__(64, PSDR_CT_WPE) void k_col_tail(ColTailArgs a) {
     static_assert(NG % 32 == 0 && NG <= 256, "groups per row");
     constexpr int NC = NG / 16, LOGNG = NG == 64 ? 6 : (NG == 128 ? 7 : 8);
-    static_assert(WV >= 1 && (NC / 2) % WV == 0, "chunk pairs per wave");
-    constexpr int CPW = NC / WV;  // chunks per wave
     __shared__ __attribute__((aligned(16))) int8_t sq[64 * NG];
-    const int cl = threadIdx.x & 63, wv = threadIdx.x >> 6, c0 = blockIdx.x * 64, c = c0 + cl, f = blockIdx.y;
+    const int cl = threadIdx.x, c0 = blockIdx.x * 64, c = c0 + cl, f = blockIdx.y;
     const float *Pf = a.Pin + (size_t)f * a.in_stride;
     int8_t *Qf = a.Q + (size_t)f * a.q_stride;
     size_t qoff[12];  // byte offset of level lvl_in + d
@@ -164,23 +161,21 @@ __global__ __launch_bounds__(64 * WV, PSDR_CT_WPE) void k_col_tail(ColTailArgs a
         qoff[0] = 0;
         soff[0] = 0;
     }
-    float cs[CPW];  // sums of this wave's chunks: mode 1: chunk wv + WV j at [j]; mode 2: pair wv + WV j at [2 j] (low), [2 j + 1] (mirror)
+    float cs[NC];
     if (a.mode == 1) {
 #pragma unroll
-        for (int j = 0; j < CPW; j++) {
-            const int ch = wv + WV * j;
+        for (int ch = 0; ch < NC; ch++) {
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) v[i] = Pf[((size_t)(16 * ch + i) << a.l2L) + c];
-            cs[j] = col_chunk16<NG>(v, ch, cl, a, sq, soff);
+            cs[ch] = col_chunk16<NG>(v, ch, cl, a, sq, soff);
         }
     } else {
         // tile g's two rows of sums: the low octets (group g) and the mirror octets (group NG-1-g) of the 64 columns
 #pragma unroll
-        for (int j = 0; j < CPW / 2; j++) {
-            const int ch = wv + WV * j;
+        for (int ch = 0; ch < NC / 2; ch++) {
             float lo[16], hi[16];
-            if (a.pair) {  // (uniform) the two sums of a (tile, column) side by side: one 8-byte load
+            if constexpr (PAIRED) {  // (RecMap::pair) the two sums of a (tile, column) side by side: one 8-byte load
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     const float2 lh = *reinterpret_cast<const float2 *>(Pf + ((((size_t)(16 * ch + i) << a.l2L) + c) << 1));
@@ -194,91 +189,39 @@ __global__ __launch_bounds__(64 * WV, PSDR_CT_WPE) void k_col_tail(ColTailArgs a
                     hi[15 - i] = Pf[((size_t)(2 * (16 * ch + i) + 1) << a.l2L) + c];
                 }
             }
-            cs[2 * j] = col_chunk16<NG>(lo, ch, cl, a, sq, soff);
-            cs[2 * j + 1] = col_chunk16<NG>(hi, NC - 1 - ch, cl, a, sq, soff);
-        }
-    }
-    __syncthreads();  // the images of levels +1 .. +4 are complete
-    constexpr int DLO = LOGNG < 4 ? LOGNG : 4;
-#pragma unroll
-    for (int d = 1; d <= DLO; d++) {
-        if (a.lvl_in + d >= a.nlevels) break;
-        const int bytes = 64 * (NG >> d);  // >= 64: whole 16-byte pieces
-        int8_t *dst = Qf + qoff[d] + (size_t)c0 * (NG >> d);
-        for (int o = (int)threadIdx.x * 16; o < bytes; o += 64 * WV * 16)
-            *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(sq + soff[d] + o);
-    }
-    // the chunk sums meet in LDS (the image of levels +1 .. +4 is flushed: its memory is free once every wave has read its
-    // pieces), wave 0 takes the levels above the chunks: fs[column][chunk] floats, then their bytes behind them
-    float *fs = reinterpret_cast<float *>(sq);
-    int8_t *sq2 = sq + 64 * NC * (int)sizeof(float);
-    static_assert(64 * NC * 4 + 64 * (NG / 16) <= 64 * NG, "chunk sums + upper levels fit the image");
-    if constexpr (WV > 1) __syncthreads();
-    if constexpr (WV > 1) {
-        if (a.mode == 1) {
-#pragma unroll
-            for (int j = 0; j < CPW; j++) fs[cl * NC + wv + WV * j] = cs[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < CPW / 2; j++) {
-                fs[cl * NC + wv + WV * j] = cs[2 * j];
-                fs[cl * NC + NC - 1 - (wv + WV * j)] = cs[2 * j + 1];
-            }
-        }
-        __syncthreads();
-    }
-    if (wv != 0) return;
-    float ca[NC];
-    if constexpr (WV > 1) {
-#pragma unroll
-        for (int i = 0; i < NC; i++) ca[i] = fs[cl * NC + i];
-    } else {
-        if (a.mode == 1) {
-#pragma unroll
-            for (int i = 0; i < NC; i++) ca[i] = cs[i];
-        } else {
-#pragma unroll
-            for (int j = 0; j < NC / 2; j++) ca[j] = cs[2 * j], ca[NC - 1 - j] = cs[2 * j + 1];
+            cs[ch] = col_chunk16<NG>(lo, ch, cl, a, sq, soff);
+            cs[NC - 1 - ch] = col_chunk16<NG>(hi, NC - 1 - ch, cl, a, sq, soff);
         }
     }
     // levels +5 .. +log2(NG) over the chunk sums
-    int so2[12];
-    {
-        int so = 0;
-#pragma unroll
-        for (int d = 5; d < 12; d++) {
-            so2[d] = so;
-            so += d <= LOGNG ? 64 * (NG >> d) : 0;
-        }
-    }
 #pragma unroll
     for (int d = 5; d <= LOGNG; d++) {
         const int cnt = NG >> d;
 #pragma unroll
         for (int i = 0; i < NC / 2; i++)
-            if (i < cnt) ca[i] = __fadd_rn(ca[2 * i], ca[2 * i + 1]);
+            if (i < cnt) cs[i] = __fadd_rn(cs[2 * i], cs[2 * i + 1]);
         const int lv = a.lvl_in + d;
         if (lv < a.nlevels) {
-            int8_t *dst = sq2 + so2[d] + cl * cnt;
+            int8_t *dst = sq + soff[d] + cl * cnt;
             if (cnt >= 8)
-                store_q<8>(dst, ca, a.size_log2 - lv);
+                store_q<8>(dst, cs, a.size_log2 - lv);
             else if (cnt == 4)
-                store_q<4>(dst, ca, a.size_log2 - lv);
+                store_q<4>(dst, cs, a.size_log2 - lv);
             else if (cnt == 2)
-                store_q<2>(dst, ca, a.size_log2 - lv);
+                store_q<2>(dst, cs, a.size_log2 - lv);
             else
-                store_q<1>(dst, ca, a.size_log2 - lv);
+                store_q<1>(dst, cs, a.size_log2 - lv);
         }
     }
-    if (a.Pout) a.Pout[(size_t)f * a.out_stride + c] = ca[0];
-    __syncthreads();  // (the other waves have left: orders the LDS bytes of all lanes of this wave before the flush)
+    if (a.Pout) a.Pout[(size_t)f * a.out_stride + c] = cs[0];
+    __syncthreads();  // (one wave: orders the LDS bytes of all lanes before the flush)
 #pragma unroll
-    for (int d = 5; d <= LOGNG; d++) {
+    for (int d = 1; d <= LOGNG; d++) {
         if (a.lvl_in + d >= a.nlevels) break;
         const int bytes = 64 * (NG >> d);  // >= 64: whole 16-byte pieces
         int8_t *dst = Qf + qoff[d] + (size_t)c0 * (NG >> d);
         for (int o = cl * 16; o < bytes; o += 64 * 16)
-            *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(sq2 + so2[d] + o);
+            *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(sq + soff[d] + o);
     }
 }
 

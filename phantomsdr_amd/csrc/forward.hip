@@ -191,7 +191,6 @@ static int enqueue_tails(psdr_ctx *c) {
         t.Pin = c->d_pscr[0];
         t.in_stride = c->p_stride;
         t.mode = c->recmap.mapped;
-        t.pair = c->recmap.pair;
         t.L = c->M2;
         t.l2L = c->log2M2;
         t.lvl_in = lvl;
@@ -204,13 +203,14 @@ static int enqueue_tails(psdr_ctx *c) {
         t.out_stride = c->p_stride;
         ProfScope ps(c, K_TAIL, c->side);
         const dim3 grid((unsigned)(c->M2 / 64), (unsigned)nframes);
-        // (waves per work-group: they share ONE image in LDS - epilogue.h; 2 / 4 / 4: the chunk pairs of a row divide evenly)
         if (ng == 64)
-            hipLaunchKernelGGL((k_col_tail<64, 2>), grid, dim3(128), 0, c->side, t);
+            hipLaunchKernelGGL(k_col_tail<64>, grid, dim3(64), 0, c->side, t);
         else if (ng == 128)
-            hipLaunchKernelGGL((k_col_tail<128, 4>), grid, dim3(256), 0, c->side, t);
+            hipLaunchKernelGGL(k_col_tail<128>, grid, dim3(64), 0, c->side, t);
+        else if (c->recmap.pair)  // quartet records side by side (2048-point rows): one 8-byte load per (tile, column)
+            hipLaunchKernelGGL((k_col_tail<256, true>), grid, dim3(64), 0, c->side, t);
         else
-            hipLaunchKernelGGL((k_col_tail<256, 4>), grid, dim3(256), 0, c->side, t);
+            hipLaunchKernelGGL(k_col_tail<256>, grid, dim3(64), 0, c->side, t);
         HIPCHK(hipGetLastError());
         lvl += ilog2((size_t)ng);
         len = (size_t)c->M2;

@@ -43,6 +43,13 @@ def test_fft_passes_of_the_baseline_shapes_fit_two_waves_per_simd_without_scratc
             assert v["vgpr"] <= 256 and v["agpr"] == 0 and v["scratch"] == 0 and v["wg"] == 512, (k, v)
 
 
+def test_column_tail_fits_beside_a_pass(meta):
+    """k_col_tail runs beside the next batch's first pass: at most the 96 registers a 208-register pass work-group leaves per
+    SIMD lane (a run-time `pair` branch instead of the template parameter cost 16 registers in round 6 - and the co-residency)."""
+    for k, v in _find(meta, "psdr::k_col_tail<").items():
+        assert v["vgpr"] <= 96 and v["scratch"] == 0, (k, v)
+
+
 def test_demodulation_chain_kernels_fit_beside_a_pass(meta):
     """k_demod_chain_fixed runs in the wave slots a pass's work-group leaves on its CU (2 x 256 registers of 512 per SIMD lane
     are taken): at most 128 registers, no scratch."""
