@@ -185,10 +185,12 @@ void free_all(psdr_ctx *c) {
         H(fs.wf);
         if (fs.done) hipEventDestroy(fs.done);
         if (fs.ev_wf) hipEventDestroy(fs.ev_wf);
+        if (fs.ev_pcm) hipEventDestroy(fs.ev_pcm);
         if (fs.ev_audio) hipEventDestroy(fs.ev_audio);
     }
     if (c->ev_fetch_src) hipEventDestroy(c->ev_fetch_src);
     if (c->fetch_stream) hipStreamDestroy(c->fetch_stream);
+    if (c->fetch_stream_pcm) hipStreamDestroy(c->fetch_stream_pcm);
     for (auto &p : c->pending) {
         hipEventDestroy(p.a);
         hipEventDestroy(p.b);
@@ -735,6 +737,7 @@ int psdr::drain(psdr_ctx *c) {
     for (hipStream_t st : c->pc_s)
         if (st) HIPCHK(hipStreamSynchronize(st));
     if (c->fetch_stream) HIPCHK(hipStreamSynchronize(c->fetch_stream));
+    if (c->fetch_stream_pcm) HIPCHK(hipStreamSynchronize(c->fetch_stream_pcm));
     return PSDR_OK;
 }
 

@@ -280,7 +280,9 @@ struct psdr_ctx {
         int32_t *nan = nullptr, *pcm = nullptr;
         int8_t *wf = nullptr;
         size_t wf_cap = 0;
-        hipEvent_t done = nullptr;       // every copy of the fetch has landed
+        hipEvent_t done = nullptr;       // every copy of the fetch on the first copy stream has landed
+        hipEvent_t ev_pcm = nullptr;     // ... and the PCM (its own copy stream: it waits for the post chain, up to two steps late)
+        bool has_pcm = false;
         hipEvent_t ev_wf = nullptr;      // ... the waterfall rows (first in the copy stream: d_wfout exists once)
         hipEvent_t ev_audio = nullptr;   // ... pwr, NaN flags, float audio (what the demodulation of batch b + 2 overwrites)
         bool inflight = false;
@@ -298,7 +300,7 @@ struct psdr_ctx {
     uint64_t slot_births = 0;      // psdr_client_add calls so far (AudioSlot::born)
     int fetch_fill = 0;            // the set the next psdr_fetch_begin fills
     int fetch_cur = -1;            // the set psdr_fetched_* read: completed by the last psdr_fetch_end
-    hipStream_t fetch_stream = nullptr;
+    hipStream_t fetch_stream = nullptr, fetch_stream_pcm = nullptr;
     hipEvent_t ev_fetch_src = nullptr;
     // what the next WRITER of a device-side result buffer waits for (stream-ordered): the newest fetch that read it
     hipEvent_t guard_wf = nullptr, guard_audio[2] = {nullptr, nullptr}, guard_pcm[2] = {nullptr, nullptr};

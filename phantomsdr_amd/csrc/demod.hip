@@ -331,10 +331,12 @@ extern "C" int psdr_fetch_begin(psdr_ctx *c, unsigned what) {
     if ((what & PSDR_FETCH_PCM) && !c->post_on) return fail(PSDR_ERR_STATE, "PSDR_FETCH_PCM: post chain not enabled (psdr_set_post_chain)");
     HIPCHK(hipSetDevice(c->device));
     if (!c->fetch_stream) HIPCHK(hipStreamCreateWithFlags(&c->fetch_stream, hipStreamNonBlocking));
+    if ((what & PSDR_FETCH_PCM) && !c->fetch_stream_pcm) HIPCHK(hipStreamCreateWithFlags(&c->fetch_stream_pcm, hipStreamNonBlocking));
     if (!c->ev_fetch_src) HIPCHK(hipEventCreateWithFlags(&c->ev_fetch_src, hipEventDisableTiming));
     psdr_ctx::FetchSet &fs = c->fset[c->fetch_fill];
     if (fs.inflight) {  // both sets in flight: the older one has to land first (its results are given up: psdr_fetch_end was not called)
         HIPCHK(hipEventSynchronize(fs.done));
+        if (fs.has_pcm) HIPCHK(hipEventSynchronize(fs.ev_pcm));
         fs.inflight = false;
     }
     if (c->fetch_cur == c->fetch_fill) c->fetch_cur = -1;  // its pointers die now
@@ -342,6 +344,7 @@ extern "C" int psdr_fetch_begin(psdr_ctx *c, unsigned what) {
     if (!fs.done) HIPCHK(hipEventCreateWithFlags(&fs.done, hipEventDisableTiming));
     if (!fs.ev_wf) HIPCHK(hipEventCreateWithFlags(&fs.ev_wf, hipEventDisableTiming));
     if (!fs.ev_audio) HIPCHK(hipEventCreateWithFlags(&fs.ev_audio, hipEventDisableTiming));
+    if (!fs.ev_pcm) HIPCHK(hipEventCreateWithFlags(&fs.ev_pcm, hipEventDisableTiming));
     if (want_audio && !fs.pwr) HIPCHK(hipHostMalloc((void **)&fs.pwr, S * mb * sizeof(float), hipHostMallocDefault));
     if (want_audio && !fs.nan) HIPCHK(hipHostMalloc((void **)&fs.nan, S * mb * sizeof(int32_t), hipHostMallocDefault));
     if ((what & PSDR_FETCH_AUDIO) && !fs.audio) HIPCHK(hipHostMalloc((void **)&fs.audio, S * mb * h * sizeof(float), hipHostMallocDefault));
@@ -391,15 +394,25 @@ extern "C" int psdr_fetch_begin(psdr_ctx *c, unsigned what) {
         HIPCHK(hipEventRecord(fs.ev_audio, fst));
         c->guard_audio[c->out_set] = fs.ev_audio;
     }
-    if (what & PSDR_FETCH_PCM) {
-        // ... the PCM behind the chain's output kernel of that batch (its own stream: up to two steps after the passes) -
-        // LAST in the copy stream, so that nothing else of the fetch waits for the chain
-        if (c->chain_seq > 0 && c->pc_s[0] && c->side != c->stream)
-            HIPCHK(hipStreamWaitEvent(fst, c->ev_pc[3][(c->chain_seq - 1) % psdr_ctx::PC_SETS], 0));
-        HIPCHK(rows_d2h(fs.pcm, c->post.pcm, h * sizeof(int32_t)));
-        c->guard_pcm[c->pcm_set] = fs.done;
-    }
     HIPCHK(hipEventRecord(fs.done, fst));
+    fs.has_pcm = false;
+    if (what & PSDR_FETCH_PCM) {
+        // ... the PCM behind the chain's output kernel of that batch (up to two steps after the passes) on a copy stream of
+        // ITS OWN: on the one stream the next batch's waterfall rows and audio would queue behind a copy that waits for
+        // the chain - and the gather / demodulation that wait for THOSE copies with them (256 clients: +33 % on the step)
+        hipStream_t fsp = c->fetch_stream_pcm;
+        HIPCHK(hipStreamWaitEvent(fsp, c->ev_fetch_src, 0));
+        if (c->chain_seq > 0 && c->pc_s[0] && c->side != c->stream)
+            HIPCHK(hipStreamWaitEvent(fsp, c->ev_pc[3][(c->chain_seq - 1) % psdr_ctx::PC_SETS], 0));
+        if (F == mb)
+            HIPCHK(hipMemcpyAsync(fs.pcm, c->post.pcm, S * mb * h * sizeof(int32_t), hipMemcpyDeviceToHost, fsp));
+        else
+            HIPCHK(hipMemcpy2DAsync(fs.pcm, mb * h * sizeof(int32_t), c->post.pcm, mb * h * sizeof(int32_t), F * h * sizeof(int32_t), S,
+                                    hipMemcpyDeviceToHost, fsp));
+        HIPCHK(hipEventRecord(fs.ev_pcm, fsp));
+        c->guard_pcm[c->pcm_set] = fs.ev_pcm;
+        fs.has_pcm = true;
+    }
     fs.inflight = true;
     fs.what = what;
     fs.frames = want_audio ? (int)F : 0;
@@ -415,12 +428,13 @@ extern "C" int psdr_fetch_end(psdr_ctx *c) {
     if (!fs.inflight) return fail(PSDR_ERR_STATE, "psdr_fetch_end without a psdr_fetch_begin in flight");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventSynchronize(fs.done));
+    if (fs.has_pcm) HIPCHK(hipEventSynchronize(fs.ev_pcm));
     fs.inflight = false;
     // (everything of this fetch has landed: nothing left for a writer to wait for)
     if (c->guard_wf == fs.ev_wf) c->guard_wf = nullptr;
     for (int i = 0; i < 2; i++) {
         if (c->guard_audio[i] == fs.ev_audio) c->guard_audio[i] = nullptr;
-        if (c->guard_pcm[i] == fs.done) c->guard_pcm[i] = nullptr;
+        if (c->guard_pcm[i] == fs.ev_pcm) c->guard_pcm[i] = nullptr;
     }
     c->fetch_cur = k;
     // one-launch transforms: a flow-control timeout of the batches since the last synchronisation is reported by drain();
