@@ -457,9 +457,9 @@ def with_fetch_measure(run, eng, params, wl, F, N, nclients, plain_ms, post):
     d2h = nclients * F * (h * 4 + 8) + wf_bytes
 
     def reps(what, steps, nrep, warm=3, lag=1):
-        # lag: how many batches the host stays behind - 1 for the float audio (ready right behind the demodulation), 2 for the
-        # post chain's PCM (a batch's chain ends up to two steps after its passes: waiting for batch b - 1 right after
-        # enqueueing batch b would leave the GPU without queued work); two pinned host sets carry either
+        # lag: how many batches the host stays behind - 1 for the float audio (ready right behind the demodulation), 3 for the
+        # post chain's PCM (a batch's chain ends two to three steps after its passes: waiting for a younger batch right after
+        # enqueueing batch b would leave the GPU without queued work); the ring of PSDR_FETCH_SETS = 4 host sets carries either
         def one(n):
             inflight = 0
             for i in range(n):
@@ -503,8 +503,8 @@ def with_fetch_measure(run, eng, params, wl, F, N, nclients, plain_ms, post):
                 "copies_alone_ms": round(copy_s * 1e3, 4), "copies_alone_GB_per_s": round(d2h / copy_s / 1e9, 2)}
 
     out = {"audio_clients": nclients, "frames_per_step": F,
-           "pattern": "step(b); psdr_fetch_end(b - lag); psdr_fetch_begin(b) ... - two pinned host sets, one copy stream, the host `lag` "
-                      "batches behind (1; 2 for the post chain's PCM, which is ready up to two steps after its passes); "
+           "pattern": "step(b); psdr_fetch_end(b - lag); psdr_fetch_begin(b) ... - a ring of four pinned host sets, the host `lag` "
+                      "batches behind (1; 3 for the post chain's PCM, which is ready two to three steps after its passes, on its own copy stream); "
                       "repetitions of 50 steps between full synchronisations, median of 5"}
     try:
         what = ctx.FETCH_AUDIO | ctx.FETCH_WATERFALL
@@ -512,8 +512,8 @@ def with_fetch_measure(run, eng, params, wl, F, N, nclients, plain_ms, post):
         if post and post.get("ms_per_step"):
             ctx.set_post_chain(True)
             what = ctx.FETCH_PCM | ctx.FETCH_WATERFALL
-            out["post_chain_pcm"] = block(reps(what, 50, 5, warm=6, lag=2), post.get("ms_per_step_50_step_repetitions") or post["ms_per_step"], alone(what))
-            out["post_chain_pcm"]["host_lag_batches"] = 2
+            out["post_chain_pcm"] = block(reps(what, 50, 5, warm=6, lag=3), post.get("ms_per_step_50_step_repetitions") or post["ms_per_step"], alone(what))
+            out["post_chain_pcm"]["host_lag_batches"] = 3
             out["post_chain_pcm"]["step_without_fetch_is"] = "post_chain.ms_per_step_50_step_repetitions (the same repetition length)"
             ctx.set_post_chain(False)
     except Exception as e:

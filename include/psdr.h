@@ -224,14 +224,17 @@ int psdr_fetched_audio(psdr_ctx *ctx, int id, int frame, const float **audio, fl
  * the reference ends in host memory (src/signal.cpp:283-291 -> src/audio.cpp:26-44; src/waterfall.cpp:44-51).
  * psdr_fetch_begin enqueues the device-to-host copies of the last psdr_demod_batch* (pwr and NaN flags always; float audio
  * with PSDR_FETCH_AUDIO; the post chain's PCM with PSDR_FETCH_PCM) and of the last psdr_waterfall_batch
- * (PSDR_FETCH_WATERFALL) on a copy stream of the context, behind the kernels that produce them, into one of TWO pinned
- * host sets, and returns at once.  The caller then enqueues the next batch (psdr_process_* / psdr_demod_batch /
+ * (PSDR_FETCH_WATERFALL) on a copy stream of the context, behind the kernels that produce them, into one of
+ * PSDR_FETCH_SETS pinned host sets (a ring; a set's buffers are allocated when it is first used), and returns at once.  The caller then enqueues the next batch (psdr_process_* / psdr_demod_batch /
  * psdr_waterfall_batch): the copies run beside its FFT passes; the kernels that overwrite the device-side results wait for
  * the copies in stream order (no host wait).  psdr_fetch_end waits for the OLDEST fetch in flight; from then on
- * psdr_fetched_audio / _window / _waterfall answer from that set, until the psdr_fetch_end after the next (two sets: the
- * pointers of batch b stay valid while batch b + 1 is being copied).  A third psdr_fetch_begin without a psdr_fetch_end
- * waits for the oldest copy and gives its results up.  Frame-loop thread only.  psdr_fetch_batch = every outstanding
+ * psdr_fetched_audio / _window / _waterfall answer from that set, until the next psdr_fetch_end - its pointers stay valid
+ * until PSDR_FETCH_SETS - 1 further psdr_fetch_begin calls have been made.  How far the host stays behind is the caller's
+ * choice: one batch for the float audio; the post chain's PCM is ready up to two steps after its passes (three with
+ * hundreds of clients), so a caller that fetches it keeps two or three fetches in flight.  A psdr_fetch_begin with every
+ * set in flight waits for the oldest copy and gives its results up.  Frame-loop thread only.  psdr_fetch_batch = every outstanding
  * psdr_fetch_end + a full drain + begin(all) + end.  bench.py's `with_fetch` times this pattern. */
+#define PSDR_FETCH_SETS 4
 #define PSDR_FETCH_AUDIO 1u
 #define PSDR_FETCH_PCM 2u
 #define PSDR_FETCH_WATERFALL 4u

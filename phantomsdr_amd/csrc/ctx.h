@@ -271,7 +271,7 @@ struct psdr_ctx {
     int last_demod_frames = 0;
     uint64_t demod_seq = 0;  // number of demodulation batches so far (AudioSlot::last_seq)
     // psdr_fetch_begin / _end / psdr_fetch_batch: the served end of the path (src/signal.cpp:283-291, src/audio.cpp:26-44,
-    // src/waterfall.cpp:44-51 hand HOST buffers to the encoders).  Two pinned host sets, [slot][frame][...] each; a fetch is
+    // src/waterfall.cpp:44-51 hand HOST buffers to the encoders).  A ring of pinned host sets, [slot][frame][...] each; a fetch is
     // enqueued on `fetch_stream` behind the kernels that produce the batch's results and runs beside the next batch's passes;
     // the device buffers it reads exist once, so the next batch's WRITERS (demodulation, waterfall gather, the chain's
     // output kernel) wait for `done` of the newest fetch in stream order (fetch_guard).
@@ -296,9 +296,10 @@ struct psdr_ctx {
         };
         std::vector<Win> win;      // per audio slot: the window the batch was demodulated with
         std::vector<WfSlot> wfm;   // per waterfall slot: what psdr_waterfall_batch gathered (out_off, nsent, b_*)
-    } fset[2];
+    } fset[PSDR_FETCH_SETS];
     uint64_t slot_births = 0;      // psdr_client_add calls so far (AudioSlot::born)
-    int fetch_fill = 0;            // the set the next psdr_fetch_begin fills
+    int fetch_fill = 0;            // the set the next psdr_fetch_begin fills (a ring: the oldest in flight is fetch_fill - fetch_inflight)
+    int fetch_inflight = 0;        // fetches begun and not yet ended
     int fetch_cur = -1;            // the set psdr_fetched_* read: completed by the last psdr_fetch_end
     hipStream_t fetch_stream = nullptr, fetch_stream_pcm = nullptr;
     hipEvent_t ev_fetch_src = nullptr;

@@ -311,8 +311,8 @@ static int slot_in_last_batch(psdr_ctx *c, int id) {
 // (src/websocket.cpp:156-185 makes one pass over signal_slices per frame and every send_audio ends in host memory:
 // src/signal.cpp:283-291 -> src/audio.cpp:26-44; send_waterfall: src/waterfall.cpp:44-51.  Per-client psdr_read_audio
 // would pay a synchronisation and three copies per client and frame.)
-// psdr_fetch_begin ENQUEUES the copies of the last demodulation batch (and of the last waterfall batch) into one of two
-// pinned host sets on a copy stream, behind the kernels that produce them, and returns; psdr_fetch_end waits for the
+// psdr_fetch_begin ENQUEUES the copies of the last demodulation batch (and of the last waterfall batch) into one of a ring
+// of PSDR_FETCH_SETS pinned host sets on a copy stream, behind the kernels that produce them, and returns; psdr_fetch_end waits for the
 // oldest fetch in flight and makes its set the one psdr_fetched_* read.  Between the two the caller enqueues the NEXT batch:
 // the copies run beside its FFT passes.  The device-side result buffers exist once: the next batch's demodulation,
 // waterfall gather and PCM output wait (in stream order, no host wait) for the newest fetch's copies.
@@ -334,10 +334,11 @@ extern "C" int psdr_fetch_begin(psdr_ctx *c, unsigned what) {
     if ((what & PSDR_FETCH_PCM) && !c->fetch_stream_pcm) HIPCHK(hipStreamCreateWithFlags(&c->fetch_stream_pcm, hipStreamNonBlocking));
     if (!c->ev_fetch_src) HIPCHK(hipEventCreateWithFlags(&c->ev_fetch_src, hipEventDisableTiming));
     psdr_ctx::FetchSet &fs = c->fset[c->fetch_fill];
-    if (fs.inflight) {  // both sets in flight: the older one has to land first (its results are given up: psdr_fetch_end was not called)
+    if (fs.inflight) {  // every set in flight: the oldest one has to land first (its results are given up: psdr_fetch_end was not called)
         HIPCHK(hipEventSynchronize(fs.done));
         if (fs.has_pcm) HIPCHK(hipEventSynchronize(fs.ev_pcm));
         fs.inflight = false;
+        c->fetch_inflight--;
     }
     if (c->fetch_cur == c->fetch_fill) c->fetch_cur = -1;  // its pointers die now
     // (each block on its own: a failed allocation leaves nothing half-initialised behind for the next call)
@@ -417,19 +418,22 @@ extern "C" int psdr_fetch_begin(psdr_ctx *c, unsigned what) {
     fs.what = what;
     fs.frames = want_audio ? (int)F : 0;
     fs.seq = want_audio ? c->demod_seq : 0;
-    c->fetch_fill ^= 1;
+    c->fetch_fill = (c->fetch_fill + 1) % PSDR_FETCH_SETS;
+    c->fetch_inflight++;
     return PSDR_OK;
 }
 extern "C" int psdr_fetch_end(psdr_ctx *c) {
     if (!c) return fail(PSDR_ERR_INVALID, "null argument");
     // the oldest fetch in flight: the set that would be filled next if it is in flight, else the other one
-    int k = c->fset[c->fetch_fill].inflight ? c->fetch_fill : (c->fetch_fill ^ 1);
+    if (c->fetch_inflight <= 0) return fail(PSDR_ERR_STATE, "psdr_fetch_end without a psdr_fetch_begin in flight");
+    const int k = (c->fetch_fill - c->fetch_inflight + 2 * PSDR_FETCH_SETS) % PSDR_FETCH_SETS;
     psdr_ctx::FetchSet &fs = c->fset[k];
-    if (!fs.inflight) return fail(PSDR_ERR_STATE, "psdr_fetch_end without a psdr_fetch_begin in flight");
+    if (!fs.inflight) return fail(PSDR_ERR_STATE, "psdr_fetch_end: the fetch ring is out of step");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventSynchronize(fs.done));
     if (fs.has_pcm) HIPCHK(hipEventSynchronize(fs.ev_pcm));
     fs.inflight = false;
+    c->fetch_inflight--;
     // (everything of this fetch has landed: nothing left for a writer to wait for)
     if (c->guard_wf == fs.ev_wf) c->guard_wf = nullptr;
     for (int i = 0; i < 2; i++) {
@@ -446,7 +450,7 @@ extern "C" int psdr_fetch_batch(psdr_ctx *c) {
     if (c->n <= 0) return fail(PSDR_ERR_STATE, "context created with audio_fft_size 0");
     if (c->last_demod_frames == 0 || c->demod_seq == 0) return fail(PSDR_ERR_STATE, "no demodulated batch to fetch");
     // the synchronous form: everything there is, and the device drained (errors of the batch surface here)
-    while (c->fset[0].inflight || c->fset[1].inflight) {
+    while (c->fetch_inflight > 0) {
         int rc = psdr_fetch_end(c);
         if (rc) return rc;
     }
