@@ -97,3 +97,23 @@ def test_n_gt_1_defaults():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'main_mode = args.shard or "clients"' in src
     assert '"cpu_baseline": cpu,' in src and '"cpu_baseline": None' not in src
+
+
+def test_recorded_round6_line_carries_the_served_end_and_its_arithmetic_holds():
+    """the default line has `with_fetch` (16 clients) and `clients256.with_fetch` - the same step followed by
+    psdr_fetch_begin / _end - and what they state is consistent: bytes per step = clients x F x (n/2 x 4 + 8) + waterfall rows,
+    sustained GB/s = bytes / step, the cost ratio = the two steps' ratio (profiles/r06_bench_default.json)."""
+    import json
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r06_bench_default.json")).read().strip().splitlines()[-1])
+    F, h = d["config"]["frames_per_step"], d["config"]["audio_fft_size"] // 2
+    for blk, ncl in ((d["with_fetch"], 16), (d["clients256"]["with_fetch"], 256)):
+        assert blk.get("error") is None and blk["audio_clients"] == ncl and blk["frames_per_step"] == F
+        for key in ("float_audio", "post_chain_pcm"):
+            b = blk[key]
+            assert b["d2h_bytes_per_step"] >= ncl * F * (h * 4 + 8)                       # + the waterfall rows
+            assert b["d2h_bytes_per_step"] < ncl * F * (h * 4 + 8) + 4 * F * 1024 + 1     # (4 waterfall clients, at most 1024 bytes a row)
+            assert abs(b["d2h_GB_per_s_sustained"] - b["d2h_bytes_per_step"] / (b["ms_per_step"] * 1e-3) / 1e9) < 0.02
+            assert abs(b["over_step_without_fetch"] - b["ms_per_step"] / b["step_without_fetch_ms"]) < 2e-3
+            assert b["ms_per_step"] >= 0.995 * b["step_without_fetch_ms"]                # fetching is never cheaper than not fetching
+        # the float audio of a batch is ready right behind its demodulation: within a few per cent of the plain step
+        assert blk["float_audio"]["over_step_without_fetch"] < 1.08
