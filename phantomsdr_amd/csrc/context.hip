@@ -504,7 +504,7 @@ extern "C" int psdr_create(const psdr_config *cfg, psdr_ctx **out) {
         c->recmap.l2gpt = 0;
         c->recmap.l2rows = c->log2M2;
         c->recmap.mapped = 2;
-        c->recmap.pair = 1;  // a column's low and high record side by side (quantize.h)
+        c->recmap.pair = cp == 4 ? 1 : 0;  // quartets: a column's two records side by side (quantize.h)
         c->qt_stride = 2 * c->R;
         c->lay.mode = 2;
         c->lay.m1 = c->M1;

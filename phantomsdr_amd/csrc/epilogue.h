@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void k_real_seam(SeamArgs a) {
     for (int c = threadIdx.x; c < a.L; c += blockDim.x) {
         const float4 v0 = reinterpret_cast<const float4 *>(P)[2 * c], v1 = reinterpret_cast<const float4 *>(P)[2 * c + 1];
         float pw[8] = {Cc[c], v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z};  // elements 1..7 at [0..7)
-        const size_t rp = ((size_t)g * a.L + c) * 2 + 1;  // RecMap::pair: the HIGH octet of column c of tile g
+        const size_t rp = ((size_t)g * 2 + 1) * a.L + c;
         uint4 rec;
         pyr_record8(pw, a.size_log2, rec);
         *reinterpret_cast<uint4 *>(Qf + rp * 16) = rec;

@@ -1662,8 +1662,7 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                 }
             } else {
             // Octet kk of the thread: side = kk & 1 (known after unrolling: no per-lane selects), column c2 = (kk >> 1) * NT +
-            // tidx; a column's low and high record side by side (RecMap::pair: [tile][column][side] - a wave's two record stores
-            // of a group cover 2 KiB of adjacent records, their level-3 sums go out as ONE 8-byte store).
+            // tidx - a wave's 64 records of one side are 1 KiB of adjacent records (RecMap mode 2: [tile][side][column]).
             static_assert(L16 % 4 == 0 && NT % 16 == 0, "quarter swizzle: constant per thread");
             const float4 *P4 = reinterpret_cast<const float4 *>(Pst);
             int pbase = 4 * tidx + ((tidx >> 2) & 3);  // quarter j of the thread's row: (pbase ^ j), + 4 * NT per column group
@@ -1672,8 +1671,6 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
             for (int k0 = 0; k0 < NG; k0 += GRP) {
                 float4 v0[GRP], v1[GRP];
                 float cin[GRP];
-                float pf_low = 0.f;  // the low octet's level-3 sum waits for the high one of the same column
-                static_assert(GRP == 2, "a group = the two sides of one column");
 #pragma unroll
                 for (int j = 0; j < GRP; j++) {
                     const int kk = k0 + j, sd = kk & 1, cg = kk >> 1;
@@ -1706,14 +1703,11 @@ __global__ __launch_bounds__(L *T / 32) void k_fft_pass2_real(Pass2Args a) {
                     // high octets - k_real_seam, which runs before any consumer, writes those records again): stores the
                     // compiler can count, see the note in the lane-alternating form below.
                     {
-                        const size_t rp = (((size_t)g * L + c2i) << 1) + sd;  // RecMap mode 2, pair
+                        const size_t rp = (size_t)g * (2 * L) + (size_t)sd * L + c2i;  // RecMap mode 2
                         uint4 rec;
                         pyr_record8(pw, a.size_log2, rec);
                         *reinterpret_cast<uint4 *>(Qf + rp * 16) = rec;
-                        if (sd)
-                            *reinterpret_cast<float2 *>(Pf + rp - 1) = make_float2(pf_low, pw[0]);
-                        else
-                            pf_low = pw[0];
+                        Pf[rp] = pw[0];
                     }
                 }
                 PSDR_SCHED_FENCE();

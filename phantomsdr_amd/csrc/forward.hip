@@ -205,11 +205,9 @@ static int enqueue_tails(psdr_ctx *c) {
         const dim3 grid((unsigned)(c->M2 / 64), (unsigned)nframes);
         if (ng == 64)
             hipLaunchKernelGGL(k_col_tail<64>, grid, dim3(64), 0, c->side, t);
-        else if (ng == 128 && c->recmap.pair)  // fused real input: a (tile, column)'s two sums side by side - one 8-byte load
-            hipLaunchKernelGGL((k_col_tail<128, true>), grid, dim3(64), 0, c->side, t);
         else if (ng == 128)
             hipLaunchKernelGGL(k_col_tail<128>, grid, dim3(64), 0, c->side, t);
-        else if (c->recmap.pair)
+        else if (c->recmap.pair)  // quartet records side by side (2048-point rows): one 8-byte load per (tile, column)
             hipLaunchKernelGGL((k_col_tail<256, true>), grid, dim3(64), 0, c->side, t);
         else
             hipLaunchKernelGGL(k_col_tail<256>, grid, dim3(64), 0, c->side, t);

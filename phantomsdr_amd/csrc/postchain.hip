@@ -364,11 +364,17 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
         return PSDR_OK;
     };
     int rc = 0;
+    // (tuning build: PSDR_PC_SKIP = bit mask of chain kernels NOT launched - wrong results, a timing bound of what each costs the
+    // step: 1 gather, 2 moving averages, 4 history, 8 sub-block maxima, 16 prefix maxima, 32 w_t, 64 gain, 128 int16 output)
+    int skip = 0;
+    if (const char *e = psdr_tuning_env("PSDR_PC_SKIP")) skip = (int)strtol(e, nullptr, 0);
     {  // ---- stage 0: frame offsets, audio rows -> X
         if (seq >= NS && ((rc = wait(sg, 1, set)) || (rc = wait(sg, 3, set)))) return rc;
         ProfScope ps(c, K_POST, sg);
         hipLaunchKernelGGL(k_pc_index, dim3(nall), dim3(64), 0, sg, pa);
-        if (rows4)
+        if (skip & 1)
+            ;
+        else if (rows4)
             hipLaunchKernelGGL(k_pc_gather4, dim3(groups, nframes), dim3(256), 0, sg, pa);
         else
             hipLaunchKernelGGL(k_pc_gather, dim3(nall, nframes), dim3(256), 0, sg, pa);
@@ -380,7 +386,8 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
         if (seq >= NS && (rc = wait(sm, 3, set))) return rc;
         if (seq >= NS - 1 && (rc = wait(sm, 3, nxt))) return rc;
         ProfScope ps(c, K_POST, sm);
-        if (pa.ma_fused) {
+        if (skip & 2) {
+        } else if (pa.ma_fused) {
             if (c->post_own)
                 hipLaunchKernelGGL(k_pc_ma2<true>, dim3(rgroups), dim3(128), 0, sm, pa);
             else
@@ -401,7 +408,7 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
             hipLaunchKernelGGL((k_pc_ma<false, false>), dim3(groups), dim3(64), 0, sm, pa);
             hipLaunchKernelGGL((k_pc_ma<true, false>), dim3(groups), dim3(64), 0, sm, pa);
         }
-        hipLaunchKernelGGL(k_pc_history, dim3(nall), dim3(256), 0, sm, pa);
+        if (!(skip & 4)) hipLaunchKernelGGL(k_pc_history, dim3(nall), dim3(256), 0, sm, pa);
         HIPCHK(hipGetLastError());
         if ((rc = done(sm, 1))) return rc;
     }
@@ -411,15 +418,15 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
         if (seq >= NS && sp1 != sm && (rc = wait(sp1, 3, set))) return rc;
         {
             ProfScope ps(c, K_POST, sp1);
-            if (pa.nsub > 1) hipLaunchKernelGGL(k_pc_submax, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp1, pa);
-            hipLaunchKernelGGL(k_pc_prefix, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp1, pa);
+            if (pa.nsub > 1 && !(skip & 8)) hipLaunchKernelGGL(k_pc_submax, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp1, pa);
+            if (!(skip & 16)) hipLaunchKernelGGL(k_pc_prefix, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp1, pa);
         }
         if (split_peak) {
             if ((rc = done(sp1, 2)) || (rc = wait(sp, 2, set))) return rc;
         }
         {
             ProfScope ps(c, K_POST, sp);
-            hipLaunchKernelGGL(k_pc_want, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp, pa);
+            if (!(skip & 32)) hipLaunchKernelGGL(k_pc_want, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp, pa);
         }
         HIPCHK(hipGetLastError());
         if (!split_peak && (rc = done(sp, 2))) return rc;
@@ -428,7 +435,8 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
         if (sp != sc && (rc = wait(sc, 2, set))) return rc;
         ProfScope ps(c, K_POST, sc);
         const size_t glds = home_lds ? home_lds - 8 * 1024 : 0;
-        if (pa.attack >= pa.release) {
+        if (skip & 64) {
+        } else if (pa.attack >= pa.release) {
             if (c->post_own)
                 hipLaunchKernelGGL((k_pc_gain<true, true>), dim3(rgroups), dim3(128), 0, sc, pa);
             else
@@ -441,7 +449,9 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
         }
         if ((rc = fetch_guard_wait(c, sc, c->guard_pcm[c->pcm_set]))) return rc;  // what read this PCM buffer two batches ago has landed
         c->guard_pcm[c->pcm_set] = nullptr;
-        if (rows4)
+        if (skip & 128)
+            ;
+        else if (rows4)
             hipLaunchKernelGGL(k_pc_out4, dim3(groups, nframes), dim3(256), 0, sc, pa);
         else
             hipLaunchKernelGGL(k_pc_out, dim3(nall, nframes), dim3(256), 0, sc, pa);

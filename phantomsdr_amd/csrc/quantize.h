@@ -171,10 +171,9 @@ __device__ __forceinline__ void pyr_levels(float (&p)[CH], int8_t *Qf, size_t qo
 // (tpr = M1/CH groups per output row, gpt = T/CH groups per tile and row, rows = M2).
 struct RecMap {
     int l2tpr, l2gpt, l2rows;
-    int pair;    // mode 2: a column's LOW and HIGH records are adjacent, pos = ((g * rows) + c2) * 2 + side.  Quartets (2048-point
-                 // rows): one 16-byte store writes both (round 5: [tile][side][column], 8-byte record stores and 4-byte sum
-                 // stores: +48 % store instructions against the IQ pass).  Octets: the two 16-byte stores are neighbours and the
-                 // level-3 sums one 8-byte store.
+    int pair;    // mode 2, quartets (2048-point rows): a column's LOW and HIGH quartet records are adjacent,
+                 // pos = ((g * rows) + c2) * 2 + side - one 16-byte store writes both (round 5: [tile][side][column] like the
+                 // octets, 8-byte record stores and 4-byte sum stores: +48 % store instructions against the IQ pass)
     int mapped;  // 0: identity (level-major producers: the three-pass real-input path)
                  // 1: IQ tile-major (above)
                  // 2: fused real-input pass 2 (k_fft_pass2_real): octet (or quartet: CH = the couples of a tile) o = k / CH
