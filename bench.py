@@ -420,6 +420,8 @@ def post_chain_measure(run, eng, params, wl, F, N, nclients, plain_ms):
     try:
         # (this process creates several contexts: the chain's streams by measurement - psdr.h PSDR_OPT_POST_CHAIN_STREAMS = 1;
         # a server's one context gets the quiet hardware queues from the default creation order)
+        if os.environ.get("PSDR_BENCH_AGC_FORM") is not None:  # (A/B of the chain's two AGC forms: psdr.h PSDR_OPT_POST_CHAIN_AGC)
+            eng.ctx.set_option(eng.ctx.OPT_POST_CHAIN_AGC, int(os.environ["PSDR_BENCH_AGC_FORM"]))
         eng.ctx.set_post_chain(True, measured_streams=True)
         pk = 200
         pt = run.timed(pk, 5, min_reps=3, min_total_s=0.1)

@@ -267,8 +267,12 @@ int psdr_set_post_chain(psdr_ctx *ctx, int enable);
  *   ~60 ms measurement of launch gaps (the chain's kernels beside empty launches on the main and the side stream) - for a
  *   process that creates several contexts, where creation order lands on a busy pipe of the command processor (+15 %
  *   instead of +3 % on the step); the outcome depends on wall-clock thresholds, and a failed
- *   measurement falls back to 0. */
-enum { PSDR_OPT_POST_CHAIN_STREAMS = 1 };
+ *   measurement falls back to 0.
+ * PSDR_OPT_POST_CHAIN_AGC (any time; drains the context): the form of the chain's AGC.  1 (default): maxima of 16-sample
+ *   chunks + ONE four-wave kernel for look-ahead peak, gain recurrence and int16 conversion - a third of the memory
+ *   traffic of the other form - whenever the audio rate is a multiple of 80 Hz, the audio size a
+ *   multiple of 8 and the CUs the chain reserves hold its work-groups; 0: always the five-kernel form.  Same bits. */
+enum { PSDR_OPT_POST_CHAIN_STREAMS = 1, PSDR_OPT_POST_CHAIN_AGC = 2 };
 int psdr_set_option(psdr_ctx *ctx, int option, int value);
 /* pcm: [frames of the last demod_batch][audio_fft_size/2]; nframes = rows pcm holds (as psdr_read_audio) */
 int psdr_read_pcm(psdr_ctx *ctx, int id, int nframes, int32_t *pcm, int *nframes_out);

@@ -151,6 +151,7 @@ class Context:
         self.last_nframes = nframes
 
     OPT_POST_CHAIN_STREAMS = 1
+    OPT_POST_CHAIN_AGC = 2  # 1 (default): chunk maxima + one kernel for the AGC where the rate allows it; 0: the five-kernel form
 
     def set_option(self, option, value):
         check(self.lib.psdr_set_option(self.h, int(option), int(value)))

@@ -236,6 +236,7 @@ struct psdr_ctx {
     bool post_on = false;
     bool post_ready = false;   // the chain's buffers, events and streams exist (psdr_set_post_chain's one-time set-up went through)
     int opt_pc_streams = 0;    // PSDR_OPT_POST_CHAIN_STREAMS: 0 = creation order (deterministic), 1 = chosen by measurement
+    int opt_pc_agc = 1;        // PSDR_OPT_POST_CHAIN_AGC: 1 = chunk maxima + k_pc_agc where it applies, 0 = the five-kernel form
     PostArgs post{};
     // The chain is a pipeline across batches (round 5), in the order of a batch's data:
     //   side     index, gather (behind the demodulation)
@@ -251,6 +252,10 @@ struct psdr_ctx {
     float *post_x[PC_SETS] = {}, *post_m1[PC_SETS] = {}, *post_v1[PC_SETS] = {};
     float *post_p[PC_SETS] = {}, *post_s[PC_SETS] = {}, *post_sm[PC_SETS] = {};  // prefix maxima then g_t / w_t / sub-block maxima
     int *post_fstart[PC_SETS] = {}, *post_len[PC_SETS] = {};
+    // the AGC in one kernel behind chunk maxima (postchain.h k_pc_cm / k_pc_cscan / k_pc_agc): per set like P / S
+    float *post_cm[PC_SETS] = {}, *post_cp[PC_SETS] = {}, *post_cs[PC_SETS] = {};
+    int *post_falive[PC_SETS] = {};
+    bool post_agc_ok = false;  // the rate / audio size allow it (L % 16 == 0, h % 4 == 0, h >= 16, D % 4 == 0)
     uint64_t chain_seq = 0;
     bool chain_pending = false;
     int post_reserve = 8;  // CUs the FFT passes leave free while the chain is on (a multiple of 8: one per XCD); 0: none

@@ -65,6 +65,12 @@ __device__ __forceinline__ size_t pc_el(int t) { return ((size_t)(t >> 2) << 8) 
 __device__ __forceinline__ pc_f4 *pc_row4(float *lane_base, int q) { return reinterpret_cast<pc_f4 *>(lane_base) + (size_t)q * 64; }
 __device__ __forceinline__ const pc_f4 *pc_row4(const float *lane_base, int q) { return reinterpret_cast<const pc_f4 *>(lane_base) + (size_t)q * 64; }
 
+__device__ __forceinline__ int pc_mul24(int x, int y) {
+    int p;
+    asm("v_mul_i32_i24_e32 %0, %1, %2" : "=v"(p) : "v"(x), "v"(y));
+    return p;
+}
+
 template <int I, int N, typename F>
 __device__ __forceinline__ void pc_static_for(F &&f) {
     if constexpr (I < N) {
@@ -88,6 +94,8 @@ __global__ __launch_bounds__(64) void k_pc_index(PostArgs a) {
         const unsigned long long m = __ballot(alive);
         const int before = __popcll(m & ((1ull << lane) - 1ull));
         if (f < a.nframes) fs[f] = alive ? (cnt + before) * a.h : -1;
+        // (the inverse, for the kernel that walks the STREAM - k_pc_agc: the k-th surviving frame, lane-interleaved like the streams)
+        if (alive && a.falive) a.falive[((size_t)(slot >> 6) * a.max_batch + (cnt + before)) * 64 + (slot & 63)] = f;
         cnt += __popcll(m);
     }
     if (lane == 0) a.len[slot] = cnt * a.h;
@@ -819,6 +827,374 @@ __global__ __launch_bounds__(256) void k_pc_history(PostArgs a) {
         if (!a.ma_fused) mn[pc_el(r)] = m[pc_el(r + T)];
     }
     for (int r = threadIdx.x; r < a.L - 1; r += blockDim.x) vn[pc_el(a.vo + r)] = v[pc_el(a.vo + r + T)];
+}
+
+// ==== the AGC in ONE kernel behind chunk maxima (round 6) ==============================================================
+// What the chain costs the step is its TRAFFIC (profiles/r06_post_chain_ablation.json: 0.6 - 0.8 % of the step per pass of
+// 4 bytes per sample and client over a stream, beside passes that are bound by the memory system): the five kernels above
+// - sub-block maxima, prefix maxima, w_t, gain, int16 - read or write a stream eleven times.  This form reads V1 twice
+// and writes the PCM once:
+//   k_pc_cm      CM[c] = max |V1| over CHUNK c = the 16 floats [16 c, 16 c + 16) of a slot's V1 (history pad included)
+//   k_pc_cscan   van Herk one level up: CP / CS = prefix / suffix maxima of CM inside blocks of W = L/16 - 1 chunks
+//   k_pc_agc     per chunk b of 16 samples (t = 16 b + i; the window of output step t is V1[t + 1 .. t + L], vo = 1):
+//                    peak_t = max( |V1[t+1 .. 16 b + 15]|,  max CM[b+1 .. b+W],  |V1[16 (b + L/16) .. t + L]| )
+//                             (a suffix of chunk b, W whole chunks = max(CS[b+1], CP[b+W]), a prefix of chunk b + L/16)
+//                    w_t = desired / (peak_t + 1e-10), the gain recurrence, delayed sample V1[t + 1] * gain -> int16
+// max is exact and associative: the peak is the reference's monotonic deque's bit for bit, however it is grouped.
+// Needs L % 16 == 0 (vo = 1: sample 0's row is chunk L/16's first float), h % 4 == 0, h >= 16 - every audio rate that is a
+// multiple of 80 Hz with the usual audio sizes; anything else keeps the kernels above.
+//
+// k_pc_agc is a pipeline of FOUR waves, one per SIMD of a CU the passes leave free (each names v255 / a255, PC_OWN_SIMD):
+//   waves 1-3 (producers)  chunk by chunk: the loads (three rounds ahead, a ring of register sets), suffix / prefix maxima,
+//                          the division, w -> LDS; two rounds later the gains of the same chunk come back through LDS:
+//                          delayed sample * gain, int16 conversion, the store to pcm[slot][frame][j] (the frame of a stream
+//                          position through FA, the list of a slot's surviving frames)
+//   wave 0   (recurrence)  takes a round's w from LDS, runs the gain recurrence (three dependent operations per sample: the
+//                          one thing here that cannot be spread), leaves the gains in LDS; no memory operation in its loop
+// A work-group owns a.lanes slots; with 32 (16) of them a producer wave works on two (four) chunks at once - lane = (chunk of
+// the wave's set, slot) - so the recurrence, not the division, bounds the kernel.  One barrier per ROUND of 3 * 64 / a.lanes
+// chunks.  w and g are double-buffered by round parity: producers write w of round r while the recurrence reads round r - 1
+// and they read g of round r - 2.
+constexpr int PC_AGC_NP = 3;     // producer waves
+constexpr int PC_AGC_AHEAD = 2;  // rounds between a producer's loads and their use (~4600 cycles: k_pc_gain's twelve blocks)
+static_assert(16 * 3 <= PSDR_PC_PAD, "producers read up to two chunks past the longest stream: inside the padding");
+
+// CM[group][chunk][lane]: grid (groups of 64 slots, ceil(nchunks / 16)), one wave, 16 chunks each
+__global__ __launch_bounds__(64) void k_pc_cm(PostArgs a, int nchunks) {
+    const int slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= a.slots || a.slot_ci[slot] < 0) return;
+    const float *v1 = a.V1 + pc_base(slot, a.pv);
+    float *cm = a.CM + ((size_t)blockIdx.x * a.nch) * 64 + threadIdx.x;
+    const int c0 = blockIdx.y * 16, c1 = min(c0 + 16, nchunks);
+    for (int c = c0; c < c1; c += 4) {
+        pc_f4 v[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[k][q] = *pc_row4(v1, 4 * min(c + k, c1 - 1) + q);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float m = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) m = fmaxf(m, fabsf(v[k][q][i]));
+            if (c + k < c1) cm[(size_t)(c + k) * 64] = m;
+        }
+    }
+}
+
+// CP[c] = max CM[block start .. c], CS[c] = max CM[c .. block end], blocks of W chunks: grid (groups, blocks), one wave
+__global__ __launch_bounds__(64) void k_pc_cscan(PostArgs a, int nchunks, int W) {
+    const int slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= a.slots || a.slot_ci[slot] < 0) return;
+    const size_t base = ((size_t)blockIdx.x * a.nch) * 64 + threadIdx.x;
+    const float *cm = a.CM + base;
+    float *cp = a.CP + base, *cs = a.CS + base;
+    const int c0 = blockIdx.y * W, c1 = min(c0 + W, nchunks);
+    float run = 0.f;
+    for (int c = c0; c < c1; c += 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = cm[(size_t)min(c + i, c1 - 1) * 64];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (c + i < c1) {
+                run = fmaxf(run, v[i]);
+                cp[(size_t)(c + i) * 64] = run;
+            }
+    }
+    run = 0.f;
+    for (int c = c1 - 1; c >= c0; c -= 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = cm[(size_t)max(c - i, c0) * 64];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (c - i >= c0) {
+                run = fmaxf(run, v[i]);
+                cs[(size_t)(c - i) * 64] = run;
+            }
+    }
+}
+
+// rows of dropped frames (and every row of a paused client) are zero in the PCM: grid (groups of 64 slots, frame) like
+// k_pc_out4 - which wrote them on its way; the fused kernel only walks the surviving frames
+__global__ __launch_bounds__(256) void k_pc_zero(PostArgs a) {
+    const int slot = blockIdx.x * 64 + (threadIdx.x & 63), f = blockIdx.y;
+    if (slot >= a.slots || a.slot_ci[slot] < 0) return;
+    if (a.fstart[(size_t)slot * a.max_batch + f] >= 0) return;
+    pc_i4 *dst = reinterpret_cast<pc_i4 *>(a.pcm + ((size_t)slot * a.max_batch + f) * a.h);
+    for (int j4 = threadIdx.x >> 6; j4 < (a.h >> 2); j4 += 4) dst[j4] = pc_i4{0, 0, 0, 0};
+}
+
+template <bool ATT_FASTER>
+__global__ __launch_bounds__(64 * (1 + PC_AGC_NP)) void k_pc_agc(PostArgs a) {
+    constexpr int NP = PC_AGC_NP, AH = PC_AGC_AHEAD;
+    // [buffer][chunk of the round (up to NP * 4)][row group][slot lane] - 16 floats per chunk and slot: NP * 64 * 16 floats per
+    // round whatever a.lanes is (12 KiB), w and g, two buffers each: 48 KiB
+    __shared__ pc_f4 wbuf[2][NP * 64 * 4], gbuf[2][NP * 64 * 4];
+    __shared__ pc_f4 dbuf[2][NP * 64 * 4];  // the delayed samples of a round's chunks, from produce(r) to emit(r) (a lane's own: registers are what the ring needs)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lanes = a.lanes, sub = 64 / lanes;  // chunks a producer wave works on at once
+    const int cpr = NP * sub;                      // chunks per round
+    const int wpg = 64 / lanes;
+    const int g64 = (int)blockIdx.x / wpg;                    // group of 64 slots
+    const int sl0 = ((int)blockIdx.x % wpg) * lanes;          // first slot lane of the work-group inside its group
+    PC_OWN_SIMD();
+    const int L = a.L, LC = L >> 4, W = LC - 1;
+    // the group's longest stream decides the trip count (lanes of a group may have dropped frames, be paused or not listed)
+    int Tm = 0;
+    {
+        const int s = g64 * 64 + sl0 + (lane & (lanes - 1));
+        const int ci = s < a.slots ? a.slot_ci[s] : -1;
+        Tm = ci >= 0 ? a.len[s] : 0;
+#pragma unroll
+        for (int d = 32; d; d >>= 1) Tm = max(Tm, __shfl_xor(Tm, d, 64));
+    }
+    const int nchk = (Tm + 15) >> 4;               // chunks with a sample
+    // (at least two rounds: the producers' timeline below has two rounds in front of and two behind its steady state; a round
+    // without samples runs on values nobody uses - the gain stays, the stores go to the dump line)
+    const int nrounds = max((nchk + cpr - 1) / cpr, 2);
+    auto lds_at = [&](int chunk_in_round, int q, int sl) { return (chunk_in_round * 4 + q) * lanes + sl; };
+    if (wid == 0) {
+        // ---- the recurrence wave: lane = slot lane
+        __builtin_amdgcn_s_setprio(PSDR_PC_SETPRIO);
+        const int sl = lane;
+        const int slot = g64 * 64 + sl0 + sl;
+        const int ci = (sl < lanes && slot < a.slots) ? a.slot_ci[slot] : -1;
+        const bool listed = ci >= 0;
+        const int T = listed ? a.len[slot] : 0;
+        float gain = listed ? a.agc_gain[slot] : 0.f;
+        int n0 = listed ? a.agc_n0[slot] : 0;
+        if (listed && a.clients[ci].agc_reset) {  // AGC::reset() on a demodulation change (src/signal.cpp:322-326)
+            gain = 0.f;
+            n0 = 0;
+        }
+        const float g_init = gain;
+        // while the look-ahead buffer is filling (t < tfill: right after a reset / for a new client) the reference outputs 0
+        // and leaves the gain alone (src/utils/audioprocessing.cpp:40-54)
+        const int tfill = min(T, max(0, L - 1 - n0));
+        const float att = a.attack, rel = a.release;
+        auto step = [&](float w) -> float {  // (see k_pc_gain: both candidates side by side, the pick is a min / max)
+            const float d = __fsub_rn(w, gain);
+            const float ga = __fmaf_rn(att, d, gain), gr = __fmaf_rn(rel, d, gain);
+            gain = ATT_FASTER ? fminf(ga, gr) : fmaxf(ga, gr);
+            return gain;
+        };
+        const bool mine = sl < lanes;  // (the other lanes idle along, barriers included)
+        // round r of the recurrence runs one barrier behind the producers' round r
+        __syncthreads();  // producers: w of round 0 written
+        for (int r = 0; r < nrounds; r++) {
+            const pc_f4 *wb = wbuf[r & 1];
+            pc_f4 *gb = gbuf[r & 1];
+            pc_f4 wv[4];
+            if (mine) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) wv[q] = wb[lds_at(0, q, sl)];
+            }
+            for (int k = 0; k < cpr; k++) {
+                const int c = r * cpr + k;
+                pc_f4 cur[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) cur[q] = wv[q];
+                if (mine && k + 1 < cpr) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) wv[q] = wb[lds_at(k + 1, q, sl)];
+                }
+                // a chunk that is not wholly inside [tfill, T) for some lane with a stream: the careful form
+                const bool whole = 16 * c >= tfill && 16 * c + 16 <= T;
+                const bool careful = __any(mine && T > 0 && !whole);
+                pc_f4 g[4];
+                if (!careful) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) g[i >> 2][i & 3] = step(cur[i >> 2][i & 3]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int t = 16 * c + i;
+                        const float before = gain;
+                        const float gk = step(cur[i >> 2][i & 3]);
+                        if (!(t >= tfill && t < T)) gain = before;  // buffer still filling / past the lane's stream: the gain stays
+                        g[i >> 2][i & 3] = t < tfill ? 0.f : gk;
+                    }
+                }
+                if (mine) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) gb[lds_at(k, q, sl)] = g[q];
+                }
+            }
+            __syncthreads();
+        }
+        __syncthreads();  // (the producers' two rounds of output behind the last recurrence round)
+        __syncthreads();
+        if (listed) {
+            a.agc_gain[slot] = T > 0 ? gain : g_init;
+            a.agc_n0[slot] = min(n0 + T, L);
+        }
+        return;
+    }
+    // ---- producer wave p: chunk (r * cpr + p * sub + j) of round r for lane = (j, slot lane)
+    const int p = wid - 1;
+    const int sl = lane & (lanes - 1), j = lane / lanes;
+    const int slot = g64 * 64 + sl0 + sl;
+    const int ci = slot < a.slots ? a.slot_ci[slot] : -1;
+    const bool listed = ci >= 0;
+    const int T = listed ? a.len[slot] : 0;
+    const float *__restrict__ V = a.V1 + pc_base(min(slot, a.slots - 1), a.pv);
+    const size_t cbase = ((size_t)g64 * a.nch) * 64 + (size_t)(sl0 + sl);
+    const float *__restrict__ CS = a.CS + cbase;
+    const float *__restrict__ CP = a.CP + cbase;
+    const int *__restrict__ FA = a.falive + ((size_t)g64 * a.max_batch) * 64 + (size_t)(sl0 + sl);
+    int32_t *__restrict__ pcm = a.pcm + (size_t)min(slot, a.slots - 1) * a.max_batch * a.h;
+    int32_t *dump = a.pcm_dump + 4 * (int)threadIdx.x;
+    const int kin = p * sub + j;  // the lane's chunk inside a round
+    const int h = a.h;
+    const unsigned hmagic = a.h_magic;  // ceil(2^32 / h): t / h = umulhi(t, hmagic) for t * h < 2^32
+    struct Set {
+        pc_f4 nr[4], fr[4];
+        float nx;  // the first float of the next chunk (the delayed sample of the chunk's last step)
+        float cs, cp;
+        int fa0, fa1;
+    };
+    Set ring[AH + 1];
+    int dst[2][4];     // by round parity: the places of a chunk's row groups in the PCM (int32 index from the slot's base; < 0: no sample)
+    auto fetch = [&](auto kc, int r) {  // UNCONDITIONAL (see k_pc_ma2): past the stream's end inside the padding, values never used
+        constexpr int k = decltype(kc)::value;
+        const int c = min(r * cpr + kin, nchk);  // (the rounds past the last chunk read its neighbour again)
+        const pc_f4 *n = pc_row4(V, 4 * c), *f = pc_row4(V, 4 * (c + LC));
+#pragma unroll
+        for (int q = 0; q < 4; q++) ring[k].nr[q] = n[(size_t)q * 64];
+        ring[k].nx = *reinterpret_cast<const float *>(n + (size_t)4 * 64);
+#pragma unroll
+        for (int q = 0; q < 4; q++) ring[k].fr[q] = f[(size_t)q * 64];
+        ring[k].cs = CS[(size_t)(c + 1) * 64];
+        ring[k].cp = CP[(size_t)(c + W) * 64];
+        const int k0 = min((int)__umulhi((unsigned)(16 * c), hmagic), a.max_batch - 1), k1 = min(k0 + 1, a.max_batch - 1);
+        ring[k].fa0 = FA[(size_t)k0 * 64];
+        ring[k].fa1 = FA[(size_t)k1 * 64];
+    };
+    auto produce = [&](auto kc, auto pc, int r) {
+        constexpr int k = decltype(kc)::value, P = decltype(pc)::value;
+        const Set &s = ring[k];
+        const int c = r * cpr + kin;
+        // suffix maxima of |chunk c| from position i + 1, prefix maxima of |chunk c + L/16| up to position i
+        float sf[17], pf[16];
+        sf[16] = 0.f;
+#pragma unroll
+        for (int i = 15; i >= 1; i--) sf[i] = fmaxf(sf[i + 1], fabsf(s.nr[i >> 2][i & 3]));
+        pf[0] = fabsf(s.fr[0][0]);
+#pragma unroll
+        for (int i = 1; i < 16; i++) pf[i] = fmaxf(pf[i - 1], fabsf(s.fr[i >> 2][i & 3]));
+        const float mid = fmaxf(s.cs, s.cp);
+        pc_f4 w[4];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const float peak = fmaxf(fmaxf(sf[i + 1], mid), pf[i]);
+            w[i >> 2][i & 3] = __fdiv_rn(a.desired, __fadd_rn(peak, 1e-10f));
+        }
+        // (the chunk's first float is in no window of its own steps; without a use the compiler recycles its register right
+        // behind the load - and waits for the load to land first, a round trip to memory in every round)
+        asm volatile("" ::"v"(s.nr[0][0]));
+        pc_f4 *wb = wbuf[r & 1];
+#pragma unroll
+        for (int q = 0; q < 4; q++) wb[lds_at(kin, q, sl)] = w[q];
+        // the delayed samples V1[t + 1] and where they go: frame ordinal k = t / h of row group q (a chunk touches at most
+        // two frames: h >= 16), the surviving frame FA[k], offset t - k h
+        const int t0 = 16 * c;
+        const int k0 = (int)__umulhi((unsigned)t0, hmagic);
+        pc_f4 *db = dbuf[P] + ((wid - 1) * 4) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            pc_f4 dl;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int e = 4 * q + i + 1;
+                dl[i] = e < 16 ? s.nr[(e >> 2) & 3][e & 3] : s.nx;
+            }
+            db[q * 64] = dl;
+            const int t = t0 + 4 * q;
+            const int second = t >= __mul24(k0 + 1, h) ? 1 : 0;
+            const int fr = second ? s.fa1 : s.fa0;
+            // (an opaque 24-bit multiplication: the compiler's own is a 64-bit multiply-add whose don't-care upper addend it
+            // leaves in whatever register - one a load of this round is still writing: a wait for that load)
+            const int off = pc_mul24(fr - (k0 + second), h) + t;
+            dst[P][q] = t < T ? off : -1;  // (T = 0 for a slot that is not listed)
+        }
+    };
+    auto emit = [&](auto pc, int r) {  // the gains of round r are in gbuf[r & 1]
+        constexpr int P = decltype(pc)::value;
+        const pc_f4 *gb = gbuf[r & 1];
+        const pc_f4 *db = dbuf[P] + ((wid - 1) * 4) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const pc_f4 g = gb[lds_at(kin, q, sl)], dl = db[q * 64];
+            pc_i4 o;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float y = g[i] == 0.f ? 0.f : __fmul_rn(dl[i], g[i]);
+                int v = (int)__fmaf_rn(y, 16384.f, 32768.5f) - 32768;  // dsp_float_to_int16, src/utils/dsp.cpp:152-165
+                o[i] = v > 32767 ? 32767 : (v < -32768 ? -32768 : v);
+            }
+            // (an UNCONDITIONAL store: a row group without a sample goes to a dump line of its own - see the timeline below)
+            *reinterpret_cast<pc_i4 *>(dst[P][q] >= 0 ? pcm + dst[P][q] : dump) = o;
+        }
+    };
+    // Producer timeline: round rr sits between barriers #rr and #rr+1: fetch(rr + AH), emit(rr - 2) [its gains were written by the
+    // recurrence during round rr - 1], produce(rr) [read by the recurrence one barrier later].  dly / dst of round rr live until
+    // emit(rr) two rounds later: two parities suffice because emit(rr - 2) comes BEFORE produce(rr).  The steady state
+    // (rounds 2 .. nrounds - 1) is branch-free - every fetch, store and LDS operation unconditional - so that the compiler
+    // can COUNT the memory operations between a load and its use (a conditional one turns every wait into vmcnt(0): a drain
+    // of three rounds of prefetch and of the stores behind them); the first two and the last two rounds stand outside.
+    static_assert(AH == 2, "ring position = round mod 3, parity = round mod 2: six rounds per trip");
+    pc_static_for<0, AH>([&](auto kc) { fetch(kc, decltype(kc)::value); });
+    {   // rounds 0 and 1: nothing to emit yet
+        fetch(std::integral_constant<int, 2>{}, AH);
+        produce(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0);
+        __syncthreads();
+        fetch(std::integral_constant<int, 0>{}, AH + 1);
+        produce(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, 1);
+        __syncthreads();
+    }
+    auto round = [&](auto jc, auto pc, int rr) {
+        constexpr int J = decltype(jc)::value;  // rr mod 3
+        // (scheduling fences: the scheduler otherwise hoists the first uses of a LATER round's loads - the |x| of its maxima - to
+        // the top of the six-round block, and the wait for them with it: the ring's two rounds of distance gone)
+        fetch(std::integral_constant<int, (J + AH) % (AH + 1)>{}, rr + AH);
+        __builtin_amdgcn_sched_barrier(0);
+        emit(pc, rr - 2);
+        __builtin_amdgcn_sched_barrier(0);
+        produce(jc, pc, rr);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    int r = 2;  // (2 mod 3 = 2, 2 mod 2 = 0)
+    for (; r + 6 <= nrounds; r += 6) {
+        round(I2{}, I0{}, r);
+        round(I0{}, I1{}, r + 1);
+        round(I1{}, I0{}, r + 2);
+        round(I2{}, I1{}, r + 3);
+        round(I0{}, I0{}, r + 4);
+        round(I1{}, I1{}, r + 5);
+    }
+    if (r < nrounds) round(I2{}, I0{}, r), r++;
+    if (r < nrounds) round(I0{}, I1{}, r), r++;
+    if (r < nrounds) round(I1{}, I0{}, r), r++;
+    if (r < nrounds) round(I2{}, I1{}, r), r++;
+    if (r < nrounds) round(I0{}, I0{}, r), r++;
+    // the last two rounds' gains (rounds nrounds and nrounds + 1 of the timeline: emit only)
+    for (int e = 0; e < 2; e++) {
+        const int rr = nrounds + e;
+        if (rr & 1)
+            emit(std::integral_constant<int, 1>{}, rr - 2);
+        else
+            emit(std::integral_constant<int, 0>{}, rr - 2);
+        __syncthreads();
+    }
+    __syncthreads();  // (nrounds + 3 in either kind of wave)
 }
 
 }  // namespace psdr

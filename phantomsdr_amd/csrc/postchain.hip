@@ -152,6 +152,14 @@ extern "C" int psdr_set_option(psdr_ctx *c, int option, int value) {
         if (c->post_ready) return fail(PSDR_ERR_STATE, "PSDR_OPT_POST_CHAIN_STREAMS after the post chain was set up");
         c->opt_pc_streams = value;
         return PSDR_OK;
+    case PSDR_OPT_POST_CHAIN_AGC: {
+        if (value != 0 && value != 1) return fail(PSDR_ERR_INVALID, "PSDR_OPT_POST_CHAIN_AGC: 0 (five kernels) or 1 (one kernel behind chunk maxima), not %d", value);
+        HIPCHK(hipSetDevice(c->device));
+        const int rc = drain(c);
+        if (rc) return rc;
+        c->opt_pc_agc = value;
+        return PSDR_OK;
+    }
     default:
         return fail(PSDR_ERR_INVALID, "unknown option %d", option);
     }
@@ -177,7 +185,8 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
             c->post = PostArgs{};
             c->pcm_pool[0] = c->pcm_pool[1] = nullptr;
             for (int i = 0; i < psdr_ctx::PC_SETS; i++)
-                c->post_fstart[i] = c->post_len[i] = nullptr, c->post_x[i] = c->post_m1[i] = c->post_v1[i] = c->post_p[i] = c->post_s[i] = c->post_sm[i] = nullptr;
+                c->post_fstart[i] = c->post_len[i] = c->post_falive[i] = nullptr, c->post_x[i] = c->post_m1[i] = c->post_v1[i] = c->post_p[i] = c->post_s[i] = c->post_sm[i] = c->post_cm[i] = c->post_cp[i] = c->post_cs[i] = nullptr;
+            c->post_agc_ok = false;
         };
         const int rate = c->cfg.audio_rate;
         if (rate < 750) return fail(PSDR_ERR_INVALID, "audio_rate %d too small for the DC blocker", rate);
@@ -215,6 +224,11 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
         a.nsub = (a.L + 255) / 256;
         a.sb = (a.L + a.nsub - 1) / a.nsub;
         const size_t nblk = (((size_t)a.L - 1 + Tm) + a.L - 1) / a.L;
+        // the AGC in one kernel (postchain.h k_pc_agc): whole chunks of 16 floats must line up with sample 0's row and with the
+        // row groups of a frame; stream position / h by one 32-bit multiplication
+        c->post_agc_ok = (a.L % 16) == 0 && a.L >= 32 && a.vo == 1 && (h % 4) == 0 && h >= 16 && (a.D % 4) == 0 && (Tm + 4096) * h < ((size_t)1 << 32);
+        a.nch = (int)((size_t)a.L / 16 + (Tm + 15) / 16 + 8);
+        a.h_magic = (unsigned)((((uint64_t)1 << 32) + h - 1) / h);
         int rc = 0;
         for (int i = 0; i < psdr_ctx::PC_SETS && !rc; i++) {
             rc = alloc((void **)&c->post_fstart[i], S * c->max_batch * sizeof(int));
@@ -225,12 +239,19 @@ extern "C" int psdr_set_post_chain(psdr_ctx *c, int enable) {
             if (!rc) rc = alloc((void **)&c->post_p[i], a.pv * S64 * sizeof(float));
             if (!rc) rc = alloc((void **)&c->post_s[i], a.pv * S64 * sizeof(float));
             if (!rc) rc = alloc((void **)&c->post_sm[i], S64 * nblk * a.nsub * sizeof(float));
+            if (c->post_agc_ok) {
+                if (!rc) rc = alloc((void **)&c->post_cm[i], S64 * a.nch * sizeof(float));
+                if (!rc) rc = alloc((void **)&c->post_cp[i], S64 * a.nch * sizeof(float));
+                if (!rc) rc = alloc((void **)&c->post_cs[i], S64 * a.nch * sizeof(float));
+                if (!rc) rc = alloc((void **)&c->post_falive[i], S64 * c->max_batch * sizeof(int));
+            }
             for (auto &stage : c->ev_pc)
                 if (!rc && !stage[i] && hipEventCreateWithFlags(&stage[i], hipEventDisableTiming) != hipSuccess)
                     rc = fail(PSDR_ERR_HIP, "post chain: event creation failed");
         }
         for (int k = 0; k < 2 && !rc; k++) rc = alloc((void **)&c->pcm_pool[k], S * Tm * sizeof(int32_t));
         a.pcm = c->pcm_pool[0];
+        if (!rc) rc = alloc((void **)&a.pcm_dump, 64 * (1 + PC_AGC_NP) * 16);
         if (!rc) rc = alloc((void **)&a.dc_s1, S * sizeof(float));
         if (!rc) rc = alloc((void **)&a.dc_s2, S * sizeof(float));
         if (!rc) rc = alloc((void **)&a.agc_gain, S * sizeof(float));
@@ -323,6 +344,11 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
     // beside a pass's work-group (128 KiB of 160)
     size_t home_lds = c->post_reserve > 0 ? 34 * 1024 : 0;
     const bool rows4 = (c->post.h & 3) == 0 && (c->post.D & 3) == 0;  // every frame starts on a row group: the lane = slot gather / output
+    // The AGC as chunk maxima + ONE four-wave kernel (postchain.h k_pc_agc: V1 read twice, the PCM written once - the five
+    // kernels of the other form pass over a stream eleven times) whenever the rate allows it and its work-groups - a whole
+    // CU each: four waves that own their SIMD - have the CUs the passes leave free
+    bool agc_fused = c->post_agc_ok && c->post_own && c->opt_pc_agc != 0 && c->post_lanes <= 32;
+    if (const char *e = psdr_tuning_env("PSDR_PC_FUSED")) agc_fused = agc_fused && atoi(e) != 0;  // (tuning build)
     // this batch's PCM goes to the other of two buffers (the copy of the last batch's to the host may still read its own)
     c->pcm_set ^= 1;
     c->post.pcm = c->pcm_pool[c->pcm_set];
@@ -341,6 +367,8 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
     pa.SM = c->post_sm[set];
     pa.fstart = c->post_fstart[set];
     pa.len = c->post_len[set];
+    pa.CM = c->post_cm[set], pa.CP = c->post_cp[set], pa.CS = c->post_cs[set];
+    pa.falive = c->post_falive[set];
     pa.ma_fused = pa.D == 32 ? 1 : 0;  // both averages in one loop (postchain.h)
     const int nall = nact + npaused;
     const unsigned groups = (unsigned)((pa.slots + 63) / 64);
@@ -412,51 +440,77 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
         HIPCHK(hipGetLastError());
         if ((rc = done(sm, 1))) return rc;
     }
-    {  // ---- stage 2: look-ahead peak and w_t (parallel along time)
-        hipStream_t sp1 = split_peak ? sm : sp;  // (P[set]'s last readers - gain / output of batch b - 3 - were waited for in stage 1)
-        if (sp1 != sm && (rc = wait(sp1, 1, set))) return rc;
-        if (seq >= NS && sp1 != sm && (rc = wait(sp1, 3, set))) return rc;
+    if (agc_fused) {
+        // ---- stage 2: chunk maxima of |V1| and their block scans, behind the moving averages on THEIR stream (P / S / SM are not
+        // used; CM / CP / CS of this set were last read by stage 3 of batch b - 3: waited for in stage 1)
+        const int nchunks = (int)((pa.vo + pa.L - 1 + Tb + 15) / 16);
+        const int W = pa.L / 16 - 1;
         {
-            ProfScope ps(c, K_POST, sp1);
-            if (pa.nsub > 1 && !(skip & 8)) hipLaunchKernelGGL(k_pc_submax, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp1, pa);
-            if (!(skip & 16)) hipLaunchKernelGGL(k_pc_prefix, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp1, pa);
+            ProfScope ps(c, K_POST, sm);
+            if (!(skip & 8)) hipLaunchKernelGGL(k_pc_cm, dim3(groups, (nchunks + 15) / 16), dim3(64), 0, sm, pa, nchunks);
+            if (!(skip & 16)) hipLaunchKernelGGL(k_pc_cscan, dim3(groups, (nchunks + W - 1) / W), dim3(64), 0, sm, pa, nchunks, W);
+            HIPCHK(hipGetLastError());
         }
-        if (split_peak) {
-            if ((rc = done(sp1, 2)) || (rc = wait(sp, 2, set))) return rc;
-        }
-        {
-            ProfScope ps(c, K_POST, sp);
-            if (!(skip & 32)) hipLaunchKernelGGL(k_pc_want, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp, pa);
-        }
-        HIPCHK(hipGetLastError());
-        if (!split_peak && (rc = done(sp, 2))) return rc;
-    }
-    {  // ---- stage 3: the gain recurrence (sequential), int16 output
-        if (sp != sc && (rc = wait(sc, 2, set))) return rc;
+        if (sm != sc && ((rc = done(sm, 2)) || (rc = wait(sc, 2, set)))) return rc;
+        // ---- stage 3: w_t, the gain recurrence, int16 - one kernel
         ProfScope ps(c, K_POST, sc);
-        const size_t glds = home_lds ? home_lds - 8 * 1024 : 0;
-        if (skip & 64) {
-        } else if (pa.attack >= pa.release) {
-            if (c->post_own)
-                hipLaunchKernelGGL((k_pc_gain<true, true>), dim3(rgroups), dim3(128), 0, sc, pa);
-            else
-                hipLaunchKernelGGL((k_pc_gain<true, false>), dim3(rgroups), dim3(128), glds, sc, pa);
-        } else {
-            if (c->post_own)
-                hipLaunchKernelGGL((k_pc_gain<false, true>), dim3(rgroups), dim3(128), 0, sc, pa);
-            else
-                hipLaunchKernelGGL((k_pc_gain<false, false>), dim3(rgroups), dim3(128), glds, sc, pa);
-        }
         if ((rc = fetch_guard_wait(c, sc, c->guard_pcm[c->pcm_set]))) return rc;  // what read this PCM buffer two batches ago has landed
         c->guard_pcm[c->pcm_set] = nullptr;
-        if (skip & 128)
-            ;
-        else if (rows4)
-            hipLaunchKernelGGL(k_pc_out4, dim3(groups, nframes), dim3(256), 0, sc, pa);
+        if (!(skip & 128)) hipLaunchKernelGGL(k_pc_zero, dim3(groups, nframes), dim3(256), 0, sc, pa);
+        if (skip & 64) {
+        } else if (pa.attack >= pa.release)
+            hipLaunchKernelGGL(k_pc_agc<true>, dim3(rgroups), dim3(64 * (1 + PC_AGC_NP)), 0, sc, pa);
         else
-            hipLaunchKernelGGL(k_pc_out, dim3(nall, nframes), dim3(256), 0, sc, pa);
+            hipLaunchKernelGGL(k_pc_agc<false>, dim3(rgroups), dim3(64 * (1 + PC_AGC_NP)), 0, sc, pa);
         HIPCHK(hipGetLastError());
         if ((rc = done(sc, 3))) return rc;
+    } else {
+        {  // ---- stage 2: look-ahead peak and w_t (parallel along time)
+            hipStream_t sp1 = split_peak ? sm : sp;  // (P[set]'s last readers - gain / output of batch b - 3 - were waited for in stage 1)
+            if (sp1 != sm && (rc = wait(sp1, 1, set))) return rc;
+            if (seq >= NS && sp1 != sm && (rc = wait(sp1, 3, set))) return rc;
+            {
+                ProfScope ps(c, K_POST, sp1);
+                if (pa.nsub > 1 && !(skip & 8)) hipLaunchKernelGGL(k_pc_submax, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp1, pa);
+                if (!(skip & 16)) hipLaunchKernelGGL(k_pc_prefix, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp1, pa);
+            }
+            if (split_peak) {
+                if ((rc = done(sp1, 2)) || (rc = wait(sp, 2, set))) return rc;
+            }
+            {
+                ProfScope ps(c, K_POST, sp);
+                if (!(skip & 32)) hipLaunchKernelGGL(k_pc_want, dim3(groups, nblk * pa.nsub), dim3(64), 0, sp, pa);
+            }
+            HIPCHK(hipGetLastError());
+            if (!split_peak && (rc = done(sp, 2))) return rc;
+        }
+        {  // ---- stage 3: the gain recurrence (sequential), int16 output
+            if (sp != sc && (rc = wait(sc, 2, set))) return rc;
+            ProfScope ps(c, K_POST, sc);
+            const size_t glds = home_lds ? home_lds - 8 * 1024 : 0;
+            if (skip & 64) {
+            } else if (pa.attack >= pa.release) {
+                if (c->post_own)
+                    hipLaunchKernelGGL((k_pc_gain<true, true>), dim3(rgroups), dim3(128), 0, sc, pa);
+                else
+                    hipLaunchKernelGGL((k_pc_gain<true, false>), dim3(rgroups), dim3(128), glds, sc, pa);
+            } else {
+                if (c->post_own)
+                    hipLaunchKernelGGL((k_pc_gain<false, true>), dim3(rgroups), dim3(128), 0, sc, pa);
+                else
+                    hipLaunchKernelGGL((k_pc_gain<false, false>), dim3(rgroups), dim3(128), glds, sc, pa);
+            }
+            if ((rc = fetch_guard_wait(c, sc, c->guard_pcm[c->pcm_set]))) return rc;  // what read this PCM buffer two batches ago has landed
+            c->guard_pcm[c->pcm_set] = nullptr;
+            if (skip & 128)
+                ;
+            else if (rows4)
+                hipLaunchKernelGGL(k_pc_out4, dim3(groups, nframes), dim3(256), 0, sc, pa);
+            else
+                hipLaunchKernelGGL(k_pc_out, dim3(nall, nframes), dim3(256), 0, sc, pa);
+            HIPCHK(hipGetLastError());
+            if ((rc = done(sc, 3))) return rc;
+        }
     }
     if (piped) c->chain_pending = true;
     c->chain_seq++;

@@ -52,7 +52,13 @@ struct PostArgs {
     float *agc_gain;
     int *agc_n0;  // samples pushed since the last reset, saturating at L
     int ma_fused;  // k_pc_ma2 keeps M1's history itself (k_pc_history leaves M1 alone)
-    int lanes;     // k_pc_ma2 / k_pc_gain: slots per work-group (16, 32 or 64 lanes of its waves in use)
+    int lanes;     // k_pc_ma2 / k_pc_gain / k_pc_agc: slots per work-group (16, 32 or 64 lanes of its waves in use)
+    // the AGC behind chunk maxima (k_pc_cm / k_pc_cscan / k_pc_agc, postchain.h): [groups of 64 slots][nch chunks of 16 floats][64]
+    float *CM, *CP, *CS;  // maxima of |V1| per chunk; prefix / suffix maxima of CM inside blocks of L/16 - 1 chunks
+    int nch;
+    int *falive;          // [groups][max_batch][64] the k-th surviving frame of a slot's stream (k_pc_index)
+    unsigned h_magic;     // ceil(2^32 / h): stream position / h by one multiplication
+    int32_t *pcm_dump;    // 16 bytes per thread of a k_pc_agc work-group: where its unconditional stores of row groups without a sample go
 };
 
 struct WfClient {

@@ -393,9 +393,11 @@ def test_error_paths():
         ctx.close()
 
 
-@pytest.mark.parametrize("audio_rate,F,nb,n", [(12000, 8, 5, 248), (192000, 128, 5, 248), (12000, 7, 6, 252), (48000, 33, 5, 248),
-                                                  (6000, 9, 4, 360), (44100, 40, 5, 248)])
-def test_post_chain_bit_exact(audio_rate, F, nb, n):
+@pytest.mark.parametrize("audio_rate,F,nb,n,agc_form",
+                         [(12000, 8, 5, 248, 1), (192000, 128, 5, 248, 1), (12000, 7, 6, 252, 1), (48000, 33, 5, 248, 1),
+                          (6000, 9, 4, 360, 1), (44100, 40, 5, 248, 1),
+                          (12000, 8, 5, 248, 0), (48000, 33, 5, 248, 0), (6000, 9, 4, 360, 0)])
+def test_post_chain_bit_exact(audio_rate, F, nb, n, agc_form):
     """DC blocker + AGC + int16 conversion on the GPU (psdr_set_post_chain) against the oracle's
     chain fed with the SAME float audio (the GPU's own demodulator output): the recurrences are
     sequential f32, so the PCM must be identical.  Covers the AGC look-ahead start-up (2400
@@ -406,7 +408,11 @@ def test_post_chain_bit_exact(audio_rate, F, nb, n):
     groups of the chain's lane-interleaved streams (the scalar gather / output kernels), 7 of them: streams that are
     not whole 16-step blocks.  48000 (the other shipped configs' rate: D = 128) and 6000 (D = 16): the two-wave kernel for
     any power-of-two delay, its ring of sums in LDS, streams that end inside a block (33 and 9 frames); 44100: D = 116,
-    the generic two-kernel path with a division."""
+    the generic two-kernel path with a division.  agc_form (psdr.h PSDR_OPT_POST_CHAIN_AGC): 1 = the default - maxima of
+    16-sample chunks + ONE kernel for look-ahead peak, gain and int16 wherever the rate and the audio size allow it (all
+    cases but n = 252: frames that are not whole row groups, and 44100: a look-ahead of 8820 samples is not whole chunks;
+    the streams here end inside a chunk, inside a round of the kernel's pipeline, and - F = 8 / 9 - before its third round),
+    0 = the five-kernel form everywhere."""
     from phantomsdr_amd import AudioClient, Context
     N = 1 << 14
     R, levels = N, levels_for(N)
@@ -416,6 +422,7 @@ def test_post_chain_bit_exact(audio_rate, F, nb, n):
     ctx = Context(N, False, levels, additional_size=n, audio_fft_size=n, audio_rate=audio_rate,
                   input_format="s16", max_batch=F, max_clients=4)
     try:
+        ctx.set_option(ctx.OPT_POST_CHAIN_AGC, agc_form)
         ctx.set_post_chain(True)
         d = ctx.dev_alloc(raw.nbytes)
         ctx.h2d(d, raw)
@@ -499,10 +506,12 @@ def test_post_chain_many_clients(max_clients):
         ctx.close()
 
 
-def test_post_chain_skips_nan_frames():
+@pytest.mark.parametrize("agc_form", [1, 0])
+def test_post_chain_skips_nan_frames(agc_form):
     """A frame whose audio contains a NaN is dropped by the reference before the chain
     (src/signal.cpp:266-271): the chain's state must advance only over the surviving frames.  A second client beside it
-    loses none: the two lanes of the chain's kernels (lane = slot) walk streams of different lengths in the same wave."""
+    loses none: the two lanes of the chain's kernels (lane = slot) walk streams of different lengths in the same wave.
+    The PCM rows of the dropped frames are zero (either form of the AGC, psdr.h PSDR_OPT_POST_CHAIN_AGC)."""
     import ctypes as C
     from phantomsdr_amd import AudioClient, Context
     from phantomsdr_amd._lib import check
@@ -513,6 +522,7 @@ def test_post_chain_skips_nan_frames():
     ctx = Context(N, False, levels, additional_size=n, audio_fft_size=n, audio_rate=12000,
                   input_format="s16", max_batch=F, max_clients=3)
     try:
+        ctx.set_option(ctx.OPT_POST_CHAIN_AGC, agc_form)
         ctx.set_post_chain(True)
         d = ctx.dev_alloc(raw.nbytes)
         ctx.h2d(d, raw)
@@ -540,6 +550,7 @@ def test_post_chain_skips_nan_frames():
             for f in range(F):
                 if nan[f]:
                     dropped_total += 1
+                    assert not pcm[f].any(), f"batch {b} frame {f}: the PCM row of a dropped frame is zero"
                     continue
                 want = ch.process(audio[f])
                 assert np.array_equal(pcm[f], want), f"batch {b} frame {f}"
@@ -643,6 +654,9 @@ def test_post_chain_pipeline_matches_the_drained_sequence(N, F, nb, sps, every):
         eng = SpectrumEngine(sps, N, False, input_format="s16", max_batch=F, max_clients=12, audio_sps=12000)
         try:
             assert eng.params["audio_fft_size"] == 360
+            # (the drained reference in the five-kernel form of the AGC, the piped run in the default one: chunk maxima + one
+            # kernel - two schedules AND two forms, one set of bits)
+            eng.ctx.set_option(eng.ctx.OPT_POST_CHAIN_AGC, 0 if drained else 1)
             eng.ctx.set_post_chain(True)
             cl = [eng.add_audio_client(1000 + 3000 * i, 1000 + 3000 * i + (0 if m == "USB" else 120), 1000 + 3000 * i + 240, m)
                   for i, m in enumerate(["USB", "LSB", "AM", "FM"] * 3)]
@@ -671,3 +685,92 @@ def test_post_chain_pipeline_matches_the_drained_sequence(N, F, nb, sps, every):
             assert np.array_equal(pcm, rp), f"batch {b} client {ci} pcm"
             assert np.array_equal(audio.view(np.uint32), ra.view(np.uint32)) and np.array_equal(nan, rn)
     assert any(np.abs(c[0]).max() > 0 for c in got[nb - 1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nclients,F,n", [(40, 7, 360), (90, 5, 248), (5, 33, 360)])
+def test_post_chain_agc_forms_agree_under_churn(nclients, F, n):
+    """The two forms of the post chain's AGC (psdr.h PSDR_OPT_POST_CHAIN_AGC: chunk maxima + one four-wave kernel / the five
+    kernels) on the same batches with everything that makes the lanes of a work-group differ: clients that join late (a
+    look-ahead buffer still filling), pause for a batch (an empty stream, state frozen), change mode (AGC reset), leave (the
+    slot re-used by a new client), frames dropped by the NaN guard (streams of different lengths inside one wave: 7 frames of
+    180 samples end inside a 16-sample chunk), 40 / 90 clients = more than one work-group of 32 slots.  PCM bit for bit
+    between the forms in every batch, and against the oracle's chain for the clients that are never paused or poisoned."""
+    import ctypes as C
+    from phantomsdr_amd import AudioClient, Context
+    from phantomsdr_amd._lib import check
+    N, nb = 1 << 14, 7
+    levels = levels_for(N)
+    x = synth_stream((nb * F + 1) * (N // 2), False, seed=91, fft_size=N)
+    raw = quantize_raw(x, "s16", False)
+    modes = ("USB", "LSB", "AM", "FM")
+
+    def run(form):
+        rng = np.random.default_rng(5)
+        ctx = Context(N, False, levels, additional_size=n, audio_fft_size=n, audio_rate=12000, input_format="s16", max_batch=F,
+                      max_clients=nclients + 2)
+        out, audio_out = [], []
+        try:
+            ctx.set_option(ctx.OPT_POST_CHAIN_AGC, form)
+            ctx.set_post_chain(True)
+            d = ctx.dev_alloc(raw.nbytes)
+            ctx.h2d(d, raw)
+            hb = ctx.half_frame_bytes()
+
+            def add(i):
+                g = AudioClient(ctx)
+                mode = modes[i % 4]
+                m = int(rng.integers(400, N - 400))
+                l, r = (m, m + 100) if mode == "USB" else (m - 100, m) if mode == "LSB" else (m - 100, m + 100)
+                g.set_audio_demodulation(mode)
+                g.set_audio_range(l, float(m), r)
+                g.centre = m
+                return g
+            cl = [add(i) for i in range(nclients - nclients // 4)]  # a quarter joins later
+            for b in range(nb):
+                if b == 2:
+                    cl += [add(100 + i) for i in range(nclients // 4)]
+                if b == 3:
+                    for g in cl[1::5]:
+                        g.set_paused(True)
+                    cl[2].set_audio_demodulation("AM" if cl[2].demodulation < 2 else "USB")
+                if b == 4:
+                    for g in cl[1::5]:
+                        g.set_paused(False)
+                    cl[3].on_close()
+                    cl[3] = add(200)
+                ctx.process_batch(d, F, offset_bytes=b * F * hb)
+                if b in (1, 5):  # NaN into the slice of client 0 in two frames: dropped by the NaN guard
+                    p, nbytes = C.c_void_p(), C.c_size_t()
+                    check(ctx.lib.psdr_spectrum_device_ptr(ctx.h, 0, C.byref(p), C.byref(nbytes)))
+                    ctx.synchronize()
+                    for f in (1, F - 1):
+                        k = cl[0].centre + 20  # (client 0 is USB: its slice is [centre, centre + 100))
+                        ctx.h2d(p, np.full(2, np.nan, np.float32), offset=(f * N + k) * 8)
+                ctx.demod_batch(b * F)
+                out.append([g.read_pcm(F).copy() for g in cl])
+                audio_out.append([tuple(np.asarray(v).copy() for v in g.read_audio(F)) for g in cl])
+            ctx.dev_free(d)
+        finally:
+            ctx.close()
+        return out, audio_out
+    (one, audio), (five, _) = run(1), run(0)
+    dropped = 0
+    for b in range(nb):
+        assert len(one[b]) == len(five[b])
+        for ci, (p1, p5) in enumerate(zip(one[b], five[b])):
+            assert np.array_equal(p1, p5), f"batch {b} client {ci}: {np.count_nonzero(p1 != p5)} samples differ between the forms"
+        dropped += int(audio[b][0][2].sum())
+    assert dropped >= 2, "the NaN guard dropped nothing: the test did not exercise streams of different lengths"
+    # against the oracle: clients that are never paused, poisoned, re-moded or replaced (indices 5.. that are not 1 mod 5)
+    for ci in [i for i in range(5, len(one[0])) if i % 5 != 1][:6]:
+        ch = O.PostChain(12000)
+        opened = 0
+        for b in range(nb):
+            a, _, nan = audio[b][ci]
+            assert not nan.any()
+            for f in range(F):
+                want = ch.process(a[f])
+                assert np.array_equal(one[b][ci][f], want), f"client {ci} batch {b} frame {f} against the oracle"
+                opened += int(np.count_nonzero(want))
+        assert opened > 0
