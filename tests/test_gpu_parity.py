@@ -748,8 +748,9 @@ def test_post_chain_agc_forms_agree_under_churn(nclients, F, n):
                         k = cl[0].centre + 20  # (client 0 is USB: its slice is [centre, centre + 100))
                         ctx.h2d(p, np.full(2, np.nan, np.float32), offset=(f * N + k) * 8)
                 ctx.demod_batch(b * F)
-                out.append([g.read_pcm(F).copy() for g in cl])
-                audio_out.append([tuple(np.asarray(v).copy() for v in g.read_audio(F)) for g in cl])
+                sits_out = set(range(1, len(cl), 5)) if b == 3 else set()  # (a paused client has no results to read in that batch)
+                out.append([None if i in sits_out else g.read_pcm(F).copy() for i, g in enumerate(cl)])
+                audio_out.append([None if i in sits_out else tuple(np.asarray(v).copy() for v in g.read_audio(F)) for i, g in enumerate(cl)])
             ctx.dev_free(d)
         finally:
             ctx.close()
@@ -759,6 +760,8 @@ def test_post_chain_agc_forms_agree_under_churn(nclients, F, n):
     for b in range(nb):
         assert len(one[b]) == len(five[b])
         for ci, (p1, p5) in enumerate(zip(one[b], five[b])):
+            if p1 is None:
+                continue
             assert np.array_equal(p1, p5), f"batch {b} client {ci}: {np.count_nonzero(p1 != p5)} samples differ between the forms"
         dropped += int(audio[b][0][2].sum())
     assert dropped >= 2, "the NaN guard dropped nothing: the test did not exercise streams of different lengths"

@@ -32,6 +32,8 @@ sps = 70_000_000 if args.real else 35_000_000
 eng = SpectrumEngine(sps, N, args.real, input_format="s16", max_batch=F, max_clients=max(args.clients, 1),
                      max_waterfall_clients=4, audio_sps=args.audio_sps)
 if args.post:
+    if os.environ.get("PSDR_BENCH_AGC_FORM") is not None:  # (A/B of the chain's two AGC forms: psdr.h PSDR_OPT_POST_CHAIN_AGC)
+        eng.ctx.set_option(eng.ctx.OPT_POST_CHAIN_AGC, int(os.environ["PSDR_BENCH_AGC_FORM"]))
     eng.ctx.set_post_chain(True)
 hb = eng.ctx.half_frame_bytes()
 nb = max(1, (args.ring_mib << 20) // (hb * F))
