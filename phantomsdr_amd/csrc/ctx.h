@@ -255,6 +255,7 @@ struct psdr_ctx {
     // the AGC in one kernel behind chunk maxima (postchain.h k_pc_cm / k_pc_cscan / k_pc_agc): per set like P / S
     float *post_cm[PC_SETS] = {}, *post_cp[PC_SETS] = {}, *post_cs[PC_SETS] = {};
     int *post_falive[PC_SETS] = {};
+    bool post_direct = false;  // the last chain batch's moving averages read d_audio themselves (k_pc_ma2 DIRECT)
     bool post_agc_ok = false;  // the rate / audio size allow it (L % 16 == 0, h % 4 == 0, h >= 16, D % 4 == 0)
     uint64_t chain_seq = 0;
     bool chain_pending = false;

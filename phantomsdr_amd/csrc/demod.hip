@@ -167,6 +167,11 @@ static int demod_impl(psdr_ctx *c, const cf *spec, size_t spec_stride, int nfram
         int rc = fetch_guard_wait(c, c->side, c->guard_audio[c->out_set]);
         if (rc) return rc;
         c->guard_audio[c->out_set] = nullptr;
+        // ... and the post chain's moving averages of that batch, which read its audio rows themselves (postchain.h k_pc_ma2
+        // DIRECT) on a stream of their own, up to two steps behind the passes (psdr_set_post_chain drains: the chain has
+        // been on for every batch since chain_seq started to count)
+        if (c->post_on && c->post_direct && c->chain_seq >= 2 && c->pc_s[0] && c->side != c->stream)
+            HIPCHK(hipStreamWaitEvent(c->side, c->ev_pc[1][(c->chain_seq - 2) % psdr_ctx::PC_SETS], 0));
     }
     HIPCHK(hipMemcpyAsync(d_clients, h_clients, c->post_on ? S * (sizeof(ClientParams) + sizeof(int)) : (size_t)nact * sizeof(ClientParams),
                           hipMemcpyHostToDevice, c->side));

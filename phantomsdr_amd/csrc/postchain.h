@@ -71,6 +71,11 @@ __device__ __forceinline__ int pc_mul24(int x, int y) {
     return p;
 }
 
+// may a slot's new samples be read from the demodulator's rows as they lie (k_pc_ma2 DIRECT)?  Its stream is the whole batch
+// (nothing dropped, not paused) and at least as long as the DC delay (k_pc_history takes the next history from the same rows);
+// a slot without a stream does not care.  k_pc_ma2, k_pc_gather4 and k_pc_history decide from this one predicate.
+__device__ __forceinline__ bool pc_direct_ok(bool listed, int T, int Tfull, int D) { return !listed || T == 0 || (T == Tfull && T >= D); }
+
 template <int I, int N, typename F>
 __device__ __forceinline__ void pc_static_for(F &&f) {
     if constexpr (I < N) {
@@ -119,7 +124,16 @@ __global__ __launch_bounds__(256) void k_pc_gather(PostArgs a) {
 typedef int pc_i4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_pc_gather4(PostArgs a) {
     const int slot = blockIdx.x * 64 + (threadIdx.x & 63), f = blockIdx.y;
-    if (slot >= a.slots || a.slot_ci[slot] < 0) return;
+    const bool listed = slot < a.slots && a.slot_ci[slot] >= 0;
+    if (a.direct) {
+        // the slots of a k_pc_ma2 work-group (a.lanes consecutive ones) whose streams are all the demodulator's rows as they
+        // lie: the moving averages read a.audio themselves (k_pc_ma2 DIRECT) - nothing to gather
+        const unsigned long long ok = __ballot(pc_direct_ok(listed, listed ? a.len[slot] : 0, a.nframes * a.h, a.D));
+        const int first = (int)(threadIdx.x & 63) & ~(a.lanes - 1);
+        const unsigned long long grp = a.lanes == 64 ? ~0ull : (((1ull << a.lanes) - 1ull) << first);
+        if ((ok & grp) == grp) return;
+    }
+    if (!listed) return;
     const int pos = a.fstart[(size_t)slot * a.max_batch + f];
     if (pos < 0) return;
     const pc_f4 *src = reinterpret_cast<const pc_f4 *>(a.audio + ((size_t)slot * a.max_batch + f) * a.h);
@@ -198,11 +212,20 @@ __global__ __launch_bounds__(128) void k_pc_ma2(PostArgs a) {
     int nmax = nfull;
 #pragma unroll
     for (int d = 32; d; d >>= 1) nmax = max(nmax, __shfl_xor(nmax, d, 64));
+    // DIRECT (round 6, a.direct): when every stream of the work-group is the demodulator's rows as they lie - no frame dropped,
+    // nobody paused in mid-batch - the new samples are read from a.audio itself and k_pc_gather4 leaves the work-group's X
+    // rows alone (it takes the same decision from the same numbers): a pass of 4 bytes per sample written and one read less,
+    // of the fifteen the chain cost the step by (profiles/r06_post_chain_ablation.json).  A lane's 16-byte pieces then lie
+    // max_batch * h floats apart - a load touches a.lanes lines instead of a.lanes / 8 - but each line serves eight of them
+    // in a row, and the loader wave has the time.
+    const bool direct = a.direct && __all(pc_direct_ok(listed, T, a.nframes * a.h, D));
     if (lane >= a.lanes) return;  // (the wave goes on, barriers included, with the lanes that own a slot)
     float *__restrict__ X = a.X + pc_base(slot, a.px);
     float *__restrict__ M1 = a.M1 + pc_base(slot, a.px);
     float *__restrict__ M1n = a.M1n + pc_base(slot, a.px);
     float *__restrict__ V1 = a.V1 + pc_base(slot, a.pv);
+    const float *__restrict__ aud = a.audio + (size_t)min(slot, a.slots - 1) * a.max_batch * a.h;
+    auto xrow = [&](int r) -> float { return (direct && r >= D) ? aud[r - D] : X[pc_el(r)]; };  // row r of the stream: D history rows, then the samples
     const float rD = 1.0f / 32.0f, nrD = -rD;
     if (wid == 0) {
         // ---- wave 0: s1_t = (s1 - x_{t-32}) + x_t
@@ -216,13 +239,18 @@ __global__ __launch_bounds__(128) void k_pc_ma2(PostArgs a) {
             xr[RING - 2][q] = *pc_row4(X, q);      // block -2
             xr[RING - 1][q] = *pc_row4(X, 4 + q);  // block -1
         }
+        // block blk of the new samples: base + blk * bstep floats, its four row groups qstep floats apart (X: lane-interleaved;
+        // direct: the slot's audio rows, blocks past the slot's own rows clamped - X has its padding for that)
+        const float *fbase = direct ? aud : X + (size_t)(D >> 2) * 256;
+        const int bstep = direct ? KB : 4 * 256, qstep = direct ? 4 : 256;
+        const int blast = direct ? (a.max_batch * a.h) / KB - 1 : 0x7fffffff;
         auto fetch = [&](auto kc, int blk) {
             constexpr int k = decltype(kc)::value;
             // UNCONDITIONAL: a load under an exec mask makes the compiler wait with vmcnt(0) at the top of every block.
             // Blocks up to nmax + AHEAD are read: inside the pitch's PC_PAD floats of padding, values never used.
-            const pc_f4 *src = pc_row4(X, (D + blk * KB) >> 2);
+            const float *src = fbase + (size_t)min(blk, blast) * bstep;
 #pragma unroll
-            for (int q = 0; q < 4; q++) xr[k][q] = src[q * 64];
+            for (int q = 0; q < 4; q++) xr[k][q] = *reinterpret_cast<const pc_f4 *>(src + q * qstep);
         };
         pc_f4 sv[4] = {};
         auto block = [&](auto jc, int b) {
@@ -344,11 +372,11 @@ __global__ __launch_bounds__(128) void k_pc_ma2(PostArgs a) {
     }
     const int v0 = a.vo + a.L - 1;
     for (int t = t1; t < T; t++) {
-        s1 = __fadd_rn(__fadd_rn(s1, -X[pc_el(t)]), X[pc_el(D + t)]);
+        s1 = __fadd_rn(__fadd_rn(s1, -xrow(t)), xrow(D + t));
         const float m1 = __fmul_rn(s1, rD);
         s2 = __fadd_rn(__fadd_rn(s2, -M1[pc_el(t)]), m1);
         M1[pc_el(D + t)] = m1;
-        V1[pc_el(v0 + t)] = __fsub_rn(X[pc_el(t + 1)], __fmul_rn(s2, rD));
+        V1[pc_el(v0 + t)] = __fsub_rn(xrow(t + 1), __fmul_rn(s2, rD));
     }
     // the last 32 m1 values in time order become rows 0..31 of the NEXT set (X's own history is moved by k_pc_history)
 #pragma unroll
@@ -822,8 +850,12 @@ __global__ __launch_bounds__(256) void k_pc_history(PostArgs a) {
     const int T = a.len[slot];
     const float *x = a.X + pc_base(slot, a.px), *m = a.M1 + pc_base(slot, a.px), *v = a.V1 + pc_base(slot, a.pv);
     float *xn = a.Xn + pc_base(slot, a.px), *mn = a.M1n + pc_base(slot, a.px), *vn = a.V1n + pc_base(slot, a.pv);
+    // (k_pc_ma2 DIRECT: a stream that is the demodulator's rows as they lie may never have been gathered into X - its last D
+    // samples are the last D of those rows; T >= D then, pc_direct_ok)
+    const bool from_audio = a.direct && T > 0 && pc_direct_ok(true, T, a.nframes * a.h, a.D);
+    const float *aud = a.audio + (size_t)slot * a.max_batch * a.h;
     for (int r = threadIdx.x; r < a.D; r += blockDim.x) {
-        xn[pc_el(r)] = x[pc_el(r + T)];
+        xn[pc_el(r)] = from_audio ? aud[T - a.D + r] : x[pc_el(r + T)];
         if (!a.ma_fused) mn[pc_el(r)] = m[pc_el(r + T)];
     }
     for (int r = threadIdx.x; r < a.L - 1; r += blockDim.x) vn[pc_el(a.vo + r)] = v[pc_el(a.vo + r + T)];

@@ -370,6 +370,11 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
     pa.CM = c->post_cm[set], pa.CP = c->post_cp[set], pa.CS = c->post_cs[set];
     pa.falive = c->post_falive[set];
     pa.ma_fused = pa.D == 32 ? 1 : 0;  // both averages in one loop (postchain.h)
+    // ... which may read the demodulator's rows themselves instead of a gathered copy (k_pc_ma2 DIRECT; part of the round-6
+    // form of the chain, PSDR_OPT_POST_CHAIN_AGC = 1; the demodulation two batches on waits for this batch's stage 1: demod.hip)
+    pa.direct = (pa.ma_fused && rows4 && c->opt_pc_agc != 0) ? 1 : 0;
+    if (const char *e = psdr_tuning_env("PSDR_PC_DIRECT")) pa.direct = pa.direct && atoi(e) != 0;  // (tuning build)
+    c->post_direct = pa.direct != 0;
     const int nall = nact + npaused;
     const unsigned groups = (unsigned)((pa.slots + 63) / 64);
     pa.lanes = c->post_lanes;

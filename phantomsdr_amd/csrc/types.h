@@ -58,6 +58,7 @@ struct PostArgs {
     int nch;
     int *falive;          // [groups][max_batch][64] the k-th surviving frame of a slot's stream (k_pc_index)
     unsigned h_magic;     // ceil(2^32 / h): stream position / h by one multiplication
+    int direct;           // k_pc_ma2 may read a work-group's new samples from `audio` itself (k_pc_gather4 then skips it)
     int32_t *pcm_dump;    // 16 bytes per thread of a k_pc_agc work-group: where its unconditional stores of row groups without a sample go
 };
 
