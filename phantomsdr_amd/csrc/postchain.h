@@ -191,10 +191,15 @@ __global__ __launch_bounds__(64) void k_pc_ma(PostArgs a) {
 // the in-memory history (wave 1).  Lanes of a group may have streams of different lengths (dropped frames, paused
 // clients): the trip count is the group's maximum, a lane past its own end keeps its state.
 constexpr int PC_MA_RING = 12;  // wave 0's register sets of x: blocks b-2 .. b (in use), b+1 .. b+9 in flight
-template <bool OWN>
-__global__ __launch_bounds__(128) void k_pc_ma2(PostArgs a) {
+// CMW (round 6, with the one-kernel AGC): a THIRD wave takes the blocks of output from wave 1 through LDS, stores them and
+// leaves the maximum of |V1| over each 16-sample block as CM[L/16 + b] - the chunk maxima k_pc_agc's look-ahead peak is made
+// of, without another pass over V1 (k_pc_cm then covers the L/16 history chunks only).  Wave 1 swaps four global stores per
+// block for four LDS writes: the same number of instructions in its loop.
+template <bool OWN, bool CMW = false>
+__global__ __launch_bounds__(CMW ? 192 : 128) void k_pc_ma2(PostArgs a) {
     __shared__ pc_f4 hand[2][8][64];  // [buffer][0-3: x of the block, 4-7: s1 of the block][lane]: 16 KiB
     __shared__ float fin[64];         // wave 0's s1 after its last block
+    __shared__ pc_f4 ohand[CMW ? 2 : 1][4][CMW ? 64 : 1];  // CMW: [buffer][row group][lane] a block of output on its way to wave 2
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     // a work-group owns a.lanes (16, 32 or 64) consecutive slots of a group of 64: lane = slot & (a.lanes - 1), the other
     // lanes leave below.  (A recurrence costs the same for 1 lane or 64, but its memory operations do not: 1 KiB loads and
@@ -296,6 +301,34 @@ __global__ __launch_bounds__(128) void k_pc_ma2(PostArgs a) {
         __syncthreads();
         return;
     }
+    if constexpr (CMW) {
+        if (wid == 2) {
+            // ---- wave 2: block b of output from LDS (complete behind the barrier that ends wave 1's block b; wave 1 writes that
+            // buffer again in block b + 2, two barriers on) -> V1, and its maximum -> CM[L/16 + b]
+            const int vq = (a.vo + a.L - 1) >> 2;
+            float *__restrict__ cm = a.CM + ((size_t)(slot >> 6) * a.nch + (size_t)(a.L >> 4)) * 64 + (size_t)(slot & 63);
+            __syncthreads();
+            __syncthreads();
+            __syncthreads();
+            for (int b = 0; b < nmax; b++) {
+                __syncthreads();
+                pc_f4 o[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) o[q] = ohand[b & 1][q][lane];
+                if (b < nfull) {
+                    float m = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        *pc_row4(V1, vq + b * (KB / 4) + q) = o[q];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) m = fmaxf(m, fabsf(o[q][i]));
+                    }
+                    cm[(size_t)b * 64] = m;
+                }
+            }
+            return;
+        }
+    }
     // ---- wave 1: s2_t = (s2 - m1_{t-32}) + m1_t, out_t = x_{t-31} - s2_t / 32, one block behind wave 0
     // m1 = s1 / 32 is exact (a power of two), so rounding (s2 - m1_old) + m1 and x - s2 / 32 after the exact products is the
     // reference's arithmetic with three fused operations instead of five:
@@ -344,7 +377,12 @@ __global__ __launch_bounds__(128) void k_pc_ma2(PostArgs a) {
                 o[i >> 2][i & 3] = __fmaf_rn(s2, nrD, xd);
             }
 #pragma unroll
-            for (int q = 0; q < 4; q++) *pc_row4(V1, vq + b * (KB / 4) + q) = o[q];
+            for (int q = 0; q < 4; q++) {
+                if constexpr (CMW)
+                    ohand[b & 1][q][lane] = o[q];
+                else
+                    *pc_row4(V1, vq + b * (KB / 4) + q) = o[q];
+            }
         }
         __syncthreads();
     };

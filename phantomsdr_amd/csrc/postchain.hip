@@ -349,6 +349,9 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
     // CU each: four waves that own their SIMD - have the CUs the passes leave free
     bool agc_fused = c->post_agc_ok && c->post_own && c->opt_pc_agc != 0 && c->post_lanes <= 32;
     if (const char *e = psdr_tuning_env("PSDR_PC_FUSED")) agc_fused = agc_fused && atoi(e) != 0;  // (tuning build)
+    // ... and the chunk maxima of the new samples from a third wave of the moving averages (k_pc_ma2 CMW) instead of a pass over
+    // V1, while the free CUs hold a three-wave work-group of those beside every four-wave one of the AGC (a CU each)
+    bool ma_cmw = false;  // (set below, once the work-group count is known)
     // this batch's PCM goes to the other of two buffers (the copy of the last batch's to the host may still read its own)
     c->pcm_set ^= 1;
     c->post.pcm = c->pcm_pool[c->pcm_set];
@@ -379,6 +382,8 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
     const unsigned groups = (unsigned)((pa.slots + 63) / 64);
     pa.lanes = c->post_lanes;
     const unsigned rgroups = groups * (unsigned)(64 / pa.lanes);  // work-groups of each of the two recurrence kernels
+    ma_cmw = agc_fused && pa.D == 32 && 2 * (int)rgroups <= c->post_reserve;
+    if (const char *e = psdr_tuning_env("PSDR_PC_CMW")) ma_cmw = ma_cmw && atoi(e) != 0;  // (tuning build)
     if (rgroups > 16 || c->post_own) home_lds = 0;  // (waves that own a SIMD fit nowhere else anyway)
     const size_t Tb = (size_t)nframes * pa.h;  // longest possible stream of this batch
     const unsigned nblk = (unsigned)((pa.L - 1 + Tb + pa.L - 1) / pa.L);
@@ -420,6 +425,8 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
         if (seq >= NS - 1 && (rc = wait(sm, 3, nxt))) return rc;
         ProfScope ps(c, K_POST, sm);
         if (skip & 2) {
+        } else if (pa.ma_fused && ma_cmw) {
+            hipLaunchKernelGGL((k_pc_ma2<true, true>), dim3(rgroups), dim3(192), 0, sm, pa);
         } else if (pa.ma_fused) {
             if (c->post_own)
                 hipLaunchKernelGGL(k_pc_ma2<true>, dim3(rgroups), dim3(128), 0, sm, pa);
@@ -452,7 +459,8 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
         const int W = pa.L / 16 - 1;
         {
             ProfScope ps(c, K_POST, sm);
-            if (!(skip & 8)) hipLaunchKernelGGL(k_pc_cm, dim3(groups, (nchunks + 15) / 16), dim3(64), 0, sm, pa, nchunks);
+            const int ncm = ma_cmw ? pa.L / 16 : nchunks;  // (k_pc_ma2 CMW left the new samples' chunk maxima: the history chunks only)
+            if (!(skip & 8)) hipLaunchKernelGGL(k_pc_cm, dim3(groups, (ncm + 15) / 16), dim3(64), 0, sm, pa, ncm);
             if (!(skip & 16)) hipLaunchKernelGGL(k_pc_cscan, dim3(groups, (nchunks + W - 1) / W), dim3(64), 0, sm, pa, nchunks, W);
             HIPCHK(hipGetLastError());
         }

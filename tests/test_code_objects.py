@@ -25,7 +25,7 @@ def test_recurrence_waves_of_the_post_chain_own_their_simd(meta):
     """PC_OWN_SIMD() (postchain.h) names v255 / a255 so that the kernel's allocation is a SIMD lane's whole register file:
     512 registers, nothing else fits on the SIMD.  If a compiler stops honouring the clobber the
     kernels still run - beside other waves, slower - and nothing else would notice."""
-    for name in ("psdr::k_pc_ma2<true>", "psdr::k_pc_mad<true>", "psdr::k_pc_gain<false, true>", "psdr::k_pc_gain<true, true>",
+    for name in ("psdr::k_pc_ma2<true, false>", "psdr::k_pc_ma2<true, true>", "psdr::k_pc_mad<true>", "psdr::k_pc_gain<false, true>", "psdr::k_pc_gain<true, true>",
                  "psdr::k_pc_agc<true>", "psdr::k_pc_agc<false>"):
         for k, v in _find(meta, name).items():
             assert v["vgpr"] == 512 and v["agpr"] == 256, (k, v)
@@ -33,8 +33,11 @@ def test_recurrence_waves_of_the_post_chain_own_their_simd(meta):
     # register sets is what the three rounds of prefetch live in)
     for k, v in _find(meta, "psdr::k_pc_agc<").items():
         assert v["wg"] == 256 and v["scratch"] == 0 and v["lds"] <= 80 * 1024, (k, v)
+    # the moving averages with their third wave (block maxima for that kernel): three SIMDs of a CU
+    for k, v in _find(meta, "psdr::k_pc_ma2<true, true>").items():
+        assert v["wg"] == 192 and v["scratch"] == 0, (k, v)
     # ... and the plain forms do NOT (they are the ones that share a CU with a pass when no CU is left free)
-    for name in ("psdr::k_pc_ma2<false>", "psdr::k_pc_gain<false, false>", "psdr::k_pc_gain<true, false>"):
+    for name in ("psdr::k_pc_ma2<false, false>", "psdr::k_pc_gain<false, false>", "psdr::k_pc_gain<true, false>"):
         for k, v in _find(meta, name).items():
             assert v["vgpr"] <= 256 and v["agpr"] == 0, (k, v)
 
