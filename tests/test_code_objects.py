@@ -63,3 +63,7 @@ def test_demodulation_chain_kernels_fit_beside_a_pass(meta):
     are taken): at most 128 registers, no scratch."""
     for k, v in _find(meta, "psdr::k_demod_chain_fixed<").items():
         assert v["vgpr"] <= 128 and v["scratch"] == 0, (k, v)
+    # n = 360 (the 12 kHz audio of every BASELINE shape): the 80 registers per SIMD lane that cfg2's second pass and the PAIR first
+    # passes leave (DESIGN.md 3.5) - allocated in eights, so 81 would be 88 and the kernel would wait for a CU without a pass
+    for k, v in _find(meta, "psdr::k_demod_chain_fixed<360").items():
+        assert v["vgpr"] <= 80, (k, v)
