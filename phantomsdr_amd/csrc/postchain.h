@@ -36,6 +36,13 @@
 //                 w_t = desired / (peak_t + 1e-10)
 //   k_pc_gain     the gain recurrence                              (sequential)
 //   k_pc_out      delayed sample * gain, int16 conversion, straight into pcm[slot][frame][j]
+// Round 6 (PSDR_OPT_POST_CHAIN_AGC = 1, the default; what the chain costs the step is its memory traffic - see the end of
+// this file): k_pc_submax / _prefix / _want / _gain / _out become
+//   k_pc_cm / k_pc_cscan   maxima of |V1| per chunk of 16 floats and their block scans (history chunks only when the moving
+//                 averages leave the maxima of the new samples on their way: k_pc_ma2 CMW)
+//   k_pc_agc      look-ahead peak, w_t, the gain recurrence and the int16 output in ONE four-wave kernel
+//   k_pc_zero     zero rows for dropped frames
+// and k_pc_ma2 reads the demodulator's rows itself where a work-group's streams are whole (DIRECT: no k_pc_gather4 for it).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
