@@ -517,6 +517,18 @@ def with_fetch_measure(run, eng, params, wl, F, N, nclients, plain_ms, post):
             out["post_chain_pcm"] = block(reps(what, 50, 5, warm=6, lag=3), post.get("ms_per_step_50_step_repetitions") or post["ms_per_step"], alone(what))
             out["post_chain_pcm"]["host_lag_batches"] = 3
             out["post_chain_pcm"]["step_without_fetch_is"] = "post_chain.ms_per_step_50_step_repetitions (the same repetition length)"
+            # the same with the PCM as int16 rows (psdr.h PSDR_OPT_POST_CHAIN_PCM16): half the bytes to the host - with hundreds of
+            # clients the copy is what bounds this path
+            try:
+                ctx.set_option(ctx.OPT_POST_CHAIN_PCM16, 1)
+                d2h_full = d2h
+                d2h = nclients * F * (h * 2 + 8) + wf_bytes
+                out["post_chain_pcm16"] = block(reps(what, 50, 5, warm=6, lag=3), post.get("ms_per_step_50_step_repetitions") or post["ms_per_step"], alone(what))
+                out["post_chain_pcm16"]["host_lag_batches"] = 3
+                out["post_chain_pcm16"]["note"] = "PSDR_OPT_POST_CHAIN_PCM16 = 1: int16 PCM rows (the reference's int32 buffer holds 16-bit values)"
+                d2h = d2h_full
+            finally:
+                ctx.set_option(ctx.OPT_POST_CHAIN_PCM16, 0)
             ctx.set_post_chain(False)
     except Exception as e:
         out["error"] = repr(e)

@@ -240,6 +240,9 @@ int psdr_fetched_audio(psdr_ctx *ctx, int id, int frame, const float **audio, fl
 #define PSDR_FETCH_WATERFALL 4u
 int psdr_fetch_begin(psdr_ctx *ctx, unsigned what);
 int psdr_fetch_end(psdr_ctx *ctx);
+/* one frame's PCM row (audio_fft_size/2 int16) of client `id` in the fetched set when the batch was produced with
+ * PSDR_OPT_POST_CHAIN_PCM16 = 1 (PSDR_ERR_STATE otherwise); pointer into pinned host memory, valid like psdr_fetched_audio's */
+int psdr_fetched_pcm16(psdr_ctx *ctx, int id, int frame, const int16_t **pcm);
 /* rows [nsent][r - l] of waterfall client `id` in the fetched set (pointer into pinned host memory, valid like
  * psdr_fetched_audio's), with the level and window they were GATHERED with.  PSDR_ERR_NO_DATA: the client was not
  * active in that batch.  Any output pointer may be NULL. */
@@ -271,8 +274,13 @@ int psdr_set_post_chain(psdr_ctx *ctx, int enable);
  * PSDR_OPT_POST_CHAIN_AGC (any time; drains the context): the form of the chain's AGC.  1 (default): maxima of 16-sample
  *   chunks + ONE four-wave kernel for look-ahead peak, gain recurrence and int16 conversion - a third of the memory
  *   traffic of the other form - whenever the audio rate is a multiple of 80 Hz, the audio size a
- *   multiple of 8 and the CUs the chain reserves hold its work-groups; 0: always the five-kernel form.  Same bits. */
-enum { PSDR_OPT_POST_CHAIN_STREAMS = 1, PSDR_OPT_POST_CHAIN_AGC = 2 };
+ *   multiple of 8 and the CUs the chain reserves hold its work-groups; 0: always the five-kernel form.  Same bits.
+ * PSDR_OPT_POST_CHAIN_PCM16 (any time; drains the context): 1 = the chain writes its PCM as int16 rows instead of the int32
+ *   buffer the reference hands its encoder (dsp_float_to_int16's output, src/utils/dsp.cpp:152-165, holds 16-bit values):
+ *   half the bytes for psdr_fetch_begin(PSDR_FETCH_PCM) to move - with hundreds of clients the copy to the host is what
+ *   bounds the served path.  psdr_fetched_pcm16 hands the rows out; psdr_fetched_audio's pcm is NULL for
+ *   such a batch; psdr_read_pcm still delivers int32 (widened on the host).  0 (default): int32 rows. */
+enum { PSDR_OPT_POST_CHAIN_STREAMS = 1, PSDR_OPT_POST_CHAIN_AGC = 2, PSDR_OPT_POST_CHAIN_PCM16 = 3 };
 int psdr_set_option(psdr_ctx *ctx, int option, int value);
 /* pcm: [frames of the last demod_batch][audio_fft_size/2]; nframes = rows pcm holds (as psdr_read_audio) */
 int psdr_read_pcm(psdr_ctx *ctx, int id, int nframes, int32_t *pcm, int *nframes_out);

@@ -98,6 +98,7 @@ SYMBOLS = [
     ("psdr_fetched_window", _i, [_vp, _i, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     ("psdr_abi_version", _i, []),
     ("psdr_fetch_begin", _i, [_vp, C.c_uint]),
+    ("psdr_fetched_pcm16", _i, [_vp, _i, _i, C.POINTER(C.POINTER(C.c_int16))]),
     ("psdr_fetch_end", _i, [_vp]),
     ("psdr_fetched_waterfall", _i, [_vp, _i, C.POINTER(C.POINTER(C.c_int8)), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     ("psdr_get_kernel_samples", _i, [_vp, C.c_char_p, C.POINTER(C.c_double), _i, C.POINTER(_i)]),

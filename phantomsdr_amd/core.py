@@ -151,6 +151,7 @@ class Context:
         self.last_nframes = nframes
 
     OPT_POST_CHAIN_STREAMS = 1
+    OPT_POST_CHAIN_PCM16 = 3  # 1: the chain's PCM as int16 rows (half the bytes to the host; fetched_pcm16), 0 (default): int32 rows
     OPT_POST_CHAIN_AGC = 2  # 1 (default): chunk maxima + one kernel for the AGC where the rate allows it; 0: the five-kernel form
 
     def set_option(self, option, value):
@@ -194,6 +195,12 @@ class Context:
         if not pcm:
             return au, pw.value, nan.value
         return au, pw.value, nan.value, (np.ctypeslib.as_array(pc, shape=(h,)).copy() if pc else None)
+
+    def fetched_pcm16(self, cid, frame):
+        """the int16 PCM row [n/2] (copy) of one frame of the fetched batch (OPT_POST_CHAIN_PCM16 = 1)"""
+        pc = C.POINTER(C.c_int16)()
+        check(self.lib.psdr_fetched_pcm16(self.h, int(cid), int(frame), C.byref(pc)))
+        return np.ctypeslib.as_array(pc, shape=(self.cfg.audio_fft_size // 2,)).copy()
 
     def fetched_waterfall(self, wid):
         """(rows [nsent][r - l] copy, level, l, r) of a waterfall client in the fetched batch"""

@@ -236,6 +236,8 @@ struct psdr_ctx {
     bool post_on = false;
     bool post_ready = false;   // the chain's buffers, events and streams exist (psdr_set_post_chain's one-time set-up went through)
     int opt_pc_streams = 0;    // PSDR_OPT_POST_CHAIN_STREAMS: 0 = creation order (deterministic), 1 = chosen by measurement
+    int opt_pc_pcm16 = 0;      // PSDR_OPT_POST_CHAIN_PCM16: the chain's PCM as int16 rows (half the bytes to the host)
+    bool pcm_is16 = false;     // ... of the last chain batch (what a fetch / psdr_read_pcm finds in the PCM buffer)
     int opt_pc_agc = 1;        // PSDR_OPT_POST_CHAIN_AGC: 1 = chunk maxima + k_pc_agc where it applies, 0 = the five-kernel form
     PostArgs post{};
     // The chain is a pipeline across batches (round 5), in the order of a batch's data:
@@ -289,6 +291,7 @@ struct psdr_ctx {
         hipEvent_t done = nullptr;       // every copy of the fetch on the first copy stream has landed
         hipEvent_t ev_pcm = nullptr;     // ... and the PCM (its own copy stream: it waits for the post chain, up to two steps late)
         bool has_pcm = false;
+        bool pcm16 = false;              // its PCM rows are int16 (PSDR_OPT_POST_CHAIN_PCM16 at that batch)
         hipEvent_t ev_wf = nullptr;      // ... the waterfall rows (first in the copy stream: d_wfout exists once)
         hipEvent_t ev_audio = nullptr;   // ... pwr, NaN flags, float audio (what the demodulation of batch b + 2 overwrites)
         bool inflight = false;

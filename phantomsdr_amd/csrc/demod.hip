@@ -410,11 +410,13 @@ extern "C" int psdr_fetch_begin(psdr_ctx *c, unsigned what) {
         HIPCHK(hipStreamWaitEvent(fsp, c->ev_fetch_src, 0));
         if (c->chain_seq > 0 && c->pc_s[0] && c->side != c->stream)
             HIPCHK(hipStreamWaitEvent(fsp, c->ev_pc[3][(c->chain_seq - 1) % psdr_ctx::PC_SETS], 0));
+        // (PSDR_OPT_POST_CHAIN_PCM16: the rows are int16 - the same buffers, half the bytes)
+        const size_t sb = c->pcm_is16 ? sizeof(int16_t) : sizeof(int32_t);
+        fs.pcm16 = c->pcm_is16;
         if (F == mb)
-            HIPCHK(hipMemcpyAsync(fs.pcm, c->post.pcm, S * mb * h * sizeof(int32_t), hipMemcpyDeviceToHost, fsp));
+            HIPCHK(hipMemcpyAsync(fs.pcm, c->post.pcm, S * mb * h * sb, hipMemcpyDeviceToHost, fsp));
         else
-            HIPCHK(hipMemcpy2DAsync(fs.pcm, mb * h * sizeof(int32_t), c->post.pcm, mb * h * sizeof(int32_t), F * h * sizeof(int32_t), S,
-                                    hipMemcpyDeviceToHost, fsp));
+            HIPCHK(hipMemcpy2DAsync(fs.pcm, mb * h * sb, c->post.pcm, mb * h * sb, F * h * sb, S, hipMemcpyDeviceToHost, fsp));
         HIPCHK(hipEventRecord(fs.ev_pcm, fsp));
         c->guard_pcm[c->pcm_set] = fs.ev_pcm;
         fs.has_pcm = true;
@@ -506,7 +508,25 @@ extern "C" int psdr_fetched_audio(psdr_ctx *c, int id, int frame, const float **
     if (audio) *audio = (fs->what & PSDR_FETCH_AUDIO) ? fs->audio + row * h : nullptr;
     if (pwr) *pwr = fs->pwr[row];
     if (nan_flag) *nan_flag = fs->nan[row];
-    if (pcm) *pcm = (fs->what & PSDR_FETCH_PCM) ? fs->pcm + row * h : nullptr;
+    if (pcm) *pcm = ((fs->what & PSDR_FETCH_PCM) && !fs->pcm16) ? fs->pcm + row * h : nullptr;  // (int16 rows: psdr_fetched_pcm16)
+    return PSDR_OK;
+}
+extern "C" int psdr_fetched_pcm16(psdr_ctx *c, int id, int frame, const int16_t **pcm) {
+    if (!c || !pcm) return fail(PSDR_ERR_INVALID, "null argument");
+    const psdr_ctx::FetchSet *fs = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(c->mtx);
+        int rc = check_slot(c, id);
+        if (rc) return rc;
+        if ((rc = fetched_set(c, &fs))) return rc;
+        if (fs->seq == 0 || !(fs->what & PSDR_FETCH_PCM)) return fail(PSDR_ERR_STATE, "the fetched batch carries no PCM (PSDR_FETCH_PCM)");
+        if (!fs->pcm16) return fail(PSDR_ERR_STATE, "the fetched PCM rows are int32 (PSDR_OPT_POST_CHAIN_PCM16 was 0 for that batch): psdr_fetched_audio");
+        if ((size_t)id >= fs->win.size() || fs->win[id].last_seq != fs->seq || fs->win[id].born != c->aslots[id].born)
+            return fail(PSDR_ERR_NO_DATA, "client %d was not part of the fetched batch", id);
+    }
+    if (frame < 0 || frame >= fs->frames) return fail(PSDR_ERR_INVALID, "frame %d not in the fetched batch of %d", frame, fs->frames);
+    const size_t h = (size_t)c->n / 2, mb = (size_t)c->max_batch, row = (size_t)id * mb + (size_t)frame;
+    *pcm = reinterpret_cast<const int16_t *>(fs->pcm) + row * h;
     return PSDR_OK;
 }
 extern "C" int psdr_fetched_waterfall(psdr_ctx *c, int id, const int8_t **rows, int *nsent_out, int *level_out, int *l_out, int *r_out) {
@@ -543,7 +563,13 @@ extern "C" int psdr_read_pcm(psdr_ctx *c, int id, int nframes, int32_t *pcm, int
         rc = drain(c);
         if (rc) return rc;
     }
-    HIPCHK(hipMemcpy(pcm, c->post.pcm + (size_t)id * mb * h, F * h * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (c->pcm_is16) {  // PSDR_OPT_POST_CHAIN_PCM16: the rows are int16 on the device; this call still delivers the reference's int32 buffer
+        std::vector<int16_t> tmp(F * h);
+        HIPCHK(hipMemcpy(tmp.data(), reinterpret_cast<const int16_t *>(c->post.pcm) + (size_t)id * mb * h, F * h * sizeof(int16_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < F * h; i++) pcm[i] = tmp[i];
+    } else {
+        HIPCHK(hipMemcpy(pcm, c->post.pcm + (size_t)id * mb * h, F * h * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
     if (nframes_out) *nframes_out = (int)F;
     return PSDR_OK;
 }

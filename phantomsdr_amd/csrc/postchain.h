@@ -129,6 +129,11 @@ __global__ __launch_bounds__(256) void k_pc_gather(PostArgs a) {
 // thread (lane, j / 4) - 16 bytes from the client's audio row (64 rows per wave, each line used up over eight turns),
 // one contiguous KiB into X per wave
 typedef int pc_i4 __attribute__((ext_vector_type(4)));
+typedef int pc_i2 __attribute__((ext_vector_type(2)));
+// four clamped samples as int16 (PSDR_OPT_POST_CHAIN_PCM16: half the bytes on their way to the host)
+__device__ __forceinline__ pc_i2 pc_pack16(pc_i4 o) {
+    return pc_i2{(int)(((unsigned)o[0] & 0xffffu) | ((unsigned)o[1] << 16)), (int)(((unsigned)o[2] & 0xffffu) | ((unsigned)o[3] << 16))};
+}
 __global__ __launch_bounds__(256) void k_pc_gather4(PostArgs a) {
     const int slot = blockIdx.x * 64 + (threadIdx.x & 63), f = blockIdx.y;
     const bool listed = slot < a.slots && a.slot_ci[slot] >= 0;
@@ -860,7 +865,10 @@ __global__ __launch_bounds__(256) void k_pc_out(PostArgs a) {
             v = (int)__fmaf_rn(y, 16384.f, 32768.5f) - 32768;
             v = v > 32767 ? 32767 : (v < -32768 ? -32768 : v);
         }
-        dst[j] = v;
+        if (a.pcm16)
+            reinterpret_cast<int16_t *>(a.pcm)[((size_t)slot * a.max_batch + f) * a.h + j] = (int16_t)v;
+        else
+            dst[j] = v;
     }
 }
 
@@ -883,7 +891,10 @@ __global__ __launch_bounds__(256) void k_pc_out4(PostArgs a) {
                 o[i] = v > 32767 ? 32767 : (v < -32768 ? -32768 : v);
             }
         }
-        dst[j4] = o;
+        if (a.pcm16)
+            reinterpret_cast<pc_i2 *>(reinterpret_cast<int16_t *>(a.pcm) + ((size_t)slot * a.max_batch + f) * a.h)[j4] = pc_pack16(o);
+        else
+            dst[j4] = o;
     }
 }
 
@@ -1001,11 +1012,16 @@ __global__ __launch_bounds__(256) void k_pc_zero(PostArgs a) {
     const int slot = blockIdx.x * 64 + (threadIdx.x & 63), f = blockIdx.y;
     if (slot >= a.slots || a.slot_ci[slot] < 0) return;
     if (a.fstart[(size_t)slot * a.max_batch + f] >= 0) return;
+    if (a.pcm16) {
+        pc_i2 *dst = reinterpret_cast<pc_i2 *>(reinterpret_cast<int16_t *>(a.pcm) + ((size_t)slot * a.max_batch + f) * a.h);
+        for (int j4 = threadIdx.x >> 6; j4 < (a.h >> 2); j4 += 4) dst[j4] = pc_i2{0, 0};
+        return;
+    }
     pc_i4 *dst = reinterpret_cast<pc_i4 *>(a.pcm + ((size_t)slot * a.max_batch + f) * a.h);
     for (int j4 = threadIdx.x >> 6; j4 < (a.h >> 2); j4 += 4) dst[j4] = pc_i4{0, 0, 0, 0};
 }
 
-template <bool ATT_FASTER>
+template <bool ATT_FASTER, bool PCM16 = false>
 __global__ __launch_bounds__(64 * (1 + PC_AGC_NP)) void k_pc_agc(PostArgs a) {
     constexpr int NP = PC_AGC_NP, AH = PC_AGC_AHEAD;
     // [buffer][chunk of the round (up to NP * 4)][row group][slot lane] - 16 floats per chunk and slot: NP * 64 * 16 floats per
@@ -1123,8 +1139,10 @@ __global__ __launch_bounds__(64 * (1 + PC_AGC_NP)) void k_pc_agc(PostArgs a) {
     const float *__restrict__ CS = a.CS + cbase;
     const float *__restrict__ CP = a.CP + cbase;
     const int *__restrict__ FA = a.falive + ((size_t)g64 * a.max_batch) * 64 + (size_t)(sl0 + sl);
-    int32_t *__restrict__ pcm = a.pcm + (size_t)min(slot, a.slots - 1) * a.max_batch * a.h;
-    int32_t *dump = a.pcm_dump + 4 * (int)threadIdx.x;
+    // (PCM16: the rows as int16 - the same buffer, half of it; a row group is 8 bytes then)
+    using pcm_t = std::conditional_t<PCM16, int16_t, int32_t>;
+    pcm_t *__restrict__ pcm = reinterpret_cast<pcm_t *>(a.pcm) + (size_t)min(slot, a.slots - 1) * a.max_batch * a.h;
+    pcm_t *dump = reinterpret_cast<pcm_t *>(a.pcm_dump + 4 * (int)threadIdx.x);
     const int kin = p * sub + j;  // the lane's chunk inside a round
     const int h = a.h;
     const unsigned hmagic = a.h_magic;  // ceil(2^32 / h): t / h = umulhi(t, hmagic) for t * h < 2^32
@@ -1214,7 +1232,11 @@ __global__ __launch_bounds__(64 * (1 + PC_AGC_NP)) void k_pc_agc(PostArgs a) {
                 o[i] = v > 32767 ? 32767 : (v < -32768 ? -32768 : v);
             }
             // (an UNCONDITIONAL store: a row group without a sample goes to a dump line of its own - see the timeline below)
-            *reinterpret_cast<pc_i4 *>(dst[P][q] >= 0 ? pcm + dst[P][q] : dump) = o;
+            pcm_t *where = dst[P][q] >= 0 ? pcm + dst[P][q] : dump;
+            if constexpr (PCM16)
+                *reinterpret_cast<pc_i2 *>(where) = pc_pack16(o);
+            else
+                *reinterpret_cast<pc_i4 *>(where) = o;
         }
     };
     // Producer timeline: round rr sits between barriers #rr and #rr+1: fetch(rr + AH), emit(rr - 2) [its gains were written by the

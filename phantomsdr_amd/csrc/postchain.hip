@@ -152,6 +152,14 @@ extern "C" int psdr_set_option(psdr_ctx *c, int option, int value) {
         if (c->post_ready) return fail(PSDR_ERR_STATE, "PSDR_OPT_POST_CHAIN_STREAMS after the post chain was set up");
         c->opt_pc_streams = value;
         return PSDR_OK;
+    case PSDR_OPT_POST_CHAIN_PCM16: {
+        if (value != 0 && value != 1) return fail(PSDR_ERR_INVALID, "PSDR_OPT_POST_CHAIN_PCM16: 0 (int32 rows, the reference's buffer) or 1 (int16 rows), not %d", value);
+        HIPCHK(hipSetDevice(c->device));
+        const int rc = drain(c);
+        if (rc) return rc;
+        c->opt_pc_pcm16 = value;
+        return PSDR_OK;
+    }
     case PSDR_OPT_POST_CHAIN_AGC: {
         if (value != 0 && value != 1) return fail(PSDR_ERR_INVALID, "PSDR_OPT_POST_CHAIN_AGC: 0 (five kernels) or 1 (one kernel behind chunk maxima), not %d", value);
         HIPCHK(hipSetDevice(c->device));
@@ -356,6 +364,8 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
     c->pcm_set ^= 1;
     c->post.pcm = c->pcm_pool[c->pcm_set];
     PostArgs pa = c->post;
+    pa.pcm16 = c->opt_pc_pcm16;
+    c->pcm_is16 = pa.pcm16 != 0;
     pa.audio = c->d_audio;  // (of THIS demodulation batch: the result sets alternate)
     pa.nan_flags = c->d_nan;
     pa.clients = d_clients;
@@ -471,10 +481,17 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
         c->guard_pcm[c->pcm_set] = nullptr;
         if (!(skip & 128)) hipLaunchKernelGGL(k_pc_zero, dim3(groups, nframes), dim3(256), 0, sc, pa);
         if (skip & 64) {
-        } else if (pa.attack >= pa.release)
-            hipLaunchKernelGGL(k_pc_agc<true>, dim3(rgroups), dim3(64 * (1 + PC_AGC_NP)), 0, sc, pa);
-        else
-            hipLaunchKernelGGL(k_pc_agc<false>, dim3(rgroups), dim3(64 * (1 + PC_AGC_NP)), 0, sc, pa);
+        } else if (pa.attack >= pa.release) {
+            if (pa.pcm16)
+                hipLaunchKernelGGL((k_pc_agc<true, true>), dim3(rgroups), dim3(64 * (1 + PC_AGC_NP)), 0, sc, pa);
+            else
+                hipLaunchKernelGGL((k_pc_agc<true, false>), dim3(rgroups), dim3(64 * (1 + PC_AGC_NP)), 0, sc, pa);
+        } else {
+            if (pa.pcm16)
+                hipLaunchKernelGGL((k_pc_agc<false, true>), dim3(rgroups), dim3(64 * (1 + PC_AGC_NP)), 0, sc, pa);
+            else
+                hipLaunchKernelGGL((k_pc_agc<false, false>), dim3(rgroups), dim3(64 * (1 + PC_AGC_NP)), 0, sc, pa);
+        }
         HIPCHK(hipGetLastError());
         if ((rc = done(sc, 3))) return rc;
     } else {

@@ -46,7 +46,8 @@ struct PostArgs {
     float *P, *S;                     // like V1: P = prefix maxima of |V1| per row, then g_t; S = w_t (both at sample t's row vo + L-1 + t)
     float *SM;                        // [groups][sub-blocks][64] maxima of whole sub-blocks (look-ahead longer than one sub-block)
     int sb, nsub;                     // sub-block length (rows), sub-blocks per look-ahead block of L rows
-    int32_t *pcm;                     // [slots][max_batch][h]
+    int32_t *pcm;                     // [slots][max_batch][h] (pcm16: the same rows as int16, in the front half of the buffer)
+    int pcm16;                        // PSDR_OPT_POST_CHAIN_PCM16: the output kernels store int16 instead of int32
     // carried state
     float *dc_s1, *dc_s2;             // [slots] running sums
     float *agc_gain;

@@ -26,7 +26,7 @@ def test_recurrence_waves_of_the_post_chain_own_their_simd(meta):
     512 registers, nothing else fits on the SIMD.  If a compiler stops honouring the clobber the
     kernels still run - beside other waves, slower - and nothing else would notice."""
     for name in ("psdr::k_pc_ma2<true, false>", "psdr::k_pc_ma2<true, true>", "psdr::k_pc_mad<true>", "psdr::k_pc_gain<false, true>", "psdr::k_pc_gain<true, true>",
-                 "psdr::k_pc_agc<true>", "psdr::k_pc_agc<false>"):
+                 "psdr::k_pc_agc<true, false>", "psdr::k_pc_agc<false, false>", "psdr::k_pc_agc<true, true>", "psdr::k_pc_agc<false, true>"):
         for k, v in _find(meta, name).items():
             assert v["vgpr"] == 512 and v["agpr"] == 256, (k, v)
     # the one-kernel AGC: four such waves = a whole CU per work-group, 72 KiB of LDS, nothing spilled (its producers' ring of

@@ -777,3 +777,71 @@ def test_post_chain_agc_forms_agree_under_churn(nclients, F, n):
                 assert np.array_equal(one[b][ci][f], want), f"client {ci} batch {b} frame {f} against the oracle"
                 opened += int(np.count_nonzero(want))
         assert opened > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,agc_form", [(248, 1), (248, 0), (252, 1), (360, 1)])
+def test_post_chain_pcm16_rows_are_the_int32_rows(n, agc_form):
+    """PSDR_OPT_POST_CHAIN_PCM16 = 1: the chain's output kernels (k_pc_agc, k_pc_out4 - and k_pc_out where frames are not whole
+    row groups: n = 252 -, k_pc_zero for dropped frames) store int16 rows; psdr_read_pcm still delivers the reference's int32
+    buffer (widened on the host), psdr_fetch_begin(PSDR_FETCH_PCM) moves half the bytes and psdr_fetched_pcm16 hands the rows
+    out (psdr_fetched_audio's pcm is NULL then).  Against the oracle's chain on the GPU's own float audio, bit for bit; then
+    the option off again: int32 rows as before."""
+    import ctypes as C
+    from phantomsdr_amd import AudioClient, Context
+    from phantomsdr_amd._lib import check
+    N, F, nb = 1 << 14, 24, 4
+    x = synth_stream((nb * F + 1) * (N // 2), False, seed=79, fft_size=N)
+    raw = quantize_raw(x, "s16", False)
+    ctx = Context(N, False, levels_for(N), additional_size=n, audio_fft_size=n, audio_rate=12000, input_format="s16", max_batch=F,
+                  max_clients=6)
+    try:
+        ctx.set_option(ctx.OPT_POST_CHAIN_AGC, agc_form)
+        ctx.set_option(ctx.OPT_POST_CHAIN_PCM16, 1)
+        ctx.set_post_chain(True)
+        d = ctx.dev_alloc(raw.nbytes)
+        ctx.h2d(d, raw)
+        gcl, chains = [], []
+        for i, mode in enumerate(("USB", "AM", "FM", "LSB")):
+            g = AudioClient(ctx)
+            g.set_audio_demodulation(mode)
+            m = 2000 + 2500 * i
+            l, r = (m, m + 100) if mode == "USB" else (m - 100, m) if mode == "LSB" else (m - 100, m + 100)
+            g.set_audio_range(l, float(m), r)
+            gcl.append(g)
+            chains.append(O.PostChain(12000))
+        hb = ctx.half_frame_bytes()
+        opened = 0
+        for b in range(nb):
+            if b == nb - 1:
+                ctx.set_option(ctx.OPT_POST_CHAIN_PCM16, 0)  # (drains; the state of the chain carries over)
+            ctx.process_batch(d, F, offset_bytes=b * F * hb)
+            if b == 1:  # a frame of client 0 dropped by the NaN guard: its row is zero in either width
+                p, nbytes = C.c_void_p(), C.c_size_t()
+                check(ctx.lib.psdr_spectrum_device_ptr(ctx.h, 0, C.byref(p), C.byref(nbytes)))
+                ctx.synchronize()
+                ctx.h2d(p, np.full(2, np.nan, np.float32), offset=(3 * N + 2050) * 8)
+            ctx.demod_batch(b * F)
+            ctx.fetch_begin(ctx.FETCH_PCM)
+            ctx.fetch_end()
+            for ci, (g, ch) in enumerate(zip(gcl, chains)):
+                audio, _, nan = g.read_audio(F)
+                pcm = g.read_pcm(F)
+                for f in range(F):
+                    _, _, _, p32 = ctx.fetched_audio(g.id, f, pcm=True)
+                    if b < nb - 1:
+                        assert p32 is None
+                        row = ctx.fetched_pcm16(g.id, f)
+                        assert row.dtype == np.int16 and np.array_equal(row.astype(np.int32), pcm[f]), (b, ci, f)
+                    else:
+                        assert np.array_equal(p32, pcm[f]), (b, ci, f)
+                    if nan[f]:
+                        assert not pcm[f].any()
+                        continue
+                    want = ch.process(audio[f])
+                    assert np.array_equal(pcm[f], want), f"batch {b} client {ci} frame {f}"
+                    opened += int(np.count_nonzero(want))
+        assert opened > 1000
+        ctx.dev_free(d)
+    finally:
+        ctx.close()
