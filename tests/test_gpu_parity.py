@@ -396,7 +396,7 @@ def test_error_paths():
 @pytest.mark.parametrize("audio_rate,F,nb,n,agc_form",
                          [(12000, 8, 5, 248, 1), (192000, 128, 5, 248, 1), (12000, 7, 6, 252, 1), (48000, 33, 5, 248, 1),
                           (6000, 9, 4, 360, 1), (44100, 40, 5, 248, 1),
-                          (12000, 8, 5, 248, 0), (48000, 33, 5, 248, 0), (6000, 9, 4, 360, 0)])
+                          (12000, 8, 5, 248, 0), (48000, 33, 5, 248, 0), (6000, 9, 4, 360, 0), (12000, 8, 6, 248, 2)])
 def test_post_chain_bit_exact(audio_rate, F, nb, n, agc_form):
     """DC blocker + AGC + int16 conversion on the GPU (psdr_set_post_chain) against the oracle's
     chain fed with the SAME float audio (the GPU's own demodulator output): the recurrences are
@@ -412,7 +412,8 @@ def test_post_chain_bit_exact(audio_rate, F, nb, n, agc_form):
     16-sample chunks + ONE kernel for look-ahead peak, gain and int16 wherever the rate and the audio size allow it (all
     cases but n = 252: frames that are not whole row groups, and 44100: a look-ahead of 8820 samples is not whole chunks;
     the streams here end inside a chunk, inside a round of the kernel's pipeline, and - F = 8 / 9 - before its third round),
-    0 = the five-kernel form everywhere."""
+    0 = the five-kernel form everywhere, 2 = the form changes with every batch (psdr_set_option between batches: the chain's
+    carried state - histories, running sums, gain - is the same in both)."""
     from phantomsdr_amd import AudioClient, Context
     N = 1 << 14
     R, levels = N, levels_for(N)
@@ -422,7 +423,7 @@ def test_post_chain_bit_exact(audio_rate, F, nb, n, agc_form):
     ctx = Context(N, False, levels, additional_size=n, audio_fft_size=n, audio_rate=audio_rate,
                   input_format="s16", max_batch=F, max_clients=4)
     try:
-        ctx.set_option(ctx.OPT_POST_CHAIN_AGC, agc_form)
+        ctx.set_option(ctx.OPT_POST_CHAIN_AGC, agc_form & 1)
         ctx.set_post_chain(True)
         d = ctx.dev_alloc(raw.nbytes)
         ctx.h2d(d, raw)
@@ -437,6 +438,8 @@ def test_post_chain_bit_exact(audio_rate, F, nb, n, agc_form):
         hb = ctx.half_frame_bytes()
         total = 0
         for b in range(nb):
+            if agc_form == 2:
+                ctx.set_option(ctx.OPT_POST_CHAIN_AGC, b & 1)
             if b == 2:  # mode change of client 0: AGC reset
                 gcl[0].set_audio_demodulation("LSB")
                 chains[0].reset_agc()
