@@ -402,6 +402,9 @@ int psdr::post_chain_enqueue(psdr_ctx *c, const ClientParams *d_clients, const i
     //   V1[set] rows >= L-1                   averages(b)    <- peak / output of batch b - 3
     //   X / M1 / V1[nxt] history rows         history(b)     <- averages(b - 2) (same stream), peak / output of batch b - 2
     //   P / S / SM[set]                       peak(b)        <- gain / output of batch b - 3
+    //   CM / CP / CS[set] (one-kernel AGC)    averages(b) [CMW], chunk maxima / scans(b) on the averages' stream  <- k_pc_agc of batch b - 3
+    //   falive[set]                           index(b)       <- k_pc_agc of batch b - 3
+    //   d_audio[b mod 2] (DIRECT)             demodulation(b) <- averages / history of batch b - 2 (the wait is in demod.hip)
     // i.e. a stage waits for its predecessor of THIS batch and for the output stage of the batch that had the set.
     auto wait = [&](hipStream_t st, int stage, int which) -> int {
         if (piped) HIPCHK(hipStreamWaitEvent(st, c->ev_pc[stage][which], 0));
