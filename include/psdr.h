@@ -271,10 +271,13 @@ int psdr_set_post_chain(psdr_ctx *ctx, int enable);
  *   process that creates several contexts, where creation order lands on a busy pipe of the command processor (+15 %
  *   instead of +3 % on the step); the outcome depends on wall-clock thresholds, and a failed
  *   measurement falls back to 0.
- * PSDR_OPT_POST_CHAIN_AGC (any time; drains the context): the form of the chain's AGC.  1 (default): maxima of 16-sample
- *   chunks + ONE four-wave kernel for look-ahead peak, gain recurrence and int16 conversion - a third of the memory
- *   traffic of the other form - whenever the audio rate is a multiple of 80 Hz, the audio size a
- *   multiple of 8 and the CUs the chain reserves hold its work-groups; 0: always the five-kernel form.  Same bits.
+ * PSDR_OPT_POST_CHAIN_AGC (any time; drains the context): the form of the chain.  1 (default): the AGC as maxima of 16-sample
+ *   chunks + ONE four-wave kernel for look-ahead peak, gain recurrence and int16 conversion - whenever the audio rate is a
+ *   multiple of 80 Hz, the audio size a multiple of 8 and the CUs the chain reserves hold its work-groups - and the DC
+ *   blocker's moving averages reading the demodulated rows themselves (no gathered copy while no frame is dropped and no
+ *   client paused) and leaving the chunk maxima on their way: a third of the memory traffic of the other form, which is
+ *   what the chain costs the FFT passes.  0: round 5's form everywhere (gather + five AGC kernels).
+ *   Same bits either way, and the chain's carried state is the same: the forms may alternate between batches.
  * PSDR_OPT_POST_CHAIN_PCM16 (any time; drains the context): 1 = the chain writes its PCM as int16 rows instead of the int32
  *   buffer the reference hands its encoder (dsp_float_to_int16's output, src/utils/dsp.cpp:152-165, holds 16-bit values):
  *   half the bytes for psdr_fetch_begin(PSDR_FETCH_PCM) to move - with hundreds of clients the copy to the host is what
