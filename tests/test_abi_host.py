@@ -56,6 +56,18 @@ def test_config_struct_matches_header():
     assert C.sizeof(psdr_config) == 4 * len(fields)
 
 
+def test_option_and_fetch_constants_of_the_python_mirror_match_the_header():
+    """psdr_set_option's knobs and psdr_fetch_begin's bits are plain integers in include/psdr.h; phantomsdr_amd.core carries
+    copies - a renumbered enum would silently set another option."""
+    from phantomsdr_amd.core import Context
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "psdr.h")).read(), flags=re.S)
+    enum = dict((k, int(v)) for k, v in re.findall(r"(PSDR_OPT_[A-Z0-9_]+)\s*=\s*(\d+)", txt))
+    assert enum == {"PSDR_OPT_POST_CHAIN_STREAMS": Context.OPT_POST_CHAIN_STREAMS, "PSDR_OPT_POST_CHAIN_AGC": Context.OPT_POST_CHAIN_AGC,
+                    "PSDR_OPT_POST_CHAIN_PCM16": Context.OPT_POST_CHAIN_PCM16}
+    bits = dict((k, int(v)) for k, v in re.findall(r"#define\s+(PSDR_FETCH_(?:AUDIO|PCM|WATERFALL))\s+(\d+)u", txt))
+    assert bits == {"PSDR_FETCH_AUDIO": Context.FETCH_AUDIO, "PSDR_FETCH_PCM": Context.FETCH_PCM, "PSDR_FETCH_WATERFALL": Context.FETCH_WATERFALL}
+
+
 def test_no_oracle_in_product_path():
     """the product never imports/links the oracle (it is test infrastructure only)"""
     pkg = os.path.join(ROOT, "phantomsdr_amd")
