@@ -848,3 +848,52 @@ def test_post_chain_pcm16_rows_are_the_int32_rows(n, agc_form):
         ctx.dev_free(d)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("agc_form", [1, 0])
+def test_post_chain_batches_shorter_than_max_batch(agc_form):
+    """Batches of 7, 16, 3, 16, 1, 12 frames in a context sized for 16: the chain's streams are the frames that WERE processed
+    (the moving averages read them from the demodulator's rows where they lie - rows [slot][max_batch][h], a batch fills the
+    first nframes of them), its histories carry over whatever the batch lengths; 124-sample frames, so most streams end
+    inside a 16-sample chunk.  Against the oracle's chain, bit for bit."""
+    from phantomsdr_amd import AudioClient, Context
+    N, n, MB = 1 << 14, 248, 16
+    sizes = [7, 16, 3, 16, 1, 12, 16, 16, 5]
+    total = sum(sizes)
+    x = synth_stream((total + 1) * (N // 2), False, seed=80, fft_size=N)
+    raw = quantize_raw(x, "s16", False)
+    ctx = Context(N, False, levels_for(N), additional_size=n, audio_fft_size=n, audio_rate=12000, input_format="s16", max_batch=MB,
+                  max_clients=5)
+    try:
+        ctx.set_option(ctx.OPT_POST_CHAIN_AGC, agc_form)
+        ctx.set_post_chain(True)
+        d = ctx.dev_alloc(raw.nbytes)
+        ctx.h2d(d, raw)
+        gcl, chains = [], []
+        for i, mode in enumerate(("USB", "AM", "FM", "LSB", "AM")):
+            g = AudioClient(ctx)
+            g.set_audio_demodulation(mode)
+            m = 1500 + 2900 * i
+            l, r = (m, m + 100) if mode == "USB" else (m - 100, m) if mode == "LSB" else (m - 100, m + 100)
+            g.set_audio_range(l, float(m), r)
+            gcl.append(g)
+            chains.append(O.PostChain(12000))
+        hb = ctx.half_frame_bytes()
+        f0 = opened = 0
+        for F in sizes:
+            ctx.process_batch(d, F, offset_bytes=f0 * hb)
+            ctx.demod_batch(f0)
+            for ci, (g, ch) in enumerate(zip(gcl, chains)):
+                audio, _, nan = g.read_audio(MB)
+                pcm = g.read_pcm(MB)
+                assert not nan[:F].any()
+                for f in range(F):
+                    want = ch.process(audio[f])
+                    assert np.array_equal(pcm[f], want), f"batch at frame {f0} ({F} frames) client {ci} frame {f}"
+                    opened += int(np.count_nonzero(want))
+            f0 += F
+        assert opened > 1000
+        ctx.dev_free(d)
+    finally:
+        ctx.close()
