@@ -933,7 +933,7 @@ __global__ __launch_bounds__(256) void k_pc_history(PostArgs a) {
 // multiple of 80 Hz with the usual audio sizes; anything else keeps the kernels above.
 //
 // k_pc_agc is a pipeline of FOUR waves, one per SIMD of a CU the passes leave free (each names v255 / a255, PC_OWN_SIMD):
-//   waves 1-3 (producers)  chunk by chunk: the loads (three rounds ahead, a ring of register sets), suffix / prefix maxima,
+//   waves 1-3 (producers)  chunk by chunk: the loads (two rounds ahead, a ring of three register sets), suffix / prefix maxima,
 //                          the division, w -> LDS; two rounds later the gains of the same chunk come back through LDS:
 //                          delayed sample * gain, int16 conversion, the store to pcm[slot][frame][j] (the frame of a stream
 //                          position through FA, the list of a slot's surviving frames)
@@ -1240,11 +1240,11 @@ __global__ __launch_bounds__(64 * (1 + PC_AGC_NP)) void k_pc_agc(PostArgs a) {
         }
     };
     // Producer timeline: round rr sits between barriers #rr and #rr+1: fetch(rr + AH), emit(rr - 2) [its gains were written by the
-    // recurrence during round rr - 1], produce(rr) [read by the recurrence one barrier later].  dly / dst of round rr live until
+    // recurrence during round rr - 1], produce(rr) [read by the recurrence one barrier later].  the delayed samples (dbuf) and dst of round rr live until
     // emit(rr) two rounds later: two parities suffice because emit(rr - 2) comes BEFORE produce(rr).  The steady state
     // (rounds 2 .. nrounds - 1) is branch-free - every fetch, store and LDS operation unconditional - so that the compiler
     // can COUNT the memory operations between a load and its use (a conditional one turns every wait into vmcnt(0): a drain
-    // of three rounds of prefetch and of the stores behind them); the first two and the last two rounds stand outside.
+    // of two rounds of prefetch and of the stores behind them); the first two and the last two rounds stand outside.
     static_assert(AH == 2, "ring position = round mod 3, parity = round mod 2: six rounds per trip");
     pc_static_for<0, AH>([&](auto kc) { fetch(kc, decltype(kc)::value); });
     {   // rounds 0 and 1: nothing to emit yet

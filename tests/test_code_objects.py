@@ -30,7 +30,7 @@ def test_recurrence_waves_of_the_post_chain_own_their_simd(meta):
         for k, v in _find(meta, name).items():
             assert v["vgpr"] == 512 and v["agpr"] == 256, (k, v)
     # the one-kernel AGC: four such waves = a whole CU per work-group, 72 KiB of LDS, nothing spilled (its producers' ring of
-    # register sets is what the three rounds of prefetch live in)
+    # register sets is what the two rounds of prefetch live in)
     for k, v in _find(meta, "psdr::k_pc_agc<").items():
         assert v["wg"] == 256 and v["scratch"] == 0 and v["lds"] <= 80 * 1024, (k, v)
     # the moving averages with their third wave (block maxima for that kernel): three SIMDs of a CU
