@@ -1240,7 +1240,7 @@ __global__ __launch_bounds__(64 * (1 + PC_AGC_NP)) void k_pc_agc(PostArgs a) {
         }
     };
     // Producer timeline: round rr sits between barriers #rr and #rr+1: fetch(rr + AH), emit(rr - 2) [its gains were written by the
-    // recurrence during round rr - 1], produce(rr) [read by the recurrence one barrier later].  the delayed samples (dbuf) and dst of round rr live until
+    // recurrence during round rr - 1], produce(rr) [read by the recurrence one barrier later].  The delayed samples (dbuf) and dst of round rr live until
     // emit(rr) two rounds later: two parities suffice because emit(rr - 2) comes BEFORE produce(rr).  The steady state
     // (rounds 2 .. nrounds - 1) is branch-free - every fetch, store and LDS operation unconditional - so that the compiler
     // can COUNT the memory operations between a load and its use (a conditional one turns every wait into vmcnt(0): a drain
