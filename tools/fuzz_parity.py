@@ -84,6 +84,13 @@ def one_case(rng, case):
                   max_batch=F, max_clients=ncl, max_waterfall_clients=3, skip_num=skip)
     try:
         if post:
+            # (round 6: now and then round 5's form of the chain, and / or its PCM as int16 rows - psdr_read_pcm delivers int32 either
+            # way; drawn from a generator of its own so that the cases themselves are the ones of earlier rounds)
+            r6 = np.random.default_rng(600000 + case)
+            if r6.random() < 0.3:
+                ctx.set_option(ctx.OPT_POST_CHAIN_AGC, 0)
+            if r6.random() < 0.3:
+                ctx.set_option(ctx.OPT_POST_CHAIN_PCM16, 1)
             ctx.set_post_chain(True)
         d = ctx.dev_alloc(raw.nbytes)
         ctx.h2d(d, raw)
